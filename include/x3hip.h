@@ -1,0 +1,109 @@
+/*
+ * x3hip.h -- C ABI of libx3hip.so: the MI355X (gfx950) implementation of the x3 hot path.
+ *
+ * The reference has no plugin/FFI surface; its hot path is a set of static-linkage C functions driven by
+ * main().  This header is the drop-in boundary for that path: plain C, caller-owned buffers,
+ * integer status codes instead of abort(), one opaque handle per GPU, thread-safe across handles.  Each entry
+ * point names the reference interface it replaces (file:line in the reference tree).
+ *
+ * The library has NO CPU implementation: every call needs a gfx950 device and returns X3H_E_NO_DEVICE
+ * (or the HIP error) otherwise.
+ */
+#ifndef X3HIP_H
+#define X3HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define X3H_ABI_VERSION 1
+
+/* status codes (the reference abort()s on every error: file.c:9-18, x3.c:515,547,554,583) */
+enum {
+	X3H_OK            = 0,
+	X3H_E_ARG         = -1, /* bad argument (NULL buffer, chunk > X3H_MAX_CHUNK, ...)             */
+	X3H_E_NOMEM       = -2, /* host or device allocation failed                                  */
+	X3H_E_OUTPUT_FULL = -3, /* caller's output capacity too small (see x3h_compress_bound)        */
+	X3H_E_CORRUPT     = -4, /* decoder: not an x3 stream                                          */
+	X3H_E_NO_DEVICE   = -5, /* no usable HIP device                                               */
+	X3H_E_HIP         = -6, /* a HIP runtime call failed (x3h_last_hip_error() has the code)      */
+	X3H_E_INTERNAL    = -7  /* a device-side workspace bound was violated (bug)                   */
+};
+
+#define X3H_MAX_CHUNK ((size_t)1 << 28) /* one stream <= 256 MiB (32-bit positions / pool offsets on the device) */
+
+/* The tunables the reference keeps in file-scope globals.  Defaults: x3h_default_params().
+ *   window_bytes    set_forward_window()   backend.c:8-18   (CLI -w N means N*1024, x3.c:503)
+ *   max_match_count set_max_match_count()  backend.c:21-31  (CLI -t)
+ *   factor1/factor2 set_magic_factor1/2()  backend.c:33-54  (CLI -m / -n)
+ *   nl_mode         g_nl                   x3.c:355-370     (CLI -x)                                   */
+typedef struct x3h_params {
+	uint32_t window_bytes;
+	int32_t  max_match_count;
+	uint32_t factor1;
+	uint32_t factor2;
+	int32_t  nl_mode;
+} x3h_params;
+
+/* What the reference prints on stderr after a run (x3.c:662-693), plus device timings. */
+typedef struct x3h_stats {
+	uint64_t events[5];     /* E_CTX0, E_CTX1, E_IDX1, E_NEW, E_EOF counts (x3.c:42,684)               */
+	uint64_t dict_elems;    /* dict_get_elems()      x3.c:693                                          */
+	uint64_t ctx0_entries;  /* tag_pair_get_elems()  x3.c:693                                          */
+	uint64_t steps;         /* parse steps = hits + misses (x3.c:669)                                   */
+	double   ms_total;      /* device time of the whole call (inputs resident -> outputs resident)      */
+	double   ms_scan;       /* K1: window scan                                                          */
+	double   ms_parse;      /* K2: dictionary + parse                                                   */
+	double   ms_code;       /* K3: models + arithmetic coder + bit output                               */
+	double   ms_copy;       /* host<->device staging (0 for device-resident calls)                      */
+} x3h_stats;
+
+typedef struct x3h_ctx x3h_ctx; /* one per GPU: device, stream, growable workspace */
+
+int          x3h_abi_version(void);
+const char  *x3h_strerror(int status);
+int          x3h_last_hip_error(void);
+int          x3h_device_count(void);
+void         x3h_default_params(x3h_params *prm);           /* backend.c:8,21,33-34 ; x3.c:355            */
+size_t       x3h_compress_bound(size_t n);                  /* replaces the unchecked 2*isize of x3.c:580 */
+
+/* create()/destroy() of the reference (x3.c:225-249, 436-458) become handle life time. */
+int  x3h_ctx_create(x3h_ctx **ctx, int device);
+void x3h_ctx_destroy(x3h_ctx *ctx);
+
+/* Whole path, host buffers.  Replaces   create(); bio_open(); ac_init(); compress(ptr,size,&bio);
+ * ac_encode_flush(); bio_close();   (x3.c:562,593-604).  `in` needs no padding (the W zero bytes of
+ * x3.c:579,590 are added on the device).  *out_len is a multiple of 4 (bio.c:105-112).               */
+int x3h_compress(x3h_ctx *ctx, const x3h_params *prm, const uint8_t *in, size_t n,
+                 uint8_t *out, size_t cap, size_t *out_len, x3h_stats *stats);
+
+/* Independent chunks, each coded as its own x3 stream (== `x3 -z` on that chunk alone).
+ * Chunk c is in[offsets[c] .. offsets[c+1]); its stream is written at out + c*out_stride (out_stride a
+ * multiple of 4, >= the capacity wanted per chunk) and its length to out_lens[c].
+ * `in`/`out` are HOST pointers here.                                                                   */
+int x3h_compress_chunks(x3h_ctx *ctx, const x3h_params *prm, const uint8_t *in, const uint64_t *offsets,
+                        int nchunks, uint8_t *out, uint64_t out_stride, uint64_t *out_lens, x3h_stats *stats);
+
+/* Same, but `d_in` and `d_out` are DEVICE pointers on ctx's GPU (inputs already resident in HBM, outputs left
+ * there); offsets/out_lens stay host arrays.  This is the call bench.py times.                          */
+int x3h_compress_chunks_dev(x3h_ctx *ctx, const x3h_params *prm, const void *d_in, const uint64_t *offsets,
+                            int nchunks, void *d_out, uint64_t out_stride, uint64_t *out_lens, x3h_stats *stats);
+
+/* Stage-level entry points (kernel parity tests; the seams named in SURVEY.md 8(b)).
+ *  x3h_scan_m      : K1 alone.  m_out[p] = max{ i : count[i] > min(T, count[0]-1) } (0 if T<=0 or count[0]<2) with
+ *                    count[] of backend.c:56-74; find_best_match(p) = 1 + max{ i <= m[p] : filters of backend.c:79-90 }.
+ *  x3h_scan_counts : K1's raw histogram, counts_out[p*32+i] = count[i] at p (backend.c:62-74).
+ *  x3h_parse       : K1+K2.  Token list of the parse loop x3.c:379-429: tok_info < 2^31 is a hit on that tag;
+ *                    otherwise bit31 set, bits0..5 = fragment length, bit30 = fragment already in the dictionary.  */
+int x3h_scan_m(x3h_ctx *ctx, const x3h_params *prm, const uint8_t *in, size_t n, uint8_t *m_out);
+int x3h_scan_counts(x3h_ctx *ctx, const x3h_params *prm, const uint8_t *in, size_t n, uint32_t *counts_out);
+int x3h_parse(x3h_ctx *ctx, const x3h_params *prm, const uint8_t *in, size_t n,
+              uint32_t *tok_pos, uint32_t *tok_info, size_t tok_cap, size_t *ntok, uint64_t *dict_elems);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* X3HIP_H */

@@ -1,0 +1,119 @@
+"""Parity tests proper: the HIP library (through the C ABI) against the golden vectors of the real reference and
+against the oracle on seeded inputs.  Bit-exact is the bar everywhere (byte / integer / index work)."""
+import numpy as np
+import pytest
+
+import golden_util
+import oracle_lib
+from x3_compressor_amd import _lib, synth
+
+pytestmark = pytest.mark.gpu
+CASES = sorted(golden_util.load_cases().keys())
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    ctx = _lib.X3Context(0)  # raises loudly if libx3hip.so or the GPU is missing
+    yield ctx
+    ctx.close()
+
+
+def first_diff(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    n = min(len(a), len(b))
+    d = np.nonzero(a[:n] != b[:n])[0]
+    return int(d[0]) if len(d) else (n if len(a) != len(b) else -1)
+
+
+# ---- whole path vs the reference's own outputs --------------------------------------------------------------
+@pytest.mark.parametrize("name", CASES)
+def test_stream_equals_reference_golden(gpu, golden, name):
+    c = golden[name]
+    got = gpu.compress(c["data"], _lib.params_from_args(c["args"]))
+    assert got == c["expect"], f"first differing byte {first_diff(np.frombuffer(got, np.uint8), np.frombuffer(c['expect'], np.uint8))}"
+
+
+# ---- stage level --------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["gpl16k_default", "quad4096_w2_t4", "zeros5000", "records_w8_t16", "cfg4_zipf32k_w64_t256",
+                                  "cfg2_english32k_w64_t256", "rand4096_w4_t8", "gpl8k_t0", "range256_x8_w1_t1"])
+def test_scan_m_equals_oracle(gpu, oracle, golden, name):
+    c = golden[name]
+    m = gpu.scan_m(c["data"], _lib.params_from_args(c["args"]))
+    mo = oracle.scan_m(c["data"], oracle_lib.params_from_args(c["args"]))
+    assert np.array_equal(m, mo), f"first diff at position {first_diff(m, mo)}"
+
+
+@pytest.mark.parametrize("name", ["gpl16k_default", "records_w8_t16", "zeros1024"])
+def test_scan_counts_equal_oracle(gpu, oracle, golden, name):
+    """backend.c:62-74: the full 32-bin histogram, not just the selected length."""
+    c = golden[name]
+    prm = _lib.params_from_args(c["args"])
+    cnt = gpu.scan_counts(c["data"], prm)
+    rng = np.random.default_rng(3)
+    for p in [0, 1, len(c["data"]) - 1, *rng.integers(0, len(c["data"]), 24)]:
+        assert np.array_equal(cnt[p], oracle.count(c["data"], int(p), prm.window_bytes)), f"position {p}"
+
+
+@pytest.mark.parametrize("name", [n for n in CASES if not n.startswith(("cfg3", "cfg5"))])
+def test_parse_tokens_equal_oracle(gpu, oracle, golden, name):
+    c = golden[name]
+    tp, ti, d = gpu.parse(c["data"], _lib.params_from_args(c["args"]))
+    _, op, oi, st = oracle.trace(c["data"], oracle_lib.params_from_args(c["args"]))
+    assert d == st.dict_elems
+    assert np.array_equal(tp, op), f"positions diverge at step {first_diff(tp, op)}"
+    assert np.array_equal(ti, oi), f"tokens diverge at step {first_diff(ti, oi)}"
+
+
+# ---- seeded inputs vs the oracle ------------------------------------------------------------------------------
+SEEDED = [
+    ("english96k_w64_t256", lambda: synth.english_like(96 * 1024).tobytes(), dict(w_kib=64, t=256)),
+    ("zipf64k_w64_t256", lambda: synth.zipf_bytes(64 * 1024, offset=12345).tobytes(), dict(w_kib=64, t=256)),
+    ("english24k_w256_t1024", lambda: synth.english_like(24 * 1024, seed=7).tobytes(), dict(w_kib=256, t=1024)),
+    ("binary_mix_w16_t32", lambda: (np.random.default_rng(9).integers(0, 4, 50000, dtype=np.uint8) * 17).tobytes() + bytes(3000)
+                                   + bytes(range(256)) * 20, dict(w_kib=16, t=32)),
+    ("block_edge_2048", lambda: synth.english_like(2048).tobytes(), dict(w_kib=2, t=4)),
+    ("block_edge_2049", lambda: synth.english_like(2049).tobytes(), dict(w_kib=2, t=4)),
+    ("tiny_window_w0", lambda: synth.english_like(3000).tobytes(), dict(w_kib=1, t=1)),
+    ("many_fragments_t1", lambda: np.random.default_rng(4).integers(0, 256, 40000, dtype=np.uint8).tobytes(), dict(w_kib=4, t=1)),
+]
+
+
+@pytest.mark.parametrize("name,make,kw", SEEDED, ids=[s[0] for s in SEEDED])
+def test_stream_equals_oracle_on_seeded_input(gpu, oracle, name, make, kw):
+    data = make()
+    got = gpu.compress(data, _lib.make_params(**kw))
+    want, st = oracle.compress(data, oracle_lib.params(**kw), want_stats=True)
+    assert got == want, f"first differing byte {first_diff(np.frombuffer(got, np.uint8), np.frombuffer(want, np.uint8))}"
+    gs = gpu.last_stats
+    assert list(gs.events)[:4] == list(st.events)[:4] and gs.dict_elems == st.dict_elems
+    assert gs.ctx0_entries == st.ctx0_entries and gs.steps == st.steps
+
+
+def test_chunks_are_independent_streams(gpu, oracle):
+    """chunk output == `x3 -z` of that chunk alone; ragged sizes incl. an empty chunk."""
+    data = synth.english_like(70000).tobytes()
+    cuts = [0, 20000, 20000, 20001, 45000, 70000]
+    kw = dict(w_kib=8, t=16)
+    outs = gpu.compress_chunks(data, cuts, _lib.make_params(**kw))
+    for i, o in enumerate(outs):
+        assert o == oracle.compress(data[cuts[i]:cuts[i + 1]], oracle_lib.params(**kw)), f"chunk {i}"
+
+
+def test_output_capacity_is_checked(gpu):
+    data = np.random.default_rng(1).integers(0, 256, 5000, dtype=np.uint8).tobytes()
+    with pytest.raises(_lib.X3Error) as e:
+        gpu.compress(data, _lib.make_params(), cap=1000)
+    assert e.value.status == -3  # X3H_E_OUTPUT_FULL; the reference would overrun its 2n buffer (x3.c:580)
+
+
+# ---- BASELINE.json full size: size-independent properties ---------------------------------------------------------
+def test_full_size_dickens_like_round_trip(gpu, oracle):
+    """config 2 shape (10 192 446 bytes, -w 64 -t 256): the oracle's decoder (restating x3.c:285-353) must reproduce the
+    input from the GPU stream, and the stream must be self-consistent (word padded, events add up)."""
+    data = synth.english_like(synth.DICKENS_BYTES)
+    stream = gpu.compress(data, _lib.make_params(w_kib=64, t=256))
+    st = gpu.last_stats
+    assert len(stream) % 4 == 0 and 0 < len(stream) < len(data)
+    assert sum(list(st.events)[:4]) == st.steps
+    rc, back = oracle.decompress(stream, len(data) + 64)
+    assert rc == 0 and back == data.tobytes()

@@ -1,0 +1,186 @@
+"""ctypes binding of the C ABI in include/x3hip.h.
+
+The product library is ``csrc/libx3hip.so`` (hipcc, gfx950).  There is no CPU implementation and no fallback:
+if the library is missing, or no GPU is present, construction fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_SO = os.path.join(HERE, "csrc", "libx3hip.so")
+
+# every symbol include/x3hip.h declares (tests check that the built library exports all of them)
+ABI_SYMBOLS = (
+    "x3h_abi_version", "x3h_strerror", "x3h_last_hip_error", "x3h_device_count", "x3h_default_params",
+    "x3h_compress_bound", "x3h_ctx_create", "x3h_ctx_destroy", "x3h_compress", "x3h_compress_chunks",
+    "x3h_compress_chunks_dev", "x3h_scan_m", "x3h_scan_counts", "x3h_parse",
+)
+
+TOK_MISS, TOK_DUP = 0x80000000, 0x40000000
+
+
+class Params(C.Structure):
+    _fields_ = [("window_bytes", C.c_uint32), ("max_match_count", C.c_int32), ("factor1", C.c_uint32),
+                ("factor2", C.c_uint32), ("nl_mode", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("events", C.c_uint64 * 5), ("dict_elems", C.c_uint64), ("ctx0_entries", C.c_uint64),
+                ("steps", C.c_uint64), ("ms_total", C.c_double), ("ms_scan", C.c_double), ("ms_parse", C.c_double),
+                ("ms_code", C.c_double), ("ms_copy", C.c_double)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "events"}
+        d["events"] = list(self.events)
+        return d
+
+
+class X3Error(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"x3hip status {status}: {msg}")
+        self.status = status
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    path = path or os.environ.get("X3HIP_LIBRARY") or DEFAULT_SO
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: the x3 hot path only exists as HIP kernels for gfx950; build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C x3_compressor_amd/csrc`). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    u8p = C.c_void_p
+    lib.x3h_abi_version.restype = C.c_int
+    lib.x3h_strerror.restype = C.c_char_p
+    lib.x3h_strerror.argtypes = [C.c_int]
+    lib.x3h_last_hip_error.restype = C.c_int
+    lib.x3h_device_count.restype = C.c_int
+    lib.x3h_default_params.argtypes = [C.POINTER(Params)]
+    lib.x3h_default_params.restype = None
+    lib.x3h_compress_bound.restype = C.c_size_t
+    lib.x3h_compress_bound.argtypes = [C.c_size_t]
+    lib.x3h_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    lib.x3h_ctx_destroy.argtypes = [C.c_void_p]
+    lib.x3h_ctx_destroy.restype = None
+    lib.x3h_compress.argtypes = [C.c_void_p, C.POINTER(Params), u8p, C.c_size_t, u8p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(Stats)]
+    lib.x3h_compress_chunks.argtypes = [C.c_void_p, C.POINTER(Params), u8p, C.c_void_p, C.c_int, u8p, C.c_uint64, C.c_void_p, C.POINTER(Stats)]
+    lib.x3h_compress_chunks_dev.argtypes = lib.x3h_compress_chunks.argtypes
+    lib.x3h_scan_m.argtypes = [C.c_void_p, C.POINTER(Params), u8p, C.c_size_t, u8p]
+    lib.x3h_scan_counts.argtypes = [C.c_void_p, C.POINTER(Params), u8p, C.c_size_t, C.c_void_p]
+    lib.x3h_parse.argtypes = [C.c_void_p, C.POINTER(Params), u8p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
+                              C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]
+    return lib
+
+
+def make_params(w_kib: int = 8, t: int = 15, m: int = 4, n: int = 0, x: int = 0) -> Params:
+    """The x3 CLI knobs: -w (KiB), -t, -m, -n, -x  (x3.c:499-513)."""
+    return Params(int(w_kib) * 1024, int(t), int(m), int(n), int(x))
+
+
+def params_from_args(args) -> Params:
+    kw = {}
+    it = iter(args)
+    for a in it:
+        if a == "-w": kw["w_kib"] = int(next(it))
+        elif a == "-t": kw["t"] = int(next(it))
+        elif a == "-m": kw["m"] = int(next(it))
+        elif a == "-n": kw["n"] = int(next(it))
+        elif a == "-x": kw["x"] = 1
+        else: raise ValueError(a)
+    return make_params(**kw)
+
+
+def _u8(data) -> np.ndarray:
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data, dtype=np.uint8)
+    return np.frombuffer(bytes(data), dtype=np.uint8)
+
+
+class X3Context:
+    """One handle per GPU (x3h_ctx): device, stream and growable HBM workspace."""
+
+    def __init__(self, device: int = 0, library: str | None = None):
+        self.lib = load_library(library)
+        self._h = C.c_void_p()
+        self._check(self.lib.x3h_ctx_create(C.byref(self._h), int(device)))
+        self.device = device
+        self.last_stats: Stats | None = None
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.x3h_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, status):
+        if status != 0:
+            raise X3Error(status, self.lib.x3h_strerror(status).decode() + f" (hip error {self.lib.x3h_last_hip_error()})")
+
+    # ---- whole path ------------------------------------------------------------------------------------
+    def compress(self, data, prm: Params, cap: int | None = None) -> bytes:
+        a = _u8(data)
+        cap = self.lib.x3h_compress_bound(a.size) if cap is None else cap
+        out = np.empty(cap, dtype=np.uint8)
+        n_out, st = C.c_size_t(0), Stats()
+        self._check(self.lib.x3h_compress(self._h, C.byref(prm), a.ctypes.data if a.size else None, a.size,
+                                          out.ctypes.data, cap, C.byref(n_out), C.byref(st)))
+        self.last_stats = st
+        return out[:n_out.value].tobytes()
+
+    def compress_chunks(self, data, offsets, prm: Params, stride: int | None = None) -> list[bytes]:
+        a = _u8(data)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        nch = off.size - 1
+        if stride is None:
+            stride = int(self.lib.x3h_compress_bound(int(np.diff(off.astype(np.int64)).max(initial=0))))
+        stride = (stride + 3) & ~3
+        out = np.empty(stride * nch, dtype=np.uint8)
+        lens = np.zeros(nch, dtype=np.uint64)
+        st = Stats()
+        self._check(self.lib.x3h_compress_chunks(self._h, C.byref(prm), a.ctypes.data if a.size else None, off.ctypes.data, nch,
+                                                 out.ctypes.data, stride, lens.ctypes.data, C.byref(st)))
+        self.last_stats = st
+        return [out[i * stride:i * stride + int(lens[i])].tobytes() for i in range(nch)]
+
+    def compress_chunks_dev(self, d_in: int, offsets, prm: Params, d_out: int, stride: int):
+        """Device-resident call: d_in/d_out are raw device addresses (e.g. torch.Tensor.data_ptr()). -> (lens, Stats)"""
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        nch = off.size - 1
+        lens = np.zeros(nch, dtype=np.uint64)
+        st = Stats()
+        self._check(self.lib.x3h_compress_chunks_dev(self._h, C.byref(prm), C.c_void_p(d_in), off.ctypes.data, nch,
+                                                     C.c_void_p(d_out), stride, lens.ctypes.data, C.byref(st)))
+        self.last_stats = st
+        return lens, st
+
+    # ---- stage level (parity tests) ----------------------------------------------------------------------
+    def scan_m(self, data, prm: Params) -> np.ndarray:
+        a = _u8(data)
+        m = np.empty(a.size, dtype=np.uint8)
+        self._check(self.lib.x3h_scan_m(self._h, C.byref(prm), a.ctypes.data if a.size else None, a.size, m.ctypes.data if a.size else None))
+        return m
+
+    def scan_counts(self, data, prm: Params) -> np.ndarray:
+        a = _u8(data)
+        cnt = np.empty((a.size, 32), dtype=np.uint32)
+        self._check(self.lib.x3h_scan_counts(self._h, C.byref(prm), a.ctypes.data if a.size else None, a.size, cnt.ctypes.data if a.size else None))
+        return cnt
+
+    def parse(self, data, prm: Params):
+        a = _u8(data)
+        tp = np.empty(a.size + 1, dtype=np.uint32)
+        ti = np.empty(a.size + 1, dtype=np.uint32)
+        ntok, d = C.c_size_t(0), C.c_uint64(0)
+        self._check(self.lib.x3h_parse(self._h, C.byref(prm), a.ctypes.data if a.size else None, a.size, tp.ctypes.data, ti.ctypes.data,
+                                       tp.size, C.byref(ntok), C.byref(d)))
+        return tp[:ntok.value].copy(), ti[:ntok.value].copy(), int(d.value)

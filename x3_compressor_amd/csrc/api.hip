@@ -1,0 +1,398 @@
+/*
+ * api.hip -- host side of libx3hip.so: the C ABI of include/x3hip.h on top of the three kernels.
+ *
+ * Data layout in HBM for a batch of independent chunks (streams):
+ *   pad    : every chunk copied to a 256-byte aligned slot of  n + W + X3_PAD_EXTRA  bytes, tail zeroed -- the
+ *            W zero bytes of x3.c:579,590 that take part in the scan and in dictionary compares (never the next chunk)
+ *   m      : one byte per position, same slots (K1 -> K2)
+ *   dict_pos/dict_len/tok_pos/tok_info : n+16 entries per chunk (worst case: every byte its own fragment)
+ *   ht     : 2^ceil(log2(2(n+1))) slots per chunk, K2 uses the first 2^hlog of them
+ *   mtf/idxfreq/ctx1 (per tag), ctx0 (per pair), item pool, pair map : sized AFTER K2 from the exact number of
+ *            elements D and hits H of each chunk: pool 8H+64 items (doubling arrays waste < 4x of <= 2H items),
+ *            pair map 2^ceil(log2(2(H+2))) slots -- provable bounds, no device-side allocation failure path.
+ */
+#include "x3_kernels.h"
+#include "../../include/x3hip.h"
+
+#ifdef X3_EMU
+#include "hip_shim.h"
+#endif
+
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <new>
+
+extern "C" void x3k_launch_scan(const X3ScanArgs *a, uint32_t max_len, uint32_t nchunks, hipStream_t st);
+extern "C" void x3k_launch_parse(const X3ParseArgs *a, uint32_t nchunks, hipStream_t st);
+extern "C" void x3k_launch_code(const X3CodeArgs *a, uint32_t nchunks, hipStream_t st);
+
+static thread_local int g_last_hip = 0;
+
+#define HIPCHK(expr)                                                   \
+	do {                                                               \
+		hipError_t e__ = (expr);                                       \
+		if (e__ != hipSuccess) { g_last_hip = (int)e__; return e__ == hipErrorOutOfMemory ? X3H_E_NOMEM : X3H_E_HIP; } \
+	} while (0)
+#define CHK(expr) do { int r__ = (expr); if (r__ != X3H_OK) return r__; } while (0)
+
+struct DevBuf {
+	void *p = nullptr;
+	size_t cap = 0;
+	int reserve(size_t bytes)
+	{
+		if (bytes <= cap) return X3H_OK;
+		if (p) { hipFree(p); p = nullptr; cap = 0; }
+		size_t want = bytes + bytes / 8 + 4096;
+		hipError_t e = hipMalloc(&p, want);
+		if (e != hipSuccess) { p = nullptr; g_last_hip = (int)e; return X3H_E_NOMEM; }
+		cap = want;
+		return X3H_OK;
+	}
+	void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+	template <typename T> T *as() const { return (T *)p; }
+};
+
+struct x3h_ctx {
+	int device = 0;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+	DevBuf pad, m, dict_pos, dict_len, ht, tok_pos, tok_info, chunks, presult, cresult;
+	DevBuf mtf, idxfreq, ctx1, ctx0, items, pkey, pval, out, counts;
+	std::vector<X3Chunk> hchunks;
+	std::vector<X3ParseResult> hparse;
+	std::vector<X3CodeResult> hcode;
+};
+
+static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+static inline uint32_t ceil_log2(uint64_t v) { uint32_t l = 0; while (((uint64_t)1 << l) < v) l++; return l; }
+
+extern "C" int x3h_abi_version(void) { return X3H_ABI_VERSION; }
+extern "C" int x3h_last_hip_error(void) { return g_last_hip; }
+
+extern "C" const char *x3h_strerror(int s)
+{
+	switch (s) {
+		case X3H_OK: return "ok";
+		case X3H_E_ARG: return "bad argument";
+		case X3H_E_NOMEM: return "out of memory";
+		case X3H_E_OUTPUT_FULL: return "output buffer too small";
+		case X3H_E_CORRUPT: return "corrupt stream";
+		case X3H_E_NO_DEVICE: return "no HIP device";
+		case X3H_E_HIP: return "HIP runtime error";
+		case X3H_E_INTERNAL: return "internal workspace bound violated";
+		default: return "unknown status";
+	}
+}
+
+extern "C" int x3h_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+extern "C" void x3h_default_params(x3h_params *p)
+{
+	p->window_bytes = 8 * 1024;
+	p->max_match_count = 15;
+	p->factor1 = 4;
+	p->factor2 = 0;
+	p->nl_mode = 0;
+}
+
+extern "C" size_t x3h_compress_bound(size_t n)
+{
+	/* a 1-byte fragment costs three coder symbols of < 31 bits each; + EOF, flush, word padding */
+	return 12 * n + 64;
+}
+
+extern "C" int x3h_ctx_create(x3h_ctx **out, int device)
+{
+	if (!out) return X3H_E_ARG;
+	*out = nullptr;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return X3H_E_NO_DEVICE;
+	if (device < 0 || device >= n) return X3H_E_ARG;
+	HIPCHK(hipSetDevice(device));
+	x3h_ctx *c = new (std::nothrow) x3h_ctx();
+	if (!c) return X3H_E_NOMEM;
+	c->device = device;
+	if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return X3H_E_HIP; }
+	for (int i = 0; i < 6; i++)
+		if (hipEventCreate(&c->ev[i]) != hipSuccess) { x3h_ctx_destroy(c); return X3H_E_HIP; }
+	*out = c;
+	return X3H_OK;
+}
+
+extern "C" void x3h_ctx_destroy(x3h_ctx *c)
+{
+	if (!c) return;
+	hipSetDevice(c->device);
+	if (c->stream) hipStreamSynchronize(c->stream);
+	DevBuf *bufs[] = { &c->pad, &c->m, &c->dict_pos, &c->dict_len, &c->ht, &c->tok_pos, &c->tok_info, &c->chunks, &c->presult,
+		               &c->cresult, &c->mtf, &c->idxfreq, &c->ctx1, &c->ctx0, &c->items, &c->pkey, &c->pval, &c->out, &c->counts };
+	for (DevBuf *b : bufs) b->release();
+	for (int i = 0; i < 6; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
+	if (c->stream) hipStreamDestroy(c->stream);
+	delete c;
+}
+
+/* ------------------------------------------------------------------------------------------------------------ */
+enum Stage { STAGE_SCAN = 1, STAGE_PARSE = 2, STAGE_CODE = 3 };
+
+struct RunIO {
+	const uint8_t *src; bool src_dev;   /* chunk c = src[offsets[c] .. offsets[c+1]) */
+	const uint64_t *offsets; int nchunks;
+	uint8_t *dst; bool dst_dev; uint64_t dst_stride; uint64_t *out_lens; /* STAGE_CODE only */
+	bool want_counts;
+};
+
+static int stage_inputs(x3h_ctx *c, const x3h_params *prm, const RunIO &io, uint64_t *max_len_out)
+{
+	const int nc = io.nchunks;
+	c->hchunks.assign((size_t)nc, X3Chunk());
+	uint64_t boff = 0, eoff = 0, hoff = 0, max_len = 0;
+	for (int i = 0; i < nc; i++) {
+		if (io.offsets[i + 1] < io.offsets[i]) return X3H_E_ARG;
+		const uint64_t len = io.offsets[i + 1] - io.offsets[i];
+		if (len > X3H_MAX_CHUNK) return X3H_E_ARG;
+		X3Chunk &k = c->hchunks[(size_t)i];
+		k.byte_off = boff;
+		k.len = (uint32_t)len;
+		k.elem_off = eoff;
+		k.ht_log2_max = ceil_log2(2 * (len + 1));
+		if (k.ht_log2_max < X3_HT_LOG2_MIN) k.ht_log2_max = X3_HT_LOG2_MIN;
+		k.ht_off = hoff;
+		boff += align_up(len + prm->window_bytes + X3_PAD_EXTRA, 256);
+		eoff += len + 16;
+		hoff += (uint64_t)1 << k.ht_log2_max;
+		if (len > max_len) max_len = len;
+	}
+	*max_len_out = max_len;
+	CHK(c->pad.reserve(boff + 256));
+	CHK(c->m.reserve(boff + 256));
+	CHK(c->dict_pos.reserve(eoff * 4));
+	CHK(c->dict_len.reserve(eoff));
+	CHK(c->tok_pos.reserve(eoff * 4));
+	CHK(c->tok_info.reserve(eoff * 4));
+	CHK(c->ht.reserve(hoff * 4));
+	CHK(c->chunks.reserve((size_t)nc * sizeof(X3Chunk)));
+	CHK(c->presult.reserve((size_t)nc * sizeof(X3ParseResult)));
+	CHK(c->cresult.reserve((size_t)nc * sizeof(X3CodeResult)));
+
+	HIPCHK(hipMemsetAsync(c->pad.p, 0, boff + 256, c->stream));
+	for (int i = 0; i < nc; i++) {
+		const X3Chunk &k = c->hchunks[(size_t)i];
+		if (!k.len) continue;
+		HIPCHK(hipMemcpyAsync(c->pad.as<uint8_t>() + k.byte_off, io.src + io.offsets[i], k.len,
+		                      io.src_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+	}
+	HIPCHK(hipMemcpyAsync(c->chunks.p, c->hchunks.data(), (size_t)nc * sizeof(X3Chunk), hipMemcpyHostToDevice, c->stream));
+	return X3H_OK;
+}
+
+static int run(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage upto, x3h_stats *stats)
+{
+	if (!c || !io.offsets || io.nchunks <= 0 || (!io.src && io.offsets[io.nchunks] != io.offsets[0])) return X3H_E_ARG;
+	x3h_params dp;
+	if (!prm_in) { x3h_default_params(&dp); prm_in = &dp; }
+	const x3h_params prm = *prm_in;
+	if (prm.window_bytes > (1u << 30)) return X3H_E_ARG;
+	HIPCHK(hipSetDevice(c->device));
+	const int nc = io.nchunks;
+	uint64_t max_len = 0;
+
+	HIPCHK(hipEventRecord(c->ev[0], c->stream));
+	CHK(stage_inputs(c, &prm, io, &max_len));
+	HIPCHK(hipEventRecord(c->ev[1], c->stream));
+
+	/* ---- K1 ---- */
+	X3ScanArgs sa;
+	sa.bytes = c->pad.as<uint8_t>();
+	sa.chunks = c->chunks.as<X3Chunk>();
+	sa.m = c->m.as<uint8_t>();
+	sa.counts = nullptr;
+	sa.window = prm.window_bytes;
+	sa.max_match_count = prm.max_match_count;
+	if (io.want_counts) {
+		CHK(c->counts.reserve((size_t)c->hchunks[0].len * 32 * 4 + 256));
+		sa.counts = c->counts.as<uint32_t>();
+	}
+	x3k_launch_scan(&sa, (uint32_t)max_len, (uint32_t)nc, c->stream);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(c->ev[2], c->stream));
+	if (upto == STAGE_SCAN) { HIPCHK(hipStreamSynchronize(c->stream)); return X3H_OK; }
+
+	/* ---- K2 ---- */
+	X3ParseArgs pa;
+	pa.bytes = sa.bytes; pa.chunks = sa.chunks; pa.m = sa.m;
+	pa.dict_pos = c->dict_pos.as<uint32_t>(); pa.dict_len = c->dict_len.as<uint8_t>();
+	pa.ht = c->ht.as<uint32_t>();
+	pa.tok_pos = c->tok_pos.as<uint32_t>(); pa.tok_info = c->tok_info.as<uint32_t>();
+	pa.result = c->presult.as<X3ParseResult>();
+	pa.factor1 = prm.factor1; pa.factor2 = prm.factor2; pa.nl_mode = prm.nl_mode;
+	x3k_launch_parse(&pa, (uint32_t)nc, c->stream);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(c->ev[3], c->stream));
+	c->hparse.resize((size_t)nc);
+	HIPCHK(hipMemcpyAsync(c->hparse.data(), c->presult.p, (size_t)nc * sizeof(X3ParseResult), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	if (upto == STAGE_PARSE) return X3H_OK;
+
+	/* ---- K3 workspace from the exact D / hits of every chunk ---- */
+	uint64_t toff = 0, c0off = 0, ioff = 0, poff = 0, ooff = 0;
+	for (int i = 0; i < nc; i++) {
+		X3Chunk &k = c->hchunks[(size_t)i];
+		const X3ParseResult &r = c->hparse[(size_t)i];
+		k.tag_off = toff;
+		k.ctx0_off = c0off;
+		k.item_off = ioff;
+		k.item_cap = 8 * (uint64_t)r.hits + 64;
+		k.pair_log2 = ceil_log2(2 * ((uint64_t)r.hits + 2));
+		k.pair_off = poff;
+		toff += (uint64_t)r.dict_elems + 8;
+		c0off += (uint64_t)r.hits + 8;
+		ioff += k.item_cap;
+		poff += (uint64_t)1 << k.pair_log2;
+		if (io.dst_dev) {
+			k.out_off = (uint64_t)i * io.dst_stride;
+			k.out_cap = io.dst_stride & ~(uint64_t)3;
+		} else {
+			uint64_t cap = io.dst_stride & ~(uint64_t)3, bound = align_up(x3h_compress_bound(k.len), 4);
+			if (cap > bound) cap = bound;
+			k.out_off = ooff;
+			k.out_cap = cap;
+			ooff += align_up(cap, 256);
+		}
+	}
+	CHK(c->mtf.reserve(toff * 4));
+	CHK(c->idxfreq.reserve(toff * 4));
+	CHK(c->ctx1.reserve(toff * sizeof(X3CtxHdr)));
+	CHK(c->ctx0.reserve(c0off * sizeof(X3CtxHdr)));
+	CHK(c->items.reserve(ioff * 8));
+	CHK(c->pkey.reserve(poff * 8));
+	CHK(c->pval.reserve(poff * 4));
+	if (!io.dst_dev) CHK(c->out.reserve(ooff + 256));
+	HIPCHK(hipMemsetAsync(c->ctx1.p, 0, toff * sizeof(X3CtxHdr), c->stream));
+	HIPCHK(hipMemsetAsync(c->ctx0.p, 0, c0off * sizeof(X3CtxHdr), c->stream));
+	HIPCHK(hipMemsetAsync(c->pkey.p, 0, poff * 8, c->stream));
+	HIPCHK(hipMemcpyAsync(c->chunks.p, c->hchunks.data(), (size_t)nc * sizeof(X3Chunk), hipMemcpyHostToDevice, c->stream));
+
+	X3CodeArgs ca;
+	ca.bytes = sa.bytes; ca.chunks = sa.chunks;
+	ca.tok_pos = pa.tok_pos; ca.tok_info = pa.tok_info; ca.parsed = pa.result;
+	ca.mtf = c->mtf.as<uint32_t>(); ca.idxfreq = c->idxfreq.as<uint32_t>();
+	ca.ctx1 = c->ctx1.as<X3CtxHdr>(); ca.ctx0 = c->ctx0.as<X3CtxHdr>();
+	ca.items = c->items.as<uint64_t>();
+	ca.pair_key = c->pkey.as<uint64_t>(); ca.pair_val = c->pval.as<uint32_t>();
+	ca.out = io.dst_dev ? io.dst : c->out.as<uint8_t>();
+	ca.result = c->cresult.as<X3CodeResult>();
+	HIPCHK(hipEventRecord(c->ev[4], c->stream));
+	x3k_launch_code(&ca, (uint32_t)nc, c->stream);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(c->ev[5], c->stream));
+	c->hcode.resize((size_t)nc);
+	HIPCHK(hipMemcpyAsync(c->hcode.data(), c->cresult.p, (size_t)nc * sizeof(X3CodeResult), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+
+	int rc = X3H_OK;
+	for (int i = 0; i < nc; i++) {
+		const X3CodeResult &r = c->hcode[(size_t)i];
+		if (r.status == X3_ST_OUT_FULL) rc = X3H_E_OUTPUT_FULL;
+		else if (r.status != X3_ST_OK && rc == X3H_OK) rc = X3H_E_INTERNAL;
+		if (io.out_lens) io.out_lens[i] = r.out_len;
+	}
+	if (rc == X3H_OK && !io.dst_dev) {
+		for (int i = 0; i < nc; i++) {
+			const X3Chunk &k = c->hchunks[(size_t)i];
+			HIPCHK(hipMemcpyAsync(io.dst + (uint64_t)i * io.dst_stride, c->out.as<uint8_t>() + k.out_off, c->hcode[(size_t)i].out_len,
+			                      hipMemcpyDeviceToHost, c->stream));
+		}
+		HIPCHK(hipStreamSynchronize(c->stream));
+	}
+	if (stats) {
+		memset(stats, 0, sizeof(*stats));
+		for (int i = 0; i < nc; i++) {
+			for (int e = 0; e < 5; e++) stats->events[e] += c->hcode[(size_t)i].events[e];
+			stats->dict_elems += c->hparse[(size_t)i].dict_elems;
+			stats->ctx0_entries += c->hcode[(size_t)i].pairs;
+			stats->steps += c->hparse[(size_t)i].ntok;
+		}
+		float ms = 0;
+		hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); stats->ms_copy = ms;
+		hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); stats->ms_scan = ms;
+		hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); stats->ms_parse = ms;
+		hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); stats->ms_code = ms;
+		hipEventElapsedTime(&ms, c->ev[0], c->ev[5]); stats->ms_total = ms;
+	}
+	return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------------------ */
+extern "C" int x3h_compress(x3h_ctx *ctx, const x3h_params *prm, const uint8_t *in, size_t n,
+                            uint8_t *out, size_t cap, size_t *out_len, x3h_stats *stats)
+{
+	if (!ctx || !out || !out_len || (!in && n) || cap < 4) return X3H_E_ARG;
+	uint64_t off[2] = { 0, n }, len = 0;
+	RunIO io = { in, false, off, 1, out, false, cap, &len, false };
+	int rc = run(ctx, prm, io, STAGE_CODE, stats);
+	*out_len = (size_t)len;
+	return rc;
+}
+
+extern "C" int x3h_compress_chunks(x3h_ctx *ctx, const x3h_params *prm, const uint8_t *in, const uint64_t *offsets,
+                                   int nchunks, uint8_t *out, uint64_t out_stride, uint64_t *out_lens, x3h_stats *stats)
+{
+	if (!ctx || !out || !out_lens || out_stride < 4) return X3H_E_ARG;
+	RunIO io = { in, false, offsets, nchunks, out, false, out_stride, out_lens, false };
+	return run(ctx, prm, io, STAGE_CODE, stats);
+}
+
+extern "C" int x3h_compress_chunks_dev(x3h_ctx *ctx, const x3h_params *prm, const void *d_in, const uint64_t *offsets,
+                                       int nchunks, void *d_out, uint64_t out_stride, uint64_t *out_lens, x3h_stats *stats)
+{
+	if (!ctx || !d_out || !out_lens || out_stride < 4 || (out_stride & 3)) return X3H_E_ARG;
+	RunIO io = { (const uint8_t *)d_in, true, offsets, nchunks, (uint8_t *)d_out, true, out_stride, out_lens, false };
+	return run(ctx, prm, io, STAGE_CODE, stats);
+}
+
+extern "C" int x3h_scan_m(x3h_ctx *ctx, const x3h_params *prm, const uint8_t *in, size_t n, uint8_t *m_out)
+{
+	if (!ctx || (!in && n) || (!m_out && n)) return X3H_E_ARG;
+	uint64_t off[2] = { 0, n };
+	RunIO io = { in, false, off, 1, nullptr, false, 0, nullptr, false };
+	CHK(run(ctx, prm, io, STAGE_SCAN, nullptr));
+	if (n) {
+		HIPCHK(hipMemcpy(m_out, ctx->m.as<uint8_t>() + ctx->hchunks[0].byte_off, n, hipMemcpyDeviceToHost));
+	}
+	return X3H_OK;
+}
+
+extern "C" int x3h_scan_counts(x3h_ctx *ctx, const x3h_params *prm, const uint8_t *in, size_t n, uint32_t *counts_out)
+{
+	if (!ctx || (!in && n) || (!counts_out && n)) return X3H_E_ARG;
+	uint64_t off[2] = { 0, n };
+	RunIO io = { in, false, off, 1, nullptr, false, 0, nullptr, true };
+	CHK(run(ctx, prm, io, STAGE_SCAN, nullptr));
+	if (n) {
+		HIPCHK(hipMemcpy(counts_out, ctx->counts.p, n * 32 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	}
+	return X3H_OK;
+}
+
+extern "C" int x3h_parse(x3h_ctx *ctx, const x3h_params *prm, const uint8_t *in, size_t n,
+                         uint32_t *tok_pos, uint32_t *tok_info, size_t tok_cap, size_t *ntok, uint64_t *dict_elems)
+{
+	if (!ctx || (!in && n) || !ntok) return X3H_E_ARG;
+	uint64_t off[2] = { 0, n };
+	RunIO io = { in, false, off, 1, nullptr, false, 0, nullptr, false };
+	CHK(run(ctx, prm, io, STAGE_PARSE, nullptr));
+	const X3ParseResult &r = ctx->hparse[0];
+	*ntok = r.ntok;
+	if (dict_elems) *dict_elems = r.dict_elems;
+	size_t k = r.ntok < tok_cap ? r.ntok : tok_cap;
+	if (k && tok_pos) HIPCHK(hipMemcpy(tok_pos, ctx->tok_pos.as<uint32_t>() + ctx->hchunks[0].elem_off, k * 4, hipMemcpyDeviceToHost));
+	if (k && tok_info) HIPCHK(hipMemcpy(tok_info, ctx->tok_info.as<uint32_t>() + ctx->hchunks[0].elem_off, k * 4, hipMemcpyDeviceToHost));
+	return X3H_OK;
+}

@@ -1,0 +1,235 @@
+/*
+ * parse.hip -- K2: the parse loop (reference: x3.c:372-429) with the dictionary search
+ * (dict.c:105-130,148-157) and the dictionary-aware half of find_best_match (backend.c:76-99).
+ *
+ * What the reference does per step at p: L0 = longest dictionary string that prefixes p; F = find_best_match(p);
+ * hit iff L0 exists, nl(L0) >= F and p+L0 <= end (x3.c:383), else a new fragment of min(F, end-p) bytes is coded
+ * and, unless already present (x3.c:412), appended to the dictionary (tag = insertion ordinal, dict.c:100).
+ * The parse never reads model / context / coder state, so it runs ahead of K3 and hands it a token list.
+ *
+ * MI355X mapping: one 256-thread workgroup per stream.
+ *   - dictionary = (pos,len) references into the input (an element IS input bytes) + an exact-match hash table
+ *     keyed by (len, bytes) in global memory (L2 resident);
+ *   - for a block of X3_PARSE_PB positions the workgroup caches in LDS the longest dictionary match L[q]/tag E[q] of
+ *     every position (all threads probe all lengths present in the dictionary), plus m[q] from K1;
+ *   - wave 0 then walks the parse serially out of LDS: lanes 0..31 evaluate the filters of backend.c:79-90 for the
+ *     32 candidate lengths at once, one ballot picks F (closed form, scan.hip header);
+ *   - a new element only changes L/E where its bytes occur: all threads patch the cached block (and the hash
+ *     table is doubled/rebuilt cooperatively when half full); then wave 0 continues.
+ */
+#include "x3_kernels.h"
+
+#define PB X3_PARSE_PB
+#define PBL (PB + 32)       /* positions with cached L/E: filters look 31 ahead              */
+#define PBB (PB + 32 + 32)  /* bytes staged: a 32-byte compare at the last cached position   */
+
+#define FNV_OFF 2166136261u
+#define FNV_MUL 16777619u
+
+__device__ static __forceinline__ uint32_t ht_slot(uint32_t h, uint32_t len, uint32_t hlog)
+{
+	uint32_t x = (h ^ (len * 0x9E3779B1u)) * 0x85EBCA6Bu;
+	x ^= x >> 15;
+	x *= 0xC2B2AE35u;
+	return x >> (32 - hlog);
+}
+
+/* state shared by the workgroup */
+struct ParseShared {
+	uint32_t p, blk, D, lenmask, hlog, flag, ntok, hits;
+	uint32_t new_pos, new_len, new_tag, rebuild;
+};
+enum { FLAG_REFILL = 1, FLAG_PATCH = 2, FLAG_DONE = 3 };
+
+__device__ static void x3_parse_body(const X3ParseArgs &a)
+{
+	X3_LDS uint8_t sb[PBB + 8];
+	X3_LDS uint8_t sL[PBL];
+	X3_LDS uint32_t sE[PBL];
+	X3_LDS uint8_t sM[PB];
+	X3_LDS ParseShared S;
+
+	const X3Chunk ck = a.chunks[blockIdx.x];
+	const uint32_t n = ck.len;
+	const uint8_t *b = a.bytes + ck.byte_off;
+	const uint8_t *mm = a.m + ck.byte_off;
+	uint32_t *dpos = a.dict_pos + ck.elem_off;
+	uint8_t *dlen = a.dict_len + ck.elem_off;
+	uint32_t *ht = a.ht + ck.ht_off;
+	uint32_t *tpos = a.tok_pos + ck.elem_off;
+	uint32_t *tinf = a.tok_info + ck.elem_off;
+	const uint32_t tid = threadIdx.x, lane = x3_lane(), wave = tid / X3_WAVE;
+	const uint32_t f1 = a.factor1, f2 = a.factor2;
+
+	if (tid == 0) {
+		S.p = 0; S.blk = 0; S.D = 0; S.lenmask = 0; S.hlog = X3_HT_LOG2_MIN < ck.ht_log2_max ? X3_HT_LOG2_MIN : ck.ht_log2_max;
+		S.flag = n ? FLAG_REFILL : FLAG_DONE; S.ntok = 0; S.hits = 0; S.rebuild = 0;
+	}
+	for (uint32_t i = tid; i < (1u << (X3_HT_LOG2_MIN < ck.ht_log2_max ? X3_HT_LOG2_MIN : ck.ht_log2_max)); i += X3_PARSE_THREADS) ht[i] = 0;
+	__syncthreads();
+
+	while (S.flag != FLAG_DONE) { /* S.flag is only written between the two barriers below: uniform */
+		const uint32_t flag = S.flag;
+		if (flag == FLAG_REFILL) {
+			/* ---- stage bytes, m, and the longest dictionary match of every position of the block ---- */
+			const uint32_t blk = S.p;
+			const uint32_t lenmask = S.lenmask, hlog = S.hlog, hmask = (1u << hlog) - 1;
+			for (uint32_t i = tid; i < PBB; i += X3_PARSE_THREADS) sb[i] = b[(uint64_t)blk + i];
+			for (uint32_t i = tid; i < PB; i += X3_PARSE_THREADS) sM[i] = mm[(uint64_t)blk + i];
+			__syncthreads();
+			const uint32_t maxlen = lenmask ? 32 - (uint32_t)x3_clz32(lenmask) : 0;
+			for (uint32_t i = tid; i < PBL; i += X3_PARSE_THREADS) {
+				uint32_t h = FNV_OFF, best = 0, btag = 0;
+				for (uint32_t l = 1; l <= maxlen; l++) {
+					h = (h ^ sb[i + l - 1]) * FNV_MUL;
+					if (!((lenmask >> (l - 1)) & 1)) continue;
+					uint32_t slot = ht_slot(h, l, hlog);
+					for (uint32_t e = ht[slot]; e != 0; slot = (slot + 1) & hmask, e = ht[slot]) {
+						const uint32_t tag = e - 1;
+						if (dlen[tag] != l) continue;
+						const uint8_t *ds = b + dpos[tag];
+						uint32_t k = 0;
+						while (k < l && ds[k] == sb[i + k]) k++;
+						if (k == l) { best = l; btag = tag; break; }
+					}
+				}
+				sL[i] = (uint8_t)best;
+				sE[i] = btag;
+			}
+			if (tid == 0) S.blk = blk;
+		} else if (flag == FLAG_PATCH) {
+			/* ---- a new element: grow the table if half full, then patch the cached block ---- */
+			const uint32_t blk = S.blk, np = S.new_pos, nl = S.new_len, nt = S.new_tag;
+			if (S.rebuild) {
+				const uint32_t hlog = S.hlog, hmask = (1u << hlog) - 1, D = S.D;
+				for (uint32_t i = tid; i <= hmask; i += X3_PARSE_THREADS) ht[i] = 0;
+				__syncthreads();
+				for (uint32_t t = tid; t < D; t += X3_PARSE_THREADS) {
+					const uint8_t *ds = b + dpos[t];
+					const uint32_t l = dlen[t];
+					uint32_t h = FNV_OFF;
+					for (uint32_t k = 0; k < l; k++) h = (h ^ ds[k]) * FNV_MUL;
+					uint32_t slot = ht_slot(h, l, hlog);
+					while (atomicCAS(&ht[slot], 0u, t + 1) != 0u) slot = (slot + 1) & hmask;
+				}
+			}
+			const uint32_t first = S.p - blk; /* positions before the parse pointer are never read again */
+			const uint32_t src = np - blk;    /* the element's bytes are inside the staged block */
+			for (uint32_t i = first + tid; i < PBL; i += X3_PARSE_THREADS) {
+				if (sL[i] >= nl) continue;
+				uint32_t k = 0;
+				while (k < nl && sb[i + k] == sb[src + k]) k++;
+				if (k == nl) { sL[i] = (uint8_t)nl; sE[i] = nt; }
+			}
+		}
+		__syncthreads();
+
+		if (wave == 0) {
+			/* ---- serial parse out of LDS ---- */
+			uint32_t p = S.p, ntok = S.ntok, hits = S.hits, D = S.D, lenmask = S.lenmask, hlog = S.hlog;
+			const uint32_t blk = S.blk;
+			uint32_t out_flag = 0;
+			for (;;) {
+				if (p >= n) { out_flag = FLAG_DONE; break; }
+				const uint32_t idx = p - blk;
+				if (idx >= PB) { out_flag = FLAG_REFILL; break; }
+				const uint32_t Li = lane < 32 ? sL[idx + (lane & 31)] : 0;
+				const uint32_t mp = sM[idx];
+				/* backend.c:79-83 : reject length i+1 when a dictionary string at p+i is "long enough" */
+				int ok = 1;
+				if (lane >= 2 && f1 > 0 && Li != 0 && (uint64_t)Li * f1 > (uint64_t)(lane + 1)) ok = 0;
+				if (f2 > 0) { /* backend.c:84-90 : max over o in [1,i] of (L(p+o)-o)*factor2 > i+1 */
+					int v = (lane >= 1 && lane < 32 && Li != 0) ? (int)Li - (int)lane : -(1 << 20);
+					for (unsigned d = 1; d < 32; d <<= 1) {
+						int u = (int)x3_shfl_up_u32((uint32_t)v, d);
+						if (lane >= d && u > v) v = u;
+					}
+					if (lane >= 1 && (int64_t)v * (int64_t)(int)f2 > (int64_t)(lane + 1)) ok = 0;
+				}
+				uint64_t okm = x3_ballot(ok && lane <= mp && lane < 32);
+				const uint32_t F = 1 + (63 - (uint32_t)x3_clz64(okm | 1)); /* lane 0 always passes */
+				const uint32_t L0 = x3_bcast_u32(Li, 0);
+				uint32_t nlL0 = L0;
+				if (a.nl_mode) nlL0 = L0 == 1 ? 1 : L0 == 2 ? 4 : L0 == 3 ? 6 : L0 == 4 ? 8 : 9999; /* x3.c:357-370 */
+				if (L0 != 0 && nlL0 >= F && p + L0 <= n) {
+					if (lane == 0) { tpos[ntok] = p; tinf[ntok] = sE[idx]; }
+					ntok++; hits++;
+					p += L0;
+					continue;
+				}
+				uint32_t len = F;
+				if (p + len > n) len = n - p; /* x3.c:402-404 */
+				/* x3.c:412 : is this exact fragment already an element? */
+				int dup = 0;
+				if (L0 == len) dup = 1;
+				else if (L0 > len && ((lenmask >> (len - 1)) & 1)) {
+					uint32_t h = FNV_OFF;
+					for (uint32_t k = 0; k < len; k++) h = (h ^ sb[idx + k]) * FNV_MUL;
+					const uint32_t hmask = (1u << hlog) - 1;
+					uint32_t slot = ht_slot(h, len, hlog);
+					for (uint32_t e = ht[slot]; e != 0; slot = (slot + 1) & hmask, e = ht[slot]) {
+						const uint32_t tag = e - 1;
+						if (dlen[tag] != len) continue;
+						const uint8_t *ds = b + dpos[tag];
+						uint32_t k = 0;
+						while (k < len && ds[k] == sb[idx + k]) k++;
+						if (k == len) { dup = 1; break; }
+					}
+				}
+				if (lane == 0) { tpos[ntok] = p; tinf[ntok] = X3_TOK_MISS | (dup ? X3_TOK_DUP : 0u) | len; }
+				ntok++;
+				x3_wave_sync(); /* every lane has finished probing before lane 0 inserts */
+				if (!dup) {
+					const uint32_t tag = D;
+					uint32_t rebuild = 0;
+					if (2 * (D + 1) > (1u << hlog) && hlog < ck.ht_log2_max) { hlog++; rebuild = 1; }
+					if (lane == 0) {
+						dpos[tag] = p;
+						dlen[tag] = (uint8_t)len;
+						if (!rebuild) {
+							uint32_t h = FNV_OFF;
+							for (uint32_t k = 0; k < len; k++) h = (h ^ sb[idx + k]) * FNV_MUL;
+							const uint32_t hmask = (1u << hlog) - 1;
+							uint32_t slot = ht_slot(h, len, hlog);
+							while (ht[slot] != 0) slot = (slot + 1) & hmask;
+							ht[slot] = tag + 1;
+						}
+						S.new_pos = p; S.new_len = len; S.new_tag = tag; S.rebuild = rebuild;
+					}
+					D++;
+					lenmask |= 1u << (len - 1);
+					p += len;
+					out_flag = p >= n ? FLAG_DONE : FLAG_PATCH;
+					break;
+				}
+				p += len;
+			}
+			if (lane == 0) {
+				S.p = p; S.ntok = ntok; S.hits = hits; S.D = D; S.lenmask = lenmask; S.hlog = hlog;
+				S.flag = out_flag;
+			}
+		}
+		__syncthreads();
+	}
+
+	if (tid == 0) {
+		X3ParseResult r;
+		r.ntok = S.ntok; r.dict_elems = S.D; r.hits = S.hits; r.status = X3_ST_OK;
+		a.result[blockIdx.x] = r;
+	}
+}
+
+#ifndef X3_EMU
+__global__ void __launch_bounds__(X3_PARSE_THREADS) x3_parse_kernel(X3ParseArgs a) { x3_parse_body(a); }
+
+extern "C" void x3k_launch_parse(const X3ParseArgs *a, uint32_t nchunks, hipStream_t st)
+{
+	hipLaunchKernelGGL(x3_parse_kernel, dim3(nchunks), dim3(X3_PARSE_THREADS), 0, st, *a);
+}
+#else
+static void parse_tramp(void *p) { x3_parse_body(*(const X3ParseArgs *)p); }
+extern "C" void x3k_launch_parse(const X3ParseArgs *a, uint32_t nchunks, void *)
+{
+	x3emu_launch(parse_tramp, (void *)a, dim3(nchunks), dim3(X3_PARSE_THREADS));
+}
+#endif

@@ -1,0 +1,89 @@
+/*
+ * simt.h -- the one include of every kernel source.
+ *
+ * Product build (hipcc --offload-arch=gfx950): this is <hip/hip_runtime.h> plus a few helpers.
+ *
+ * X3_EMU build (plain g++, TESTS ONLY, tests/emu/): a small functional SIMT emulator so that the very
+ * same kernel sources can be executed, single-stepped and sanitised on a machine without a GPU.
+ * One fiber (ucontext) per GPU thread, 64 consecutive fibers form a wave; __ballot/__shfl/__syncthreads
+ * are rendezvous points.  It models semantics only (no timing, no memory model): it exists to catch logic
+ * errors before a kernel is sent to a real MI355X.  Nothing in the shipped library is compiled with X3_EMU,
+ * and the emulator is never a fallback: libx3hip.so has no CPU path.
+ */
+#ifndef X3_SIMT_H
+#define X3_SIMT_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#define X3_WAVE 64
+
+#ifndef X3_EMU
+/* ------------------------------------------------------------------------------------------------ */
+#include <hip/hip_runtime.h>
+
+#define X3_LDS __shared__
+
+__device__ __forceinline__ unsigned x3_lane() { return threadIdx.x & (X3_WAVE - 1); }
+__device__ __forceinline__ uint64_t x3_ballot(int p) { return __ballot(p); }
+__device__ __forceinline__ uint32_t x3_bcast_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, X3_WAVE); }
+__device__ __forceinline__ uint32_t x3_shfl_up_u32(uint32_t v, unsigned d) { return (uint32_t)__shfl_up((int)v, d, X3_WAVE); }
+__device__ __forceinline__ uint32_t x3_shfl_xor_u32(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, X3_WAVE); }
+/* Orders this wave's earlier LDS/global accesses before its later ones when different lanes touch the same
+ * address (the compiler only tracks per-lane dependencies). */
+__device__ __forceinline__ void x3_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+__device__ __forceinline__ int x3_popc64(uint64_t v) { return __popcll(v); }
+__device__ __forceinline__ int x3_ctz64(uint64_t v) { return __ffsll((long long)v) - 1; }           /* v != 0 */
+__device__ __forceinline__ int x3_ctz32(uint32_t v) { return __ffs((int)v) - 1; }                   /* v != 0 */
+__device__ __forceinline__ int x3_clz64(uint64_t v) { return __clzll((long long)v); }               /* v != 0 */
+__device__ __forceinline__ int x3_clz32(uint32_t v) { return __clz((int)v); }                       /* v != 0 */
+
+#else
+/* ------------------------------------------------------------------------------------------------ */
+#include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __restrict__
+#define __launch_bounds__(...)
+#define X3_LDS static
+
+struct x3emu_dim3 { unsigned x, y, z; x3emu_dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+typedef x3emu_dim3 dim3;
+
+extern x3emu_dim3 threadIdx, blockIdx, blockDim, gridDim; /* switched per fiber by the scheduler */
+
+void     x3emu_syncthreads();
+uint64_t x3emu_ballot(int p);
+uint32_t x3emu_shfl(uint32_t v, int src_lane);
+
+#define __syncthreads() x3emu_syncthreads()
+
+static inline unsigned x3_lane() { return threadIdx.x & (X3_WAVE - 1); }
+static inline uint64_t x3_ballot(int p) { return x3emu_ballot(p); }
+static inline uint32_t x3_bcast_u32(uint32_t v, int src) { return x3emu_shfl(v, src); }
+static inline uint32_t x3_shfl_up_u32(uint32_t v, unsigned d) { int l = (int)x3_lane(); return x3emu_shfl(v, l >= (int)d ? l - (int)d : l); }
+static inline uint32_t x3_shfl_xor_u32(uint32_t v, int m) { return x3emu_shfl(v, (int)x3_lane() ^ m); }
+static inline void x3_wave_sync() { (void)x3emu_ballot(0); }
+static inline int x3_popc64(uint64_t v) { return __builtin_popcountll(v); }
+static inline int x3_ctz64(uint64_t v) { return __builtin_ctzll(v); }
+static inline int x3_ctz32(uint32_t v) { return __builtin_ctz(v); }
+static inline int x3_clz64(uint64_t v) { return __builtin_clzll(v); }
+static inline int x3_clz32(uint32_t v) { return __builtin_clz(v); }
+
+template <typename T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
+template <typename T> static inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <typename T> static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
+template <typename T> static inline T atomicCAS(T *p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
+static inline void __threadfence() {}
+static inline void __threadfence_block() {}
+
+/* run `fn(arg)` as a kernel: grid x block fibers, blocks one after another */
+void x3emu_launch(void (*fn)(void *), void *arg, dim3 grid, dim3 block);
+
+#endif /* X3_EMU */
+#endif /* X3_SIMT_H */

@@ -1,0 +1,160 @@
+/*
+ * x3_cli.c -- the x3 command line, host side in C, on top of the C ABI of include/x3hip.h.
+ *
+ * Same letters, defaults and file-name rules as the reference's main() (x3.c:479-548): -z -d -f -k -h -t N -w N(KiB)
+ * -m N -n N -x, 0/1/2 positional arguments, "<in>.x3" default output, no clobber without -f.  Compressed output
+ * is the raw x3 code stream (no header), bit-identical to the reference for the same input and parameters.
+ * The statistics block on stderr follows x3.c:662-693 for the integer fields (the float size estimates are not
+ * reproduced).  Errors print a message and exit(1) instead of abort().
+ *
+ * Additive option:  -g N   use GPU N (default 0).
+ */
+#define _POSIX_C_SOURCE 200809L
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include "../../include/x3hip.h"
+
+static void die(const char *msg) { fprintf(stderr, "%s\n", msg); exit(1); }
+
+static void print_help(const char *path) /* x3.c:465-477 */
+{
+	fprintf(stderr, "Usage :\n\t%s [arguments] [input-file] [output-file]\n\n", path);
+	fprintf(stderr, "Arguments :\n");
+	fprintf(stderr, " -d     : force decompression\n");
+	fprintf(stderr, " -z     : force compression\n");
+	fprintf(stderr, " -f     : overwrite existing output file\n");
+	fprintf(stderr, " -k     : keep (don't delete) input file (default)\n");
+	fprintf(stderr, " -h     : print this message\n");
+	fprintf(stderr, " -t NUM : maximum number of matches (affects compression ratio and speed)\n");
+	fprintf(stderr, " -w NUM : window size (in kilobytes, affects compression ratio and speed)\n");
+	fprintf(stderr, " -m NUM : magic factor (affects compression ratio and speed)\n");
+	fprintf(stderr, " -g NUM : GPU to use (default 0)\n");
+}
+
+static FILE *open_output(const char *path, int force) /* force_fopen, file.c:47-55 */
+{
+	if (!force && access(path, F_OK) != -1) die("File already exists");
+	return fopen(path, "w");
+}
+
+static unsigned char *read_all(FILE *f, size_t *n) /* fsize + fload, file.c:7-45 */
+{
+	long begin = ftell(f);
+	if (begin == -1L) die("Stream is not seekable");
+	if (fseek(f, 0, SEEK_END)) die("seek failed");
+	long end = ftell(f);
+	if (end == -1L || fseek(f, begin, SEEK_SET)) die("seek failed");
+	*n = (size_t)(end - begin);
+	unsigned char *p = malloc(*n ? *n : 1);
+	if (!p) die("out of memory");
+	if (fread(p, 1, *n, f) < *n) die("short read");
+	return p;
+}
+
+int main(int argc, char *argv[])
+{
+	int decompress = 0, force = 0, gpu = 0, o;
+	x3h_params prm;
+	x3h_default_params(&prm);
+
+	while ((o = getopt(argc, argv, "zdfkht:w:m:n:xg:")) != -1) { /* x3.c:484 */
+		switch (o) {
+			case 'z': decompress = 0; break;
+			case 'd': decompress = 1; break;
+			case 'f': force = 1; break;
+			case 'k': break;
+			case 'h': print_help(argv[0]); return 0;
+			case 't': prm.max_match_count = atoi(optarg); break;
+			case 'w': prm.window_bytes = (uint32_t)atoi(optarg) * 1024u; break;
+			case 'm': prm.factor1 = (uint32_t)atoi(optarg); break;
+			case 'n': prm.factor2 = (uint32_t)atoi(optarg); break;
+			case 'x': prm.nl_mode = 1; break;
+			case 'g': gpu = atoi(optarg); break;
+			default: die("Unexpected argument");
+		}
+	}
+
+	FILE *istream = NULL, *ostream = NULL;
+	switch (argc - optind) { /* x3.c:522-548 */
+		case 0: istream = stdin; ostream = stdout; break;
+		case 1: {
+			istream = fopen(argv[optind], "r");
+			if (!decompress) {
+				char path[4096 + 8];
+				snprintf(path, sizeof path, "%s.x3", argv[optind]);
+				ostream = open_output(path, force);
+			} else {
+				char *dot = strrchr(argv[optind], '.');
+				if (dot) *dot = 0;
+				ostream = open_output(argv[optind], force);
+			}
+			break;
+		}
+		case 2:
+			istream = fopen(argv[optind], "r");
+			ostream = open_output(argv[optind + 1], force);
+			break;
+		default: die("Unexpected argument");
+	}
+	fprintf(stderr, "%s\n", decompress ? "Decompressing..." : "Compressing...");
+	if (!istream) die("Cannot open input file");
+	if (!ostream) die("Cannot open output file");
+
+	x3h_ctx *ctx = NULL;
+	int rc = x3h_ctx_create(&ctx, gpu);
+	if (rc != X3H_OK) { fprintf(stderr, "x3: %s (the hot path only exists as gfx950 HIP kernels; no CPU fallback)\n", x3h_strerror(rc)); return 1; }
+
+	size_t isize = 0, osize = 0;
+	unsigned char *iptr = read_all(istream, &isize), *optr = NULL;
+	x3h_stats st;
+	memset(&st, 0, sizeof st);
+
+	if (!decompress) {
+		fprintf(stderr, "max match count: %i\n", prm.max_match_count);
+		fprintf(stderr, "forward window: %zu\n", (size_t)prm.window_bytes);
+		fprintf(stderr, "magic factor 1: %zu\n", (size_t)prm.factor1);
+		fprintf(stderr, "magic factor 2: %zu\n", (size_t)prm.factor2);
+		size_t cap = x3h_compress_bound(isize);
+		optr = malloc(cap);
+		if (!optr) die("out of memory");
+		rc = x3h_compress(ctx, &prm, iptr, isize, optr, cap, &osize, &st);
+		if (rc != X3H_OK) { fprintf(stderr, "x3: compress failed: %s\n", x3h_strerror(rc)); return 1; }
+		fprintf(stderr, "elapsed time: %f\n", st.ms_total / 1000.0);
+		fprintf(stderr, "  device ms: scan %.3f parse %.3f code %.3f copy %.3f\n", st.ms_scan, st.ms_parse, st.ms_code, st.ms_copy);
+	} else {
+#ifdef X3H_HAVE_DECOMPRESS
+		size_t cap = isize * 64 + 65536; /* the reference assumes <= 64:1 (x3.c:621); grow until it fits */
+		for (;;) {
+			optr = malloc(cap);
+			if (!optr) die("out of memory");
+			rc = x3h_decompress(ctx, iptr, isize, optr, cap, &osize, &st);
+			if (rc != X3H_E_OUTPUT_FULL) break;
+			free(optr);
+			cap *= 4;
+		}
+		if (rc != X3H_OK) { fprintf(stderr, "x3: decompress failed: %s\n", x3h_strerror(rc)); return 1; }
+		fprintf(stderr, "elapsed time: %f\n", st.ms_total / 1000.0);
+#else
+		die("decompression is not built into this version");
+#endif
+	}
+	if (fwrite(optr, 1, osize, ostream) < osize) die("short write");
+
+	size_t size = decompress ? osize : isize, asize = decompress ? isize : osize;
+	fprintf(stderr, "input stream size: %zu\n", size);
+	fprintf(stderr, "dictionary: hit %llu, miss %llu\n", (unsigned long long)(st.events[0] + st.events[1] + st.events[2]),
+	        (unsigned long long)st.events[3]);
+	fprintf(stderr, "real compression ratio: %f\n", asize ? size / (float)asize : 0.f);
+	fprintf(stderr, "number of events: ctx0 %llu, ctx1 %llu, miss1 %llu, new %llu\n", (unsigned long long)st.events[0],
+	        (unsigned long long)st.events[1], (unsigned long long)st.events[2], (unsigned long long)st.events[3]);
+	fprintf(stderr, "context entries: ctx0 %llu, ctx1 %llu\n", (unsigned long long)st.ctx0_entries, (unsigned long long)st.dict_elems);
+
+	x3h_ctx_destroy(ctx);
+	free(iptr);
+	free(optr);
+	fclose(istream);
+	fclose(ostream);
+	return 0;
+}

@@ -1,0 +1,109 @@
+/*
+ * x3_kernels.h -- argument blocks and constants shared by the HIP kernels and their host launcher.
+ *
+ * Pipeline per stream (chunk), all stages on the GPU:
+ *   K1 x3_scan   : forward-window prefix histogram -> one byte m[p] per position     (backend.c:56-74, 76-78)
+ *   K2 x3_parse  : dictionary longest-match + best-match selection + parse loop      (dict.c:105-157, backend.c:76-99, x3.c:372-429)
+ *   K3 x3_code   : move-to-front rank, context models, mode choice, arithmetic coder, bit output
+ *                                                                                    (dict.c:132-146, context.c, tag_pair.c, x3.c:132-270, ac.c:46-126, bio.c:49-112)
+ */
+#ifndef X3_KERNELS_H
+#define X3_KERNELS_H
+
+#include "simt.h"
+
+#define X3_MAXLEN        32u     /* MAX_MATCH_LEN, backend.h:7-10 */
+#define X3_PAD_EXTRA     4096u   /* readable zero bytes after n + window: scan over-reads and the parse block stage stay in bounds */
+
+/* event alphabet, x3.c:33-40 */
+#define X3_E_CTX0 0
+#define X3_E_CTX1 1
+#define X3_E_IDX1 2
+#define X3_E_NEW  3
+#define X3_E_EOF  4
+
+/* token trace produced by K2, consumed by K3 */
+#define X3_TOK_MISS 0x80000000u
+#define X3_TOK_DUP  0x40000000u
+
+/* device status words */
+#define X3_ST_OK        0u
+#define X3_ST_OUT_FULL  1u   /* output buffer too small                                  */
+#define X3_ST_POOL_FULL 2u   /* a workspace bound was violated (would be a sizing bug)    */
+
+struct X3Chunk {           /* one independent x3 stream */
+	uint64_t byte_off;     /* offset of the chunk in the padded byte buffer (and in m[])                 */
+	uint32_t len;          /* n: input bytes                                                             */
+	uint32_t ht_log2_max;  /* K2: log2 of the hash-table slots reserved for this chunk                   */
+	uint64_t elem_off;     /* K2: offset (elements) into dict_pos/dict_len/tok_pos/tok_info              */
+	uint64_t ht_off;       /* K2: offset (slots) into ht                                                 */
+	/* K3 workspace, filled by the host after K2 reported D and hits */
+	uint64_t tag_off;      /* offset (elements) into mtf / idxfreq / ctx1                                */
+	uint64_t ctx0_off;     /* offset (headers) into ctx0                                                 */
+	uint64_t item_off;     /* offset (items) into the context item pool                                  */
+	uint64_t item_cap;     /* items reserved                                                             */
+	uint64_t pair_off;     /* offset (slots) into pair_key/pair_val                                      */
+	uint32_t pair_log2;    /* log2 slots of the pair map                                                 */
+	uint32_t _pad;
+	uint64_t out_off;      /* byte offset of the chunk's stream in the output buffer                     */
+	uint64_t out_cap;      /* bytes reserved (multiple of 4)                                             */
+};
+
+struct X3ParseResult { uint32_t ntok, dict_elems, hits, status; };
+struct X3CodeResult  { uint32_t out_len, status, pairs, _r; uint32_t events[8]; };
+
+struct X3CtxHdr { uint32_t off, items, cap, total; };   /* one context: items live in the pool at [off, off+items) */
+
+/* ---- K1 ------------------------------------------------------------------------------------------- */
+#define X3_SCAN_TP      32     /* positions per workgroup tile                                    */
+#define X3_SCAN_THREADS 256
+
+struct X3ScanArgs {
+	const uint8_t *bytes;       /* padded chunks                                                  */
+	const X3Chunk *chunks;
+	uint8_t *m;                 /* out, same layout as bytes                                      */
+	uint32_t *counts;           /* optional (tests): [chunk 0 only][position][32] full histogram  */
+	uint32_t window;            /* W bytes (x3.c:503)                                             */
+	int32_t  max_match_count;   /* T                                                              */
+};
+
+/* ---- K2 ------------------------------------------------------------------------------------------- */
+#define X3_PARSE_THREADS 256
+#define X3_PARSE_PB      2048  /* positions whose dictionary matches are cached in LDS            */
+#define X3_HT_LOG2_MIN   10
+
+struct X3ParseArgs {
+	const uint8_t *bytes;
+	const X3Chunk *chunks;
+	const uint8_t *m;
+	uint32_t *dict_pos;         /* element e of a chunk is bytes[dict_pos[e] .. +dict_len[e]) ; tag == e */
+	uint8_t  *dict_len;
+	uint32_t *ht;               /* open addressing, slot = tag+1, 0 = empty                       */
+	uint32_t *tok_pos;
+	uint32_t *tok_info;
+	X3ParseResult *result;
+	uint32_t factor1, factor2;
+	int32_t  nl_mode;
+};
+
+/* ---- K3 ------------------------------------------------------------------------------------------- */
+#define X3_CODE_THREADS 64
+
+struct X3CodeArgs {
+	const uint8_t *bytes;
+	const X3Chunk *chunks;
+	const uint32_t *tok_pos;
+	const uint32_t *tok_info;
+	const X3ParseResult *parsed;
+	uint32_t *mtf;              /* tags in recency order (dict.c:132-146 == move-to-front)         */
+	uint32_t *idxfreq;          /* model_index1 frequencies by rank (x3.c:50,187-188,419)          */
+	X3CtxHdr *ctx1;             /* by tag (x3.c:148)                                               */
+	X3CtxHdr *ctx0;             /* by pair ordinal (x3.c:147)                                      */
+	uint64_t *items;            /* (tag << 32) | freq, first-seen order (context.c:42-56)          */
+	uint64_t *pair_key;         /* ((tag0 << 32) | tag1) + 1 ; 0 = empty   (tag_pair.c)            */
+	uint32_t *pair_val;
+	uint8_t  *out;
+	X3CodeResult *result;
+};
+
+#endif /* X3_KERNELS_H */
