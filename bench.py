@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 from x3_compressor_amd import _lib, synth
+from x3_compressor_amd import dist as xdist
 
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 
@@ -83,6 +84,8 @@ def main():
 
     def step():
         lens, st = ctx.compress_chunks_dev(d_in.data_ptr(), offsets, prm, d_out.data_ptr(), stride)
+        if world > 1:  # the one exchange step of the path: finished streams -> rank 0 over RCCL/xGMI
+            xdist.gather_device_streams(d_out, stride, lens)
         return int(lens[0]), st
 
     def barrier():
