@@ -11,12 +11,7 @@
  *            elements D and hits H of each chunk: pool 8H+64 items (doubling arrays waste < 4x of <= 2H items),
  *            pair map 2^ceil(log2(2(H+2))) slots -- provable bounds, no device-side allocation failure path.
  */
-#include "x3_kernels.h"
-#include "../../include/x3hip.h"
-
-#ifdef X3_EMU
-#include "hip_shim.h"
-#endif
+#include "x3_host.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -27,37 +22,16 @@ extern "C" void x3k_launch_scan(const X3ScanArgs *a, uint32_t max_len, uint32_t 
 extern "C" void x3k_launch_parse(const X3ParseArgs *a, uint32_t nchunks, hipStream_t st);
 extern "C" void x3k_launch_code(const X3CodeArgs *a, uint32_t nchunks, hipStream_t st);
 
-static thread_local int g_last_hip = 0;
-
-#define HIPCHK(expr)                                                   \
-	do {                                                               \
-		hipError_t e__ = (expr);                                       \
-		if (e__ != hipSuccess) { g_last_hip = (int)e__; return e__ == hipErrorOutOfMemory ? X3H_E_NOMEM : X3H_E_HIP; } \
-	} while (0)
-#define CHK(expr) do { int r__ = (expr); if (r__ != X3H_OK) return r__; } while (0)
-
-struct DevBuf {
-	void *p = nullptr;
-	size_t cap = 0;
-	int reserve(size_t bytes)
-	{
-		if (bytes <= cap) return X3H_OK;
-		if (p) { hipFree(p); p = nullptr; cap = 0; }
-		size_t want = bytes + bytes / 8 + 4096;
-		hipError_t e = hipMalloc(&p, want);
-		if (e != hipSuccess) { p = nullptr; g_last_hip = (int)e; return X3H_E_NOMEM; }
-		cap = want;
-		return X3H_OK;
-	}
-	void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
-	template <typename T> T *as() const { return (T *)p; }
-};
+thread_local int x3_last_hip = 0;
+#define g_last_hip x3_last_hip
 
 struct x3h_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-	DevBuf pad, m, dict_pos, dict_len, ht, tok_pos, tok_info, chunks, presult, cresult;
+	DevBuf pad, m, dict_pos, dict_len, ht, tok_pos, tok_info, tok_hb, tok_nb, chunks, presult, cresult;
+	X3Code2Bufs c2;
+	int code_v1 = 0;
 	DevBuf mtf, idxfreq, ctx1, ctx0, items, pkey, pval, out, counts;
 	std::vector<X3Chunk> hchunks;
 	std::vector<X3ParseResult> hparse;
@@ -118,6 +92,7 @@ extern "C" int x3h_ctx_create(x3h_ctx **out, int device)
 	x3h_ctx *c = new (std::nothrow) x3h_ctx();
 	if (!c) return X3H_E_NOMEM;
 	c->device = device;
+	{ const char *e = getenv("X3H_CODE_V1"); c->code_v1 = e && *e && *e != '0'; }
 	if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return X3H_E_HIP; }
 	for (int i = 0; i < 6; i++)
 		if (hipEventCreate(&c->ev[i]) != hipSuccess) { x3h_ctx_destroy(c); return X3H_E_HIP; }
@@ -130,9 +105,11 @@ extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 	if (!c) return;
 	hipSetDevice(c->device);
 	if (c->stream) hipStreamSynchronize(c->stream);
-	DevBuf *bufs[] = { &c->pad, &c->m, &c->dict_pos, &c->dict_len, &c->ht, &c->tok_pos, &c->tok_info, &c->chunks, &c->presult,
+	DevBuf *bufs[] = { &c->pad, &c->m, &c->dict_pos, &c->dict_len, &c->ht, &c->tok_pos, &c->tok_info, &c->tok_hb, &c->tok_nb, &c->chunks, &c->presult,
+		               &c->c2.tmp, &c->c2.offs, &c->c2.chunkmeta, &c->c2.idxfreq, &c->c2.hsym, &c->c2.maxred,
 		               &c->cresult, &c->mtf, &c->idxfreq, &c->ctx1, &c->ctx0, &c->items, &c->pkey, &c->pval, &c->out, &c->counts };
 	for (DevBuf *b : bufs) b->release();
+	for (DevBuf &b : c->c2.a) b.release();
 	for (int i = 0; i < 6; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
 	if (c->stream) hipStreamDestroy(c->stream);
 	delete c;
@@ -176,6 +153,8 @@ static int stage_inputs(x3h_ctx *c, const x3h_params *prm, const RunIO &io, uint
 	CHK(c->dict_len.reserve(eoff));
 	CHK(c->tok_pos.reserve(eoff * 4));
 	CHK(c->tok_info.reserve(eoff * 4));
+	CHK(c->tok_hb.reserve(eoff * 4));
+	CHK(c->tok_nb.reserve(eoff * 4));
 	CHK(c->ht.reserve(hoff * 4));
 	CHK(c->chunks.reserve((size_t)nc * sizeof(X3Chunk)));
 	CHK(c->presult.reserve((size_t)nc * sizeof(X3ParseResult)));
@@ -230,6 +209,7 @@ static int run(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage upto
 	pa.dict_pos = c->dict_pos.as<uint32_t>(); pa.dict_len = c->dict_len.as<uint8_t>();
 	pa.ht = c->ht.as<uint32_t>();
 	pa.tok_pos = c->tok_pos.as<uint32_t>(); pa.tok_info = c->tok_info.as<uint32_t>();
+	pa.tok_hb = c->tok_hb.as<uint32_t>(); pa.tok_nb = c->tok_nb.as<uint32_t>();
 	pa.result = c->presult.as<X3ParseResult>();
 	pa.factor1 = prm.factor1; pa.factor2 = prm.factor2; pa.nl_mode = prm.nl_mode;
 	x3k_launch_parse(&pa, (uint32_t)nc, c->stream);
@@ -266,31 +246,38 @@ static int run(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage upto
 			ooff += align_up(cap, 256);
 		}
 	}
-	CHK(c->mtf.reserve(toff * 4));
-	CHK(c->idxfreq.reserve(toff * 4));
-	CHK(c->ctx1.reserve(toff * sizeof(X3CtxHdr)));
-	CHK(c->ctx0.reserve(c0off * sizeof(X3CtxHdr)));
-	CHK(c->items.reserve(ioff * 8));
-	CHK(c->pkey.reserve(poff * 8));
-	CHK(c->pval.reserve(poff * 4));
 	if (!io.dst_dev) CHK(c->out.reserve(ooff + 256));
-	HIPCHK(hipMemsetAsync(c->ctx1.p, 0, toff * sizeof(X3CtxHdr), c->stream));
-	HIPCHK(hipMemsetAsync(c->ctx0.p, 0, c0off * sizeof(X3CtxHdr), c->stream));
-	HIPCHK(hipMemsetAsync(c->pkey.p, 0, poff * 8, c->stream));
+	uint8_t *d_out = io.dst_dev ? io.dst : c->out.as<uint8_t>();
 	HIPCHK(hipMemcpyAsync(c->chunks.p, c->hchunks.data(), (size_t)nc * sizeof(X3Chunk), hipMemcpyHostToDevice, c->stream));
-
-	X3CodeArgs ca;
-	ca.bytes = sa.bytes; ca.chunks = sa.chunks;
-	ca.tok_pos = pa.tok_pos; ca.tok_info = pa.tok_info; ca.parsed = pa.result;
-	ca.mtf = c->mtf.as<uint32_t>(); ca.idxfreq = c->idxfreq.as<uint32_t>();
-	ca.ctx1 = c->ctx1.as<X3CtxHdr>(); ca.ctx0 = c->ctx0.as<X3CtxHdr>();
-	ca.items = c->items.as<uint64_t>();
-	ca.pair_key = c->pkey.as<uint64_t>(); ca.pair_val = c->pval.as<uint32_t>();
-	ca.out = io.dst_dev ? io.dst : c->out.as<uint8_t>();
-	ca.result = c->cresult.as<X3CodeResult>();
 	HIPCHK(hipEventRecord(c->ev[4], c->stream));
-	x3k_launch_code(&ca, (uint32_t)nc, c->stream);
-	HIPCHK(hipGetLastError());
+	if (!c->code_v1) {
+		/* v2: parallel feature extraction (sorts / scans / count-smaller-before) + two thin serial passes (code2.hip) */
+		CHK(x3_code_v2_run(c->c2, c->stream, nc, c->hchunks.data(), c->chunks.as<X3Chunk>(), c->hparse.data(), pa.result,
+		                   sa.bytes, pa.tok_pos, pa.tok_info, pa.tok_hb, pa.tok_nb, d_out, c->cresult.as<X3CodeResult>()));
+	} else {
+		/* v1 (kept for A/B runs, X3H_CODE_V1=1): one wavefront per stream walks the tokens over growable tables (code.hip) */
+		CHK(c->mtf.reserve(toff * 4));
+		CHK(c->idxfreq.reserve(toff * 4));
+		CHK(c->ctx1.reserve(toff * sizeof(X3CtxHdr)));
+		CHK(c->ctx0.reserve(c0off * sizeof(X3CtxHdr)));
+		CHK(c->items.reserve(ioff * 8));
+		CHK(c->pkey.reserve(poff * 8));
+		CHK(c->pval.reserve(poff * 4));
+		HIPCHK(hipMemsetAsync(c->ctx1.p, 0, toff * sizeof(X3CtxHdr), c->stream));
+		HIPCHK(hipMemsetAsync(c->ctx0.p, 0, c0off * sizeof(X3CtxHdr), c->stream));
+		HIPCHK(hipMemsetAsync(c->pkey.p, 0, poff * 8, c->stream));
+		X3CodeArgs ca;
+		ca.bytes = sa.bytes; ca.chunks = sa.chunks;
+		ca.tok_pos = pa.tok_pos; ca.tok_info = pa.tok_info; ca.parsed = pa.result;
+		ca.mtf = c->mtf.as<uint32_t>(); ca.idxfreq = c->idxfreq.as<uint32_t>();
+		ca.ctx1 = c->ctx1.as<X3CtxHdr>(); ca.ctx0 = c->ctx0.as<X3CtxHdr>();
+		ca.items = c->items.as<uint64_t>();
+		ca.pair_key = c->pkey.as<uint64_t>(); ca.pair_val = c->pval.as<uint32_t>();
+		ca.out = d_out;
+		ca.result = c->cresult.as<X3CodeResult>();
+		x3k_launch_code(&ca, (uint32_t)nc, c->stream);
+		HIPCHK(hipGetLastError());
+	}
 	HIPCHK(hipEventRecord(c->ev[5], c->stream));
 	c->hcode.resize((size_t)nc);
 	HIPCHK(hipMemcpyAsync(c->hcode.data(), c->cresult.p, (size_t)nc * sizeof(X3CodeResult), hipMemcpyDeviceToHost, c->stream));

@@ -58,6 +58,8 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 	uint32_t *ht = a.ht + ck.ht_off;
 	uint32_t *tpos = a.tok_pos + ck.elem_off;
 	uint32_t *tinf = a.tok_info + ck.elem_off;
+	uint32_t *thb = a.tok_hb + ck.elem_off; /* hits before this step   */
+	uint32_t *tnb = a.tok_nb + ck.elem_off; /* dictionary elements before this step */
 	const uint32_t tid = threadIdx.x, lane = x3_lane(), wave = tid / X3_WAVE;
 	const uint32_t f1 = a.factor1, f2 = a.factor2;
 
@@ -152,7 +154,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 				uint32_t nlL0 = L0;
 				if (a.nl_mode) nlL0 = L0 == 1 ? 1 : L0 == 2 ? 4 : L0 == 3 ? 6 : L0 == 4 ? 8 : 9999; /* x3.c:357-370 */
 				if (L0 != 0 && nlL0 >= F && p + L0 <= n) {
-					if (lane == 0) { tpos[ntok] = p; tinf[ntok] = sE[idx]; }
+					if (lane == 0) { tpos[ntok] = p; tinf[ntok] = sE[idx]; thb[ntok] = hits; tnb[ntok] = D; }
 					ntok++; hits++;
 					p += L0;
 					continue;
@@ -176,7 +178,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 						if (k == len) { dup = 1; break; }
 					}
 				}
-				if (lane == 0) { tpos[ntok] = p; tinf[ntok] = X3_TOK_MISS | (dup ? X3_TOK_DUP : 0u) | len; }
+				if (lane == 0) { tpos[ntok] = p; tinf[ntok] = X3_TOK_MISS | (dup ? X3_TOK_DUP : 0u) | len; thb[ntok] = hits; tnb[ntok] = D; }
 				ntok++;
 				x3_wave_sync(); /* every lane has finished probing before lane 0 inserts */
 				if (!dup) {

@@ -1,0 +1,85 @@
+/*
+ * x3_host.h -- host-side helpers shared by api.hip / code2.hip / prims.hip: growable device buffers, status macros,
+ * an element-wise launcher (x3_foreach) and the three library primitives of the v2 coding stage
+ * (stable radix sort of (key,value) pairs, exclusive sum scan, inclusive max scan -- rocPRIM on the GPU).
+ */
+#ifndef X3_HOST_H
+#define X3_HOST_H
+
+#include "x3_kernels.h"
+#include "../../include/x3hip.h"
+
+#ifdef X3_EMU
+#include "hip_shim.h"
+#endif
+
+#include <stddef.h>
+#include <stdint.h>
+
+extern thread_local int x3_last_hip;
+
+#define HIPCHK(expr)                                                   \
+	do {                                                               \
+		hipError_t e__ = (expr);                                       \
+		if (e__ != hipSuccess) { x3_last_hip = (int)e__; return e__ == hipErrorOutOfMemory ? X3H_E_NOMEM : X3H_E_HIP; } \
+	} while (0)
+#define CHK(expr) do { int r__ = (expr); if (r__ != X3H_OK) return r__; } while (0)
+
+struct DevBuf {
+	void *p = nullptr;
+	size_t cap = 0;
+	int reserve(size_t bytes)
+	{
+		if (bytes <= cap) return X3H_OK;
+		if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+		size_t want = bytes + bytes / 8 + 4096;
+		hipError_t e = hipMalloc(&p, want);
+		if (e != hipSuccess) { p = nullptr; x3_last_hip = (int)e; return X3H_E_NOMEM; }
+		cap = want;
+		return X3H_OK;
+	}
+	void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+	template <typename T> T *as() const { return (T *)p; }
+};
+
+/* ---- element-wise launcher: f(i) for i in [0,n) ---------------------------------------------------------- */
+#ifndef X3_EMU
+template <class F> __global__ void __launch_bounds__(256) x3_foreach_kernel(size_t n, F f)
+{
+	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	if (i < n) f(i);
+}
+template <class F> static inline void x3_foreach(size_t n, hipStream_t st, F f)
+{
+	if (!n) return;
+	hipLaunchKernelGGL(x3_foreach_kernel<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, f);
+}
+#define X3_LAMBDA [=] __device__
+#else
+template <class F> static inline void x3_foreach(size_t n, hipStream_t, F f) { for (size_t i = 0; i < n; i++) f(i); }
+#define X3_LAMBDA [=]
+#endif
+
+/* ---- library primitives (prims.hip) ---------------------------------------------------------------------- */
+/* stable LSD radix sort on key bits [0,bits) */
+int x3p_sort_pairs(DevBuf &tmp, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, int bits, hipStream_t st);
+/* out[i] = sum in[0..i) for i in [0,n]; `in` must have n+1 readable entries (in[n] is ignored), out n+1 writable */
+int x3p_excl_scan(DevBuf &tmp, const uint32_t *in, uint32_t *out, size_t n, hipStream_t st);
+/* out[i] = max in[0..i] */
+int x3p_incl_max_scan(DevBuf &tmp, const uint32_t *in, uint32_t *out, size_t n, hipStream_t st);
+
+/* ---- v2 coding stage (code2.hip) ------------------------------------------------------------------------- */
+struct X3Code2Bufs {
+	DevBuf tmp, offs, chunkmeta;
+	DevBuf a[48]; /* u32 work arrays of max(hits, events)+4 entries */
+	DevBuf idxfreq, hsym, maxred;
+};
+
+struct X3Code2Stats { double ms_features, ms_pass1, ms_post, ms_pass2; };
+
+int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h_chunks, const X3Chunk *d_chunks,
+                   const X3ParseResult *h_parsed, const X3ParseResult *d_parsed,
+                   const uint8_t *d_bytes, const uint32_t *tok_pos, const uint32_t *tok_info, const uint32_t *tok_hb,
+                   const uint32_t *tok_nb, uint8_t *d_out, X3CodeResult *d_result);
+
+#endif /* X3_HOST_H */

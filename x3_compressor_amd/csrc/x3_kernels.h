@@ -81,6 +81,8 @@ struct X3ParseArgs {
 	uint32_t *ht;               /* open addressing, slot = tag+1, 0 = empty                       */
 	uint32_t *tok_pos;
 	uint32_t *tok_info;
+	uint32_t *tok_hb;           /* per step: number of hits before it (index of a hit among the hits)            */
+	uint32_t *tok_nb;           /* per step: dictionary elements before it (== tag a new fragment would get)     */
 	X3ParseResult *result;
 	uint32_t factor1, factor2;
 	int32_t  nl_mode;
