@@ -29,7 +29,7 @@ struct x3h_ctx {
 	int device = 0;
 	hipStream_t stream = nullptr;
 	hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-	DevBuf pad, m, dict_pos, dict_len, ht, tok_pos, tok_info, tok_hb, tok_nb, chunks, presult, cresult;
+	DevBuf pad, m, dict_pos, dict_len, ht, tok_pos, tok_info, tok_hb, tok_nb, tok_mb, chunks, presult, cresult;
 	X3Code2Bufs c2;
 	int code_v1 = 0;
 	DevBuf mtf, idxfreq, ctx1, ctx0, items, pkey, pval, out, counts;
@@ -105,7 +105,7 @@ extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 	if (!c) return;
 	hipSetDevice(c->device);
 	if (c->stream) hipStreamSynchronize(c->stream);
-	DevBuf *bufs[] = { &c->pad, &c->m, &c->dict_pos, &c->dict_len, &c->ht, &c->tok_pos, &c->tok_info, &c->tok_hb, &c->tok_nb, &c->chunks, &c->presult,
+	DevBuf *bufs[] = { &c->pad, &c->m, &c->dict_pos, &c->dict_len, &c->ht, &c->tok_pos, &c->tok_info, &c->tok_hb, &c->tok_nb, &c->tok_mb, &c->chunks, &c->presult,
 		               &c->c2.tmp, &c->c2.offs, &c->c2.chunkmeta, &c->c2.idxfreq, &c->c2.hsym, &c->c2.maxred,
 		               &c->cresult, &c->mtf, &c->idxfreq, &c->ctx1, &c->ctx0, &c->items, &c->pkey, &c->pval, &c->out, &c->counts };
 	for (DevBuf *b : bufs) b->release();
@@ -155,6 +155,7 @@ static int stage_inputs(x3h_ctx *c, const x3h_params *prm, const RunIO &io, uint
 	CHK(c->tok_info.reserve(eoff * 4));
 	CHK(c->tok_hb.reserve(eoff * 4));
 	CHK(c->tok_nb.reserve(eoff * 4));
+	CHK(c->tok_mb.reserve(eoff * 4));
 	CHK(c->ht.reserve(hoff * 4));
 	CHK(c->chunks.reserve((size_t)nc * sizeof(X3Chunk)));
 	CHK(c->presult.reserve((size_t)nc * sizeof(X3ParseResult)));
@@ -209,7 +210,7 @@ static int run(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage upto
 	pa.dict_pos = c->dict_pos.as<uint32_t>(); pa.dict_len = c->dict_len.as<uint8_t>();
 	pa.ht = c->ht.as<uint32_t>();
 	pa.tok_pos = c->tok_pos.as<uint32_t>(); pa.tok_info = c->tok_info.as<uint32_t>();
-	pa.tok_hb = c->tok_hb.as<uint32_t>(); pa.tok_nb = c->tok_nb.as<uint32_t>();
+	pa.tok_hb = c->tok_hb.as<uint32_t>(); pa.tok_nb = c->tok_nb.as<uint32_t>(); pa.tok_mb = c->tok_mb.as<uint32_t>();
 	pa.result = c->presult.as<X3ParseResult>();
 	pa.factor1 = prm.factor1; pa.factor2 = prm.factor2; pa.nl_mode = prm.nl_mode;
 	x3k_launch_parse(&pa, (uint32_t)nc, c->stream);
@@ -253,7 +254,7 @@ static int run(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage upto
 	if (!c->code_v1) {
 		/* v2: parallel feature extraction (sorts / scans / count-smaller-before) + two thin serial passes (code2.hip) */
 		CHK(x3_code_v2_run(c->c2, c->stream, nc, c->hchunks.data(), c->chunks.as<X3Chunk>(), c->hparse.data(), pa.result,
-		                   sa.bytes, pa.tok_pos, pa.tok_info, pa.tok_hb, pa.tok_nb, d_out, c->cresult.as<X3CodeResult>()));
+		                   sa.bytes, pa.tok_pos, pa.tok_info, pa.tok_hb, pa.tok_nb, pa.tok_mb, d_out, c->cresult.as<X3CodeResult>()));
 	} else {
 		/* v1 (kept for A/B runs, X3H_CODE_V1=1): one wavefront per stream walks the tokens over growable tables (code.hip) */
 		CHK(c->mtf.reserve(toff * 4));

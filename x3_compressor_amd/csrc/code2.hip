@@ -96,13 +96,21 @@ struct X3ModesArgs {
 	const uint32_t *rank, *dk, *step;  /* per hit: MTF rank, dictionary size at that step, step index */
 	uint32_t *idxfreq;                 /* per tag slot (by rank), pre-set to 1 */
 	uint32_t *mode, *rfreq, *itot;     /* out per hit */
+	uint32_t *pe0, *pe1;               /* out per hit: model_events freq of E_CTX0 / E_CTX1 before the hit */
+	uint32_t *evfinal;                 /* out per chunk: final ev0, ev1, ev2, (pad) */
 };
+
+#define X3_IDXF_LDS 32768u /* ranks whose model_index1 frequency lives in LDS (128 KiB); beyond that: global memory */
 
 __device__ static void x3_modes_body(const X3ModesArgs &a)
 {
+	X3_LDS uint32_t sidx[X3_IDXF_LDS];
 	const uint32_t c = blockIdx.x, lane = x3_lane();
-	const uint32_t H = a.parsed[c].hits, h0 = a.ho[c];
+	const uint32_t H = a.parsed[c].hits, h0 = a.ho[c], Dc = a.parsed[c].dict_elems;
 	uint32_t *idxf = a.idxfreq + a.dof[c];
+	const uint32_t nl = Dc < X3_IDXF_LDS ? Dc : X3_IDXF_LDS;
+	for (uint32_t i = lane; i < nl; i += X3_WAVE) sidx[i] = 1;
+	x3_wave_sync();
 	uint32_t ev0 = 1024, ev1 = 1024, ev2 = 1, nidx = 0;
 	/* every lane walks the same sequence (wave-uniform); lane 0 owns the stores.  64 hits are fetched per round so the
 	 * feature loads are coalesced and off the dependent chain. */
@@ -112,194 +120,138 @@ __device__ static void x3_modes_body(const X3ModesArgs &a)
 		const uint32_t vf0 = in ? a.f0[g] : 0, vt0 = in ? a.t0[g] : 1, vf1 = in ? a.f1[g] : 0, vt1 = in ? a.t1[g] : 1;
 		const uint32_t vr = in ? a.rank[g] : 0, vd = in ? a.dk[g] : 1, vs = in ? a.step[g] : 0;
 		/* the parts of the products that do not depend on the serial state: (float)freq / (float)total (context.c:114-133) */
-		const float q0 = (float)vf0 / (float)vt0, q1 = (float)vf1 / (float)vt1;
-		uint32_t mymode = 0, myrf = 0, myit = 0;
+		const float q0 = vf0 ? (float)vf0 / (float)vt0 : 0.f, q1 = vf1 ? (float)vf1 / (float)vt1 : 0.f;
+		const float vfet = (float)(2051u + vs); /* model_events.total: 2051 + one per earlier step */
+		uint32_t mymode = 0, myrf = 0, myit = 0, mye0 = 0, mye1 = 0;
 		const uint32_t cnt = H - base < X3_WAVE ? H - base : X3_WAVE;
 		for (uint32_t l = 0; l < cnt; l++) {
-			const uint32_t f0 = x3_bcast_u32(vf0, (int)l), f1 = x3_bcast_u32(vf1, (int)l);
-			const float p0q = __uint_as_float(x3_bcast_u32(__float_as_uint(q0), (int)l));
-			const float p1q = __uint_as_float(x3_bcast_u32(__float_as_uint(q1), (int)l));
-			const uint32_t r = x3_bcast_u32(vr, (int)l), dk = x3_bcast_u32(vd, (int)l), sk = x3_bcast_u32(vs, (int)l);
-			const uint32_t rf = idxf[r];
+			const float p0q = __uint_as_float(x3_readlane_u32(__float_as_uint(q0), l));
+			const float p1q = __uint_as_float(x3_readlane_u32(__float_as_uint(q1), l));
+			const float fet = __uint_as_float(x3_readlane_u32(__float_as_uint(vfet), l));
+			const uint32_t r = x3_readlane_u32(vr, l), dk = x3_readlane_u32(vd, l);
+			const uint32_t rf = r < X3_IDXF_LDS ? sidx[r] : idxf[r];
 			const uint32_t itot = dk + nidx;
-			const float fet = (float)(2051u + sk); /* model_events.total: 2051 + one per earlier step */
-			float p0 = 0.f, p1 = 0.f;
-			if (f0) p0 = ((float)ev0 / fet) * p0q;
-			if (f1) p1 = ((float)ev1 / fet) * p1q;
+			/* x3.c:152-160: a context that does not hold the tag has probability 0 (q == 0 exactly then) */
+			const float p0 = p0q != 0.f ? ((float)ev0 / fet) * p0q : 0.f;
+			const float p1 = p1q != 0.f ? ((float)ev1 / fet) * p1q : 0.f;
 			const float pi = ((float)ev2 / fet) * ((float)rf / (float)itot);
 			uint32_t mode = X3_E_IDX1;
 			float best = pi;
 			if (p0 > best) { mode = X3_E_CTX0; best = p0; }
 			if (p1 > best) { mode = X3_E_CTX1; best = p1; }
+			if (lane == l) { mye0 = ev0; mye1 = ev1; }
 			if (mode == X3_E_CTX0) ev0++;
 			else if (mode == X3_E_CTX1) ev1++;
 			else {
 				ev2++; nidx++;
-				x3_wave_sync(); /* every lane has read idxf[r] */
-				if (lane == 0) idxf[r] = rf + 1;
+				x3_wave_sync(); /* every lane has read the frequency of rank r */
+				if (lane == 0) { if (r < X3_IDXF_LDS) sidx[r] = rf + 1; else idxf[r] = rf + 1; }
 				x3_wave_sync(); /* the next hit may read this rank */
 			}
 			if (lane == l) { mymode = mode; myrf = rf; myit = itot; }
 		}
-		if (in) { a.mode[g] = mymode; a.rfreq[g] = myrf; a.itot[g] = myit; }
+		if (in) { a.mode[g] = mymode; a.rfreq[g] = myrf; a.itot[g] = myit; a.pe0[g] = mye0; a.pe1[g] = mye1; }
 	}
+	if (lane == 0) { a.evfinal[4 * c + 0] = ev0; a.evfinal[4 * c + 1] = ev1; a.evfinal[4 * c + 2] = ev2; a.evfinal[4 * c + 3] = 0; }
 }
 
 /* ============================================================================================================
- * serial pass 2: arithmetic coder + bit output over the prepared symbols
+ * serial pass 2: the arithmetic-coder interval recurrence ALONE (ac.c:77-85 + the renormalisation of ac.c:46-75).
+ *
+ * Per coded symbol (cum, freq, total):   step = range / total;  hi = lo + step*(cum+freq) - 1;  lo = lo + step*cum.
+ *   - the division is a multiply by M = floor(2^62/total)+1 computed by the 64 lanes in parallel for 64 symbols at a
+ *     time (exact for range <= 2^31, total < 2^31: the error n*eps/2^62 < 2^-31 < 1/total never crosses an integer);
+ *   - E1/E2 (ac.c:49-67) shifts out the n leading bits on which lo and hi agree:  n = clz(lo ^ hi) - 1;
+ *   - E3 (ac.c:70-74) then drops the k leading positions (below the top bit) where lo has 1 and hi has 0.
+ * Nothing is written to the bit stream here: the kernel records (n, the n emitted bits, k) per symbol, and the
+ * pending-bit bookkeeping (mScale) + bit placement become prefix sums over those records (emit stage below).
  * ============================================================================================================ */
-struct X3AcArgs {
-	const uint8_t *bytes;
-	const X3Chunk *chunks;
-	const X3ParseResult *parsed;
-	const uint32_t *tok_pos, *tok_info, *tok_hb;
-	const uint32_t *ho;
-	const uint32_t *scum, *sfreq, *stot, *mode; /* per hit: the tag/index symbol and the chosen mode */
-	const uint32_t *npairs;                       /* per chunk (stats) */
-	uint8_t *out;
-	X3CodeResult *result;
+struct X3Ac2Args {
+	const uint32_t *yo;                   /* per chunk: first symbol (nc+1) */
+	const uint32_t *scum, *sfreq, *stot;  /* per symbol */
+	uint32_t *rec_nk, *rec_bits;          /* out per symbol: n | k<<8, and the top n bits of lo before the shift */
+	uint32_t *final_lo;                   /* out per chunk */
 };
 
-struct Coder2 {
-	uint32_t lo, hi, pending, acc, cnt, w, capw, full;
-	uint32_t *out32;
-};
+__device__ static __forceinline__ uint32_t x3_mulhi_u32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 
-__device__ static __forceinline__ void c2_put(Coder2 &c, uint32_t bit, uint32_t lane)
-{
-	c.acc |= bit << c.cnt;
-	if (++c.cnt == 32) {
-		if (c.w < c.capw) { if (lane == 0) c.out32[c.w] = c.acc; } else c.full = 1;
-		c.w++; c.acc = 0; c.cnt = 0;
-	}
-}
-
-__device__ static __forceinline__ void c2_encode(Coder2 &c, uint32_t cum_lo, uint32_t cum_hi, uint32_t total, uint32_t lane)
-{
-	const uint32_t step = (c.hi - c.lo + 1) / total; /* ac.c:77-85 */
-	c.hi = c.lo + step * cum_hi - 1;
-	c.lo = c.lo + step * cum_lo;
-	for (;;) { /* ac.c:46-67 */
-		if (c.hi < 0x40000000u) {
-			c2_put(c, 0, lane);
-			c.lo = 2 * c.lo; c.hi = 2 * c.hi + 1;
-			for (; c.pending > 0; c.pending--) c2_put(c, 1, lane);
-		} else if (c.lo >= 0x40000000u) {
-			c2_put(c, 1, lane);
-			c.lo = 2 * (c.lo - 0x40000000u); c.hi = 2 * (c.hi - 0x40000000u) + 1;
-			for (; c.pending > 0; c.pending--) c2_put(c, 0, lane);
-		} else break;
-	}
-	while (c.lo >= 0x20000000u && c.hi < 0x60000000u) { /* ac.c:69-74 */
-		c.pending++;
-		c.lo = 2 * (c.lo - 0x20000000u); c.hi = 2 * (c.hi - 0x20000000u) + 1;
-	}
-}
-
-__device__ static __forceinline__ uint32_t wsum(uint32_t v)
-{
-	for (int m = 32; m >= 1; m >>= 1) v += x3_shfl_xor_u32(v, m);
-	return v;
-}
-
-__device__ static void x3_ac_body(const X3AcArgs &a)
+__device__ static void x3_ac2_body(const X3Ac2Args &a)
 {
 	const uint32_t c = blockIdx.x, lane = x3_lane();
-	const X3Chunk ck = a.chunks[c];
-	const X3ParseResult pr = a.parsed[c];
-	const uint8_t *b = a.bytes + ck.byte_off;
-	const uint32_t *tpos = a.tok_pos + ck.elem_off, *tinf = a.tok_info + ck.elem_off, *thb = a.tok_hb + ck.elem_off;
-	const uint32_t h0 = a.ho[c];
-
-	Coder2 cd;
-	cd.lo = 0; cd.hi = 0x7FFFFFFFu; cd.pending = 0; cd.acc = 0; cd.cnt = 0; cd.w = 0;
-	cd.capw = (uint32_t)(ck.out_cap / 4); cd.full = 0; cd.out32 = (uint32_t *)(a.out + ck.out_off);
-
-	uint32_t ev0 = 1024, ev1 = 1024, ev2 = 1, ev3 = 1, evtotal = 2051; /* x3.c:236-244 */
-	uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0;
-	uint32_t lf = 1, lftotal = 32;
-	uint32_t cf0 = 1, cf1 = 1, cf2 = 1, cf3 = 1, cftotal = 256;
-
-	for (uint32_t base = 0; base < pr.ntok; base += X3_WAVE) {
-		/* coalesced fetch of 64 steps and of the hit symbols they refer to */
-		const bool in = base + lane < pr.ntok;
-		const uint32_t vinfo = in ? tinf[base + lane] : 0, vpos = in ? tpos[base + lane] : 0;
-		uint32_t vcum = 0, vfreq = 0, vtot = 1, vmode = 0;
-		if (in && !(vinfo & X3_TOK_MISS)) {
-			const uint32_t g = h0 + thb[base + lane];
-			vcum = a.scum[g]; vfreq = a.sfreq[g]; vtot = a.stot[g]; vmode = a.mode[g];
-		}
-		const uint32_t cnt = pr.ntok - base < X3_WAVE ? pr.ntok - base : X3_WAVE;
+	const uint32_t y0 = a.yo[c], Y = a.yo[c + 1] - y0;
+	uint32_t lo = 0, hi = 0x7FFFFFFFu; /* ac_init, ac.c:35-41 */
+	for (uint32_t base = 0; base < Y; base += X3_WAVE) {
+		const bool in = base + lane < Y;
+		const uint32_t vcum = in ? a.scum[y0 + base + lane] : 0, vfq = in ? a.sfreq[y0 + base + lane] : 1;
+		const uint32_t vtot = in ? a.stot[y0 + base + lane] : 1;
+		const uint64_t M = ((uint64_t)1 << 62) / vtot + 1;
+		const uint32_t vmh = (uint32_t)(M >> 32), vml = (uint32_t)M, vchi = vcum + vfq;
+		uint32_t mynk = 0, mybits = 0;
+		const uint32_t cnt = Y - base < X3_WAVE ? Y - base : X3_WAVE;
 		for (uint32_t l = 0; l < cnt; l++) {
-			const uint32_t info = x3_bcast_u32(vinfo, (int)l);
-			if (!(info & X3_TOK_MISS)) {
-				const uint32_t mode = x3_bcast_u32(vmode, (int)l), cum = x3_bcast_u32(vcum, (int)l);
-				const uint32_t fq = x3_bcast_u32(vfreq, (int)l), tot = x3_bcast_u32(vtot, (int)l);
-				if (mode == X3_E_CTX0) { c2_encode(cd, 0, ev0, evtotal, lane); ev0++; n0++; }
-				else if (mode == X3_E_CTX1) { c2_encode(cd, ev0, ev0 + ev1, evtotal, lane); ev1++; n1++; }
-				else { c2_encode(cd, ev0 + ev1, ev0 + ev1 + ev2, evtotal, lane); ev2++; n2++; }
-				evtotal++;
-				c2_encode(cd, cum, cum + fq, tot, lane);
-			} else {
-				const uint32_t len = info & 0x3Fu, pos = x3_bcast_u32(vpos, (int)l);
-				c2_encode(cd, ev0 + ev1 + ev2, ev0 + ev1 + ev2 + ev3, evtotal, lane); /* x3.c:253-255 */
-				ev3++; n3++; evtotal++;
-				{
-					const uint32_t sym = len - 1;
-					const uint32_t cum = wsum(lane < sym ? lf : 0u);
-					const uint32_t fq = x3_bcast_u32(lf, (int)sym);
-					c2_encode(cd, cum, cum + fq, lftotal, lane);
-					if (lane == sym) lf++;
-					lftotal++;
-				}
-				for (uint32_t j = 0; j < len; j++) {
-					const uint32_t ch = b[(uint64_t)pos + j];
-					const uint32_t owner = ch >> 2, sub = ch & 3;
-					uint32_t part = 0;
-					if (lane < owner) part = cf0 + cf1 + cf2 + cf3;
-					else if (lane == owner) part = (sub > 0 ? cf0 : 0) + (sub > 1 ? cf1 : 0) + (sub > 2 ? cf2 : 0);
-					const uint32_t cum = wsum(part);
-					const uint32_t mine = sub == 0 ? cf0 : sub == 1 ? cf1 : sub == 2 ? cf2 : cf3;
-					const uint32_t fq = x3_bcast_u32(mine, (int)owner);
-					c2_encode(cd, cum, cum + fq, cftotal, lane);
-					if (lane == owner) { if (sub == 0) cf0++; else if (sub == 1) cf1++; else if (sub == 2) cf2++; else cf3++; }
-					cftotal++;
-				}
-			}
+			const uint32_t clo = x3_readlane_u32(vcum, l), chi = x3_readlane_u32(vchi, l);
+			const uint32_t mh = x3_readlane_u32(vmh, l), ml = x3_readlane_u32(vml, l);
+			const uint32_t range = hi - lo + 1;
+			const uint64_t u = (uint64_t)range * mh + x3_mulhi_u32(range, ml);
+			const uint32_t step = (uint32_t)(u >> 30);
+			const uint32_t nhi = lo + step * chi - 1, nlo = lo + step * clo;
+			const uint32_t x = nlo ^ nhi;
+			const uint32_t n = x ? (uint32_t)x3_clz32(x) - 1 : 31u;
+			const uint32_t bits = n ? nlo >> (31 - n) : 0u;
+			const uint32_t ones = n >= 31 ? 0x7FFFFFFFu : ((1u << n) - 1);
+			lo = n >= 31 ? 0u : (nlo << n) & 0x7FFFFFFFu;
+			hi = n >= 31 ? 0x7FFFFFFFu : ((nhi << n) | ones) & 0x7FFFFFFFu;
+			const uint32_t yv = (~lo | hi) & 0x3FFFFFFFu;
+			const uint32_t k = yv ? (uint32_t)x3_clz32(yv) - 2 : 30u;
+			lo = (lo << k) & 0x3FFFFFFFu;
+			hi = (((hi << k) | ((1u << k) - 1)) & 0x3FFFFFFFu) | 0x40000000u;
+			if (lane == l) { mynk = n | (k << 8); mybits = bits; }
 		}
-		if (cd.full) break;
+		if (in) { a.rec_nk[y0 + base + lane] = mynk; a.rec_bits[y0 + base + lane] = mybits; }
 	}
-
-	/* E_EOF (x3.c:432-433), ac_encode_flush (ac.c:115-126), bio_close (bio.c:105-112) */
-	c2_encode(cd, evtotal - 1, evtotal, evtotal, lane);
-	if (cd.lo < 0x20000000u) {
-		c2_put(cd, 0, lane);
-		for (uint32_t i = 0; i < cd.pending + 1; i++) c2_put(cd, 1, lane);
-	} else c2_put(cd, 1, lane);
-	if (cd.cnt > 0) {
-		if (cd.w < cd.capw) { if (lane == 0) cd.out32[cd.w] = cd.acc; } else cd.full = 1;
-		cd.w++;
-	}
-	if (lane == 0) {
-		X3CodeResult r;
-		r.out_len = cd.w * 4; r.status = cd.full ? X3_ST_OUT_FULL : X3_ST_OK; r.pairs = a.npairs[c]; r._r = 0;
-		r.events[0] = n0; r.events[1] = n1; r.events[2] = n2; r.events[3] = n3;
-		r.events[4] = r.events[5] = r.events[6] = r.events[7] = 0;
-		a.result[c] = r;
-	}
+	if (lane == 0) a.final_lo[c] = lo;
 }
 
 #ifndef X3_EMU
 __global__ void __launch_bounds__(X3_WAVE) x3_modes_kernel(X3ModesArgs a) { x3_modes_body(a); }
-__global__ void __launch_bounds__(X3_WAVE) x3_ac_kernel(X3AcArgs a) { x3_ac_body(a); }
+__global__ void __launch_bounds__(X3_WAVE) x3_ac2_kernel(X3Ac2Args a) { x3_ac2_body(a); }
 static void launch_modes(const X3ModesArgs &a, uint32_t nchunks, hipStream_t st) { hipLaunchKernelGGL(x3_modes_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, a); }
-static void launch_ac(const X3AcArgs &a, uint32_t nchunks, hipStream_t st) { hipLaunchKernelGGL(x3_ac_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, a); }
+static void launch_ac2(const X3Ac2Args &a, uint32_t nchunks, hipStream_t st) { hipLaunchKernelGGL(x3_ac2_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, a); }
+__device__ static __forceinline__ uint32_t x3_brev32(uint32_t v) { return __brev(v); }
 #else
 static void modes_tramp(void *p) { x3_modes_body(*(const X3ModesArgs *)p); }
-static void ac_tramp(void *p) { x3_ac_body(*(const X3AcArgs *)p); }
+static void ac2_tramp(void *p) { x3_ac2_body(*(const X3Ac2Args *)p); }
 static void launch_modes(const X3ModesArgs &a, uint32_t nchunks, hipStream_t) { x3emu_launch(modes_tramp, (void *)&a, dim3(nchunks), dim3(X3_WAVE)); }
-static void launch_ac(const X3AcArgs &a, uint32_t nchunks, hipStream_t) { x3emu_launch(ac_tramp, (void *)&a, dim3(nchunks), dim3(X3_WAVE)); }
+static void launch_ac2(const X3Ac2Args &a, uint32_t nchunks, hipStream_t) { x3emu_launch(ac2_tramp, (void *)&a, dim3(nchunks), dim3(X3_WAVE)); }
+static inline uint32_t x3_brev32(uint32_t v) { uint32_t r = 0; for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i); return r; }
 #endif
+
+/* OR `nbits` (<= 32) bits of `val` into the little-endian 32-bit word stream at bit position `bitpos` (bio.c:49-72 layout) */
+__device__ static __forceinline__ void x3_or_bits(uint32_t *out32, uint32_t capw, uint64_t bitpos, uint32_t val, uint32_t nbits)
+{
+	if (!nbits) return;
+	if (nbits < 32) val &= (1u << nbits) - 1;
+	const uint64_t w = bitpos >> 5;
+	const uint32_t sh = (uint32_t)(bitpos & 31);
+	const uint32_t v0 = val << sh;
+	if (v0 && w < capw) atomicOr(&out32[w], v0);
+	if (sh && sh + nbits > 32) {
+		const uint32_t v1 = val >> (32 - sh);
+		if (v1 && w + 1 < capw) atomicOr(&out32[w + 1], v1);
+	}
+}
+
+/* a run of `count` equal bits */
+__device__ static __forceinline__ void x3_or_run(uint32_t *out32, uint32_t capw, uint64_t bitpos, uint32_t bit, uint32_t count)
+{
+	if (!bit) return; /* the stream is pre-zeroed */
+	while (count) {
+		const uint32_t c = count < 32 ? count : 32;
+		x3_or_bits(out32, capw, bitpos, 0xFFFFFFFFu, c);
+		bitpos += c;
+		count -= c;
+	}
+}
 
 /* ============================================================================================================
  * context statistics of every hit for one context family (group id G per hit):
@@ -354,28 +306,37 @@ static int ctx_stats(X3Code2Bufs &B, hipStream_t st, size_t nH, int gbits, int t
 int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h_chunks, const X3Chunk *d_chunks,
                    const X3ParseResult *h_parsed, const X3ParseResult *d_parsed,
                    const uint8_t *d_bytes, const uint32_t *tok_pos, const uint32_t *tok_info, const uint32_t *tok_hb,
-                   const uint32_t *tok_nb, uint8_t *d_out, X3CodeResult *d_result)
+                   const uint32_t *tok_nb, const uint32_t *tok_mb, uint8_t *d_out, X3CodeResult *d_result)
 {
 	const uint32_t nc = (uint32_t)nchunks;
 	/* ---- index spaces: steps, hits, MTF events (hits + inserted elements), tags ---- */
-	std::vector<uint32_t> so(nc + 1), ho(nc + 1), eo(nc + 1), dof(nc + 1);
-	uint64_t s = 0, h = 0, e = 0, d = 0;
+	std::vector<uint32_t> so(nc + 1), ho(nc + 1), eo(nc + 1), dof(nc + 1), mo(nc + 1), bo(nc + 1), yo(nc + 1);
+	uint64_t s = 0, h = 0, e = 0, d = 0, mi = 0, by = 0, y = 0;
 	for (uint32_t c = 0; c < nc; c++) {
-		so[c] = (uint32_t)s; ho[c] = (uint32_t)h; eo[c] = (uint32_t)e; dof[c] = (uint32_t)d;
+		so[c] = (uint32_t)s; ho[c] = (uint32_t)h; eo[c] = (uint32_t)e; dof[c] = (uint32_t)d; mo[c] = (uint32_t)mi; bo[c] = (uint32_t)by; yo[c] = (uint32_t)y;
 		s += h_parsed[c].ntok; h += h_parsed[c].hits; e += (uint64_t)h_parsed[c].hits + h_parsed[c].dict_elems; d += h_parsed[c].dict_elems;
+		mi += h_parsed[c].ntok - h_parsed[c].hits; by += h_parsed[c].miss_bytes;
+		y += 2ull * h_parsed[c].ntok + h_parsed[c].miss_bytes + 1; /* two symbols per step, one per new-fragment byte, E_EOF */
 	}
-	if (s >= (1ull << 31) || e >= (1ull << 31)) return X3H_E_ARG; /* one batch: < 2^31 steps */
-	so[nc] = (uint32_t)s; ho[nc] = (uint32_t)h; eo[nc] = (uint32_t)e; dof[nc] = (uint32_t)d;
-	const size_t nS = s, nH = h, nE = e, nD = d;
-	const size_t nA = (nE > nH ? nE : nH) + 4;
+	if (s >= (1ull << 31) || e >= (1ull << 31) || y >= (1ull << 31)) return X3H_E_ARG; /* one batch: < 2^31 coded symbols */
+	so[nc] = (uint32_t)s; ho[nc] = (uint32_t)h; eo[nc] = (uint32_t)e; dof[nc] = (uint32_t)d; mo[nc] = (uint32_t)mi; bo[nc] = (uint32_t)by; yo[nc] = (uint32_t)y;
+	const size_t nS = s, nH = h, nE = e, nD = d, nM = mi, nB = by, nY = y;
+	size_t nA = nE > nH ? nE : nH;
+	if (nM > nA) nA = nM;
+	if (nB > nA) nA = nB;
+	nA += 4;
 
-	CHK(B.offs.reserve((size_t)(nc + 1) * 4 * 4));
+	CHK(B.offs.reserve((size_t)(nc + 1) * 7 * 4));
 	uint32_t *d_so = B.offs.as<uint32_t>(), *d_ho = d_so + (nc + 1), *d_eo = d_ho + (nc + 1), *d_dof = d_eo + (nc + 1);
+	uint32_t *d_mo = d_dof + (nc + 1), *d_bo = d_mo + (nc + 1), *d_yo = d_bo + (nc + 1);
+	HIPCHK(hipMemcpyAsync(d_mo, mo.data(), (nc + 1) * 4, hipMemcpyHostToDevice, st));
+	HIPCHK(hipMemcpyAsync(d_bo, bo.data(), (nc + 1) * 4, hipMemcpyHostToDevice, st));
+	HIPCHK(hipMemcpyAsync(d_yo, yo.data(), (nc + 1) * 4, hipMemcpyHostToDevice, st));
 	HIPCHK(hipMemcpyAsync(d_so, so.data(), (nc + 1) * 4, hipMemcpyHostToDevice, st));
 	HIPCHK(hipMemcpyAsync(d_ho, ho.data(), (nc + 1) * 4, hipMemcpyHostToDevice, st));
 	HIPCHK(hipMemcpyAsync(d_eo, eo.data(), (nc + 1) * 4, hipMemcpyHostToDevice, st));
 	HIPCHK(hipMemcpyAsync(d_dof, dof.data(), (nc + 1) * 4, hipMemcpyHostToDevice, st));
-	CHK(B.chunkmeta.reserve((size_t)nc * 4 * 4 + 64));
+	CHK(B.chunkmeta.reserve((size_t)nc * 10 * 4 + 64));
 	uint32_t *m_pairbase = B.chunkmeta.as<uint32_t>(), *m_npairs = m_pairbase + nc, *m_first00 = m_npairs + nc, *m_ord00 = m_first00 + nc;
 	CHK(B.maxred.reserve(64));
 	CHK(B.idxfreq.reserve((nD + 4) * 4));
@@ -390,6 +351,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	uint32_t *f0 = A[10], *t0 = A[11], *c0 = A[12], *f1 = A[13], *t1 = A[14], *c1 = A[15];
 	uint32_t *mode = A[16], *rfreq = A[17], *itot = A[18], *rcum = A[19];
 	uint32_t **T = A + 20; /* 28 temporaries */
+	uint32_t *m_evfinal = m_ord00 + nc, *m_finallo = m_evfinal + 4 * nc; /* per chunk: 4 + 1 words */
 
 	if (nH > 0) {
 		/* ---- F1: per step -> per hit / per event records ---- */
@@ -494,7 +456,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		X3ModesArgs ma;
 		ma.parsed = d_parsed; ma.ho = d_ho; ma.dof = d_dof;
 		ma.f0 = f0; ma.t0 = t0; ma.f1 = f1; ma.t1 = t1; ma.rank = h_rank; ma.dk = h_dk; ma.step = h_step;
-		ma.idxfreq = idxf; ma.mode = mode; ma.rfreq = rfreq; ma.itot = itot;
+		ma.idxfreq = idxf; ma.mode = mode; ma.rfreq = rfreq; ma.itot = itot; ma.pe0 = T[26]; ma.pe1 = T[27]; ma.evfinal = m_evfinal;
 		launch_modes(ma, nc, st);
 		HIPCHK(hipGetLastError());
 
@@ -528,17 +490,145 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 			scum[i] = cu; sfreq[i] = fq; stot[i] = to;
 		});
 	} else {
-		x3_foreach(nc, st, X3_LAMBDA(size_t c) { m_npairs[c] = 0; });
+		x3_foreach(nc, st, X3_LAMBDA(size_t c) { m_npairs[c] = 0; m_evfinal[4 * c] = 1024; m_evfinal[4 * c + 1] = 1024; m_evfinal[4 * c + 2] = 1; m_evfinal[4 * c + 3] = 0; });
+	}
+	const uint32_t *hs_cum = T[0], *hs_freq = T[1], *hs_tot = T[2], *pe0 = T[26], *pe1 = T[27];
+
+	/* ---- new fragments: model_match_size (32 symbols) and model_chars (256 symbols) are adaptive order-0 models
+	 *      (x3.c:259-267): cum_freq = symbol + #{earlier smaller}, freq = 1 + #{earlier equal}, total = alphabet + index ---- */
+	const size_t nMS = (nM > nB ? nM : nB) + 4;
+	uint32_t *Q[16];
+	for (int i = 0; i < 16; i++) { CHK(B.ms[i].reserve(nMS * 4)); Q[i] = B.ms[i].as<uint32_t>(); }
+	uint32_t *lval = Q[0], *lsm = Q[1], *leq = Q[2], *bval = Q[3], *bsm = Q[4], *beq = Q[5];
+	x3_foreach(nS, st, X3_LAMBDA(size_t gs) {
+		const uint32_t c = find_chunk(d_so, nc, (uint32_t)gs);
+		const uint32_t k = (uint32_t)gs - d_so[c];
+		const uint64_t base = d_chunks[c].elem_off;
+		const uint32_t info = tok_info[base + k];
+		if (info & X3_TOK_MISS) {
+			const uint32_t len = info & 0x3Fu, hb = tok_hb[base + k], mb = tok_mb[base + k];
+			lval[d_mo[c] + (k - hb)] = len - 1;
+			const uint8_t *p = d_bytes + d_chunks[c].byte_off + tok_pos[base + k];
+			for (uint32_t j = 0; j < len; j++) bval[d_bo[c] + mb + j] = p[j];
+		}
+	});
+	for (int which = 0; which < 2; which++) {
+		const size_t n = which ? nB : nM;
+		if (!n) continue;
+		const int abits = which ? 8 : 5;
+		const uint32_t *val = which ? bval : lval, *off = which ? d_bo : d_mo;
+		uint32_t *osm = which ? bsm : lsm, *oeq = which ? beq : leq;
+		uint32_t *iota = Q[6], *key = Q[7], *ks = Q[8], *vs = Q[9], *rsf = Q[10], *rs = Q[11], *bs = Q[12], *be = Q[13], *kc = Q[14];
+		x3_foreach(n, st, X3_LAMBDA(size_t i) {
+			const uint32_t c = find_chunk(off, nc, (uint32_t)i);
+			iota[i] = (uint32_t)i;
+			key[i] = val[i] | (c << abits);
+			kc[i] = val[i]; bs[i] = off[c]; be[i] = off[c + 1];
+		});
+		CHK(x3p_sort_pairs(B.tmp, key, ks, iota, vs, n, abits + bits_for(nc), st));
+		x3_foreach(n, st, X3_LAMBDA(size_t i) { rsf[i] = (i > 0 && ks[i - 1] != ks[i]) ? (uint32_t)i : 0u; });
+		CHK(x3p_incl_max_scan(B.tmp, rsf, rs, n, st));
+		x3_foreach(n, st, X3_LAMBDA(size_t i) { oeq[vs[i]] = (uint32_t)i - rs[i]; });
+		CHK(csb_run(B, st, n, abits, kc, bs, be, osm, T + 8)); /* the hit/event work arrays also cover nM and nB (nA above) */
 	}
 
-	/* ---- serial pass 2: arithmetic coder ---- */
-	X3AcArgs aa;
-	aa.bytes = d_bytes; aa.chunks = d_chunks; aa.parsed = d_parsed;
-	aa.tok_pos = tok_pos; aa.tok_info = tok_info; aa.tok_hb = tok_hb; aa.ho = d_ho;
-	aa.scum = T[0]; aa.sfreq = T[1]; aa.stot = T[2]; aa.mode = mode; aa.npairs = m_npairs;
-	aa.out = d_out; aa.result = d_result;
-	launch_ac(aa, nc, st);
+	/* ---- the coded symbols, in coding order: symbol index of step k = 2k + (new-fragment bytes before k) ---- */
+	uint32_t *Yv[12];
+	for (int i = 0; i < 12; i++) { CHK(B.y[i].reserve((nY + 4) * 4)); Yv[i] = B.y[i].as<uint32_t>(); }
+	uint32_t *sy_cum = Yv[0], *sy_freq = Yv[1], *sy_tot = Yv[2], *rec_nk = Yv[3], *rec_bits = Yv[4];
+	x3_foreach(nS, st, X3_LAMBDA(size_t gs) {
+		const uint32_t c = find_chunk(d_so, nc, (uint32_t)gs);
+		const uint32_t k = (uint32_t)gs - d_so[c];
+		const uint64_t base = d_chunks[c].elem_off;
+		const uint32_t info = tok_info[base + k], hb = tok_hb[base + k], mb = tok_mb[base + k];
+		uint32_t yi = d_yo[c] + 2 * k + mb;
+		const uint32_t evtotal = 2051u + k; /* model_events: 1024+1024+1+1+1 (x3.c:236-244), +1 per step */
+		if (!(info & X3_TOK_MISS)) {
+			const uint32_t gh = d_ho[c] + hb, m = mode[gh], e0 = pe0[gh], e1 = pe1[gh];
+			const uint32_t e2 = 2049u + hb - e0 - e1; /* every hit bumps exactly one of the three */
+			sy_cum[yi] = m == X3_E_CTX0 ? 0u : m == X3_E_CTX1 ? e0 : e0 + e1;
+			sy_freq[yi] = m == X3_E_CTX0 ? e0 : m == X3_E_CTX1 ? e1 : e2;
+			sy_tot[yi] = evtotal;
+			sy_cum[yi + 1] = hs_cum[gh]; sy_freq[yi + 1] = hs_freq[gh]; sy_tot[yi + 1] = hs_tot[gh];
+		} else {
+			const uint32_t len = info & 0x3Fu, mk = k - hb; /* mk = new fragments before this one */
+			sy_cum[yi] = 2049u + hb; sy_freq[yi] = 1u + mk; sy_tot[yi] = evtotal; /* E_NEW */
+			const uint32_t gm = d_mo[c] + mk;
+			sy_cum[yi + 1] = (len - 1) + lsm[gm]; sy_freq[yi + 1] = 1u + leq[gm]; sy_tot[yi + 1] = 32u + mk;
+			for (uint32_t j = 0; j < len; j++) {
+				const uint32_t gb = d_bo[c] + mb + j;
+				sy_cum[yi + 2 + j] = bval[gb] + bsm[gb]; sy_freq[yi + 2 + j] = 1u + beq[gb]; sy_tot[yi + 2 + j] = 256u + mb + j;
+			}
+		}
+	});
+	x3_foreach(nc, st, X3_LAMBDA(size_t c) { /* E_EOF, x3.c:432-433 */
+		const uint32_t yi = d_yo[c + 1] - 1, evtotal = 2051u + d_parsed[c].ntok;
+		sy_cum[yi] = evtotal - 1; sy_freq[yi] = 1; sy_tot[yi] = evtotal;
+	});
+
+	/* ---- serial pass 2: interval recurrence ---- */
+	X3Ac2Args aa;
+	aa.yo = d_yo; aa.scum = sy_cum; aa.sfreq = sy_freq; aa.stot = sy_tot; aa.rec_nk = rec_nk; aa.rec_bits = rec_bits; aa.final_lo = m_finallo;
+	launch_ac2(aa, nc, st);
 	HIPCHK(hipGetLastError());
-	(void)h_chunks; (void)tok_nb;
+
+	/* ---- bit emission (ac.c:49-67 put_bit + mScale, bio.c:49-72) as prefix sums over the records ----
+	 * pending after symbol i  = sum of k over (last symbol that shifted out bits (n>=1) or stream start .. i]
+	 * bits written by symbol i = n + pending before it (when n >= 1): first bit, the pending bits inverted, the other n-1 bits */
+	uint32_t *kk = Yv[5], *rv = Yv[6], *Kex = Yv[7], *LE = Yv[8], *len = Yv[9], *pos = Yv[10], *pend = Yv[11];
+	x3_foreach(nY, st, X3_LAMBDA(size_t i) {
+		const uint32_t nk = rec_nk[i];
+		const uint32_t c = find_chunk(d_yo, nc, (uint32_t)i);
+		kk[i] = nk >> 8;
+		rv[i] = ((nk & 0xFF) >= 1 || i == d_yo[c]) ? (uint32_t)i + 1 : 0u;
+	});
+	CHK(x3p_excl_scan(B.tmp, kk, Kex, nY, st));
+	CHK(x3p_incl_max_scan(B.tmp, rv, LE, nY, st));
+	x3_foreach(nY, st, X3_LAMBDA(size_t i) { pend[i] = Kex[i + 1] - Kex[LE[i] - 1]; });
+	x3_foreach(nY, st, X3_LAMBDA(size_t i) {
+		const uint32_t n = rec_nk[i] & 0xFF;
+		const uint32_t c = find_chunk(d_yo, nc, (uint32_t)i);
+		len[i] = n >= 1 ? n + (i == d_yo[c] ? 0u : pend[i - 1]) : 0u;
+	});
+	CHK(x3p_excl_scan(B.tmp, len, pos, nY, st));
+	for (uint32_t c = 0; c < nc; c++) /* the stream is assembled with ORs */
+		if (h_chunks[c].out_cap) HIPCHK(hipMemsetAsync(d_out + h_chunks[c].out_off, 0, h_chunks[c].out_cap, st));
+	x3_foreach(nY, st, X3_LAMBDA(size_t i) {
+		const uint32_t ln = len[i];
+		if (!ln) return;
+		const uint32_t c = find_chunk(d_yo, nc, (uint32_t)i);
+		uint32_t *out32 = (uint32_t *)(d_out + d_chunks[c].out_off);
+		const uint32_t capw = (uint32_t)(d_chunks[c].out_cap / 4);
+		const uint32_t n = rec_nk[i] & 0xFF, pd = ln - n;
+		const uint64_t bp = pos[i] - pos[d_yo[c]];
+		const uint32_t rev = x3_brev32(rec_bits[i]) >> (32 - n); /* bit j = j-th emitted bit */
+		if (!pd) x3_or_bits(out32, capw, bp, rev, n);
+		else {
+			x3_or_bits(out32, capw, bp, rev & 1u, 1);
+			x3_or_run(out32, capw, bp + 1, (rev & 1u) ^ 1u, pd);
+			x3_or_bits(out32, capw, bp + 1 + pd, rev >> 1, n - 1);
+		}
+	});
+	x3_foreach(nc, st, X3_LAMBDA(size_t c) { /* ac_encode_flush (ac.c:115-126) + bio_close (bio.c:105-112) + result */
+		uint32_t *out32 = (uint32_t *)(d_out + d_chunks[c].out_off);
+		const uint32_t capw = (uint32_t)(d_chunks[c].out_cap / 4);
+		const uint32_t last = d_yo[c + 1] - 1;
+		uint64_t nbits = pos[d_yo[c + 1]] - pos[d_yo[c]];
+		if (m_finallo[c] < 0x20000000u) {
+			x3_or_run(out32, capw, nbits + 1, 1u, pend[last] + 1); /* '0' then mScale+1 ones */
+			nbits += 2 + (uint64_t)pend[last];
+		} else {
+			x3_or_bits(out32, capw, nbits, 1u, 1);
+			nbits += 1;
+		}
+		const uint64_t words = (nbits + 31) / 32;
+		X3CodeResult r;
+		r.out_len = (uint32_t)(words * 4); r.status = words > capw ? X3_ST_OUT_FULL : X3_ST_OK; r.pairs = m_npairs[c]; r._r = 0;
+		r.events[0] = m_evfinal[4 * c] - 1024; r.events[1] = m_evfinal[4 * c + 1] - 1024; r.events[2] = m_evfinal[4 * c + 2] - 1;
+		r.events[3] = d_parsed[c].ntok - d_parsed[c].hits;
+		r.events[4] = r.events[5] = r.events[6] = r.events[7] = 0;
+		d_result[c] = r;
+	});
+	(void)tok_nb;
 	return X3H_OK;
 }

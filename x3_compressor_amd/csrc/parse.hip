@@ -36,7 +36,7 @@ __device__ static __forceinline__ uint32_t ht_slot(uint32_t h, uint32_t len, uin
 
 /* state shared by the workgroup */
 struct ParseShared {
-	uint32_t p, blk, D, lenmask, hlog, flag, ntok, hits;
+	uint32_t p, blk, D, lenmask, hlog, flag, ntok, hits, mbytes;
 	uint32_t new_pos, new_len, new_tag, rebuild;
 };
 enum { FLAG_REFILL = 1, FLAG_PATCH = 2, FLAG_DONE = 3 };
@@ -60,12 +60,13 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 	uint32_t *tinf = a.tok_info + ck.elem_off;
 	uint32_t *thb = a.tok_hb + ck.elem_off; /* hits before this step   */
 	uint32_t *tnb = a.tok_nb + ck.elem_off; /* dictionary elements before this step */
+	uint32_t *tmb = a.tok_mb + ck.elem_off; /* new-fragment bytes before this step   */
 	const uint32_t tid = threadIdx.x, lane = x3_lane(), wave = tid / X3_WAVE;
 	const uint32_t f1 = a.factor1, f2 = a.factor2;
 
 	if (tid == 0) {
 		S.p = 0; S.blk = 0; S.D = 0; S.lenmask = 0; S.hlog = X3_HT_LOG2_MIN < ck.ht_log2_max ? X3_HT_LOG2_MIN : ck.ht_log2_max;
-		S.flag = n ? FLAG_REFILL : FLAG_DONE; S.ntok = 0; S.hits = 0; S.rebuild = 0;
+		S.flag = n ? FLAG_REFILL : FLAG_DONE; S.ntok = 0; S.hits = 0; S.rebuild = 0; S.mbytes = 0;
 	}
 	for (uint32_t i = tid; i < (1u << (X3_HT_LOG2_MIN < ck.ht_log2_max ? X3_HT_LOG2_MIN : ck.ht_log2_max)); i += X3_PARSE_THREADS) ht[i] = 0;
 	__syncthreads();
@@ -128,7 +129,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 
 		if (wave == 0) {
 			/* ---- serial parse out of LDS ---- */
-			uint32_t p = S.p, ntok = S.ntok, hits = S.hits, D = S.D, lenmask = S.lenmask, hlog = S.hlog;
+			uint32_t p = S.p, ntok = S.ntok, hits = S.hits, D = S.D, lenmask = S.lenmask, hlog = S.hlog, mbytes = S.mbytes;
 			const uint32_t blk = S.blk;
 			uint32_t out_flag = 0;
 			for (;;) {
@@ -154,7 +155,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 				uint32_t nlL0 = L0;
 				if (a.nl_mode) nlL0 = L0 == 1 ? 1 : L0 == 2 ? 4 : L0 == 3 ? 6 : L0 == 4 ? 8 : 9999; /* x3.c:357-370 */
 				if (L0 != 0 && nlL0 >= F && p + L0 <= n) {
-					if (lane == 0) { tpos[ntok] = p; tinf[ntok] = sE[idx]; thb[ntok] = hits; tnb[ntok] = D; }
+					if (lane == 0) { tpos[ntok] = p; tinf[ntok] = sE[idx]; thb[ntok] = hits; tnb[ntok] = D; tmb[ntok] = mbytes; }
 					ntok++; hits++;
 					p += L0;
 					continue;
@@ -178,7 +179,8 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 						if (k == len) { dup = 1; break; }
 					}
 				}
-				if (lane == 0) { tpos[ntok] = p; tinf[ntok] = X3_TOK_MISS | (dup ? X3_TOK_DUP : 0u) | len; thb[ntok] = hits; tnb[ntok] = D; }
+				if (lane == 0) { tpos[ntok] = p; tinf[ntok] = X3_TOK_MISS | (dup ? X3_TOK_DUP : 0u) | len; thb[ntok] = hits; tnb[ntok] = D; tmb[ntok] = mbytes; }
+				mbytes += len;
 				ntok++;
 				x3_wave_sync(); /* every lane has finished probing before lane 0 inserts */
 				if (!dup) {
@@ -207,7 +209,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 				p += len;
 			}
 			if (lane == 0) {
-				S.p = p; S.ntok = ntok; S.hits = hits; S.D = D; S.lenmask = lenmask; S.hlog = hlog;
+				S.p = p; S.ntok = ntok; S.hits = hits; S.D = D; S.lenmask = lenmask; S.hlog = hlog; S.mbytes = mbytes;
 				S.flag = out_flag;
 			}
 		}
@@ -216,7 +218,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 
 	if (tid == 0) {
 		X3ParseResult r;
-		r.ntok = S.ntok; r.dict_elems = S.D; r.hits = S.hits; r.status = X3_ST_OK;
+		r.ntok = S.ntok; r.dict_elems = S.D; r.hits = S.hits; r.status = X3_ST_OK; r.miss_bytes = S.mbytes; r._r0 = r._r1 = r._r2 = 0;
 		a.result[blockIdx.x] = r;
 	}
 }

@@ -73,6 +73,8 @@ struct X3Code2Bufs {
 	DevBuf tmp, offs, chunkmeta;
 	DevBuf a[48]; /* u32 work arrays of max(hits, events)+4 entries */
 	DevBuf idxfreq, hsym, maxred;
+	DevBuf y[12]; /* u32 arrays over coded symbols */
+	DevBuf ms[16]; /* u32 arrays over new-fragment lengths / bytes */
 };
 
 struct X3Code2Stats { double ms_features, ms_pass1, ms_post, ms_pass2; };
@@ -80,6 +82,6 @@ struct X3Code2Stats { double ms_features, ms_pass1, ms_post, ms_pass2; };
 int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h_chunks, const X3Chunk *d_chunks,
                    const X3ParseResult *h_parsed, const X3ParseResult *d_parsed,
                    const uint8_t *d_bytes, const uint32_t *tok_pos, const uint32_t *tok_info, const uint32_t *tok_hb,
-                   const uint32_t *tok_nb, uint8_t *d_out, X3CodeResult *d_result);
+                   const uint32_t *tok_nb, const uint32_t *tok_mb, uint8_t *d_out, X3CodeResult *d_result);
 
 #endif /* X3_HOST_H */

@@ -49,7 +49,7 @@ struct X3Chunk {           /* one independent x3 stream */
 	uint64_t out_cap;      /* bytes reserved (multiple of 4)                                             */
 };
 
-struct X3ParseResult { uint32_t ntok, dict_elems, hits, status; };
+struct X3ParseResult { uint32_t ntok, dict_elems, hits, status, miss_bytes, _r0, _r1, _r2; };
 struct X3CodeResult  { uint32_t out_len, status, pairs, _r; uint32_t events[8]; };
 
 struct X3CtxHdr { uint32_t off, items, cap, total; };   /* one context: items live in the pool at [off, off+items) */
@@ -83,6 +83,7 @@ struct X3ParseArgs {
 	uint32_t *tok_info;
 	uint32_t *tok_hb;           /* per step: number of hits before it (index of a hit among the hits)            */
 	uint32_t *tok_nb;           /* per step: dictionary elements before it (== tag a new fragment would get)     */
+	uint32_t *tok_mb;           /* per step: bytes of new fragments before it (symbol index = 2*step + tok_mb)   */
 	X3ParseResult *result;
 	uint32_t factor1, factor2;
 	int32_t  nl_mode;
