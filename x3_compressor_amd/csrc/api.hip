@@ -106,10 +106,12 @@ extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 	hipSetDevice(c->device);
 	if (c->stream) hipStreamSynchronize(c->stream);
 	DevBuf *bufs[] = { &c->pad, &c->m, &c->dict_pos, &c->dict_len, &c->ht, &c->tok_pos, &c->tok_info, &c->tok_hb, &c->tok_nb, &c->tok_mb, &c->chunks, &c->presult,
-		               &c->c2.tmp, &c->c2.offs, &c->c2.chunkmeta, &c->c2.idxfreq, &c->c2.hsym, &c->c2.maxred,
+		               &c->c2.tmp, &c->c2.offs, &c->c2.chunkmeta, &c->c2.idxfreq, &c->c2.hsym, &c->c2.maxred, &c->c2.pp[0], &c->c2.pp[1], &c->c2.pp[2], &c->c2.pp[3],
 		               &c->cresult, &c->mtf, &c->idxfreq, &c->ctx1, &c->ctx0, &c->items, &c->pkey, &c->pval, &c->out, &c->counts };
 	for (DevBuf *b : bufs) b->release();
 	for (DevBuf &b : c->c2.a) b.release();
+	for (DevBuf &b : c->c2.y) b.release();
+	for (DevBuf &b : c->c2.ms) b.release();
 	for (int i = 0; i < 6; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
 	if (c->stream) hipStreamDestroy(c->stream);
 	delete c;
@@ -151,11 +153,11 @@ static int stage_inputs(x3h_ctx *c, const x3h_params *prm, const RunIO &io, uint
 	CHK(c->m.reserve(boff + 256));
 	CHK(c->dict_pos.reserve(eoff * 4));
 	CHK(c->dict_len.reserve(eoff));
-	CHK(c->tok_pos.reserve(eoff * 4));
-	CHK(c->tok_info.reserve(eoff * 4));
-	CHK(c->tok_hb.reserve(eoff * 4));
-	CHK(c->tok_nb.reserve(eoff * 4));
-	CHK(c->tok_mb.reserve(eoff * 4));
+	CHK(c->tok_pos.reserve((eoff + 4) * 4));
+	CHK(c->tok_info.reserve((eoff + 4) * 4));
+	CHK(c->tok_hb.reserve((eoff + 4) * 4));
+	CHK(c->tok_nb.reserve((eoff + 4) * 4));
+	CHK(c->tok_mb.reserve((eoff + 4) * 4));
 	CHK(c->ht.reserve(hoff * 4));
 	CHK(c->chunks.reserve((size_t)nc * sizeof(X3Chunk)));
 	CHK(c->presult.reserve((size_t)nc * sizeof(X3ParseResult)));
@@ -209,12 +211,14 @@ static int run(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage upto
 	pa.bytes = sa.bytes; pa.chunks = sa.chunks; pa.m = sa.m;
 	pa.dict_pos = c->dict_pos.as<uint32_t>(); pa.dict_len = c->dict_len.as<uint8_t>();
 	pa.ht = c->ht.as<uint32_t>();
-	pa.tok_pos = c->tok_pos.as<uint32_t>(); pa.tok_info = c->tok_info.as<uint32_t>();
-	pa.tok_hb = c->tok_hb.as<uint32_t>(); pa.tok_nb = c->tok_nb.as<uint32_t>(); pa.tok_mb = c->tok_mb.as<uint32_t>();
+	pa.tok_info = c->tok_info.as<uint32_t>();
+	uint32_t *tok_pos = c->tok_pos.as<uint32_t>(), *tok_hb = c->tok_hb.as<uint32_t>(), *tok_nb = c->tok_nb.as<uint32_t>(), *tok_mb = c->tok_mb.as<uint32_t>();
 	pa.result = c->presult.as<X3ParseResult>();
 	pa.factor1 = prm.factor1; pa.factor2 = prm.factor2; pa.nl_mode = prm.nl_mode;
 	x3k_launch_parse(&pa, (uint32_t)nc, c->stream);
 	HIPCHK(hipGetLastError());
+	CHK(x3_token_postpass(c->c2, c->stream, nc, c->hchunks.data(), c->chunks.as<X3Chunk>(), pa.result, pa.tok_info, pa.dict_len,
+	                      tok_pos, tok_hb, tok_nb, tok_mb));
 	HIPCHK(hipEventRecord(c->ev[3], c->stream));
 	c->hparse.resize((size_t)nc);
 	HIPCHK(hipMemcpyAsync(c->hparse.data(), c->presult.p, (size_t)nc * sizeof(X3ParseResult), hipMemcpyDeviceToHost, c->stream));
@@ -254,7 +258,7 @@ static int run(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage upto
 	if (!c->code_v1) {
 		/* v2: parallel feature extraction (sorts / scans / count-smaller-before) + two thin serial passes (code2.hip) */
 		CHK(x3_code_v2_run(c->c2, c->stream, nc, c->hchunks.data(), c->chunks.as<X3Chunk>(), c->hparse.data(), pa.result,
-		                   sa.bytes, pa.tok_pos, pa.tok_info, pa.tok_hb, pa.tok_nb, pa.tok_mb, d_out, c->cresult.as<X3CodeResult>()));
+		                   sa.bytes, tok_pos, pa.tok_info, tok_hb, tok_nb, tok_mb, d_out, c->cresult.as<X3CodeResult>()));
 	} else {
 		/* v1 (kept for A/B runs, X3H_CODE_V1=1): one wavefront per stream walks the tokens over growable tables (code.hip) */
 		CHK(c->mtf.reserve(toff * 4));
@@ -269,7 +273,7 @@ static int run(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage upto
 		HIPCHK(hipMemsetAsync(c->pkey.p, 0, poff * 8, c->stream));
 		X3CodeArgs ca;
 		ca.bytes = sa.bytes; ca.chunks = sa.chunks;
-		ca.tok_pos = pa.tok_pos; ca.tok_info = pa.tok_info; ca.parsed = pa.result;
+		ca.tok_pos = tok_pos; ca.tok_info = pa.tok_info; ca.parsed = pa.result;
 		ca.mtf = c->mtf.as<uint32_t>(); ca.idxfreq = c->idxfreq.as<uint32_t>();
 		ca.ctx1 = c->ctx1.as<X3CtxHdr>(); ca.ctx0 = c->ctx0.as<X3CtxHdr>();
 		ca.items = c->items.as<uint64_t>();

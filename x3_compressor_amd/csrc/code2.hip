@@ -94,14 +94,20 @@ struct X3ModesArgs {
 	const uint32_t *ho, *dof;          /* per chunk: first hit, first tag */
 	const uint32_t *f0, *t0, *f1, *t1; /* per hit: freq/total in ctx0 and ctx1 (freq 0 == tag absent) */
 	const uint32_t *rank, *dk, *step;  /* per hit: MTF rank, dictionary size at that step, step index */
-	uint32_t *idxfreq;                 /* per tag slot (by rank), pre-set to 1 */
-	uint32_t *mode, *rfreq, *itot;     /* out per hit */
-	uint32_t *pe0, *pe1;               /* out per hit: model_events freq of E_CTX0 / E_CTX1 before the hit */
-	uint32_t *evfinal;                 /* out per chunk: final ev0, ev1, ev2, (pad) */
+	uint32_t *idxfreq;                 /* per tag slot (by rank), pre-set to 1: spill area for ranks >= X3_IDXF_LDS */
+	uint32_t *mode;                    /* out per hit: the chosen event (E_CTX0 / E_CTX1 / E_IDX1) */
 };
 
 #define X3_IDXF_LDS 32768u /* ranks whose model_index1 frequency lives in LDS (128 KiB); beyond that: global memory */
 
+/* A lone wavefront issues about one instruction per 5 cycles, so this loop is written for instruction count:
+ *   - the four IEEE divisions of x3.c:152-160 (ev0/tot, ev1/tot, ev2/tot, freq/idxtotal) are ONE vector division:
+ *     lane j of `num`/`den` holds operand pair j (lanes 0..2 keep model_events freqs persistently);
+ *   - the two multiplies are one v_mul (lane 2 multiplies by lane 3's quotient);
+ *   - the argmax with its tie order runs on the scalar unit, comparing the float BIT PATTERNS as unsigned integers
+ *     (all probabilities are >= +0, so the orders coincide; no NaN can arise);
+ *   - only the 2-bit mode is recorded (v_writelane); model_events / model_index1 values at every hit are recovered
+ *     afterwards by prefix sums over the modes. */
 __device__ static void x3_modes_body(const X3ModesArgs &a)
 {
 	X3_LDS uint32_t sidx[X3_IDXF_LDS];
@@ -111,48 +117,45 @@ __device__ static void x3_modes_body(const X3ModesArgs &a)
 	const uint32_t nl = Dc < X3_IDXF_LDS ? Dc : X3_IDXF_LDS;
 	for (uint32_t i = lane; i < nl; i += X3_WAVE) sidx[i] = 1;
 	x3_wave_sync();
-	uint32_t ev0 = 1024, ev1 = 1024, ev2 = 1, nidx = 0;
-	/* every lane walks the same sequence (wave-uniform); lane 0 owns the stores.  64 hits are fetched per round so the
-	 * feature loads are coalesced and off the dependent chain. */
+	uint32_t num = lane == 0 ? 1024u : lane == 1 ? 1024u : 1u; /* lanes 0..2: model_events freq of E_CTX0, E_CTX1, E_IDX1 (x3.c:239-241) */
+	uint32_t nidx = 0;
 	for (uint32_t base = 0; base < H; base += X3_WAVE) {
 		const uint32_t g = h0 + base + lane;
 		const bool in = base + lane < H;
 		const uint32_t vf0 = in ? a.f0[g] : 0, vt0 = in ? a.t0[g] : 1, vf1 = in ? a.f1[g] : 0, vt1 = in ? a.t1[g] : 1;
 		const uint32_t vr = in ? a.rank[g] : 0, vd = in ? a.dk[g] : 1, vs = in ? a.step[g] : 0;
-		/* the parts of the products that do not depend on the serial state: (float)freq / (float)total (context.c:114-133) */
-		const float q0 = vf0 ? (float)vf0 / (float)vt0 : 0.f, q1 = vf1 ? (float)vf1 / (float)vt1 : 0.f;
-		const float vfet = (float)(2051u + vs); /* model_events.total: 2051 + one per earlier step */
-		uint32_t mymode = 0, myrf = 0, myit = 0, mye0 = 0, mye1 = 0;
+		/* independent of the serial state: (float)freq / (float)total of the context item (context.c:114-133); 0 == absent */
+		const uint32_t vq0 = __float_as_uint(vf0 ? (float)vf0 / (float)vt0 : 0.f);
+		const uint32_t vq1 = __float_as_uint(vf1 ? (float)vf1 / (float)vt1 : 0.f);
+		const uint32_t vtot = 2051u + vs; /* model_events.total: 2051 + one per earlier step */
+		uint32_t rec = 0;
 		const uint32_t cnt = H - base < X3_WAVE ? H - base : X3_WAVE;
 		for (uint32_t l = 0; l < cnt; l++) {
-			const float p0q = __uint_as_float(x3_readlane_u32(__float_as_uint(q0), l));
-			const float p1q = __uint_as_float(x3_readlane_u32(__float_as_uint(q1), l));
-			const float fet = __uint_as_float(x3_readlane_u32(__float_as_uint(vfet), l));
-			const uint32_t r = x3_readlane_u32(vr, l), dk = x3_readlane_u32(vd, l);
-			const uint32_t rf = r < X3_IDXF_LDS ? sidx[r] : idxf[r];
+			const uint32_t r = x3_readlane_u32(vr, l), dk = x3_readlane_u32(vd, l), tot = x3_readlane_u32(vtot, l);
+			const uint32_t q0 = x3_readlane_u32(vq0, l), q1 = x3_readlane_u32(vq1, l);
+			const uint32_t rf = x3_readlane_u32(r < X3_IDXF_LDS ? sidx[r < X3_IDXF_LDS ? r : 0] : idxf[r], 0);
 			const uint32_t itot = dk + nidx;
-			/* x3.c:152-160: a context that does not hold the tag has probability 0 (q == 0 exactly then) */
-			const float p0 = p0q != 0.f ? ((float)ev0 / fet) * p0q : 0.f;
-			const float p1 = p1q != 0.f ? ((float)ev1 / fet) * p1q : 0.f;
-			const float pi = ((float)ev2 / fet) * ((float)rf / (float)itot);
-			uint32_t mode = X3_E_IDX1;
-			float best = pi;
+			num = x3_writelane_u32(num, rf, 3);
+			const uint32_t den = x3_writelane_u32(tot, itot, 3);
+			const float quot = (float)num / (float)den; /* lanes 0..3: ev0/tot, ev1/tot, ev2/tot, rf/itot */
+			uint32_t mult = x3_writelane_u32(q0, q1, 1);
+			mult = x3_writelane_u32(mult, x3_readlane_u32(__float_as_uint(quot), 3), 2);
+			const uint32_t p = __float_as_uint(quot * __uint_as_float(mult)); /* lane 0: p_ctx0, 1: p_ctx1, 2: p_idx1 */
+			const uint32_t p0 = x3_readlane_u32(p, 0), p1 = x3_readlane_u32(p, 1), pi = x3_readlane_u32(p, 2);
+			uint32_t mode = X3_E_IDX1, best = pi; /* x3.c:162-172: IDX1, then CTX0, then CTX1, strict > */
 			if (p0 > best) { mode = X3_E_CTX0; best = p0; }
-			if (p1 > best) { mode = X3_E_CTX1; best = p1; }
-			if (lane == l) { mye0 = ev0; mye1 = ev1; }
-			if (mode == X3_E_CTX0) ev0++;
-			else if (mode == X3_E_CTX1) ev1++;
-			else {
-				ev2++; nidx++;
-				x3_wave_sync(); /* every lane has read the frequency of rank r */
+			if (p1 > best) mode = X3_E_CTX1;
+			num = x3_writelane_u32(num, x3_readlane_u32(num, mode) + 1, mode); /* inc_model(&model_events, mode), x3.c:177 */
+			if (mode == X3_E_IDX1) { /* inc_model(&model_index1, index), x3.c:188 */
+				nidx++;
+				x3_wave_sync();
 				if (lane == 0) { if (r < X3_IDXF_LDS) sidx[r] = rf + 1; else idxf[r] = rf + 1; }
-				x3_wave_sync(); /* the next hit may read this rank */
+				x3_wave_sync();
 			}
-			if (lane == l) { mymode = mode; myrf = rf; myit = itot; }
+			rec = x3_writelane_u32(rec, mode, l);
 		}
-		if (in) { a.mode[g] = mymode; a.rfreq[g] = myrf; a.itot[g] = myit; a.pe0[g] = mye0; a.pe1[g] = mye1; }
+		if (in) a.mode[g] = rec;
 	}
-	if (lane == 0) { a.evfinal[4 * c + 0] = ev0; a.evfinal[4 * c + 1] = ev1; a.evfinal[4 * c + 2] = ev2; a.evfinal[4 * c + 3] = 0; }
 }
 
 /* ============================================================================================================
@@ -169,7 +172,7 @@ __device__ static void x3_modes_body(const X3ModesArgs &a)
 struct X3Ac2Args {
 	const uint32_t *yo;                   /* per chunk: first symbol (nc+1) */
 	const uint32_t *scum, *sfreq, *stot;  /* per symbol */
-	uint32_t *rec_nk, *rec_bits;          /* out per symbol: n | k<<8, and the top n bits of lo before the shift */
+	uint32_t *rec_nk, *rec_bits;          /* out per symbol: n | k<<8, and lo before the shift (its top n bits are the emitted bits) */
 	uint32_t *final_lo;                   /* out per chunk */
 };
 
@@ -184,30 +187,36 @@ __device__ static void x3_ac2_body(const X3Ac2Args &a)
 		const bool in = base + lane < Y;
 		const uint32_t vcum = in ? a.scum[y0 + base + lane] : 0, vfq = in ? a.sfreq[y0 + base + lane] : 1;
 		const uint32_t vtot = in ? a.stot[y0 + base + lane] : 1;
-		const uint64_t M = ((uint64_t)1 << 62) / vtot + 1;
-		const uint32_t vmh = (uint32_t)(M >> 32), vml = (uint32_t)M, vchi = vcum + vfq;
-		uint32_t mynk = 0, mybits = 0;
+		/* range / total as a multiply-shift (Granlund-Montgomery, N = 31): L = ceil(log2 total), m = ceil(2^(31+L)/total) < 2^32,
+		 * floor(range*m / 2^(31+L)) == floor(range/total) for every range <= 2^31 because m*total - 2^(31+L) < total <= 2^L.
+		 * The 64 lanes prepare (m, shift) for 64 symbols at once, off the serial chain. */
+		const uint32_t vL = vtot <= 1 ? 0u : 32u - (uint32_t)x3_clz32(vtot - 1);
+		const uint32_t vm = (uint32_t)((((uint64_t)1 << (31 + vL)) + vtot - 1) / vtot), vsh = 31 + vL, vchi = vcum + vfq;
+		uint32_t rec_a = 0, rec_b = 0;
 		const uint32_t cnt = Y - base < X3_WAVE ? Y - base : X3_WAVE;
 		for (uint32_t l = 0; l < cnt; l++) {
 			const uint32_t clo = x3_readlane_u32(vcum, l), chi = x3_readlane_u32(vchi, l);
-			const uint32_t mh = x3_readlane_u32(vmh, l), ml = x3_readlane_u32(vml, l);
-			const uint32_t range = hi - lo + 1;
-			const uint64_t u = (uint64_t)range * mh + x3_mulhi_u32(range, ml);
-			const uint32_t step = (uint32_t)(u >> 30);
+			const uint32_t m = x3_readlane_u32(vm, l), sh = x3_readlane_u32(vsh, l);
+			const uint32_t step = (uint32_t)(((uint64_t)(hi - lo + 1) * m) >> sh);
 			const uint32_t nhi = lo + step * chi - 1, nlo = lo + step * clo;
 			const uint32_t x = nlo ^ nhi;
-			const uint32_t n = x ? (uint32_t)x3_clz32(x) - 1 : 31u;
-			const uint32_t bits = n ? nlo >> (31 - n) : 0u;
-			const uint32_t ones = n >= 31 ? 0x7FFFFFFFu : ((1u << n) - 1);
-			lo = n >= 31 ? 0u : (nlo << n) & 0x7FFFFFFFu;
-			hi = n >= 31 ? 0x7FFFFFFFu : ((nhi << n) | ones) & 0x7FFFFFFFu;
-			const uint32_t yv = (~lo | hi) & 0x3FFFFFFFu;
-			const uint32_t k = yv ? (uint32_t)x3_clz32(yv) - 2 : 30u;
-			lo = (lo << k) & 0x3FFFFFFFu;
-			hi = (((hi << k) | ((1u << k) - 1)) & 0x3FFFFFFFu) | 0x40000000u;
-			if (lane == l) { mynk = n | (k << 8); mybits = bits; }
+			uint32_t n, k;
+			if (x != 0) {
+				/* E1/E2 (ac.c:49-67): the n leading bits on which lo and hi agree leave; E3 (ac.c:70-74): then the k positions
+				 * below the top bit where lo has 1 and hi has 0.  Both are left shifts, applied at once (n + k <= 30). */
+				n = (uint32_t)x3_clz32(x) - 1;
+				const uint32_t y = ((((nhi | ~nlo) << n) | ~(0xFFFFFFFFu << n)) & 0x3FFFFFFFu);
+				k = y ? (uint32_t)x3_clz32(y) - 2 : 30u - n;
+				const uint32_t s = n + k;
+				lo = (nlo << s) & 0x3FFFFFFFu;
+				hi = (((nhi << s) | ~(0xFFFFFFFFu << s)) & 0x3FFFFFFFu) | 0x40000000u;
+			} else { /* lo == hi (needs total > 2^28): all 31 bits leave */
+				n = 31; k = 0; lo = 0; hi = 0x7FFFFFFFu;
+			}
+			rec_a = x3_writelane_u32(rec_a, n | (k << 8), l);
+			rec_b = x3_writelane_u32(rec_b, nlo, l);
 		}
-		if (in) { a.rec_nk[y0 + base + lane] = mynk; a.rec_bits[y0 + base + lane] = mybits; }
+		if (in) { a.rec_nk[y0 + base + lane] = rec_a; a.rec_bits[y0 + base + lane] = rec_b; }
 	}
 	if (lane == 0) a.final_lo[c] = lo;
 }
@@ -302,6 +311,57 @@ static int ctx_stats(X3Code2Bufs &B, hipStream_t st, size_t nH, int gbits, int t
 	return X3H_OK;
 }
 
+/* ============================================================================================================
+ * K2 post-pass: the parse walker only emits one word per step (tag or fragment length); positions and the running
+ * counts the coding stage indexes with are prefix sums over that list.
+ *   tok_pos = sum of earlier step lengths (dict_len of the tag / fragment length)      (x3.c:394,422: p += len)
+ *   tok_hb  = earlier hits, tok_nb = earlier inserted elements, tok_mb = earlier new-fragment bytes
+ * ============================================================================================================ */
+int x3_token_postpass(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h_chunks, const X3Chunk *d_chunks,
+                      const X3ParseResult *d_parsed, const uint32_t *tok_info, const uint8_t *dict_len,
+                      uint32_t *tok_pos, uint32_t *tok_hb, uint32_t *tok_nb, uint32_t *tok_mb)
+{
+	const uint32_t nc = (uint32_t)nchunks;
+	std::vector<uint32_t> eo(nc + 1);
+	uint64_t tot = 0;
+	for (uint32_t c = 0; c < nc; c++) { eo[c] = (uint32_t)h_chunks[c].elem_off; tot = h_chunks[c].elem_off + h_chunks[c].len + 16; }
+	if (tot >= (1ull << 31)) return X3H_E_ARG;
+	eo[nc] = (uint32_t)tot;
+	const size_t n = tot;
+	CHK(B.offs.reserve((size_t)(nc + 1) * 8 * 4));
+	uint32_t *d_eo = B.offs.as<uint32_t>() + (size_t)(nc + 1) * 7;
+	HIPCHK(hipMemcpyAsync(d_eo, eo.data(), (nc + 1) * 4, hipMemcpyHostToDevice, st));
+	for (int i = 0; i < 4; i++) CHK(B.pp[i].reserve((n + 4) * 4));
+	uint32_t *vh = B.pp[0].as<uint32_t>(), *vn = B.pp[1].as<uint32_t>(), *vm = B.pp[2].as<uint32_t>(), *vl = B.pp[3].as<uint32_t>();
+	x3_foreach(n, st, X3_LAMBDA(size_t i) {
+		const uint32_t c = find_chunk(d_eo, nc, (uint32_t)i);
+		const uint32_t k = (uint32_t)i - d_eo[c];
+		uint32_t h = 0, nw = 0, mb = 0, ln = 0;
+		if (k < d_parsed[c].ntok) {
+			const uint32_t info = tok_info[i];
+			if (!(info & X3_TOK_MISS)) { h = 1; ln = dict_len[d_chunks[c].elem_off + info]; }
+			else { ln = mb = info & 0x3Fu; nw = (info & X3_TOK_DUP) ? 0u : 1u; }
+		}
+		vh[i] = h; vn[i] = nw; vm[i] = mb; vl[i] = ln;
+	});
+	CHK(x3p_excl_scan(B.tmp, vh, tok_hb, n, st));
+	CHK(x3p_excl_scan(B.tmp, vn, tok_nb, n, st));
+	CHK(x3p_excl_scan(B.tmp, vm, tok_mb, n, st));
+	CHK(x3p_excl_scan(B.tmp, vl, tok_pos, n, st));
+	/* make them stream-relative (every stream restarts at 0); in place: element i only needs the value at its chunk start,
+	 * which is read before any element of that chunk is rewritten only if the start itself goes last -> use a snapshot */
+	uint32_t *base = vh; /* vh..vl are dead: 4 words per chunk */
+	x3_foreach(nc, st, X3_LAMBDA(size_t c) {
+		const uint32_t s = d_eo[c];
+		base[4 * c] = tok_hb[s]; base[4 * c + 1] = tok_nb[s]; base[4 * c + 2] = tok_mb[s]; base[4 * c + 3] = tok_pos[s];
+	});
+	x3_foreach(n, st, X3_LAMBDA(size_t i) {
+		const uint32_t c = find_chunk(d_eo, nc, (uint32_t)i);
+		tok_hb[i] -= base[4 * c]; tok_nb[i] -= base[4 * c + 1]; tok_mb[i] -= base[4 * c + 2]; tok_pos[i] -= base[4 * c + 3];
+	});
+	return X3H_OK;
+}
+
 /* ============================================================================================================ */
 int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h_chunks, const X3Chunk *d_chunks,
                    const X3ParseResult *h_parsed, const X3ParseResult *d_parsed,
@@ -326,7 +386,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	if (nB > nA) nA = nB;
 	nA += 4;
 
-	CHK(B.offs.reserve((size_t)(nc + 1) * 7 * 4));
+	CHK(B.offs.reserve((size_t)(nc + 1) * 8 * 4));
 	uint32_t *d_so = B.offs.as<uint32_t>(), *d_ho = d_so + (nc + 1), *d_eo = d_ho + (nc + 1), *d_dof = d_eo + (nc + 1);
 	uint32_t *d_mo = d_dof + (nc + 1), *d_bo = d_mo + (nc + 1), *d_yo = d_bo + (nc + 1);
 	HIPCHK(hipMemcpyAsync(d_mo, mo.data(), (nc + 1) * 4, hipMemcpyHostToDevice, st));
@@ -456,28 +516,59 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		X3ModesArgs ma;
 		ma.parsed = d_parsed; ma.ho = d_ho; ma.dof = d_dof;
 		ma.f0 = f0; ma.t0 = t0; ma.f1 = f1; ma.t1 = t1; ma.rank = h_rank; ma.dk = h_dk; ma.step = h_step;
-		ma.idxfreq = idxf; ma.mode = mode; ma.rfreq = rfreq; ma.itot = itot; ma.pe0 = T[26]; ma.pe1 = T[27]; ma.evfinal = m_evfinal;
+		ma.idxfreq = idxf; ma.mode = mode;
 		launch_modes(ma, nc, st);
 		HIPCHK(hipGetLastError());
 
-		/* ---- cum_freq of the IDX1-coded ranks: rank + #{earlier IDX1 hits of the stream with a smaller rank} ---- */
-		uint32_t *zi = T[0], *ci = T[1], *key = T[2], *org = T[3], *bs = T[4], *be = T[5], *cnt = T[6];
-		x3_foreach(nH, st, X3_LAMBDA(size_t i) { zi[i] = mode[i] == X3_E_IDX1 ? 1u : 0u; });
+		/* ---- model_events / model_index1 state at every hit, recovered from the modes by prefix sums ---- */
+		uint32_t *zi = T[0], *ci = T[1], *key = T[2], *org = T[3], *bs = T[4], *be = T[5], *cnt = T[6], *kin2 = T[7];
+		uint32_t *z0 = T[17], *c0s = T[18], *z1 = T[19], *c1s = T[20], *cid = T[21], *s1k = T[22], *s1v = T[23], *s2k = T[24], *s2v = T[25];
+		uint32_t *pe0w = T[26], *pe1w = T[27];
+		x3_foreach(nH, st, X3_LAMBDA(size_t i) {
+			const uint32_t m = mode[i];
+			z0[i] = m == X3_E_CTX0 ? 1u : 0u; z1[i] = m == X3_E_CTX1 ? 1u : 0u; zi[i] = m == X3_E_IDX1 ? 1u : 0u;
+		});
+		CHK(x3p_excl_scan(B.tmp, z0, c0s, nH, st));
+		CHK(x3p_excl_scan(B.tmp, z1, c1s, nH, st));
 		CHK(x3p_excl_scan(B.tmp, zi, ci, nH, st));
 		uint32_t nI = 0;
 		HIPCHK(hipMemcpyAsync(&nI, ci + nH, 4, hipMemcpyDeviceToHost, st));
-		HIPCHK(hipStreamSynchronize(st));
 		x3_foreach(nH, st, X3_LAMBDA(size_t i) {
+			const uint32_t c = find_chunk(d_ho, nc, (uint32_t)i), lo = d_ho[c];
+			pe0w[i] = 1024u + c0s[i] - c0s[lo];          /* model_events freq of E_CTX0 before this hit */
+			pe1w[i] = 1024u + c1s[i] - c1s[lo];
+			itot[i] = h_dk[i] + ci[i] - ci[lo];          /* model_index1.total: one per element + one per earlier IDX1 use */
 			if (mode[i] == X3_E_IDX1) {
 				const uint32_t j = ci[i];
-				const uint32_t c = find_chunk(d_ho, nc, (uint32_t)i);
-				key[j] = h_rank[i]; org[j] = (uint32_t)i; bs[j] = ci[d_ho[c]]; be[j] = ci[d_ho[c + 1]];
+				key[j] = h_rank[i]; org[j] = (uint32_t)i; bs[j] = ci[lo]; be[j] = ci[d_ho[c + 1]]; cid[j] = c;
 			}
 		});
+		x3_foreach(nc, st, X3_LAMBDA(size_t c) {
+			const uint32_t lo = d_ho[c], hi = d_ho[c + 1];
+			m_evfinal[4 * c + 0] = 1024u + c0s[hi] - c0s[lo];
+			m_evfinal[4 * c + 1] = 1024u + c1s[hi] - c1s[lo];
+			m_evfinal[4 * c + 2] = 1u + ci[hi] - ci[lo];
+			m_evfinal[4 * c + 3] = 0;
+		});
+		HIPCHK(hipStreamSynchronize(st));
 		uint64_t maxD = 1;
 		for (uint32_t c = 0; c < nc; c++) if (h_parsed[c].dict_elems > maxD) maxD = h_parsed[c].dict_elems;
-		CHK(csb_run(B, st, nI, bits_for(maxD), key, bs, be, cnt, T + 8));
-		x3_foreach(nI, st, X3_LAMBDA(size_t j) { rcum[org[j]] = h_rank[org[j]] + cnt[j]; });
+		if (nI) {
+			/* freq of the coded rank = 1 + earlier IDX1 hits of the stream with the same rank: runs of (stream, rank) */
+			CHK(x3p_sort_pairs(B.tmp, key, s1k, org, s1v, nI, bits_for(maxD), st));
+			x3_foreach(nI, st, X3_LAMBDA(size_t j) { kin2[j] = find_chunk(d_ho, nc, s1v[j]); });
+			CHK(x3p_sort_pairs(B.tmp, kin2, s2k, s1v, s2v, nI, bits_for(nc), st));
+			x3_foreach(nI, st, X3_LAMBDA(size_t j) {
+				const bool start = j == 0 || s2k[j - 1] != s2k[j] || h_rank[s2v[j - 1]] != h_rank[s2v[j]];
+				z0[j] = start ? (uint32_t)j : 0u;
+			});
+			CHK(x3p_incl_max_scan(B.tmp, z0, z1, nI, st));
+			x3_foreach(nI, st, X3_LAMBDA(size_t j) { rfreq[s2v[j]] = 1u + (uint32_t)j - z1[j]; });
+			/* cum_freq of the coded rank = rank + earlier IDX1 hits of the stream with a smaller rank */
+			CHK(csb_run(B, st, nI, bits_for(maxD), key, bs, be, cnt, T + 8));
+			x3_foreach(nI, st, X3_LAMBDA(size_t j) { rcum[org[j]] = h_rank[org[j]] + cnt[j]; });
+		}
+		(void)cid;
 
 		/* ---- the tag / index symbol of every hit ---- */
 		uint32_t *scum = T[0], *sfreq = T[1], *stot = T[2]; /* zi/ci/key are dead now */
@@ -601,7 +692,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		const uint32_t capw = (uint32_t)(d_chunks[c].out_cap / 4);
 		const uint32_t n = rec_nk[i] & 0xFF, pd = ln - n;
 		const uint64_t bp = pos[i] - pos[d_yo[c]];
-		const uint32_t rev = x3_brev32(rec_bits[i]) >> (32 - n); /* bit j = j-th emitted bit */
+		const uint32_t rev = x3_brev32(rec_bits[i] << 1) & (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1)); /* bit j = j-th emitted bit = bit 30-j of lo */
 		if (!pd) x3_or_bits(out32, capw, bp, rev, n);
 		else {
 			x3_or_bits(out32, capw, bp, rev & 1u, 1);

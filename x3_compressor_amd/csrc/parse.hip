@@ -56,13 +56,11 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 	uint32_t *dpos = a.dict_pos + ck.elem_off;
 	uint8_t *dlen = a.dict_len + ck.elem_off;
 	uint32_t *ht = a.ht + ck.ht_off;
-	uint32_t *tpos = a.tok_pos + ck.elem_off;
 	uint32_t *tinf = a.tok_info + ck.elem_off;
-	uint32_t *thb = a.tok_hb + ck.elem_off; /* hits before this step   */
-	uint32_t *tnb = a.tok_nb + ck.elem_off; /* dictionary elements before this step */
-	uint32_t *tmb = a.tok_mb + ck.elem_off; /* new-fragment bytes before this step   */
 	const uint32_t tid = threadIdx.x, lane = x3_lane(), wave = tid / X3_WAVE;
 	const uint32_t f1 = a.factor1, f2 = a.factor2;
+	/* length lane+1 survives the factor1 filter iff L(p+lane) <= thr (L == 0 always does; lanes 0,1 are exempt, backend.c:79) */
+	const uint32_t thr = (lane < 2 || f1 == 0 || lane >= 32) ? 255u : (lane + 1) / f1;
 
 	if (tid == 0) {
 		S.p = 0; S.blk = 0; S.D = 0; S.lenmask = 0; S.hlog = X3_HT_LOG2_MIN < ck.ht_log2_max ? X3_HT_LOG2_MIN : ck.ht_log2_max;
@@ -128,19 +126,26 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 		__syncthreads();
 
 		if (wave == 0) {
-			/* ---- serial parse out of LDS ---- */
+			/* ---- serial parse out of LDS.  One wavefront issues ~1 instruction / 5 cycles, so the loop is written for
+			 * instruction count: the factor1 filter is one compare against a per-lane constant, a token is one
+			 * v_writelane (stored 64 at a time), and nothing but p / ntok / hits is tracked -- positions and the running
+			 * counts K3 needs are prefix sums over the token list, computed in parallel afterwards (api.hip). ---- */
 			uint32_t p = S.p, ntok = S.ntok, hits = S.hits, D = S.D, lenmask = S.lenmask, hlog = S.hlog, mbytes = S.mbytes;
 			const uint32_t blk = S.blk;
-			uint32_t out_flag = 0;
+			uint32_t out_flag = 0, rec = 0, recbase = ntok;
 			for (;;) {
+				if (ntok - recbase == X3_WAVE) { /* flush 64 buffered tokens, coalesced */
+					tinf[recbase + lane] = rec;
+					recbase = ntok;
+				}
 				if (p >= n) { out_flag = FLAG_DONE; break; }
 				const uint32_t idx = p - blk;
 				if (idx >= PB) { out_flag = FLAG_REFILL; break; }
-				const uint32_t Li = lane < 32 ? sL[idx + (lane & 31)] : 0;
+				const uint32_t Li = sL[idx + (lane & 31)];
 				const uint32_t mp = sM[idx];
-				/* backend.c:79-83 : reject length i+1 when a dictionary string at p+i is "long enough" */
-				int ok = 1;
-				if (lane >= 2 && f1 > 0 && Li != 0 && (uint64_t)Li * f1 > (uint64_t)(lane + 1)) ok = 0;
+				const uint32_t tag = sE[idx];
+				/* backend.c:79-83 : length i+1 is rejected when a dictionary string at p+i has len*factor1 > i+1 */
+				int ok = Li <= thr;
 				if (f2 > 0) { /* backend.c:84-90 : max over o in [1,i] of (L(p+o)-o)*factor2 > i+1 */
 					int v = (lane >= 1 && lane < 32 && Li != 0) ? (int)Li - (int)lane : -(1 << 20);
 					for (unsigned d = 1; d < 32; d <<= 1) {
@@ -149,13 +154,13 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 					}
 					if (lane >= 1 && (int64_t)v * (int64_t)(int)f2 > (int64_t)(lane + 1)) ok = 0;
 				}
-				uint64_t okm = x3_ballot(ok && lane <= mp && lane < 32);
-				const uint32_t F = 1 + (63 - (uint32_t)x3_clz64(okm | 1)); /* lane 0 always passes */
-				const uint32_t L0 = x3_bcast_u32(Li, 0);
+				const uint32_t okm = (uint32_t)x3_ballot(ok) & (0xFFFFFFFFu >> (31 - mp)); /* lanes 0..m[p]; lane 0 always passes */
+				const uint32_t F = 32 - (uint32_t)x3_clz32(okm | 1u);
+				const uint32_t L0 = x3_readlane_u32(Li, 0);
 				uint32_t nlL0 = L0;
 				if (a.nl_mode) nlL0 = L0 == 1 ? 1 : L0 == 2 ? 4 : L0 == 3 ? 6 : L0 == 4 ? 8 : 9999; /* x3.c:357-370 */
 				if (L0 != 0 && nlL0 >= F && p + L0 <= n) {
-					if (lane == 0) { tpos[ntok] = p; tinf[ntok] = sE[idx]; thb[ntok] = hits; tnb[ntok] = D; tmb[ntok] = mbytes; }
+					rec = x3_writelane_u32(rec, tag, ntok - recbase);
 					ntok++; hits++;
 					p += L0;
 					continue;
@@ -171,34 +176,34 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 					const uint32_t hmask = (1u << hlog) - 1;
 					uint32_t slot = ht_slot(h, len, hlog);
 					for (uint32_t e = ht[slot]; e != 0; slot = (slot + 1) & hmask, e = ht[slot]) {
-						const uint32_t tag = e - 1;
-						if (dlen[tag] != len) continue;
-						const uint8_t *ds = b + dpos[tag];
+						const uint32_t tg = e - 1;
+						if (dlen[tg] != len) continue;
+						const uint8_t *ds = b + dpos[tg];
 						uint32_t k = 0;
 						while (k < len && ds[k] == sb[idx + k]) k++;
 						if (k == len) { dup = 1; break; }
 					}
 				}
-				if (lane == 0) { tpos[ntok] = p; tinf[ntok] = X3_TOK_MISS | (dup ? X3_TOK_DUP : 0u) | len; thb[ntok] = hits; tnb[ntok] = D; tmb[ntok] = mbytes; }
-				mbytes += len;
+				rec = x3_writelane_u32(rec, X3_TOK_MISS | (dup ? X3_TOK_DUP : 0u) | len, ntok - recbase);
 				ntok++;
+				mbytes += len;
 				x3_wave_sync(); /* every lane has finished probing before lane 0 inserts */
 				if (!dup) {
-					const uint32_t tag = D;
+					const uint32_t ntag = D;
 					uint32_t rebuild = 0;
 					if (2 * (D + 1) > (1u << hlog) && hlog < ck.ht_log2_max) { hlog++; rebuild = 1; }
 					if (lane == 0) {
-						dpos[tag] = p;
-						dlen[tag] = (uint8_t)len;
+						dpos[ntag] = p;
+						dlen[ntag] = (uint8_t)len;
 						if (!rebuild) {
 							uint32_t h = FNV_OFF;
 							for (uint32_t k = 0; k < len; k++) h = (h ^ sb[idx + k]) * FNV_MUL;
 							const uint32_t hmask = (1u << hlog) - 1;
 							uint32_t slot = ht_slot(h, len, hlog);
 							while (ht[slot] != 0) slot = (slot + 1) & hmask;
-							ht[slot] = tag + 1;
+							ht[slot] = ntag + 1;
 						}
-						S.new_pos = p; S.new_len = len; S.new_tag = tag; S.rebuild = rebuild;
+						S.new_pos = p; S.new_len = len; S.new_tag = ntag; S.rebuild = rebuild;
 					}
 					D++;
 					lenmask |= 1u << (len - 1);
@@ -208,6 +213,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 				}
 				p += len;
 			}
+			if (lane < ntok - recbase) tinf[recbase + lane] = rec;
 			if (lane == 0) {
 				S.p = p; S.ntok = ntok; S.hits = hits; S.D = D; S.lenmask = lenmask; S.hlog = hlog; S.mbytes = mbytes;
 				S.flag = out_flag;

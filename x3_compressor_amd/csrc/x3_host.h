@@ -74,10 +74,15 @@ struct X3Code2Bufs {
 	DevBuf a[48]; /* u32 work arrays of max(hits, events)+4 entries */
 	DevBuf idxfreq, hsym, maxred;
 	DevBuf y[12]; /* u32 arrays over coded symbols */
+	DevBuf pp[4]; /* token post-pass temporaries */
 	DevBuf ms[16]; /* u32 arrays over new-fragment lengths / bytes */
 };
 
 struct X3Code2Stats { double ms_features, ms_pass1, ms_post, ms_pass2; };
+
+int x3_token_postpass(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h_chunks, const X3Chunk *d_chunks,
+                      const X3ParseResult *d_parsed, const uint32_t *tok_info, const uint8_t *dict_len,
+                      uint32_t *tok_pos, uint32_t *tok_hb, uint32_t *tok_nb, uint32_t *tok_mb);
 
 int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h_chunks, const X3Chunk *d_chunks,
                    const X3ParseResult *h_parsed, const X3ParseResult *d_parsed,

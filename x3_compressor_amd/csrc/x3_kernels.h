@@ -79,11 +79,7 @@ struct X3ParseArgs {
 	uint32_t *dict_pos;         /* element e of a chunk is bytes[dict_pos[e] .. +dict_len[e]) ; tag == e */
 	uint8_t  *dict_len;
 	uint32_t *ht;               /* open addressing, slot = tag+1, 0 = empty                       */
-	uint32_t *tok_pos;
-	uint32_t *tok_info;
-	uint32_t *tok_hb;           /* per step: number of hits before it (index of a hit among the hits)            */
-	uint32_t *tok_nb;           /* per step: dictionary elements before it (== tag a new fragment would get)     */
-	uint32_t *tok_mb;           /* per step: bytes of new fragments before it (symbol index = 2*step + tok_mb)   */
+	uint32_t *tok_info;         /* the only per-step output of K2: tag of the hit, or X3_TOK_MISS | dup | length               */
 	X3ParseResult *result;
 	uint32_t factor1, factor2;
 	int32_t  nl_mode;
