@@ -29,8 +29,9 @@ __device__ __forceinline__ uint64_t x3_ballot(int p) { return __ballot(p); }
 __device__ __forceinline__ uint32_t x3_bcast_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, X3_WAVE); }
 /* v[lane] for a wave-uniform lane index: one v_readlane_b32 (SGPR result) instead of a ds_bpermute round trip */
 __device__ __forceinline__ uint32_t x3_readlane_u32(uint32_t v, uint32_t lane_uniform) { return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane((int)lane_uniform)); }
-/* copy of `old` with lane `lane_uniform` replaced by the wave-uniform value `val` (one v_writelane_b32) */
-__device__ __forceinline__ uint32_t x3_writelane_u32(uint32_t old, uint32_t val, uint32_t lane_uniform) { return (uint32_t)__builtin_amdgcn_writelane((int)__builtin_amdgcn_readfirstlane((int)val), __builtin_amdgcn_readfirstlane((int)lane_uniform), (int)old); }
+/* copy of `old` with lane `lane_uniform` replaced by the wave-uniform value `val`.  (ROCm 7.2's clang has no writelane
+ * builtin and v_writelane_b32 with an SGPR lane select needs M0, which the compiler reserves: v_cmp + v_cndmask it is.) */
+__device__ __forceinline__ uint32_t x3_writelane_u32(uint32_t old, uint32_t val, uint32_t lane_uniform) { return x3_lane() == lane_uniform ? val : old; }
 __device__ __forceinline__ uint32_t x3_shfl_up_u32(uint32_t v, unsigned d) { return (uint32_t)__shfl_up((int)v, d, X3_WAVE); }
 __device__ __forceinline__ uint32_t x3_shfl_xor_u32(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, X3_WAVE); }
 /* Orders this wave's earlier LDS/global accesses before its later ones when different lanes touch the same
