@@ -92,6 +92,16 @@ int x3h_compress_chunks(x3h_ctx *ctx, const x3h_params *prm, const uint8_t *in, 
 int x3h_compress_chunks_dev(x3h_ctx *ctx, const x3h_params *prm, const void *d_in, const uint64_t *offsets,
                             int nchunks, void *d_out, uint64_t out_stride, uint64_t *out_lens, x3h_stats *stats);
 
+/* Decoder.  Replaces   bio_open(READ); ac_init(); ac_decode_init(); decompress(optr,&bio); bio_close();   (x3.c:635-647).
+ * The stream carries neither its length nor -w/-t: `cap` bounds the output (the reference assumes 64x the
+ * input, unchecked, x3.c:621); X3H_E_OUTPUT_FULL asks for a larger buffer, X3H_E_CORRUPT replaces the abort() of ac.c:178. */
+int x3h_decompress(x3h_ctx *ctx, const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len, x3h_stats *stats);
+
+/* Independent streams (e.g. the chunks of an X3C1 container): stream c is in[in_offsets[c] .. in_offsets[c+1]) and decodes
+ * into out[out_offsets[c] .. out_offsets[c+1]) (that span is its capacity); out_lens[c] receives the decoded size. Host pointers. */
+int x3h_decompress_chunks(x3h_ctx *ctx, const uint8_t *in, const uint64_t *in_offsets, int nchunks,
+                          uint8_t *out, const uint64_t *out_offsets, uint64_t *out_lens, x3h_stats *stats);
+
 /* Stage-level entry points (kernel parity tests; the seams named in SURVEY.md 8(b)).
  *  x3h_scan_m      : K1 alone.  m_out[p] = max{ i : count[i] > min(T, count[0]-1) } (0 if T<=0 or count[0]<2) with
  *                    count[] of backend.c:56-74; find_best_match(p) = 1 + max{ i <= m[p] : filters of backend.c:79-90 }.

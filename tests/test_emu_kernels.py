@@ -48,3 +48,19 @@ def test_emulated_scan_counts(emu, oracle):
     cnt = emu.scan_counts(data, _lib.make_params(w_kib=1, t=2))
     for p in (0, 1, 150, 299):
         assert np.array_equal(cnt[p], oracle.count(data, p, 1024))
+
+
+@pytest.mark.parametrize("name", ["empty", "one_byte", "abra_x100", "zeros1024", "quad4096", "records_w8_t16", "gpl8k_x", "rand4096_w4_t8"])
+def test_emulated_decoder_reproduces_golden_inputs(emu, golden, name):
+    """decode.hip (x3.c:285-353) on the reference's own streams."""
+    c = golden[name]
+    assert emu.decompress(c["expect"], len(c["data"]) + 8) == c["data"]
+
+
+def test_emulated_decoder_errors(emu, golden):
+    with pytest.raises(_lib.X3Error) as e:
+        emu.decompress(golden["zeros5000"]["expect"], 100)   # ratio > 64:1 -- the reference overruns its buffer here (x3.c:621)
+    assert e.value.status == -3
+    with pytest.raises(_lib.X3Error) as e:
+        emu.decompress(b"\x12\x34\x56\x78" * 50, 1000)
+    assert e.value.status == -4

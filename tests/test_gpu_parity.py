@@ -117,3 +117,40 @@ def test_full_size_dickens_like_round_trip(gpu, oracle):
     assert sum(list(st.events)[:4]) == st.steps
     rc, back = oracle.decompress(stream, len(data) + 64)
     assert rc == 0 and back == data.tobytes()
+    assert gpu.decompress(stream, len(data)) == back  # and the GPU decoder agrees
+
+
+# ---- decoder (x3.c:285-353, ac.c:128-198) ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", CASES)
+def test_decoder_reproduces_golden_inputs(gpu, golden, name):
+    c = golden[name]
+    assert gpu.decompress(c["expect"], len(c["data"]) + 16) == c["data"]
+
+
+def test_decoder_capacity_and_corruption(gpu, golden):
+    with pytest.raises(_lib.X3Error) as e:
+        gpu.decompress(golden["zeros5000"]["expect"], 100)  # > 64:1: the reference overruns its output buffer (x3.c:621)
+    assert e.value.status == -3
+    with pytest.raises(_lib.X3Error) as e:
+        gpu.decompress(bytes(range(7, 251)) * 4, 1 << 16)
+    assert e.value.status == -4
+    assert gpu.decompress(golden["empty"]["expect"], 0) == b""
+
+
+def test_round_trip_config5_shape(gpu):
+    """BASELINE config 5 shape at reduced size: 16-bit image-like data, -w 512 -t 4096, compress + decompress on the GPU."""
+    rng = np.random.default_rng(55)
+    x = np.cumsum(rng.integers(-6, 7, 400_000), dtype=np.int64)
+    img = ((x - x.min()) % 4096).astype("<u2")  # smooth 12-bit samples in 16-bit words, like MR slices
+    data = img.tobytes()
+    stream = gpu.compress(data, _lib.make_params(w_kib=512, t=4096))
+    assert gpu.decompress(stream, len(data)) == data
+
+
+def test_chunked_round_trip(gpu):
+    data = synth.zipf_bytes(300_000).tobytes()
+    cuts = list(range(0, 300_000, 65536)) + [300_000]
+    prm = _lib.make_params(w_kib=64, t=256)
+    streams = gpu.compress_chunks(data, cuts, prm)
+    back = gpu.decompress_chunks(streams, [cuts[i + 1] - cuts[i] for i in range(len(cuts) - 1)])
+    assert b"".join(back) == data

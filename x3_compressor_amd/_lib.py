@@ -17,7 +17,7 @@ DEFAULT_SO = os.path.join(HERE, "csrc", "libx3hip.so")
 ABI_SYMBOLS = (
     "x3h_abi_version", "x3h_strerror", "x3h_last_hip_error", "x3h_device_count", "x3h_default_params",
     "x3h_compress_bound", "x3h_ctx_create", "x3h_ctx_destroy", "x3h_compress", "x3h_compress_chunks",
-    "x3h_compress_chunks_dev", "x3h_scan_m", "x3h_scan_counts", "x3h_parse",
+    "x3h_compress_chunks_dev", "x3h_decompress", "x3h_decompress_chunks", "x3h_scan_m", "x3h_scan_counts", "x3h_parse",
 )
 
 TOK_MISS, TOK_DUP = 0x80000000, 0x40000000
@@ -68,6 +68,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.x3h_compress.argtypes = [C.c_void_p, C.POINTER(Params), u8p, C.c_size_t, u8p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(Stats)]
     lib.x3h_compress_chunks.argtypes = [C.c_void_p, C.POINTER(Params), u8p, C.c_void_p, C.c_int, u8p, C.c_uint64, C.c_void_p, C.POINTER(Stats)]
     lib.x3h_compress_chunks_dev.argtypes = lib.x3h_compress_chunks.argtypes
+    lib.x3h_decompress.argtypes = [C.c_void_p, u8p, C.c_size_t, u8p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(Stats)]
+    lib.x3h_decompress_chunks.argtypes = [C.c_void_p, u8p, C.c_void_p, C.c_int, u8p, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
     lib.x3h_scan_m.argtypes = [C.c_void_p, C.POINTER(Params), u8p, C.c_size_t, u8p]
     lib.x3h_scan_counts.argtypes = [C.c_void_p, C.POINTER(Params), u8p, C.c_size_t, C.c_void_p]
     lib.x3h_parse.argtypes = [C.c_void_p, C.POINTER(Params), u8p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
@@ -162,6 +164,27 @@ class X3Context:
                                                      C.c_void_p(d_out), stride, lens.ctypes.data, C.byref(st)))
         self.last_stats = st
         return lens, st
+
+    def decompress(self, stream, cap: int) -> bytes:
+        """x3h_decompress: `cap` bounds the output (the stream does not carry its length); X3Error(-3) if too small."""
+        a = _u8(stream)
+        out = np.empty(max(cap, 1), dtype=np.uint8)
+        n_out, st = C.c_size_t(0), Stats()
+        self._check(self.lib.x3h_decompress(self._h, a.ctypes.data if a.size else None, a.size, out.ctypes.data, cap, C.byref(n_out), C.byref(st)))
+        self.last_stats = st
+        return out[:n_out.value].tobytes()
+
+    def decompress_chunks(self, streams: list[bytes], caps: list[int]) -> list[bytes]:
+        blob = np.frombuffer(b"".join(streams), dtype=np.uint8) if sum(map(len, streams)) else np.zeros(1, np.uint8)
+        ioff = np.cumsum([0] + [len(s) for s in streams]).astype(np.uint64)
+        ooff = np.cumsum([0] + list(caps)).astype(np.uint64)
+        out = np.empty(max(int(ooff[-1]), 1), dtype=np.uint8)
+        lens = np.zeros(len(streams), dtype=np.uint64)
+        st = Stats()
+        self._check(self.lib.x3h_decompress_chunks(self._h, blob.ctypes.data, ioff.ctypes.data, len(streams), out.ctypes.data,
+                                                   ooff.ctypes.data, lens.ctypes.data, C.byref(st)))
+        self.last_stats = st
+        return [out[int(ooff[i]):int(ooff[i]) + int(lens[i])].tobytes() for i in range(len(streams))]
 
     # ---- stage level (parity tests) ----------------------------------------------------------------------
     def scan_m(self, data, prm: Params) -> np.ndarray:

@@ -21,6 +21,7 @@
 extern "C" void x3k_launch_scan(const X3ScanArgs *a, uint32_t max_len, uint32_t nchunks, hipStream_t st);
 extern "C" void x3k_launch_parse(const X3ParseArgs *a, uint32_t nchunks, hipStream_t st);
 extern "C" void x3k_launch_code(const X3CodeArgs *a, uint32_t nchunks, hipStream_t st);
+extern "C" void x3k_launch_decode(const X3DecArgs *a, uint32_t nchunks, hipStream_t st);
 
 thread_local int x3_last_hip = 0;
 #define g_last_hip x3_last_hip
@@ -33,6 +34,7 @@ struct x3h_ctx {
 	X3Code2Bufs c2;
 	int code_v1 = 0;
 	DevBuf mtf, idxfreq, ctx1, ctx0, items, pkey, pval, out, counts;
+	DevBuf din, dchunks; /* decoder: input streams, stream table */
 	std::vector<X3Chunk> hchunks;
 	std::vector<X3ParseResult> hparse;
 	std::vector<X3CodeResult> hcode;
@@ -107,7 +109,7 @@ extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 	if (c->stream) hipStreamSynchronize(c->stream);
 	DevBuf *bufs[] = { &c->pad, &c->m, &c->dict_pos, &c->dict_len, &c->ht, &c->tok_pos, &c->tok_info, &c->tok_hb, &c->tok_nb, &c->tok_mb, &c->chunks, &c->presult,
 		               &c->c2.tmp, &c->c2.offs, &c->c2.chunkmeta, &c->c2.idxfreq, &c->c2.hsym, &c->c2.maxred, &c->c2.pp[0], &c->c2.pp[1], &c->c2.pp[2], &c->c2.pp[3],
-		               &c->cresult, &c->mtf, &c->idxfreq, &c->ctx1, &c->ctx0, &c->items, &c->pkey, &c->pval, &c->out, &c->counts };
+		               &c->cresult, &c->mtf, &c->idxfreq, &c->ctx1, &c->ctx0, &c->items, &c->pkey, &c->pval, &c->out, &c->counts, &c->din, &c->dchunks };
 	for (DevBuf *b : bufs) b->release();
 	for (DevBuf &b : c->c2.a) b.release();
 	for (DevBuf &b : c->c2.y) b.release();
@@ -387,4 +389,92 @@ extern "C" int x3h_parse(x3h_ctx *ctx, const x3h_params *prm, const uint8_t *in,
 	if (k && tok_pos) HIPCHK(hipMemcpy(tok_pos, ctx->tok_pos.as<uint32_t>() + ctx->hchunks[0].elem_off, k * 4, hipMemcpyDeviceToHost));
 	if (k && tok_info) HIPCHK(hipMemcpy(tok_info, ctx->tok_info.as<uint32_t>() + ctx->hchunks[0].elem_off, k * 4, hipMemcpyDeviceToHost));
 	return X3H_OK;
+}
+
+/* ------------------------------------------------------------------------------------------------------------ */
+extern "C" int x3h_decompress_chunks(x3h_ctx *c, const uint8_t *in, const uint64_t *in_offsets, int nchunks,
+                                     uint8_t *out, const uint64_t *out_offsets, uint64_t *out_lens, x3h_stats *stats)
+{
+	if (!c || !in_offsets || !out_offsets || !out_lens || nchunks <= 0 || (!in && in_offsets[nchunks] != in_offsets[0])) return X3H_E_ARG;
+	HIPCHK(hipSetDevice(c->device));
+	const int nc = nchunks;
+	std::vector<X3DecChunk> dk((size_t)nc);
+	uint64_t ioff = 0, ooff = 0, toff = 0, c0off = 0, itoff = 0, poff = 0, hoff = 0;
+	for (int i = 0; i < nc; i++) {
+		if (in_offsets[i + 1] < in_offsets[i] || out_offsets[i + 1] < out_offsets[i]) return X3H_E_ARG;
+		const uint64_t ilen = in_offsets[i + 1] - in_offsets[i], cap = out_offsets[i + 1] - out_offsets[i];
+		if (ilen > 0xFFFFFFF0ull || cap > X3H_MAX_CHUNK) return X3H_E_ARG;
+		X3DecChunk &k = dk[(size_t)i];
+		k.in_off = ioff; k.in_len = (uint32_t)ilen; k.out_cap = (uint32_t)cap; k.out_off = ooff;
+		k.tag_off = toff; k.ctx0_off = c0off; k.item_off = itoff; k.item_cap = 8 * cap + 64;
+		k.pair_log2 = ceil_log2(2 * (cap + 2)); k.pair_off = poff;
+		k.ht_log2 = ceil_log2(2 * (cap + 1)); if (k.ht_log2 < 4) k.ht_log2 = 4; k.ht_off = hoff;
+		ioff += align_up(ilen, 16) + 16; ooff += align_up(cap, 256) + 256;
+		toff += cap + 8; c0off += cap + 8; itoff += k.item_cap; poff += (uint64_t)1 << k.pair_log2; hoff += (uint64_t)1 << k.ht_log2;
+	}
+	CHK(c->din.reserve(ioff + 64));
+	CHK(c->out.reserve(ooff + 256));
+	CHK(c->dchunks.reserve((size_t)nc * sizeof(X3DecChunk)));
+	CHK(c->cresult.reserve((size_t)nc * sizeof(X3CodeResult)));
+	CHK(c->dict_pos.reserve(toff * 4)); CHK(c->dict_len.reserve(toff));
+	CHK(c->mtf.reserve(toff * 4)); CHK(c->idxfreq.reserve(toff * 4));
+	CHK(c->ctx1.reserve(toff * sizeof(X3CtxHdr))); CHK(c->ctx0.reserve(c0off * sizeof(X3CtxHdr)));
+	CHK(c->items.reserve(itoff * 8)); CHK(c->pkey.reserve(poff * 8)); CHK(c->pval.reserve(poff * 4)); CHK(c->ht.reserve(hoff * 4));
+	HIPCHK(hipEventRecord(c->ev[0], c->stream));
+	for (int i = 0; i < nc; i++)
+		if (dk[(size_t)i].in_len)
+			HIPCHK(hipMemcpyAsync(c->din.as<uint8_t>() + dk[(size_t)i].in_off, in + in_offsets[i], dk[(size_t)i].in_len, hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemcpyAsync(c->dchunks.p, dk.data(), (size_t)nc * sizeof(X3DecChunk), hipMemcpyHostToDevice, c->stream));
+	HIPCHK(hipMemsetAsync(c->ctx1.p, 0, toff * sizeof(X3CtxHdr), c->stream));
+	HIPCHK(hipMemsetAsync(c->ctx0.p, 0, c0off * sizeof(X3CtxHdr), c->stream));
+	HIPCHK(hipMemsetAsync(c->pkey.p, 0, poff * 8, c->stream));
+	HIPCHK(hipMemsetAsync(c->ht.p, 0, hoff * 4, c->stream));
+	X3DecArgs da;
+	da.in = c->din.as<uint8_t>(); da.chunks = c->dchunks.as<X3DecChunk>(); da.out = c->out.as<uint8_t>();
+	da.dict_pos = c->dict_pos.as<uint32_t>(); da.dict_len = c->dict_len.as<uint8_t>(); da.ht = c->ht.as<uint32_t>();
+	da.mtf = c->mtf.as<uint32_t>(); da.idxfreq = c->idxfreq.as<uint32_t>();
+	da.ctx1 = c->ctx1.as<X3CtxHdr>(); da.ctx0 = c->ctx0.as<X3CtxHdr>(); da.items = c->items.as<uint64_t>();
+	da.pair_key = c->pkey.as<uint64_t>(); da.pair_val = c->pval.as<uint32_t>(); da.result = c->cresult.as<X3CodeResult>();
+	HIPCHK(hipEventRecord(c->ev[4], c->stream));
+	x3k_launch_decode(&da, (uint32_t)nc, c->stream);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(c->ev[5], c->stream));
+	c->hcode.resize((size_t)nc);
+	HIPCHK(hipMemcpyAsync(c->hcode.data(), c->cresult.p, (size_t)nc * sizeof(X3CodeResult), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	int rc = X3H_OK;
+	for (int i = 0; i < nc; i++) {
+		const X3CodeResult &r = c->hcode[(size_t)i];
+		out_lens[i] = r.out_len;
+		if (r.status == X3_ST_CORRUPT) rc = X3H_E_CORRUPT;
+		else if (r.status == X3_ST_OUT_FULL && rc == X3H_OK) rc = X3H_E_OUTPUT_FULL;
+		else if (r.status != X3_ST_OK && rc == X3H_OK) rc = X3H_E_INTERNAL;
+	}
+	if (rc == X3H_OK) {
+		for (int i = 0; i < nc; i++)
+			if (c->hcode[(size_t)i].out_len)
+				HIPCHK(hipMemcpyAsync(out + out_offsets[i], c->out.as<uint8_t>() + dk[(size_t)i].out_off, c->hcode[(size_t)i].out_len, hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream));
+	}
+	if (stats) {
+		memset(stats, 0, sizeof(*stats));
+		for (int i = 0; i < nc; i++) {
+			for (int e = 0; e < 4; e++) { stats->events[e] += c->hcode[(size_t)i].events[e]; stats->steps += c->hcode[(size_t)i].events[e]; }
+			stats->dict_elems += c->hcode[(size_t)i]._r;
+			stats->ctx0_entries += c->hcode[(size_t)i].pairs;
+		}
+		float ms = 0;
+		(void)hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); stats->ms_code = ms;
+		(void)hipEventElapsedTime(&ms, c->ev[0], c->ev[5]); stats->ms_total = ms;
+	}
+	return rc;
+}
+
+extern "C" int x3h_decompress(x3h_ctx *ctx, const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len, x3h_stats *stats)
+{
+	if (!ctx || !out_len || (!in && n) || (!out && cap)) return X3H_E_ARG;
+	uint64_t io[2] = { 0, n }, oo[2] = { 0, cap }, len = 0;
+	int rc = x3h_decompress_chunks(ctx, in, io, 1, out, oo, &len, stats);
+	*out_len = (size_t)len;
+	return rc;
 }

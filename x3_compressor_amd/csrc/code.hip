@@ -14,7 +14,7 @@
  * The mode decision reproduces the reference's float arithmetic: (float)freq / (float)total, one multiply, strict >
  * in the order IDX1, CTX0, CTX1 (x3.c:152-172).  Build with -ffp-contract=off and IEEE division.
  */
-#include "x3_kernels.h"
+#include "x3_tables.h"
 
 struct Coder {
 	uint32_t lo, hi, pending; /* ac.h:8-15; values < 2^31 */
@@ -22,12 +22,6 @@ struct Coder {
 	uint32_t w, capw, full;
 	uint32_t *out32;
 };
-
-__device__ static __forceinline__ uint32_t wave_sum(uint32_t v)
-{
-	for (int m = 32; m >= 1; m >>= 1) v += x3_shfl_xor_u32(v, m);
-	return v;
-}
 
 __device__ static __forceinline__ void put_bit(Coder &c, uint32_t bit, uint32_t lane) /* bio.c:49-72 with n = 1 */
 {
@@ -63,73 +57,6 @@ __device__ static void ac_encode(Coder &c, uint32_t cum_lo, uint32_t cum_hi, uin
 		c.lo = 2 * (c.lo - 0x20000000u);
 		c.hi = 2 * (c.hi - 0x20000000u) + 1;
 	}
-}
-
-struct CtxQ { uint32_t found, pos, freq, cum; };
-
-/* one sweep of a context's items: position of `tag`, its freq and the cumulative freq before it
- * (ctx_query_tag_item / ctx_query_tag_index / count_cum_freqs, context.c:20-40,95-133) */
-__device__ static CtxQ ctx_query(const X3CtxHdr h, const uint64_t *pool, uint32_t tag, uint32_t lane)
-{
-	CtxQ q;
-	q.found = 0; q.pos = 0; q.freq = 0; q.cum = 0;
-	for (uint32_t base = 0; base < h.items; base += X3_WAVE) {
-		const uint32_t i = base + lane;
-		const uint64_t it = i < h.items ? pool[(uint64_t)h.off + i] : 0;
-		const uint32_t fq = (uint32_t)it;
-		const uint64_t mask = x3_ballot(i < h.items && (uint32_t)(it >> 32) == tag);
-		if (mask) {
-			const uint32_t l = (uint32_t)x3_ctz64(mask);
-			q.found = 1;
-			q.pos = base + l;
-			q.freq = x3_bcast_u32(fq, (int)l);
-			q.cum += wave_sum(lane < l ? fq : 0u);
-			break;
-		}
-		q.cum += wave_sum(fq);
-	}
-	return q;
-}
-
-/* x3.c:197-209 : add the tag with freq 1 or bump its freq; total tracks calc_total_freq */
-__device__ static void ctx_touch(X3CtxHdr *hp, X3CtxHdr h, const CtxQ q, uint32_t tag, uint64_t *pool,
-                                 uint64_t &pool_top, uint64_t pool_cap, uint32_t &status, uint32_t lane)
-{
-	if (q.found) {
-		if (lane == 0) pool[(uint64_t)h.off + q.pos] += 1;
-	} else {
-		if (h.items == h.cap) {
-			const uint32_t ncap = h.cap ? 2 * h.cap : 2;
-			if (pool_top + ncap > pool_cap) { status = X3_ST_POOL_FULL; return; }
-			const uint32_t noff = (uint32_t)pool_top;
-			pool_top += ncap;
-			for (uint32_t i = lane; i < h.items; i += X3_WAVE) pool[(uint64_t)noff + i] = pool[(uint64_t)h.off + i];
-			h.off = noff;
-			h.cap = ncap;
-		}
-		if (lane == 0) pool[(uint64_t)h.off + h.items] = ((uint64_t)tag << 32) | 1u;
-		h.items++;
-	}
-	h.total++;
-	if (lane == 0) *hp = h;
-}
-
-__device__ static __forceinline__ uint32_t pair_slot(uint64_t key, uint32_t plog)
-{
-	return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> (64 - plog));
-}
-
-/* tags [0,r) move one rank down, `tag` goes to rank 0 (dict.c:132-146 after dict_set_last_pos / dict_insert_elem) */
-__device__ static void mtf_to_front(uint32_t *mtf, uint32_t r, uint32_t tag, uint32_t lane)
-{
-	for (int base = (int)(r & ~(uint32_t)(X3_WAVE - 1)); base >= 0; base -= X3_WAVE) {
-		const uint32_t j = (uint32_t)base + lane;
-		const bool act = j >= 1 && j <= r;
-		const uint32_t v = act ? mtf[j - 1] : 0;
-		x3_wave_sync(); /* every lane has read before any lane overwrites its neighbour's source */
-		if (act) mtf[j] = v;
-	}
-	if (lane == 0) mtf[0] = tag;
 }
 
 __device__ static void x3_code_body(const X3CodeArgs &a)

@@ -1,0 +1,324 @@
+/*
+ * decode.hip -- the x3 decoder (reference: decompress() x3.c:285-353, decode_tag() x3.c:58-129, decode_match() x3.c:272-283,
+ * arithmetic decoder ac.c:128-198, bit reader bio.c:30-42,74-103).
+ *
+ * Unlike the encoder, the decoder cannot run ahead of its models: which table is consulted next depends on the symbol
+ * just decoded, so the path is one dependent chain per stream.  Mapping: one wavefront per stream; the chain's state
+ * (interval, bit reader, contexts) is wave-uniform, and every linear table walk of the reference is a 64-lane sweep:
+ *   index_of_value (ac.c:167-179)        -> inclusive wave scan of 64 frequencies + ballot for the first cum > value
+ *   dict_get_index_by_tag (dict.c:174-183) -> ballot search of the move-to-front list
+ *   dict_query_elem (dict.c:148-157)     -> exact hash lookup; an element is a (pos,len) reference into the OUTPUT
+ *   dict_update_costs + qsort            -> move-to-front (x3_tables.h)
+ * Streams of a batch decode concurrently (grid = streams).  The reference's unchecked 64x output buffer (x3.c:621) is
+ * replaced by a capacity check (X3_ST_OUT_FULL), malformed input ends in X3_ST_CORRUPT instead of abort() (ac.c:178).
+ */
+#include "x3_tables.h"
+
+struct BitReader { /* bio.c:5-42 */
+	const uint8_t *p, *end;
+	uint32_t acc, cnt;
+};
+
+__device__ static __forceinline__ uint32_t br_get(BitReader &r)
+{
+	if (r.cnt == 32) {
+		if (r.end - r.p >= 4) { /* bio.c:10,35-39: past the last whole word the reader feeds 0x80000000 */
+			r.acc = (uint32_t)r.p[0] | (uint32_t)r.p[1] << 8 | (uint32_t)r.p[2] << 16 | (uint32_t)r.p[3] << 24;
+			r.p += 4;
+		} else r.acc = 0x80000000u;
+		r.cnt = 0;
+	}
+	const uint32_t b = r.acc & 1u;
+	r.acc >>= 1;
+	r.cnt++;
+	return b;
+}
+
+struct Dec { uint32_t lo, hi, buf; };
+
+/* ac_decode_symbol's interval update + ac_decode_scale (ac.c:192-195,142-165) */
+__device__ static void dec_narrow(Dec &d, BitReader &r, uint32_t step, uint32_t cum_lo, uint32_t cum_hi)
+{
+	d.hi = d.lo + step * cum_hi - 1;
+	d.lo = d.lo + step * cum_lo;
+	for (;;) {
+		if (d.hi < 0x40000000u) {
+			d.lo = 2 * d.lo; d.hi = 2 * d.hi + 1; d.buf = 2 * d.buf + br_get(r);
+		} else if (d.lo >= 0x40000000u) {
+			d.lo = 2 * (d.lo - 0x40000000u); d.hi = 2 * (d.hi - 0x40000000u) + 1; d.buf = 2 * (d.buf - 0x40000000u) + br_get(r);
+		} else break;
+	}
+	while (d.lo >= 0x20000000u && d.hi < 0x60000000u) {
+		d.lo = 2 * (d.lo - 0x20000000u); d.hi = 2 * (d.hi - 0x20000000u) + 1; d.buf = 2 * (d.buf - 0x20000000u) + br_get(r);
+	}
+}
+
+__device__ static __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane)
+{
+	for (unsigned d = 1; d < X3_WAVE; d <<= 1) {
+		const uint32_t u = x3_shfl_up_u32(v, d);
+		if (lane >= d) v += u;
+	}
+	return v;
+}
+
+/* find the symbol of a frequency array (global memory, `count` entries) that holds `value`; returns 0xFFFFFFFF if none */
+__device__ static uint32_t find_in_array(const uint32_t *freq, uint32_t count, uint32_t value, uint32_t lane, uint32_t &cum_out, uint32_t &fq_out)
+{
+	uint32_t carry = 0;
+	for (uint32_t base = 0; base < count; base += X3_WAVE) {
+		const uint32_t i = base + lane;
+		const uint32_t fq = i < count ? freq[i] : 0;
+		const uint32_t incl = wave_incl_scan(fq, lane) + carry;
+		const uint64_t mask = x3_ballot(i < count && incl > value);
+		if (mask) {
+			const uint32_t l = (uint32_t)x3_ctz64(mask);
+			fq_out = x3_bcast_u32(fq, (int)l);
+			cum_out = x3_bcast_u32(incl, (int)l) - fq_out;
+			return base + l;
+		}
+		carry = x3_bcast_u32(incl, X3_WAVE - 1);
+	}
+	return 0xFFFFFFFFu;
+}
+
+/* same over a context's item list; returns the list position */
+__device__ static uint32_t find_in_ctx(const X3CtxHdr h, const uint64_t *pool, uint32_t value, uint32_t lane, uint32_t &cum_out, uint32_t &fq_out, uint32_t &tag_out)
+{
+	uint32_t carry = 0;
+	for (uint32_t base = 0; base < h.items; base += X3_WAVE) {
+		const uint32_t i = base + lane;
+		const uint64_t it = i < h.items ? pool[(uint64_t)h.off + i] : 0;
+		const uint32_t fq = (uint32_t)it;
+		const uint32_t incl = wave_incl_scan(fq, lane) + carry;
+		const uint64_t mask = x3_ballot(i < h.items && incl > value);
+		if (mask) {
+			const uint32_t l = (uint32_t)x3_ctz64(mask);
+			fq_out = x3_bcast_u32(fq, (int)l);
+			cum_out = x3_bcast_u32(incl, (int)l) - fq_out;
+			tag_out = x3_bcast_u32((uint32_t)(it >> 32), (int)l);
+			return base + l;
+		}
+		carry = x3_bcast_u32(incl, X3_WAVE - 1);
+	}
+	return 0xFFFFFFFFu;
+}
+
+#define DFNV_OFF 2166136261u
+#define DFNV_MUL 16777619u
+
+__device__ static __forceinline__ uint32_t dht_slot(uint32_t h, uint32_t len, uint32_t hlog)
+{
+	uint32_t x = (h ^ (len * 0x9E3779B1u)) * 0x85EBCA6Bu;
+	x ^= x >> 15;
+	x *= 0xC2B2AE35u;
+	return x >> (32 - hlog);
+}
+
+__device__ static void x3_decode_body(const X3DecArgs &a)
+{
+	const X3DecChunk ck = a.chunks[blockIdx.x];
+	const uint32_t lane = x3_lane();
+	uint8_t *out = a.out + ck.out_off;
+	uint32_t *dpos = a.dict_pos + ck.tag_off;
+	uint8_t *dlen = a.dict_len + ck.tag_off;
+	uint32_t *ht = a.ht + ck.ht_off;
+	const uint32_t hlog = ck.ht_log2, hmask = (1u << hlog) - 1;
+	uint32_t *mtf = a.mtf + ck.tag_off, *idxfreq = a.idxfreq + ck.tag_off;
+	X3CtxHdr *ctx1 = a.ctx1 + ck.tag_off, *ctx0 = a.ctx0 + ck.ctx0_off;
+	uint64_t *pool = a.items + ck.item_off;
+	uint64_t *pkey = a.pair_key + ck.pair_off;
+	uint32_t *pval = a.pair_val + ck.pair_off;
+	const uint32_t plog = ck.pair_log2, pmask = (1u << plog) - 1;
+	const uint32_t cap = ck.out_cap;
+
+	BitReader br;
+	br.p = a.in + ck.in_off; br.end = br.p + ck.in_len; br.acc = 0; br.cnt = 32; /* bio_open(READ), bio.c:14-15 */
+	Dec d;
+	d.lo = 0; d.hi = 0x7FFFFFFFu; d.buf = 0; /* ac_init */
+	for (int i = 0; i < 31; i++) d.buf = (d.buf << 1) | br_get(br); /* ac_decode_init, ac.c:133-140 */
+
+	uint32_t ev[5] = { 1024, 1024, 1, 1, 1 }, evtotal = 2051; /* create(), x3.c:236-244 */
+	uint32_t nev[4] = { 0, 0, 0, 0 };
+	uint32_t lf = 1, lftotal = 32;
+	uint32_t cf0 = 1, cf1 = 1, cf2 = 1, cf3 = 1, cftotal = 256;
+	uint32_t D = 0, idxtotal = 0, npairs = 0, status = X3_ST_OK;
+	uint64_t pool_top = 0;
+	uint32_t prev1 = 0, ctx1tag = 0;
+	uint32_t p = 0;
+
+	for (;;) {
+		/* ---- the event (x3.c:293-295) ---- */
+		uint32_t step = (d.hi - d.lo + 1) / evtotal;
+		uint32_t value = step ? (d.buf - d.lo) / step : 0xFFFFFFFFu;
+		uint32_t cum = 0, decision = 5;
+		for (uint32_t s = 0; s < 5; s++) {
+			if (value >= cum && value < cum + ev[s]) { decision = s; break; }
+			cum += ev[s];
+		}
+		if (decision == 5) { status = X3_ST_CORRUPT; break; } /* the reference abort()s, ac.c:178 */
+		dec_narrow(d, br, step, cum, cum + ev[decision]);
+		ev[decision]++; evtotal++;
+		if (decision == X3_E_EOF) break;
+
+		if (decision == X3_E_NEW) {
+			/* ---- decode_match, x3.c:272-283 ---- */
+			nev[3]++;
+			uint32_t len;
+			{
+				step = (d.hi - d.lo + 1) / lftotal;
+				value = step ? (d.buf - d.lo) / step : 0xFFFFFFFFu;
+				const uint32_t incl = wave_incl_scan(lane < 32 ? lf : 0u, lane);
+				const uint64_t mask = x3_ballot(lane < 32 && incl > value);
+				if (!mask) { status = X3_ST_CORRUPT; break; }
+				const uint32_t l = (uint32_t)x3_ctz64(mask);
+				const uint32_t fq = x3_bcast_u32(lf, (int)l), cl = x3_bcast_u32(incl, (int)l) - fq;
+				dec_narrow(d, br, step, cl, cl + fq);
+				if (lane == l) lf++;
+				lftotal++;
+				len = l + 1;
+			}
+			if ((uint64_t)p + len > cap) { status = X3_ST_OUT_FULL; break; }
+			uint32_t h = DFNV_OFF;
+			int bad = 0;
+			for (uint32_t j = 0; j < len; j++) {
+				step = (d.hi - d.lo + 1) / cftotal;
+				value = step ? (d.buf - d.lo) / step : 0xFFFFFFFFu;
+				const uint32_t s4 = cf0 + cf1 + cf2 + cf3;
+				const uint32_t incl = wave_incl_scan(s4, lane);
+				const uint64_t mask = x3_ballot(incl > value);
+				if (!mask) { bad = 1; break; }
+				const uint32_t l = (uint32_t)x3_ctz64(mask);
+				const uint32_t b0 = x3_bcast_u32(cf0, (int)l), b1 = x3_bcast_u32(cf1, (int)l), b2 = x3_bcast_u32(cf2, (int)l), b3 = x3_bcast_u32(cf3, (int)l);
+				uint32_t cl = x3_bcast_u32(incl, (int)l) - (b0 + b1 + b2 + b3), sub, fq;
+				if (value < cl + b0) { sub = 0; fq = b0; }
+				else if (value < cl + b0 + b1) { sub = 1; fq = b1; cl += b0; }
+				else if (value < cl + b0 + b1 + b2) { sub = 2; fq = b2; cl += b0 + b1; }
+				else { sub = 3; fq = b3; cl += b0 + b1 + b2; }
+				dec_narrow(d, br, step, cl, cl + fq);
+				if (lane == l) { if (sub == 0) cf0++; else if (sub == 1) cf1++; else if (sub == 2) cf2++; else cf3++; }
+				cftotal++;
+				const uint32_t ch = 4 * l + sub;
+				if (lane == 0) out[p + j] = (uint8_t)ch;
+				h = (h ^ ch) * DFNV_MUL;
+			}
+			if (bad) { status = X3_ST_CORRUPT; break; }
+			x3_wave_sync(); /* the fragment is in memory for every lane */
+			/* dict_query_elem (x3.c:309): exact lookup of (len, bytes) */
+			int dup = 0;
+			uint32_t slot = dht_slot(h, len, hlog);
+			for (uint32_t e = ht[slot]; e != 0; slot = (slot + 1) & hmask, e = ht[slot]) {
+				const uint32_t tg = e - 1;
+				if (dlen[tg] != len) continue;
+				const uint8_t *ds = out + dpos[tg];
+				uint32_t k = 0;
+				while (k < len && ds[k] == out[p + k]) k++;
+				if (k == len) { dup = 1; break; }
+			}
+			x3_wave_sync();
+			if (!dup) { /* x3.c:310-317 */
+				if (lane == 0) { dpos[D] = p; dlen[D] = (uint8_t)len; ht[slot] = D + 1; }
+				mtf_to_front(mtf, D, D, lane);
+				if (lane == 0) idxfreq[D] = 1;
+				D++;
+				idxtotal++;
+			}
+			p += len;
+			prev1 = 0; ctx1tag = 0; /* x3.c:321-322 */
+			x3_wave_sync();
+			continue;
+		}
+
+		/* ---- decode_tag, x3.c:58-129 ---- */
+		if (D == 0) { status = X3_ST_CORRUPT; break; }
+		nev[decision]++;
+		uint32_t c0id = 0;
+		{
+			const uint64_t key = (((uint64_t)prev1 << 32) | ctx1tag) + 1;
+			uint32_t s = pair_slot(key, plog);
+			for (uint64_t kk = pkey[s]; kk != 0; s = (s + 1) & pmask, kk = pkey[s])
+				if (kk == key) { c0id = pval[s]; break; }
+		}
+		X3CtxHdr *h0p = ctx0 + c0id, *h1p = ctx1 + ctx1tag;
+		const X3CtxHdr h0 = *h0p, h1 = *h1p;
+		uint32_t tag = 0, rank = 0;
+		if (decision == X3_E_IDX1) {
+			step = (d.hi - d.lo + 1) / idxtotal;
+			value = step ? (d.buf - d.lo) / step : 0xFFFFFFFFu;
+			uint32_t cl = 0, fq = 0;
+			rank = find_in_array(idxfreq, D, value, lane, cl, fq);
+			if (rank == 0xFFFFFFFFu) { status = X3_ST_CORRUPT; break; }
+			dec_narrow(d, br, step, cl, cl + fq);
+			tag = mtf[rank];
+			x3_wave_sync();
+			if (lane == 0) idxfreq[rank] = fq + 1; /* inc_model(&model_index1, index), x3.c:89 */
+			idxtotal++;
+		} else {
+			const X3CtxHdr hc = decision == X3_E_CTX0 ? h0 : h1;
+			if (hc.items == 0 || hc.total == 0) { status = X3_ST_CORRUPT; break; }
+			step = (d.hi - d.lo + 1) / hc.total;
+			value = step ? (d.buf - d.lo) / step : 0xFFFFFFFFu;
+			uint32_t cl = 0, fq = 0;
+			const uint32_t pos = find_in_ctx(hc, pool, value, lane, cl, fq, tag);
+			if (pos == 0xFFFFFFFFu) { status = X3_ST_CORRUPT; break; }
+			dec_narrow(d, br, step, cl, cl + fq);
+			/* dict_get_index_by_tag (x3.c:79,84) */
+			uint32_t found = 0;
+			for (uint32_t base = 0; base < D; base += X3_WAVE) {
+				const uint32_t i = base + lane;
+				const uint64_t mask = x3_ballot(i < D && mtf[i] == tag);
+				if (mask) { rank = base + (uint32_t)x3_ctz64(mask); found = 1; break; }
+			}
+			if (!found) { status = X3_ST_CORRUPT; break; }
+		}
+		/* x3.c:99-126: both contexts learn the tag, (context1, tag) becomes a known pair */
+		const CtxQ q0 = ctx_query(h0, pool, tag, lane);
+		const CtxQ q1 = ctx_query(h1, pool, tag, lane);
+		x3_wave_sync();
+		ctx_touch(h0p, h0, q0, tag, pool, pool_top, ck.item_cap, status, lane);
+		ctx_touch(h1p, h1, q1, tag, pool, pool_top, ck.item_cap, status, lane);
+		if (status != X3_ST_OK) break;
+		{
+			const uint64_t key = (((uint64_t)ctx1tag << 32) | tag) + 1;
+			uint32_t s = pair_slot(key, plog);
+			uint64_t kk = pkey[s];
+			while (kk != 0 && kk != key) { s = (s + 1) & pmask; kk = pkey[s]; }
+			x3_wave_sync();
+			if (kk == 0) {
+				if (lane == 0) { pkey[s] = key; pval[s] = npairs; }
+				npairs++;
+			}
+		}
+		/* x3.c:332-348: copy the element, move it to the front */
+		const uint32_t len = dlen[tag], src = dpos[tag];
+		if ((uint64_t)p + len > cap) { status = X3_ST_OUT_FULL; break; }
+		if (lane < len) out[p + lane] = out[src + lane]; /* len <= 32; src + len <= p */
+		mtf_to_front(mtf, rank, tag, lane);
+		prev1 = ctx1tag;
+		ctx1tag = tag;
+		p += len;
+		x3_wave_sync();
+	}
+
+	if (lane == 0) {
+		X3CodeResult r;
+		r.out_len = p; r.status = status; r.pairs = npairs; r._r = D;
+		for (int i = 0; i < 4; i++) r.events[i] = nev[i];
+		r.events[4] = r.events[5] = r.events[6] = r.events[7] = 0;
+		a.result[blockIdx.x] = r;
+	}
+}
+
+#ifndef X3_EMU
+__global__ void __launch_bounds__(X3_WAVE) x3_decode_kernel(X3DecArgs a) { x3_decode_body(a); }
+extern "C" void x3k_launch_decode(const X3DecArgs *a, uint32_t nchunks, hipStream_t st)
+{
+	hipLaunchKernelGGL(x3_decode_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, *a);
+}
+#else
+static void decode_tramp(void *p) { x3_decode_body(*(const X3DecArgs *)p); }
+extern "C" void x3k_launch_decode(const X3DecArgs *a, uint32_t nchunks, void *)
+{
+	x3emu_launch(decode_tramp, (void *)a, dim3(nchunks), dim3(X3_WAVE));
+}
+#endif

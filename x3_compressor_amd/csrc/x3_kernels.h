@@ -105,4 +105,30 @@ struct X3CodeArgs {
 	X3CodeResult *result;
 };
 
+/* ---- decoder ------------------------------------------------------------------------------------------ */
+#define X3_ST_CORRUPT 3u     /* not an x3 stream (the reference abort()s, ac.c:178)                 */
+
+struct X3DecChunk {          /* one stream to decode; workspace sized from the output capacity       */
+	uint64_t in_off;
+	uint32_t in_len, out_cap;
+	uint64_t out_off;
+	uint64_t tag_off, ctx0_off, item_off, item_cap, pair_off, ht_off;
+	uint32_t pair_log2, ht_log2;
+};
+
+struct X3DecArgs {
+	const uint8_t *in;
+	const X3DecChunk *chunks;
+	uint8_t *out;
+	uint32_t *dict_pos;         /* element = out[dict_pos .. +dict_len)                             */
+	uint8_t  *dict_len;
+	uint32_t *ht;
+	uint32_t *mtf, *idxfreq;
+	X3CtxHdr *ctx1, *ctx0;
+	uint64_t *items;
+	uint64_t *pair_key;
+	uint32_t *pair_val;
+	X3CodeResult *result;       /* out_len = decoded bytes, _r = dictionary elements                */
+};
+
 #endif /* X3_KERNELS_H */
