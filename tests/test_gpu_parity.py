@@ -154,3 +154,27 @@ def test_chunked_round_trip(gpu):
     streams = gpu.compress_chunks(data, cuts, prm)
     back = gpu.decompress_chunks(streams, [cuts[i + 1] - cuts[i] for i in range(len(cuts) - 1)])
     assert b"".join(back) == data
+
+
+# ---- K1 v2 (sorted n-gram lists) against the brute-force sweep kernel and the oracle --------------------------------------
+def test_scan_v2_equals_brute_force_kernel(gpu, monkeypatch):
+    monkeypatch.setenv("X3H_SCAN_V1", "1")
+    brute = _lib.X3Context(0)  # reads the switch at creation
+    monkeypatch.delenv("X3H_SCAN_V1")
+    rng = np.random.default_rng(21)
+    cases = [
+        (synth.english_like(400_000).tobytes(), dict(w_kib=64, t=256)),
+        (synth.zipf_bytes(300_000).tobytes(), dict(w_kib=64, t=256)),
+        ((rng.integers(0, 4, 200_000, dtype=np.uint8) + 65).tobytes(), dict(w_kib=16, t=40)),          # DNA-like: deep walks
+        ((b"abcdefghijklmnopqrstuvwxyz0123456789" * 6000)[:200_000], dict(w_kib=32, t=100)),             # periodic: lcp 32 everywhere
+        (bytes(100_000) + synth.english_like(50_000).tobytes() + bytes(3000), dict(w_kib=8, t=15)),        # zero runs + text + zero tail
+        (synth.english_like(120_000).tobytes(), dict(w_kib=512, t=4096)),                                   # window > input
+        (synth.english_like(50_000).tobytes(), dict(w_kib=1, t=1)),
+    ]
+    try:
+        for data, kw in cases:
+            prm = _lib.make_params(**kw)
+            a, b = gpu.scan_m(data, prm), brute.scan_m(data, prm)
+            assert np.array_equal(a, b), f"{kw}: first diff at {first_diff(a, b)}"
+    finally:
+        brute.close()

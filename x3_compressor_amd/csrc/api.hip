@@ -32,7 +32,9 @@ struct x3h_ctx {
 	hipEvent_t ev[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
 	DevBuf pad, m, dict_pos, dict_len, ht, tok_pos, tok_info, tok_hb, tok_nb, tok_mb, chunks, presult, cresult;
 	X3Code2Bufs c2;
-	int code_v1 = 0;
+	X3Scan2Bufs s2;
+	int code_v1 = 0, scan_v1 = 0;
+	uint64_t pad_total = 0;
 	DevBuf mtf, idxfreq, ctx1, ctx0, items, pkey, pval, out, counts;
 	DevBuf din, dchunks; /* decoder: input streams, stream table */
 	std::vector<X3Chunk> hchunks;
@@ -95,6 +97,7 @@ extern "C" int x3h_ctx_create(x3h_ctx **out, int device)
 	if (!c) return X3H_E_NOMEM;
 	c->device = device;
 	{ const char *e = getenv("X3H_CODE_V1"); c->code_v1 = e && *e && *e != '0'; }
+	{ const char *e = getenv("X3H_SCAN_V1"); c->scan_v1 = e && *e && *e != '0'; }
 	if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return X3H_E_HIP; }
 	for (int i = 0; i < 6; i++)
 		if (hipEventCreate(&c->ev[i]) != hipSuccess) { x3h_ctx_destroy(c); return X3H_E_HIP; }
@@ -112,6 +115,8 @@ extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 		               &c->cresult, &c->mtf, &c->idxfreq, &c->ctx1, &c->ctx0, &c->items, &c->pkey, &c->pval, &c->out, &c->counts, &c->din, &c->dchunks };
 	for (DevBuf *b : bufs) b->release();
 	for (DevBuf &b : c->c2.a) b.release();
+	for (DevBuf &b : c->s2.a) b.release();
+	c->s2.misc.release();
 	for (DevBuf &b : c->c2.y) b.release();
 	for (DevBuf &b : c->c2.ms) b.release();
 	for (int i = 0; i < 6; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
@@ -151,6 +156,7 @@ static int stage_inputs(x3h_ctx *c, const x3h_params *prm, const RunIO &io, uint
 		if (len > max_len) max_len = len;
 	}
 	*max_len_out = max_len;
+	c->pad_total = boff;
 	CHK(c->pad.reserve(boff + 256));
 	CHK(c->m.reserve(boff + 256));
 	CHK(c->dict_pos.reserve(eoff * 4));
@@ -203,8 +209,14 @@ static int run(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage upto
 		CHK(c->counts.reserve((size_t)c->hchunks[0].len * 32 * 4 + 256));
 		sa.counts = c->counts.as<uint32_t>();
 	}
-	x3k_launch_scan(&sa, (uint32_t)max_len, (uint32_t)nc, c->stream);
-	HIPCHK(hipGetLastError());
+	if (io.want_counts || c->scan_v1) {
+		/* brute-force sweep (scan.hip): the raw histogram for tests, and the A/B reference of the v2 scan (X3H_SCAN_V1=1) */
+		x3k_launch_scan(&sa, (uint32_t)max_len, (uint32_t)nc, c->stream);
+		HIPCHK(hipGetLastError());
+	} else {
+		CHK(x3_scan_v2_run(c->s2, c->c2.tmp, c->stream, nc, c->hchunks.data(), c->chunks.as<X3Chunk>(), sa.bytes, sa.m, c->pad_total,
+		                   prm.window_bytes, prm.max_match_count));
+	}
 	HIPCHK(hipEventRecord(c->ev[2], c->stream));
 	if (upto == STAGE_SCAN) { HIPCHK(hipStreamSynchronize(c->stream)); return X3H_OK; }
 
