@@ -47,6 +47,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 	X3_LDS uint8_t sL[PBL];
 	X3_LDS uint32_t sE[PBL];
 	X3_LDS uint8_t sM[PB];
+	X3_LDS uint8_t sN[PB]; /* the parse step at a cached position: 0x80 | L0 for a hit, else the new fragment's length */
 	X3_LDS ParseShared S;
 
 	const X3Chunk ck = a.chunks[blockIdx.x];
@@ -59,8 +60,6 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 	uint32_t *tinf = a.tok_info + ck.elem_off;
 	const uint32_t tid = threadIdx.x, lane = x3_lane(), wave = tid / X3_WAVE;
 	const uint32_t f1 = a.factor1, f2 = a.factor2;
-	/* length lane+1 survives the factor1 filter iff L(p+lane) <= thr (L == 0 always does; lanes 0,1 are exempt, backend.c:79) */
-	const uint32_t thr = (lane < 2 || f1 == 0 || lane >= 32) ? 255u : (lane + 1) / f1;
 
 	if (tid == 0) {
 		S.p = 0; S.blk = 0; S.D = 0; S.lenmask = 0; S.hlog = X3_HT_LOG2_MIN < ck.ht_log2_max ? X3_HT_LOG2_MIN : ck.ht_log2_max;
@@ -124,11 +123,39 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 			}
 		}
 		__syncthreads();
+		{
+			/* ---- the step every cached position WOULD take under the current dictionary (backend.c:76-99 closed form +
+			 * x3.c:383,402-404).  It only changes when a new element patches L[], so all threads (re)build the table and the
+			 * serial walker below just follows it. ---- */
+			const uint32_t blk = S.blk, first = S.p >= blk ? S.p - blk : 0;
+			for (uint32_t i = first + tid; i < PB; i += X3_PARSE_THREADS) {
+				const uint32_t q = blk + i;
+				if (q >= n) break;
+				const uint32_t mp = sM[i];
+				uint32_t best = 0;
+				int vmax = -(1 << 20);
+				for (uint32_t k = 1; k <= mp; k++) {
+					const uint32_t Lk = sL[i + k];
+					bool ok = !(k >= 2 && f1 > 0 && Lk != 0 && (uint64_t)Lk * f1 > (uint64_t)(k + 1));
+					if (f2 > 0) {
+						if (Lk != 0 && (int)Lk - (int)k > vmax) vmax = (int)Lk - (int)k;
+						if ((int64_t)vmax * (int64_t)(int)f2 > (int64_t)(k + 1)) ok = false;
+					}
+					if (ok) best = k;
+				}
+				const uint32_t F = best + 1, L0 = sL[i];
+				uint32_t nlL0 = L0;
+				if (a.nl_mode) nlL0 = L0 == 1 ? 1 : L0 == 2 ? 4 : L0 == 3 ? 6 : L0 == 4 ? 8 : 9999; /* x3.c:357-370 */
+				if (L0 != 0 && nlL0 >= F && q + L0 <= n) sN[i] = (uint8_t)(0x80u | L0);
+				else sN[i] = (uint8_t)(q + F > n ? n - q : F);
+			}
+		}
+		__syncthreads();
 
 		if (wave == 0) {
 			/* ---- serial parse out of LDS.  One wavefront issues ~1 instruction / 5 cycles, so the loop is written for
-			 * instruction count: the factor1 filter is one compare against a per-lane constant, a token is one
-			 * v_writelane (stored 64 at a time), and nothing but p / ntok / hits is tracked -- positions and the running
+			 * instruction count: one table lookup per step, a token is one lane insert (stored 64 at a time), and nothing
+			 * but p / ntok / hits is tracked -- positions and the running
 			 * counts K3 needs are prefix sums over the token list, computed in parallel afterwards (api.hip). ---- */
 			uint32_t p = S.p, ntok = S.ntok, hits = S.hits, D = S.D, lenmask = S.lenmask, hlog = S.hlog, mbytes = S.mbytes;
 			const uint32_t blk = S.blk;
@@ -141,32 +168,14 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 				if (p >= n) { out_flag = FLAG_DONE; break; }
 				const uint32_t idx = p - blk;
 				if (idx >= PB) { out_flag = FLAG_REFILL; break; }
-				const uint32_t Li = sL[idx + (lane & 31)];
-				const uint32_t mp = sM[idx];
-				const uint32_t tag = sE[idx];
-				/* backend.c:79-83 : length i+1 is rejected when a dictionary string at p+i has len*factor1 > i+1 */
-				int ok = Li <= thr;
-				if (f2 > 0) { /* backend.c:84-90 : max over o in [1,i] of (L(p+o)-o)*factor2 > i+1 */
-					int v = (lane >= 1 && lane < 32 && Li != 0) ? (int)Li - (int)lane : -(1 << 20);
-					for (unsigned d = 1; d < 32; d <<= 1) {
-						int u = (int)x3_shfl_up_u32((uint32_t)v, d);
-						if (lane >= d && u > v) v = u;
-					}
-					if (lane >= 1 && (int64_t)v * (int64_t)(int)f2 > (int64_t)(lane + 1)) ok = 0;
-				}
-				const uint32_t okm = (uint32_t)x3_ballot(ok) & (0xFFFFFFFFu >> (31 - mp)); /* lanes 0..m[p]; lane 0 always passes */
-				const uint32_t F = 32 - (uint32_t)x3_clz32(okm | 1u);
-				const uint32_t L0 = x3_readlane_u32(Li, 0);
-				uint32_t nlL0 = L0;
-				if (a.nl_mode) nlL0 = L0 == 1 ? 1 : L0 == 2 ? 4 : L0 == 3 ? 6 : L0 == 4 ? 8 : 9999; /* x3.c:357-370 */
-				if (L0 != 0 && nlL0 >= F && p + L0 <= n) {
-					rec = x3_writelane_u32(rec, tag, ntok - recbase);
+				const uint32_t step = sN[idx];
+				if (step & 0x80u) { /* dictionary hit */
+					rec = x3_writelane_u32(rec, sE[idx], ntok - recbase);
 					ntok++; hits++;
-					p += L0;
+					p += step & 0x7Fu;
 					continue;
 				}
-				uint32_t len = F;
-				if (p + len > n) len = n - p; /* x3.c:402-404 */
+				const uint32_t len = step, L0 = sL[idx];
 				/* x3.c:412 : is this exact fragment already an element? */
 				int dup = 0;
 				if (L0 == len) dup = 1;
