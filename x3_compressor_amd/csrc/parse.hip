@@ -223,6 +223,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 				p += len;
 			}
 			if (lane < ntok - recbase) tinf[recbase + lane] = rec;
+			x3_wave_sync(); /* every lane has read the shared walker state before lane 0 replaces it */
 			if (lane == 0) {
 				S.p = p; S.ntok = ntok; S.hits = hits; S.D = D; S.lenmask = lenmask; S.hlog = hlog; S.mbytes = mbytes;
 				S.flag = out_flag;
