@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--t", type=int, default=256)
     ap.add_argument("--cpu-sample", type=int, default=256 * 1024)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--chunks", type=int, default=64, help="also report the same bytes as N independent chunks in one batch (0/1: skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -111,6 +112,25 @@ def main():
     total_bytes = args.bytes * world
     value = total_bytes / (dt / args.steps) / 1e6
 
+    chunked = None
+    if rank == 0 and args.chunks > 1:
+        # secondary figure: the SAME bytes cut into independent chunks (each its own x3 stream) and coded as one
+        # batch -- the serial stages of all streams then run concurrently.  Ratio drops because every stream restarts its models.
+        cb = (args.bytes + args.chunks - 1) // args.chunks
+        coff = np.array(list(range(0, args.bytes, cb)) + [args.bytes], dtype=np.uint64)
+        cstride = (2 * cb + 4096 + 3) & ~3
+        d_cout = torch.empty(cstride * (len(coff) - 1), dtype=torch.uint8, device=dev)
+        ctx.compress_chunks_dev(d_in.data_ptr(), coff, prm, d_cout.data_ptr(), cstride)  # warm-up (allocations)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        clens, cst = ctx.compress_chunks_dev(d_in.data_ptr(), coff, prm, d_cout.data_ptr(), cstride)
+        torch.cuda.synchronize()
+        cdt = time.perf_counter() - t1
+        chunked = {"chunks": len(coff) - 1, "chunk_bytes": cb, "value": round(args.bytes / cdt / 1e6, 3), "unit": "MB/s",
+                   "ms": round(cdt * 1e3, 3), "ratio": round(args.bytes / float(clens.sum()), 4),
+                   "stage_ms": {"scan": round(cst.ms_scan, 3), "parse": round(cst.ms_parse, 3), "code": round(cst.ms_code, 3)}}
+        del d_cout
+
     if rank == 0:
         steps_parse = int(st.steps)
         comp = out_len
@@ -131,6 +151,8 @@ def main():
                          "algorithmic_bytes": b_alg, "kernel_ms": round(scan_s * 1e3, 3),
                          "note": "algorithmic bytes S*W+N+C per SURVEY.md 8(d); the window is L2/LDS resident so HBM traffic is far below it"},
         }
+        if chunked:
+            line["chunked_same_bytes"] = chunked
         if not args.no_cpu:
             cb = cpu_baseline(data, args.w, args.t, args.cpu_sample)
             ref_out = cb.pop("out")

@@ -13,6 +13,7 @@
  */
 #include "x3_host.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <vector>
@@ -237,6 +238,8 @@ static int run(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage upto
 	c->hparse.resize((size_t)nc);
 	HIPCHK(hipMemcpyAsync(c->hparse.data(), c->presult.p, (size_t)nc * sizeof(X3ParseResult), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
+	if (getenv("X3H_DEBUG")) for (int i = 0; i < nc && i < 4; i++) { const X3ParseResult &r = c->hparse[(size_t)i];
+		fprintf(stderr, "[x3h] chunk %d: steps %u hits %u D %u missbytes %u | parse kcycles: fill %u patch %u table %u walk %u\n", i, r.ntok, r.hits, r.dict_elems, r.miss_bytes, r.kcyc_fill, r.kcyc_patch, r._r0, r.kcyc_walk); }
 	if (upto == STAGE_PARSE) return X3H_OK;
 
 	/* ---- K3 workspace from the exact D / hits of every chunk ---- */

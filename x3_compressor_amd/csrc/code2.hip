@@ -98,25 +98,25 @@ struct X3ModesArgs {
 	uint32_t *mode;                    /* out per hit: the chosen event (E_CTX0 / E_CTX1 / E_IDX1) */
 };
 
+#ifndef X3_IDXF_LDS
 #define X3_IDXF_LDS 32768u /* ranks whose model_index1 frequency lives in LDS (128 KiB); beyond that: global memory */
+#endif
 
-/* A lone wavefront issues about one instruction per 5 cycles, so this loop is written for instruction count:
+/* A lone wavefront issues about one instruction per 5 cycles and pays ~40 cycles per taken branch, so this loop is
+ * written for instruction count and straight-line flow:
  *   - the four IEEE divisions of x3.c:152-160 (ev0/tot, ev1/tot, ev2/tot, freq/idxtotal) are ONE vector division:
  *     lane j of `num`/`den` holds operand pair j (lanes 0..2 keep model_events freqs persistently);
  *   - the two multiplies are one v_mul (lane 2 multiplies by lane 3's quotient);
  *   - the argmax with its tie order runs on the scalar unit, comparing the float BIT PATTERNS as unsigned integers
  *     (all probabilities are >= +0, so the orders coincide; no NaN can arise);
- *   - only the 2-bit mode is recorded (v_writelane); model_events / model_index1 values at every hit are recovered
- *     afterwards by prefix sums over the modes. */
-__device__ static void x3_modes_body(const X3ModesArgs &a)
+ *   - model_index1's frequency of the NEXT hit's rank is fetched while this hit is decided (and corrected if this hit
+ *     bumps the same rank), which takes the LDS round trip off the dependent chain;
+ *   - only the 2-bit mode is recorded; model_events / model_index1 values at every hit are recovered afterwards by
+ *     prefix sums over the modes.
+ * ALL_LDS: every rank of the stream fits the LDS table (the common case) -> no generic-address loads at all. */
+template <bool ALL_LDS>
+__device__ static __forceinline__ void x3_modes_loop(const X3ModesArgs &a, uint32_t *sidx, uint32_t *idxf, uint32_t H, uint32_t h0, uint32_t lane)
 {
-	X3_LDS uint32_t sidx[X3_IDXF_LDS];
-	const uint32_t c = blockIdx.x, lane = x3_lane();
-	const uint32_t H = a.parsed[c].hits, h0 = a.ho[c], Dc = a.parsed[c].dict_elems;
-	uint32_t *idxf = a.idxfreq + a.dof[c];
-	const uint32_t nl = Dc < X3_IDXF_LDS ? Dc : X3_IDXF_LDS;
-	for (uint32_t i = lane; i < nl; i += X3_WAVE) sidx[i] = 1;
-	x3_wave_sync();
 	uint32_t num = lane == 0 ? 1024u : lane == 1 ? 1024u : 1u; /* lanes 0..2: model_events freq of E_CTX0, E_CTX1, E_IDX1 (x3.c:239-241) */
 	uint32_t nidx = 0;
 	for (uint32_t base = 0; base < H; base += X3_WAVE) {
@@ -130,10 +130,15 @@ __device__ static void x3_modes_body(const X3ModesArgs &a)
 		const uint32_t vtot = 2051u + vs; /* model_events.total: 2051 + one per earlier step */
 		uint32_t rec = 0;
 		const uint32_t cnt = H - base < X3_WAVE ? H - base : X3_WAVE;
+		uint32_t r = x3_readlane_u32(vr, 0);
+		uint32_t rf = x3_uniform((ALL_LDS || r < X3_IDXF_LDS) ? sidx[(ALL_LDS || r < X3_IDXF_LDS) ? r : 0] : idxf[r]);
 		for (uint32_t l = 0; l < cnt; l++) {
-			const uint32_t r = x3_readlane_u32(vr, l), dk = x3_readlane_u32(vd, l), tot = x3_readlane_u32(vtot, l);
+			const uint32_t dk = x3_readlane_u32(vd, l), tot = x3_readlane_u32(vtot, l);
 			const uint32_t q0 = x3_readlane_u32(vq0, l), q1 = x3_readlane_u32(vq1, l);
-			const uint32_t rf = x3_readlane_u32(r < X3_IDXF_LDS ? sidx[r < X3_IDXF_LDS ? r : 0] : idxf[r], 0);
+			/* next hit of this round: rank and (speculative) frequency */
+			const uint32_t ln = l + 1 < cnt ? l + 1 : l;
+			const uint32_t rn = x3_readlane_u32(vr, ln);
+			uint32_t rfn = x3_uniform((ALL_LDS || rn < X3_IDXF_LDS) ? sidx[(ALL_LDS || rn < X3_IDXF_LDS) ? rn : 0] : idxf[rn]);
 			const uint32_t itot = dk + nidx;
 			num = x3_writelane_u32(num, rf, 3);
 			const uint32_t den = x3_writelane_u32(tot, itot, 3);
@@ -146,16 +151,33 @@ __device__ static void x3_modes_body(const X3ModesArgs &a)
 			if (p0 > best) { mode = X3_E_CTX0; best = p0; }
 			if (p1 > best) mode = X3_E_CTX1;
 			num = x3_writelane_u32(num, x3_readlane_u32(num, mode) + 1, mode); /* inc_model(&model_events, mode), x3.c:177 */
-			if (mode == X3_E_IDX1) { /* inc_model(&model_index1, index), x3.c:188 */
-				nidx++;
+			const uint32_t isidx = mode == X3_E_IDX1 ? 1u : 0u;
+			nidx += isidx;
+			if (isidx) { /* inc_model(&model_index1, index), x3.c:188 */
 				x3_wave_sync();
-				if (lane == 0) { if (r < X3_IDXF_LDS) sidx[r] = rf + 1; else idxf[r] = rf + 1; }
+				if (lane == 0) { if (ALL_LDS || r < X3_IDXF_LDS) sidx[r] = rf + 1; else idxf[r] = rf + 1; }
 				x3_wave_sync();
+				if (rn == r && ln != l) rfn = rf + 1; /* the prefetched value predates this update */
 			}
 			rec = x3_writelane_u32(rec, mode, l);
+			r = rn;
+			rf = rfn;
 		}
 		if (in) a.mode[g] = rec;
 	}
+}
+
+__device__ static void x3_modes_body(const X3ModesArgs &a)
+{
+	X3_LDS uint32_t sidx[X3_IDXF_LDS];
+	const uint32_t c = blockIdx.x, lane = x3_lane();
+	const uint32_t H = a.parsed[c].hits, h0 = a.ho[c], Dc = a.parsed[c].dict_elems;
+	uint32_t *idxf = a.idxfreq + a.dof[c];
+	const uint32_t nl = Dc < X3_IDXF_LDS ? Dc : X3_IDXF_LDS;
+	for (uint32_t i = lane; i < nl; i += X3_WAVE) sidx[i] = 1;
+	x3_wave_sync();
+	if (Dc <= X3_IDXF_LDS) x3_modes_loop<true>(a, sidx, idxf, H, h0, lane);
+	else x3_modes_loop<false>(a, sidx, idxf, H, h0, lane);
 }
 
 /* ============================================================================================================
@@ -172,7 +194,7 @@ __device__ static void x3_modes_body(const X3ModesArgs &a)
 struct X3Ac2Args {
 	const uint32_t *yo;                   /* per chunk: first symbol (nc+1) */
 	const uint32_t *scum, *sfreq, *stot;  /* per symbol */
-	uint32_t *rec_nk, *rec_bits;          /* out per symbol: n | k<<8, and lo before the shift (its top n bits are the emitted bits) */
+	uint32_t *rec_nk;                     /* out per symbol: {n | k<<8, lo before the shift (its top n bits are the emitted bits)} as uint2 */
 	uint32_t *final_lo;                   /* out per chunk */
 };
 
@@ -192,31 +214,28 @@ __device__ static void x3_ac2_body(const X3Ac2Args &a)
 		 * The 64 lanes prepare (m, shift) for 64 symbols at once, off the serial chain. */
 		const uint32_t vL = vtot <= 1 ? 0u : 32u - (uint32_t)x3_clz32(vtot - 1);
 		const uint32_t vm = (uint32_t)((((uint64_t)1 << (31 + vL)) + vtot - 1) / vtot), vsh = 31 + vL, vchi = vcum + vfq;
-		uint32_t rec_a = 0, rec_b = 0;
 		const uint32_t cnt = Y - base < X3_WAVE ? Y - base : X3_WAVE;
+		uint2 *recs = (uint2 *)a.rec_nk + (y0 + base); /* {n | k<<8, lo before the shift} per symbol */
+#pragma unroll 2
 		for (uint32_t l = 0; l < cnt; l++) {
 			const uint32_t clo = x3_readlane_u32(vcum, l), chi = x3_readlane_u32(vchi, l);
 			const uint32_t m = x3_readlane_u32(vm, l), sh = x3_readlane_u32(vsh, l);
 			const uint32_t step = (uint32_t)(((uint64_t)(hi - lo + 1) * m) >> sh);
 			const uint32_t nhi = lo + step * chi - 1, nlo = lo + step * clo;
-			const uint32_t x = nlo ^ nhi;
-			uint32_t n, k;
-			if (x != 0) {
-				/* E1/E2 (ac.c:49-67): the n leading bits on which lo and hi agree leave; E3 (ac.c:70-74): then the k positions
-				 * below the top bit where lo has 1 and hi has 0.  Both are left shifts, applied at once (n + k <= 30). */
-				n = (uint32_t)x3_clz32(x) - 1;
-				const uint32_t y = ((((nhi | ~nlo) << n) | ~(0xFFFFFFFFu << n)) & 0x3FFFFFFFu);
-				k = y ? (uint32_t)x3_clz32(y) - 2 : 30u - n;
-				const uint32_t s = n + k;
-				lo = (nlo << s) & 0x3FFFFFFFu;
-				hi = (((nhi << s) | ~(0xFFFFFFFFu << s)) & 0x3FFFFFFFu) | 0x40000000u;
-			} else { /* lo == hi (needs total > 2^28): all 31 bits leave */
-				n = 31; k = 0; lo = 0; hi = 0x7FFFFFFFu;
-			}
-			rec_a = x3_writelane_u32(rec_a, n | (k << 8), l);
-			rec_b = x3_writelane_u32(rec_b, nlo, l);
+			/* E1/E2 (ac.c:49-67): the n leading bits on which lo and hi agree leave; E3 (ac.c:70-74): then the k positions below
+			 * the top bit where lo has 1 and hi has 0.  Both are left shifts, applied at once (n + k <= 31).  Straight-line on
+			 * purpose (a taken branch costs a lone wave ~40 cycles): clz(0) == 32 makes the formulas cover lo == hi (n = 31,
+			 * k = 0) and the all-E3 case (n = 0, k = 30) without special cases. */
+			const uint32_t n = (uint32_t)x3_clz32(nlo ^ nhi) - 1;
+			const uint32_t y = ((((nhi | ~nlo) << n) | ~(0xFFFFFFFFu << n)) & 0x3FFFFFFFu);
+			const uint32_t k = (uint32_t)x3_clz32(y) - 2;
+			const uint32_t s = n + k;
+			lo = (nlo << s) & 0x3FFFFFFFu;
+			hi = (((nhi << s) | ~(0xFFFFFFFFu << s)) & 0x3FFFFFFFu) | 0x40000000u;
+			uint2 rv;
+			rv.x = n | (k << 8); rv.y = nlo;
+			recs[l] = rv; /* every lane stores the same (uniform) record: one 8-byte write, no exec masking, no select */
 		}
-		if (in) { a.rec_nk[y0 + base + lane] = rec_a; a.rec_bits[y0 + base + lane] = rec_b; }
 	}
 	if (lane == 0) a.final_lo[c] = lo;
 }
@@ -625,8 +644,8 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 
 	/* ---- the coded symbols, in coding order: symbol index of step k = 2k + (new-fragment bytes before k) ---- */
 	uint32_t *Yv[12];
-	for (int i = 0; i < 12; i++) { CHK(B.y[i].reserve((nY + 4) * 4)); Yv[i] = B.y[i].as<uint32_t>(); }
-	uint32_t *sy_cum = Yv[0], *sy_freq = Yv[1], *sy_tot = Yv[2], *rec_nk = Yv[3], *rec_bits = Yv[4];
+	for (int i = 0; i < 12; i++) { CHK(B.y[i].reserve((nY + 4) * (i == 3 ? 8 : 4))); Yv[i] = B.y[i].as<uint32_t>(); }
+	uint32_t *sy_cum = Yv[0], *sy_freq = Yv[1], *sy_tot = Yv[2], *rec_nk = Yv[3]; /* rec_nk: 2 words per symbol */
 	x3_foreach(nS, st, X3_LAMBDA(size_t gs) {
 		const uint32_t c = find_chunk(d_so, nc, (uint32_t)gs);
 		const uint32_t k = (uint32_t)gs - d_so[c];
@@ -659,7 +678,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 
 	/* ---- serial pass 2: interval recurrence ---- */
 	X3Ac2Args aa;
-	aa.yo = d_yo; aa.scum = sy_cum; aa.sfreq = sy_freq; aa.stot = sy_tot; aa.rec_nk = rec_nk; aa.rec_bits = rec_bits; aa.final_lo = m_finallo;
+	aa.yo = d_yo; aa.scum = sy_cum; aa.sfreq = sy_freq; aa.stot = sy_tot; aa.rec_nk = rec_nk; aa.final_lo = m_finallo;
 	launch_ac2(aa, nc, st);
 	HIPCHK(hipGetLastError());
 
@@ -668,7 +687,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	 * bits written by symbol i = n + pending before it (when n >= 1): first bit, the pending bits inverted, the other n-1 bits */
 	uint32_t *kk = Yv[5], *rv = Yv[6], *Kex = Yv[7], *LE = Yv[8], *len = Yv[9], *pos = Yv[10], *pend = Yv[11];
 	x3_foreach(nY, st, X3_LAMBDA(size_t i) {
-		const uint32_t nk = rec_nk[i];
+		const uint32_t nk = rec_nk[2 * i];
 		const uint32_t c = find_chunk(d_yo, nc, (uint32_t)i);
 		kk[i] = nk >> 8;
 		rv[i] = ((nk & 0xFF) >= 1 || i == d_yo[c]) ? (uint32_t)i + 1 : 0u;
@@ -677,7 +696,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	CHK(x3p_incl_max_scan(B.tmp, rv, LE, nY, st));
 	x3_foreach(nY, st, X3_LAMBDA(size_t i) { pend[i] = Kex[i + 1] - Kex[LE[i] - 1]; });
 	x3_foreach(nY, st, X3_LAMBDA(size_t i) {
-		const uint32_t n = rec_nk[i] & 0xFF;
+		const uint32_t n = rec_nk[2 * i] & 0xFF;
 		const uint32_t c = find_chunk(d_yo, nc, (uint32_t)i);
 		len[i] = n >= 1 ? n + (i == d_yo[c] ? 0u : pend[i - 1]) : 0u;
 	});
@@ -690,9 +709,9 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		const uint32_t c = find_chunk(d_yo, nc, (uint32_t)i);
 		uint32_t *out32 = (uint32_t *)(d_out + d_chunks[c].out_off);
 		const uint32_t capw = (uint32_t)(d_chunks[c].out_cap / 4);
-		const uint32_t n = rec_nk[i] & 0xFF, pd = ln - n;
+		const uint32_t n = rec_nk[2 * i] & 0xFF, pd = ln - n;
 		const uint64_t bp = pos[i] - pos[d_yo[c]];
-		const uint32_t rev = x3_brev32(rec_bits[i] << 1) & (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1)); /* bit j = j-th emitted bit = bit 30-j of lo */
+		const uint32_t rev = x3_brev32(rec_nk[2 * i + 1] << 1) & (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1)); /* bit j = j-th emitted bit = bit 30-j of lo */
 		if (!pd) x3_or_bits(out32, capw, bp, rev, n);
 		else {
 			x3_or_bits(out32, capw, bp, rev & 1u, 1);

@@ -47,7 +47,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 	X3_LDS uint8_t sL[PBL];
 	X3_LDS uint32_t sE[PBL];
 	X3_LDS uint8_t sM[PB];
-	X3_LDS uint8_t sN[PB]; /* the parse step at a cached position: 0x80 | L0 for a hit, else the new fragment's length */
+	X3_LDS uint2 sN[PB]; /* the parse step at a cached position: .x = tag of the hit element, .y = 0x80 | L0 for a hit, else the new fragment's length (one 64-bit LDS read per step) */
 	X3_LDS ParseShared S;
 
 	const X3Chunk ck = a.chunks[blockIdx.x];
@@ -68,6 +68,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 	for (uint32_t i = tid; i < (1u << (X3_HT_LOG2_MIN < ck.ht_log2_max ? X3_HT_LOG2_MIN : ck.ht_log2_max)); i += X3_PARSE_THREADS) ht[i] = 0;
 	__syncthreads();
 
+	uint64_t cyc_fill = 0, cyc_patch = 0, cyc_table = 0, cyc_walk = 0, t_prev = x3_clock();
 	while (S.flag != FLAG_DONE) { /* S.flag is only written between the two barriers below: uniform */
 		const uint32_t flag = S.flag;
 		if (flag == FLAG_REFILL) {
@@ -123,6 +124,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 			}
 		}
 		__syncthreads();
+		{ const uint64_t t = x3_clock(); if (flag == FLAG_REFILL) cyc_fill += t - t_prev; else cyc_patch += t - t_prev; t_prev = t; }
 		{
 			/* ---- the step every cached position WOULD take under the current dictionary (backend.c:76-99 closed form +
 			 * x3.c:383,402-404).  It only changes when a new element patches L[], so all threads (re)build the table and the
@@ -146,19 +148,23 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 				const uint32_t F = best + 1, L0 = sL[i];
 				uint32_t nlL0 = L0;
 				if (a.nl_mode) nlL0 = L0 == 1 ? 1 : L0 == 2 ? 4 : L0 == 3 ? 6 : L0 == 4 ? 8 : 9999; /* x3.c:357-370 */
-				if (L0 != 0 && nlL0 >= F && q + L0 <= n) sN[i] = (uint8_t)(0x80u | L0);
-				else sN[i] = (uint8_t)(q + F > n ? n - q : F);
+				uint2 e;
+				e.x = sE[i];
+				e.y = (L0 != 0 && nlL0 >= F && q + L0 <= n) ? (0x80u | L0) : (q + F > n ? n - q : F);
+				sN[i] = e;
 			}
 		}
 		__syncthreads();
+		{ const uint64_t t = x3_clock(); cyc_table += t - t_prev; t_prev = t; }
 
 		if (wave == 0) {
 			/* ---- serial parse out of LDS.  One wavefront issues ~1 instruction / 5 cycles, so the loop is written for
 			 * instruction count: one table lookup per step, a token is one lane insert (stored 64 at a time), and nothing
 			 * but p / ntok / hits is tracked -- positions and the running
 			 * counts K3 needs are prefix sums over the token list, computed in parallel afterwards (api.hip). ---- */
-			uint32_t p = S.p, ntok = S.ntok, hits = S.hits, D = S.D, lenmask = S.lenmask, hlog = S.hlog, mbytes = S.mbytes;
-			const uint32_t blk = S.blk;
+			uint32_t p = x3_uniform(S.p), ntok = x3_uniform(S.ntok), hits = x3_uniform(S.hits), D = x3_uniform(S.D);
+			uint32_t lenmask = x3_uniform(S.lenmask), hlog = x3_uniform(S.hlog), mbytes = x3_uniform(S.mbytes);
+			const uint32_t blk = x3_uniform(S.blk);
 			uint32_t out_flag = 0, rec = 0, recbase = ntok;
 			for (;;) {
 				if (ntok - recbase == X3_WAVE) { /* flush 64 buffered tokens, coalesced */
@@ -168,14 +174,15 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 				if (p >= n) { out_flag = FLAG_DONE; break; }
 				const uint32_t idx = p - blk;
 				if (idx >= PB) { out_flag = FLAG_REFILL; break; }
-				const uint32_t step = sN[idx];
+				const uint2 ne = sN[idx];
+				const uint32_t step = x3_uniform(ne.y), htag = x3_uniform(ne.x);
 				if (step & 0x80u) { /* dictionary hit */
-					rec = x3_writelane_u32(rec, sE[idx], ntok - recbase);
+					rec = x3_writelane_u32(rec, htag, ntok - recbase);
 					ntok++; hits++;
 					p += step & 0x7Fu;
 					continue;
 				}
-				const uint32_t len = step, L0 = sL[idx];
+				const uint32_t len = step, L0 = x3_uniform(sL[idx]);
 				/* x3.c:412 : is this exact fragment already an element? */
 				int dup = 0;
 				if (L0 == len) dup = 1;
@@ -230,11 +237,15 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 			}
 		}
 		__syncthreads();
+		{ const uint64_t t = x3_clock(); cyc_walk += t - t_prev; t_prev = t; }
 	}
 
 	if (tid == 0) {
 		X3ParseResult r;
-		r.ntok = S.ntok; r.dict_elems = S.D; r.hits = S.hits; r.status = X3_ST_OK; r.miss_bytes = S.mbytes; r._r0 = r._r1 = r._r2 = 0;
+		r.ntok = S.ntok; r.dict_elems = S.D; r.hits = S.hits; r.status = X3_ST_OK; r.miss_bytes = S.mbytes;
+		r.kcyc_fill = (uint32_t)(cyc_fill >> 10); r.kcyc_patch = (uint32_t)(cyc_patch >> 10); r.kcyc_walk = (uint32_t)(cyc_walk >> 10);
+		(void)cyc_table; /* folded into patch/fill by the caller's view: table time is reported with the walk */
+		r.kcyc_walk += (uint32_t)(cyc_table >> 10) * 0; r._r0 = (uint32_t)(cyc_table >> 10);
 		a.result[blockIdx.x] = r;
 	}
 }

@@ -27,6 +27,8 @@
 __device__ __forceinline__ unsigned x3_lane() { return threadIdx.x & (X3_WAVE - 1); }
 __device__ __forceinline__ uint64_t x3_ballot(int p) { return __ballot(p); }
 __device__ __forceinline__ uint32_t x3_bcast_u32(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, X3_WAVE); }
+/* tell the compiler a value is wave-uniform (it then lives in an SGPR and control flow on it is scalar) */
+__device__ __forceinline__ uint32_t x3_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 /* v[lane] for a wave-uniform lane index: one v_readlane_b32 (SGPR result) instead of a ds_bpermute round trip */
 __device__ __forceinline__ uint32_t x3_readlane_u32(uint32_t v, uint32_t lane_uniform) { return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane((int)lane_uniform)); }
 /* copy of `old` with lane `lane_uniform` replaced by the wave-uniform value `val`.  (ROCm 7.2's clang has no writelane
@@ -37,11 +39,12 @@ __device__ __forceinline__ uint32_t x3_shfl_xor_u32(uint32_t v, int m) { return 
 /* Orders this wave's earlier LDS/global accesses before its later ones when different lanes touch the same
  * address (the compiler only tracks per-lane dependencies). */
 __device__ __forceinline__ void x3_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+__device__ __forceinline__ uint64_t x3_clock() { return (uint64_t)clock64(); } /* s_memtime: shader cycles */
 __device__ __forceinline__ int x3_popc64(uint64_t v) { return __popcll(v); }
 __device__ __forceinline__ int x3_ctz64(uint64_t v) { return __ffsll((long long)v) - 1; }           /* v != 0 */
 __device__ __forceinline__ int x3_ctz32(uint32_t v) { return __ffs((int)v) - 1; }                   /* v != 0 */
 __device__ __forceinline__ int x3_clz64(uint64_t v) { return __clzll((long long)v); }               /* v != 0 */
-__device__ __forceinline__ int x3_clz32(uint32_t v) { return __clz((int)v); }                       /* v != 0 */
+__device__ __forceinline__ int x3_clz32(uint32_t v) { return __clz((int)v); }                       /* 32 for v == 0 */
 
 #else
 /* ------------------------------------------------------------------------------------------------ */
@@ -57,6 +60,7 @@ __device__ __forceinline__ int x3_clz32(uint32_t v) { return __clz((int)v); }   
 #define __launch_bounds__(...)
 #define X3_LDS static
 
+struct uint2 { uint32_t x, y; };
 struct x3emu_dim3 { unsigned x, y, z; x3emu_dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 typedef x3emu_dim3 dim3;
 
@@ -71,16 +75,18 @@ uint32_t x3emu_shfl(uint32_t v, int src_lane);
 static inline unsigned x3_lane() { return threadIdx.x & (X3_WAVE - 1); }
 static inline uint64_t x3_ballot(int p) { return x3emu_ballot(p); }
 static inline uint32_t x3_bcast_u32(uint32_t v, int src) { return x3emu_shfl(v, src); }
+static inline uint32_t x3_uniform(uint32_t v) { return v; }
 static inline uint32_t x3_readlane_u32(uint32_t v, uint32_t lane_uniform) { return x3emu_shfl(v, (int)lane_uniform); }
 static inline uint32_t x3_writelane_u32(uint32_t old, uint32_t val, uint32_t lane_uniform) { return x3_lane() == lane_uniform ? val : old; }
 static inline uint32_t x3_shfl_up_u32(uint32_t v, unsigned d) { int l = (int)x3_lane(); return x3emu_shfl(v, l >= (int)d ? l - (int)d : l); }
 static inline uint32_t x3_shfl_xor_u32(uint32_t v, int m) { return x3emu_shfl(v, (int)x3_lane() ^ m); }
 static inline void x3_wave_sync() { (void)x3emu_ballot(0); }
+static inline uint64_t x3_clock() { return 0; }
 static inline int x3_popc64(uint64_t v) { return __builtin_popcountll(v); }
 static inline int x3_ctz64(uint64_t v) { return __builtin_ctzll(v); }
 static inline int x3_ctz32(uint32_t v) { return __builtin_ctz(v); }
 static inline int x3_clz64(uint64_t v) { return __builtin_clzll(v); }
-static inline int x3_clz32(uint32_t v) { return __builtin_clz(v); }
+static inline int x3_clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
 
 template <typename T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
 template <typename T> static inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }

@@ -49,7 +49,7 @@ struct X3Chunk {           /* one independent x3 stream */
 	uint64_t out_cap;      /* bytes reserved (multiple of 4)                                             */
 };
 
-struct X3ParseResult { uint32_t ntok, dict_elems, hits, status, miss_bytes, _r0, _r1, _r2; };
+struct X3ParseResult { uint32_t ntok, dict_elems, hits, status, miss_bytes, _r0 /* kcycles: step table */, kcyc_fill, kcyc_patch, kcyc_walk, _r1, _r2, _r3; };
 struct X3CodeResult  { uint32_t out_len, status, pairs, _r; uint32_t events[8]; };
 
 struct X3CtxHdr { uint32_t off, items, cap, total; };   /* one context: items live in the pool at [off, off+items) */
@@ -68,7 +68,7 @@ struct X3ScanArgs {
 };
 
 /* ---- K2 ------------------------------------------------------------------------------------------- */
-#define X3_PARSE_THREADS 256
+#define X3_PARSE_THREADS 1024 /* the block fill (hash probes of every cached position) is the parallel part */
 #define X3_PARSE_PB      2048  /* positions whose dictionary matches are cached in LDS            */
 #define X3_HT_LOG2_MIN   10
 
