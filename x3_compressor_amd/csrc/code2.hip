@@ -102,82 +102,114 @@ struct X3ModesArgs {
 #define X3_IDXF_LDS 32768u /* ranks whose model_index1 frequency lives in LDS (128 KiB); beyond that: global memory */
 #endif
 
-/* A lone wavefront issues about one instruction per 5 cycles and pays ~40 cycles per taken branch, so this loop is
- * written for instruction count and straight-line flow:
- *   - the four IEEE divisions of x3.c:152-160 (ev0/tot, ev1/tot, ev2/tot, freq/idxtotal) are ONE vector division:
- *     lane j of `num`/`den` holds operand pair j (lanes 0..2 keep model_events freqs persistently);
- *   - the two multiplies are one v_mul (lane 2 multiplies by lane 3's quotient);
- *   - the argmax with its tie order runs on the scalar unit, comparing the float BIT PATTERNS as unsigned integers
- *     (all probabilities are >= +0, so the orders coincide; no NaN can arise);
- *   - model_index1's frequency of the NEXT hit's rank is fetched while this hit is decided (and corrected if this hit
- *     bumps the same rank), which takes the LDS round trip off the dependent chain;
- *   - only the 2-bit mode is recorded; model_events / model_index1 values at every hit are recovered afterwards by
- *     prefix sums over the modes.
- * ALL_LDS: every rank of the stream fits the LDS table (the common case) -> no generic-address loads at all. */
+/* The mode choice of x3.c:152-172 feeds back through model_events (three counters) and model_index1 (one frequency per
+ * rank), so in the reference it is a strictly serial chain.  A lone wavefront executes such a chain at ~5 cycles per
+ * instruction; instead the wave decides 64 hits AT ONCE, one per lane, and falls back to serial evaluation only where
+ * that is provably necessary:
+ *   - at hit j of a block every counter lies in a known interval: ev_x in [E_x, E_x + j], model_index1.total in
+ *     [T, T + j], freq(rank) in [f, f + (same-rank hits of the block)];
+ *   - correctly rounded division and multiplication of non-negative operands are monotone, so evaluating the reference's
+ *     exact float expression at the interval ends brackets the true p_ctx0 / p_ctx1 / p_idx1 EXACTLY (no error terms);
+ *   - if the brackets already order the three probabilities (with the reference's tie rules), the decision is certain;
+ *   - the remaining lanes are resolved in order with exact counters (ballot/popcount over the modes decided so far),
+ *     using one vector division for the four quotients.
+ * Typically only a few percent of the hits need the serial path.  ALL_LDS: every rank fits the LDS table. */
 template <bool ALL_LDS>
-__device__ static __forceinline__ void x3_modes_loop(const X3ModesArgs &a, uint32_t *sidx, uint32_t *idxf, uint32_t H, uint32_t h0, uint32_t lane)
+__device__ static __forceinline__ void x3_modes_loop(const X3ModesArgs &a, uint32_t *sidx, uint32_t *scr, uint32_t *idxf, uint32_t H, uint32_t h0, uint32_t lane)
 {
-	uint32_t num = lane == 0 ? 1024u : lane == 1 ? 1024u : 1u; /* lanes 0..2: model_events freq of E_CTX0, E_CTX1, E_IDX1 (x3.c:239-241) */
-	uint32_t nidx = 0;
+	uint32_t E0 = 1024, E1 = 1024, E2 = 1, nidx = 0; /* model_events freqs (x3.c:239-241), IDX1 uses so far */
+	const uint64_t below = ((uint64_t)1 << lane) - 1;
 	for (uint32_t base = 0; base < H; base += X3_WAVE) {
 		const uint32_t g = h0 + base + lane;
 		const bool in = base + lane < H;
 		const uint32_t vf0 = in ? a.f0[g] : 0, vt0 = in ? a.t0[g] : 1, vf1 = in ? a.f1[g] : 0, vt1 = in ? a.t1[g] : 1;
 		const uint32_t vr = in ? a.rank[g] : 0, vd = in ? a.dk[g] : 1, vs = in ? a.step[g] : 0;
-		/* independent of the serial state: (float)freq / (float)total of the context item (context.c:114-133); 0 == absent */
-		const uint32_t vq0 = __float_as_uint(vf0 ? (float)vf0 / (float)vt0 : 0.f);
-		const uint32_t vq1 = __float_as_uint(vf1 ? (float)vf1 / (float)vt1 : 0.f);
-		const uint32_t vtot = 2051u + vs; /* model_events.total: 2051 + one per earlier step */
-		uint32_t rec = 0;
-		const uint32_t cnt = H - base < X3_WAVE ? H - base : X3_WAVE;
-		uint32_t r = x3_readlane_u32(vr, 0);
-		uint32_t rf = x3_uniform((ALL_LDS || r < X3_IDXF_LDS) ? sidx[(ALL_LDS || r < X3_IDXF_LDS) ? r : 0] : idxf[r]);
-		for (uint32_t l = 0; l < cnt; l++) {
-			const uint32_t dk = x3_readlane_u32(vd, l), tot = x3_readlane_u32(vtot, l);
-			const uint32_t q0 = x3_readlane_u32(vq0, l), q1 = x3_readlane_u32(vq1, l);
-			/* next hit of this round: rank and (speculative) frequency */
-			const uint32_t ln = l + 1 < cnt ? l + 1 : l;
-			const uint32_t rn = x3_readlane_u32(vr, ln);
-			uint32_t rfn = x3_uniform((ALL_LDS || rn < X3_IDXF_LDS) ? sidx[(ALL_LDS || rn < X3_IDXF_LDS) ? rn : 0] : idxf[rn]);
-			const uint32_t itot = dk + nidx;
-			num = x3_writelane_u32(num, rf, 3);
-			const uint32_t den = x3_writelane_u32(tot, itot, 3);
-			const float quot = (float)num / (float)den; /* lanes 0..3: ev0/tot, ev1/tot, ev2/tot, rf/itot */
-			uint32_t mult = x3_writelane_u32(q0, q1, 1);
-			mult = x3_writelane_u32(mult, x3_readlane_u32(__float_as_uint(quot), 3), 2);
-			const uint32_t p = __float_as_uint(quot * __uint_as_float(mult)); /* lane 0: p_ctx0, 1: p_ctx1, 2: p_idx1 */
-			const uint32_t p0 = x3_readlane_u32(p, 0), p1 = x3_readlane_u32(p, 1), pi = x3_readlane_u32(p, 2);
-			uint32_t mode = X3_E_IDX1, best = pi; /* x3.c:162-172: IDX1, then CTX0, then CTX1, strict > */
-			if (p0 > best) { mode = X3_E_CTX0; best = p0; }
-			if (p1 > best) mode = X3_E_CTX1;
-			num = x3_writelane_u32(num, x3_readlane_u32(num, mode) + 1, mode); /* inc_model(&model_events, mode), x3.c:177 */
-			const uint32_t isidx = mode == X3_E_IDX1 ? 1u : 0u;
-			nidx += isidx;
-			if (isidx) { /* inc_model(&model_index1, index), x3.c:188 */
-				x3_wave_sync();
-				if (lane == 0) { if (ALL_LDS || r < X3_IDXF_LDS) sidx[r] = rf + 1; else idxf[r] = rf + 1; }
-				x3_wave_sync();
-				if (rn == r && ln != l) rfn = rf + 1; /* the prefetched value predates this update */
-			}
-			rec = x3_writelane_u32(rec, mode, l);
-			r = rn;
-			rf = rfn;
+		const float q0 = vf0 ? (float)vf0 / (float)vt0 : 0.f; /* (float)freq / (float)total of the context item; 0 == absent */
+		const float q1 = vf1 ? (float)vf1 / (float)vt1 : 0.f;
+		const float ftot = (float)(2051u + vs); /* model_events.total: 2051 + one per earlier step */
+		const bool lds_r = ALL_LDS || vr < X3_IDXF_LDS;
+		const uint32_t rfmin = in ? (lds_r ? sidx[lds_r ? vr : 0] : idxf[vr]) : 1;
+		/* same-rank hits in this block (an upper bound is enough: hashed counters, collisions only widen the bracket) */
+		const uint32_t hs = vr & 255u;
+		scr[lane] = 0; scr[lane + 64] = 0; scr[lane + 128] = 0; scr[lane + 192] = 0;
+		x3_wave_sync();
+		if (in) atomicAdd(&scr[hs], 1u);
+		x3_wave_sync();
+		const uint32_t srmax = in ? scr[hs] - 1 : 0;
+		const uint32_t j = lane; /* at most j earlier hits of the block */
+		const float a0lo = (float)E0 / ftot, a0hi = (float)(E0 + j) / ftot;
+		const float a1lo = (float)E1 / ftot, a1hi = (float)(E1 + j) / ftot;
+		const float a2lo = (float)E2 / ftot, a2hi = (float)(E2 + j) / ftot;
+		const uint32_t itmin = vd + nidx;
+		const float blo = (float)rfmin / (float)(itmin + j), bhi = (float)(rfmin + srmax) / (float)itmin;
+		const uint32_t P0lo = __float_as_uint(a0lo * q0), P0hi = __float_as_uint(a0hi * q0);
+		const uint32_t P1lo = __float_as_uint(a1lo * q1), P1hi = __float_as_uint(a1hi * q1);
+		const uint32_t Pilo = __float_as_uint(a2lo * blo), Pihi = __float_as_uint(a2hi * bhi);
+		/* x3.c:162-172 as a predicate: CTX1 iff p1 > max(p0, pi); else CTX0 iff p0 > pi; else IDX1.  (floats >= +0 compare like
+		 * their bit patterns) */
+		const uint32_t mxlo = P0lo > Pilo ? P0lo : Pilo, mxhi = P0hi > Pihi ? P0hi : Pihi;
+		uint32_t mode = 3; /* 3 = undecided */
+		if (P1lo > mxhi) mode = X3_E_CTX1;
+		else if (P1hi <= mxlo) {
+			if (P0lo > Pihi) mode = X3_E_CTX0;
+			else if (P0hi <= Pilo) mode = X3_E_IDX1;
 		}
-		if (in) a.mode[g] = rec;
+#ifdef X3_EMU
+		if (getenv("X3_FORCE_AMB")) mode = 3; /* test hook: push every hit through the exact serial path */
+#endif
+		if (!in) mode = 4; /* padding lanes take no part */
+		uint64_t m0 = x3_ballot(mode == X3_E_CTX0), m1 = x3_ballot(mode == X3_E_CTX1), m2 = x3_ballot(mode == X3_E_IDX1);
+		uint64_t amb = x3_ballot(mode == 3);
+		while (amb) { /* resolve in order, exact counters */
+			const uint32_t l = (uint32_t)x3_ctz64(amb);
+			amb &= amb - 1;
+			const uint64_t bl = ((uint64_t)1 << l) - 1;
+			const uint32_t e0 = E0 + (uint32_t)x3_popc64(m0 & bl), e1 = E1 + (uint32_t)x3_popc64(m1 & bl);
+			const uint32_t e2 = E2 + (uint32_t)x3_popc64(m2 & bl), ni = nidx + (uint32_t)x3_popc64(m2 & bl);
+			const uint32_t rl = x3_readlane_u32(vr, l);
+			const uint64_t same = x3_ballot(vr == rl);
+			const uint32_t rf = x3_readlane_u32(rfmin, l) + (uint32_t)x3_popc64(m2 & same & bl);
+			const uint32_t tot = 2051u + x3_readlane_u32(vs, l), itot = x3_readlane_u32(vd, l) + ni;
+			/* lanes 0..3: ev0/tot, ev1/tot, ev2/tot, rf/itot in ONE vector division */
+			const uint32_t num = lane == 0 ? e0 : lane == 1 ? e1 : lane == 2 ? e2 : rf;
+			const uint32_t den = lane == 3 ? itot : tot;
+			const float quot = (float)num / (float)den;
+			const uint32_t ql0 = x3_readlane_u32(__float_as_uint(q0), l), ql1 = x3_readlane_u32(__float_as_uint(q1), l);
+			const uint32_t qb = x3_readlane_u32(__float_as_uint(quot), 3); /* (not inside the select: every lane must take part) */
+			const uint32_t mult = lane == 0 ? ql0 : lane == 1 ? ql1 : qb;
+			const uint32_t p = __float_as_uint(quot * __uint_as_float(mult));
+			const uint32_t p0 = x3_readlane_u32(p, 0), p1 = x3_readlane_u32(p, 1), pi = x3_readlane_u32(p, 2);
+			uint32_t md = X3_E_IDX1, best = pi;
+			if (p0 > best) { md = X3_E_CTX0; best = p0; }
+			if (p1 > best) md = X3_E_CTX1;
+			const uint64_t bit = (uint64_t)1 << l;
+			if (md == X3_E_CTX0) m0 |= bit; else if (md == X3_E_CTX1) m1 |= bit; else m2 |= bit;
+		}
+		const uint32_t fin = ((m0 >> lane) & 1) ? X3_E_CTX0 : ((m1 >> lane) & 1) ? X3_E_CTX1 : X3_E_IDX1;
+		if (in) {
+			a.mode[g] = fin;
+			if (fin == X3_E_IDX1) { if (lds_r) atomicAdd(&sidx[vr], 1u); else atomicAdd(&idxf[vr], 1u); } /* inc_model(&model_index1, index), x3.c:188 */
+		}
+		E0 += (uint32_t)x3_popc64(m0); E1 += (uint32_t)x3_popc64(m1); /* inc_model(&model_events, mode), x3.c:177 */
+		const uint32_t c2 = (uint32_t)x3_popc64(m2);
+		E2 += c2; nidx += c2;
+		x3_wave_sync();
+		(void)below;
 	}
 }
 
 __device__ static void x3_modes_body(const X3ModesArgs &a)
 {
 	X3_LDS uint32_t sidx[X3_IDXF_LDS];
+	X3_LDS uint32_t scr[256];
 	const uint32_t c = blockIdx.x, lane = x3_lane();
 	const uint32_t H = a.parsed[c].hits, h0 = a.ho[c], Dc = a.parsed[c].dict_elems;
 	uint32_t *idxf = a.idxfreq + a.dof[c];
 	const uint32_t nl = Dc < X3_IDXF_LDS ? Dc : X3_IDXF_LDS;
 	for (uint32_t i = lane; i < nl; i += X3_WAVE) sidx[i] = 1;
 	x3_wave_sync();
-	if (Dc <= X3_IDXF_LDS) x3_modes_loop<true>(a, sidx, idxf, H, h0, lane);
-	else x3_modes_loop<false>(a, sidx, idxf, H, h0, lane);
+	if (Dc <= X3_IDXF_LDS) x3_modes_loop<true>(a, sidx, scr, idxf, H, h0, lane);
+	else x3_modes_loop<false>(a, sidx, scr, idxf, H, h0, lane);
 }
 
 /* ============================================================================================================
