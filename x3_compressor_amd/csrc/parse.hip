@@ -37,7 +37,7 @@ __device__ static __forceinline__ uint32_t ht_slot(uint32_t h, uint32_t len, uin
 /* state shared by the workgroup */
 struct ParseShared {
 	uint32_t p, blk, D, lenmask, hlog, flag, ntok, hits, mbytes;
-	uint32_t new_pos, new_len, new_tag, rebuild;
+	uint32_t new_pos, new_len, new_tag, rebuild, nanchor;
 };
 enum { FLAG_REFILL = 1, FLAG_PATCH = 2, FLAG_DONE = 3 };
 
@@ -48,6 +48,9 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 	X3_LDS uint32_t sE[PBL];
 	X3_LDS uint8_t sM[PB];
 	X3_LDS uint2 sN[PB]; /* the parse step at a cached position: .x = tag of the hit element, .y = 0x80 | L0 for a hit, else the new fragment's length (one 64-bit LDS read per step) */
+	X3_LDS uint16_t sJ[4][PB]; /* jump tables by pointer doubling: sJ[r][i] = (cached index after up to 2^r consecutive hits from i) | (hits taken << 12) */
+	X3_LDS uint16_t sAi[PB];   /* anchors of the current walk: cached index where a stride of hits starts ... */
+	X3_LDS uint32_t sAt[PB];   /* ... and the token index of its first hit */
 	X3_LDS ParseShared S;
 
 	const X3Chunk ck = a.chunks[blockIdx.x];
@@ -63,7 +66,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 
 	if (tid == 0) {
 		S.p = 0; S.blk = 0; S.D = 0; S.lenmask = 0; S.hlog = X3_HT_LOG2_MIN < ck.ht_log2_max ? X3_HT_LOG2_MIN : ck.ht_log2_max;
-		S.flag = n ? FLAG_REFILL : FLAG_DONE; S.ntok = 0; S.hits = 0; S.rebuild = 0; S.mbytes = 0;
+		S.flag = n ? FLAG_REFILL : FLAG_DONE; S.ntok = 0; S.hits = 0; S.rebuild = 0; S.mbytes = 0; S.nanchor = 0;
 	}
 	for (uint32_t i = tid; i < (1u << (X3_HT_LOG2_MIN < ck.ht_log2_max ? X3_HT_LOG2_MIN : ck.ht_log2_max)); i += X3_PARSE_THREADS) ht[i] = 0;
 	__syncthreads();
@@ -153,6 +156,21 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 				e.y = (L0 != 0 && nlL0 >= F && q + L0 <= n) ? (0x80u | L0) : (q + F > n ? n - q : F);
 				sN[i] = e;
 			}
+			__syncthreads();
+			/* jump tables: a miss, the block end and the input end are absorbing (0 hits taken) */
+			for (uint32_t i = first + tid; i < PB; i += X3_PARSE_THREADS) {
+				const uint32_t st = sN[i].y;
+				sJ[0][i] = (uint16_t)((blk + i < n && (st & 0x80u)) ? ((i + (st & 0x7Fu)) | (1u << 12)) : i);
+			}
+			for (uint32_t r = 1; r < 4; r++) {
+				__syncthreads();
+				for (uint32_t i = first + tid; i < PB; i += X3_PARSE_THREADS) {
+					const uint32_t e1 = sJ[r - 1][i];
+					uint32_t pos = e1 & 0xFFFu, cnt = e1 >> 12;
+					if (pos < PB && pos >= first) { const uint32_t e2 = sJ[r - 1][pos]; pos = e2 & 0xFFFu; cnt += e2 >> 12; }
+					sJ[r][i] = (uint16_t)(pos | (cnt << 12));
+				}
+			}
 		}
 		__syncthreads();
 		{ const uint64_t t = x3_clock(); cyc_table += t - t_prev; t_prev = t; }
@@ -165,24 +183,22 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 			uint32_t p = x3_uniform(S.p), ntok = x3_uniform(S.ntok), hits = x3_uniform(S.hits), D = x3_uniform(S.D);
 			uint32_t lenmask = x3_uniform(S.lenmask), hlog = x3_uniform(S.hlog), mbytes = x3_uniform(S.mbytes);
 			const uint32_t blk = x3_uniform(S.blk);
-			uint32_t out_flag = 0, rec = 0, recbase = ntok;
+			uint32_t out_flag = 0, na = 0;
 			for (;;) {
-				if (ntok - recbase == X3_WAVE) { /* flush 64 buffered tokens, coalesced */
-					tinf[recbase + lane] = rec;
-					recbase = ntok;
-				}
 				if (p >= n) { out_flag = FLAG_DONE; break; }
 				const uint32_t idx = p - blk;
 				if (idx >= PB) { out_flag = FLAG_REFILL; break; }
-				const uint2 ne = sN[idx];
-				const uint32_t step = x3_uniform(ne.y), htag = x3_uniform(ne.x);
-				if (step & 0x80u) { /* dictionary hit */
-					rec = x3_writelane_u32(rec, htag, ntok - recbase);
-					ntok++; hits++;
-					p += step & 0x7Fu;
+				const uint32_t jmp = x3_uniform(sJ[3][idx]);
+				const uint32_t cnt = jmp >> 12;
+				if (cnt) { /* up to 8 dictionary hits in one lookup; their tokens are written by the expansion phase */
+					sAi[na] = (uint16_t)idx;
+					sAt[na] = ntok;
+					na++;
+					ntok += cnt; hits += cnt;
+					p = blk + (jmp & 0xFFFu);
 					continue;
 				}
-				const uint32_t len = step, L0 = x3_uniform(sL[idx]);
+				const uint32_t len = x3_uniform(sN[idx].y), L0 = x3_uniform(sL[idx]);
 				/* x3.c:412 : is this exact fragment already an element? */
 				int dup = 0;
 				if (L0 == len) dup = 1;
@@ -200,7 +216,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 						if (k == len) { dup = 1; break; }
 					}
 				}
-				rec = x3_writelane_u32(rec, X3_TOK_MISS | (dup ? X3_TOK_DUP : 0u) | len, ntok - recbase);
+				if (lane == 0) tinf[ntok] = X3_TOK_MISS | (dup ? X3_TOK_DUP : 0u) | len;
 				ntok++;
 				mbytes += len;
 				x3_wave_sync(); /* every lane has finished probing before lane 0 inserts */
@@ -229,11 +245,26 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 				}
 				p += len;
 			}
-			if (lane < ntok - recbase) tinf[recbase + lane] = rec;
 			x3_wave_sync(); /* every lane has read the shared walker state before lane 0 replaces it */
 			if (lane == 0) {
+				S.nanchor = na;
 				S.p = p; S.ntok = ntok; S.hits = hits; S.D = D; S.lenmask = lenmask; S.hlog = hlog; S.mbytes = mbytes;
 				S.flag = out_flag;
+			}
+		}
+		__syncthreads();
+		{
+			/* ---- expansion: anchor a covers cnt <= 8 consecutive hits; thread (a, t) finds the t-th one through the 1/2/4 tables ---- */
+			const uint32_t na = S.nanchor;
+			for (uint32_t w = tid; w < na * 8; w += X3_PARSE_THREADS) {
+				const uint32_t an = w >> 3, t = w & 7;
+				uint32_t i = sAi[an];
+				if (t < (uint32_t)(sJ[3][i] >> 12)) {
+					if (t & 4) i = sJ[2][i] & 0xFFFu;
+					if (t & 2) i = sJ[1][i] & 0xFFFu;
+					if (t & 1) i = sJ[0][i] & 0xFFFu;
+					tinf[sAt[an] + t] = sN[i].x;
+				}
 			}
 		}
 		__syncthreads();
