@@ -59,6 +59,11 @@ typedef struct x3h_stats {
 	double   ms_parse;      /* K2: dictionary + parse                                                   */
 	double   ms_code;       /* K3: models + arithmetic coder + bit output                               */
 	double   ms_copy;       /* host<->device staging (0 for device-resident calls)                      */
+	double   ms_features;   /* K3: parallel feature extraction (sorts, scans, count-smaller-before)     */
+	double   ms_modes;      /* K3: x3_modes_kernel (mode choice, x3.c:152-172)                           */
+	double   ms_coder;      /* K3: x3_ac2_kernel (arithmetic-coder interval recurrence, ac.c:46-85)      */
+	double   ms_emit;       /* K3: symbol assembly + bit emission                                        */
+	uint64_t coded_symbols; /* arithmetic-coder symbols (ac_encode calls) of the batch                   */
 } x3h_stats;
 
 typedef struct x3h_ctx x3h_ctx; /* one per GPU: device, stream, growable workspace */

@@ -115,6 +115,7 @@ extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 		               &c->c2.tmp, &c->c2.offs, &c->c2.chunkmeta, &c->c2.idxfreq, &c->c2.hsym, &c->c2.maxred, &c->c2.pp[0], &c->c2.pp[1], &c->c2.pp[2], &c->c2.pp[3],
 		               &c->cresult, &c->mtf, &c->idxfreq, &c->ctx1, &c->ctx0, &c->items, &c->pkey, &c->pval, &c->out, &c->counts, &c->din, &c->dchunks };
 	for (DevBuf *b : bufs) b->release();
+	for (int i = 0; i < 5; i++) if (c->c2.ev[i]) (void)hipEventDestroy(c->c2.ev[i]);
 	for (DevBuf &b : c->c2.a) b.release();
 	for (DevBuf &b : c->s2.a) b.release();
 	c->s2.misc.release();
@@ -334,6 +335,13 @@ static int run(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage upto
 		hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); stats->ms_parse = ms;
 		hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); stats->ms_code = ms;
 		hipEventElapsedTime(&ms, c->ev[0], c->ev[5]); stats->ms_total = ms;
+		if (!c->code_v1 && c->c2.ev[4]) {
+			(void)hipEventElapsedTime(&ms, c->c2.ev[0], c->c2.ev[1]); stats->ms_features = ms;
+			(void)hipEventElapsedTime(&ms, c->c2.ev[1], c->c2.ev[2]); stats->ms_modes = ms;
+			(void)hipEventElapsedTime(&ms, c->c2.ev[3], c->c2.ev[4]); stats->ms_coder = ms;
+			stats->ms_emit = stats->ms_code - stats->ms_features - stats->ms_modes - stats->ms_coder;
+			stats->coded_symbols = c->c2.last.symbols;
+		}
 	}
 	return rc;
 }

@@ -420,6 +420,8 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
                    const uint32_t *tok_nb, const uint32_t *tok_mb, uint8_t *d_out, X3CodeResult *d_result)
 {
 	const uint32_t nc = (uint32_t)nchunks;
+	for (int i = 0; i < 5; i++) if (!B.ev[i]) HIPCHK(hipEventCreate(&B.ev[i]));
+	HIPCHK(hipEventRecord(B.ev[0], st));
 	/* ---- index spaces: steps, hits, MTF events (hits + inserted elements), tags ---- */
 	std::vector<uint32_t> so(nc + 1), ho(nc + 1), eo(nc + 1), dof(nc + 1), mo(nc + 1), bo(nc + 1), yo(nc + 1);
 	uint64_t s = 0, h = 0, e = 0, d = 0, mi = 0, by = 0, y = 0;
@@ -563,6 +565,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	/* ---- serial pass 1: modes ---- */
 	uint32_t *idxf = B.idxfreq.as<uint32_t>();
 	x3_foreach(nD + 1, st, X3_LAMBDA(size_t i) { idxf[i] = 1; });
+	HIPCHK(hipEventRecord(B.ev[1], st));
 	if (nH > 0) {
 		X3ModesArgs ma;
 		ma.parsed = d_parsed; ma.ho = d_ho; ma.dof = d_dof;
@@ -570,6 +573,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		ma.idxfreq = idxf; ma.mode = mode;
 		launch_modes(ma, nc, st);
 		HIPCHK(hipGetLastError());
+		HIPCHK(hipEventRecord(B.ev[2], st));
 
 		/* ---- model_events / model_index1 state at every hit, recovered from the modes by prefix sums ---- */
 		uint32_t *zi = T[0], *ci = T[1], *key = T[2], *org = T[3], *bs = T[4], *be = T[5], *cnt = T[6], *kin2 = T[7];
@@ -711,8 +715,11 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	/* ---- serial pass 2: interval recurrence ---- */
 	X3Ac2Args aa;
 	aa.yo = d_yo; aa.scum = sy_cum; aa.sfreq = sy_freq; aa.stot = sy_tot; aa.rec_nk = rec_nk; aa.final_lo = m_finallo;
+	if (nH == 0) HIPCHK(hipEventRecord(B.ev[2], st));
+	HIPCHK(hipEventRecord(B.ev[3], st));
 	launch_ac2(aa, nc, st);
 	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(B.ev[4], st));
 
 	/* ---- bit emission (ac.c:49-67 put_bit + mScale, bio.c:49-72) as prefix sums over the records ----
 	 * pending after symbol i  = sum of k over (last symbol that shifted out bits (n>=1) or stream start .. i]
@@ -772,5 +779,6 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		d_result[c] = r;
 	});
 	(void)tok_nb;
+	B.last.symbols = nY;
 	return X3H_OK;
 }
