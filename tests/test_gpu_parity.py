@@ -178,3 +178,18 @@ def test_scan_v2_equals_brute_force_kernel(gpu, monkeypatch):
             assert np.array_equal(a, b), f"{kw}: first diff at {first_diff(a, b)}"
     finally:
         brute.close()
+
+
+def test_large_dictionary_60k_elements(gpu, oracle):
+    """D = 60 265 > the 32 768 ranks of the LDS index-model table: the generic (global memory) path of the modes kernel, a hash
+    table that doubled seven times in K2, and the decoder's large tables."""
+    rng = np.random.default_rng(78)
+    words = rng.integers(0, 256, (60000, 5), dtype=np.uint8)
+    data = np.repeat(words, 4, axis=0).reshape(-1).tobytes()  # every 5-byte word four times in a row
+    kw = dict(w_kib=1, t=1)
+    want, st = oracle.compress(data, oracle_lib.params(**kw), want_stats=True)
+    assert st.dict_elems > 32768
+    got = gpu.compress(data, _lib.make_params(**kw))
+    assert got == want, f"first differing byte {first_diff(np.frombuffer(got, np.uint8), np.frombuffer(want, np.uint8))}"
+    assert gpu.last_stats.dict_elems == st.dict_elems
+    assert gpu.decompress(got, len(data)) == data
