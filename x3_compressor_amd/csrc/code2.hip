@@ -225,51 +225,61 @@ __device__ static void x3_modes_body(const X3ModesArgs &a)
  * ============================================================================================================ */
 struct X3Ac2Args {
 	const uint32_t *yo;                   /* per chunk: first symbol (nc+1) */
-	const uint32_t *scum, *sfreq, *stot;  /* per symbol */
+	const uint4 *sym;                     /* per symbol: {cum, freq, magic multiplier, shift} */
 	uint32_t *rec_nk;                     /* out per symbol: {n | k<<8, lo before the shift (its top n bits are the emitted bits)} as uint2 */
 	uint32_t *final_lo;                   /* out per chunk */
 };
 
-__device__ static __forceinline__ uint32_t x3_mulhi_u32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+/* range / total as a multiply-shift (Granlund-Montgomery, N = 31): L = ceil(log2 total), m = ceil(2^(31+L)/total) < 2^32,
+ * floor(range*m / 2^(31+L)) == floor(range/total) for every range <= 2^31 because m*total - 2^(31+L) < total <= 2^L.
+ * Computed per symbol by the parallel assembly kernels, off the serial chain. */
+__device__ static __forceinline__ uint4 x3_make_symbol(uint32_t cum, uint32_t freq, uint32_t total)
+{
+	const uint32_t L = total <= 1 ? 0u : 32u - (uint32_t)x3_clz32(total - 1);
+	uint4 q;
+	q.x = cum; q.y = freq;
+	q.z = (uint32_t)((((uint64_t)1 << (31 + L)) + total - 1) / total);
+	q.w = 31 + L;
+	return q;
+}
 
+/* The serial chain, state (lo, range):  step = range / total;  lo += step*cum;  range = step*freq;  then E1/E2 (ac.c:49-67) shift out
+ * the n leading bits on which lo and hi = lo+range-1 agree and E3 (ac.c:70-74) the k positions below the top bit where lo has 1
+ * and hi has 0 -- both are left shifts, applied at once, and they simply scale the range: range <<= n+k (the shifted-out bits of
+ * lo and hi are equal, or differ by the quarter E3 subtracts from both).  clz(0) == 32 makes the formulas cover lo == hi
+ * (n = 31, k = 0) and the all-E3 case (n = 0, k = 30) without branches: a taken branch costs a lone wave ~40 cycles.
+ * Operands come through the scalar cache (s_load_dwordx4), one symbol ahead of their use. */
 __device__ static void x3_ac2_body(const X3Ac2Args &a)
 {
-	const uint32_t c = blockIdx.x, lane = x3_lane();
-	const uint32_t y0 = a.yo[c], Y = a.yo[c + 1] - y0;
-	uint32_t lo = 0, hi = 0x7FFFFFFFu; /* ac_init, ac.c:35-41 */
-	for (uint32_t base = 0; base < Y; base += X3_WAVE) {
-		const bool in = base + lane < Y;
-		const uint32_t vcum = in ? a.scum[y0 + base + lane] : 0, vfq = in ? a.sfreq[y0 + base + lane] : 1;
-		const uint32_t vtot = in ? a.stot[y0 + base + lane] : 1;
-		/* range / total as a multiply-shift (Granlund-Montgomery, N = 31): L = ceil(log2 total), m = ceil(2^(31+L)/total) < 2^32,
-		 * floor(range*m / 2^(31+L)) == floor(range/total) for every range <= 2^31 because m*total - 2^(31+L) < total <= 2^L.
-		 * The 64 lanes prepare (m, shift) for 64 symbols at once, off the serial chain. */
-		const uint32_t vL = vtot <= 1 ? 0u : 32u - (uint32_t)x3_clz32(vtot - 1);
-		const uint32_t vm = (uint32_t)((((uint64_t)1 << (31 + vL)) + vtot - 1) / vtot), vsh = 31 + vL, vchi = vcum + vfq;
-		const uint32_t cnt = Y - base < X3_WAVE ? Y - base : X3_WAVE;
-		uint2 *recs = (uint2 *)a.rec_nk + (y0 + base); /* {n | k<<8, lo before the shift} per symbol */
-#pragma unroll 2
-		for (uint32_t l = 0; l < cnt; l++) {
-			const uint32_t clo = x3_readlane_u32(vcum, l), chi = x3_readlane_u32(vchi, l);
-			const uint32_t m = x3_readlane_u32(vm, l), sh = x3_readlane_u32(vsh, l);
-			const uint32_t step = (uint32_t)(((uint64_t)(hi - lo + 1) * m) >> sh);
-			const uint32_t nhi = lo + step * chi - 1, nlo = lo + step * clo;
-			/* E1/E2 (ac.c:49-67): the n leading bits on which lo and hi agree leave; E3 (ac.c:70-74): then the k positions below
-			 * the top bit where lo has 1 and hi has 0.  Both are left shifts, applied at once (n + k <= 31).  Straight-line on
-			 * purpose (a taken branch costs a lone wave ~40 cycles): clz(0) == 32 makes the formulas cover lo == hi (n = 31,
-			 * k = 0) and the all-E3 case (n = 0, k = 30) without special cases. */
-			const uint32_t n = (uint32_t)x3_clz32(nlo ^ nhi) - 1;
-			const uint32_t y = ((((nhi | ~nlo) << n) | ~(0xFFFFFFFFu << n)) & 0x3FFFFFFFu);
-			const uint32_t k = (uint32_t)x3_clz32(y) - 2;
-			const uint32_t s = n + k;
-			lo = (nlo << s) & 0x3FFFFFFFu;
-			hi = (((nhi << s) | ~(0xFFFFFFFFu << s)) & 0x3FFFFFFFu) | 0x40000000u;
-			uint2 rv;
-			rv.x = n | (k << 8); rv.y = nlo;
-			recs[l] = rv; /* every lane stores the same (uniform) record: one 8-byte write, no exec masking, no select */
-		}
+	const uint32_t c = blockIdx.x;
+	const uint32_t y0 = x3_uniform(a.yo[c]), Y = x3_uniform(a.yo[c + 1]) - y0;
+#ifndef X3_EMU
+	/* constant address space: a uniform load from it is an s_load_dwordx4 (scalar cache), not a vector load + 4 readfirstlane.
+	 * The symbols were written by an EARLIER kernel, so the scalar cache (invalidated at kernel start) is coherent with them. */
+	typedef const uint4 __attribute__((address_space(4))) x3_cuint4;
+	x3_cuint4 *sym = (x3_cuint4 *)(uintptr_t)(a.sym + y0);
+#else
+	const uint4 *sym = a.sym + y0;
+#endif
+	uint2 *__restrict__ recs = (uint2 *)a.rec_nk + y0;
+	uint32_t lo = 0, R = 0x80000000u; /* ac_init, ac.c:35-41: [0, 0x7FFFFFFF] */
+	uint4 cur = sym[0]; /* Y >= 1: every stream codes E_EOF */
+	for (uint32_t i = 0; i < Y; i++) {
+		const uint4 nxt = sym[i + 1 < Y ? i + 1 : i];
+		const uint32_t step = (uint32_t)(((uint64_t)R * cur.z) >> cur.w);
+		const uint32_t nlo = lo + step * cur.x, sf = step * cur.y, nhi = nlo + sf - 1;
+		const uint32_t n = (uint32_t)x3_clz32(nlo ^ nhi) - 1;
+		const uint32_t y = ((((nhi | ~nlo) << n) | ~(0xFFFFFFFFu << n)) & 0x3FFFFFFFu);
+		const uint32_t k = (uint32_t)x3_clz32(y) - 2;
+		const uint32_t sh = n + k;
+		lo = (nlo << sh) & 0x3FFFFFFFu;
+		R = sf << sh;
+		uint2 rv;
+		rv.x = n | (k << 8); rv.y = nlo;
+		recs[i] = rv; /* every lane stores the same (uniform) record: one 8-byte write, no exec masking, no select */
+		cur = nxt;
 	}
-	if (lane == 0) a.final_lo[c] = lo;
+	if (x3_lane() == 0) a.final_lo[c] = lo;
 }
 
 #ifndef X3_EMU
@@ -680,8 +690,9 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 
 	/* ---- the coded symbols, in coding order: symbol index of step k = 2k + (new-fragment bytes before k) ---- */
 	uint32_t *Yv[12];
-	for (int i = 0; i < 12; i++) { CHK(B.y[i].reserve((nY + 4) * (i == 3 ? 8 : 4))); Yv[i] = B.y[i].as<uint32_t>(); }
-	uint32_t *sy_cum = Yv[0], *sy_freq = Yv[1], *sy_tot = Yv[2], *rec_nk = Yv[3]; /* rec_nk: 2 words per symbol */
+	for (int i = 0; i < 12; i++) { CHK(B.y[i].reserve((nY + 4) * (i == 0 ? 16 : i == 3 ? 8 : 4))); Yv[i] = B.y[i].as<uint32_t>(); }
+	uint4 *sy = (uint4 *)Yv[0]; /* {cum, freq, magic, shift} per symbol */
+	uint32_t *rec_nk = Yv[3]; /* 2 words per symbol */
 	x3_foreach(nS, st, X3_LAMBDA(size_t gs) {
 		const uint32_t c = find_chunk(d_so, nc, (uint32_t)gs);
 		const uint32_t k = (uint32_t)gs - d_so[c];
@@ -692,29 +703,27 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		if (!(info & X3_TOK_MISS)) {
 			const uint32_t gh = d_ho[c] + hb, m = mode[gh], e0 = pe0[gh], e1 = pe1[gh];
 			const uint32_t e2 = 2049u + hb - e0 - e1; /* every hit bumps exactly one of the three */
-			sy_cum[yi] = m == X3_E_CTX0 ? 0u : m == X3_E_CTX1 ? e0 : e0 + e1;
-			sy_freq[yi] = m == X3_E_CTX0 ? e0 : m == X3_E_CTX1 ? e1 : e2;
-			sy_tot[yi] = evtotal;
-			sy_cum[yi + 1] = hs_cum[gh]; sy_freq[yi + 1] = hs_freq[gh]; sy_tot[yi + 1] = hs_tot[gh];
+			sy[yi] = x3_make_symbol(m == X3_E_CTX0 ? 0u : m == X3_E_CTX1 ? e0 : e0 + e1, m == X3_E_CTX0 ? e0 : m == X3_E_CTX1 ? e1 : e2, evtotal);
+			sy[yi + 1] = x3_make_symbol(hs_cum[gh], hs_freq[gh], hs_tot[gh]);
 		} else {
 			const uint32_t len = info & 0x3Fu, mk = k - hb; /* mk = new fragments before this one */
-			sy_cum[yi] = 2049u + hb; sy_freq[yi] = 1u + mk; sy_tot[yi] = evtotal; /* E_NEW */
+			sy[yi] = x3_make_symbol(2049u + hb, 1u + mk, evtotal); /* E_NEW */
 			const uint32_t gm = d_mo[c] + mk;
-			sy_cum[yi + 1] = (len - 1) + lsm[gm]; sy_freq[yi + 1] = 1u + leq[gm]; sy_tot[yi + 1] = 32u + mk;
+			sy[yi + 1] = x3_make_symbol((len - 1) + lsm[gm], 1u + leq[gm], 32u + mk);
 			for (uint32_t j = 0; j < len; j++) {
 				const uint32_t gb = d_bo[c] + mb + j;
-				sy_cum[yi + 2 + j] = bval[gb] + bsm[gb]; sy_freq[yi + 2 + j] = 1u + beq[gb]; sy_tot[yi + 2 + j] = 256u + mb + j;
+				sy[yi + 2 + j] = x3_make_symbol(bval[gb] + bsm[gb], 1u + beq[gb], 256u + mb + j);
 			}
 		}
 	});
 	x3_foreach(nc, st, X3_LAMBDA(size_t c) { /* E_EOF, x3.c:432-433 */
 		const uint32_t yi = d_yo[c + 1] - 1, evtotal = 2051u + d_parsed[c].ntok;
-		sy_cum[yi] = evtotal - 1; sy_freq[yi] = 1; sy_tot[yi] = evtotal;
+		sy[yi] = x3_make_symbol(evtotal - 1, 1, evtotal);
 	});
 
 	/* ---- serial pass 2: interval recurrence ---- */
 	X3Ac2Args aa;
-	aa.yo = d_yo; aa.scum = sy_cum; aa.sfreq = sy_freq; aa.stot = sy_tot; aa.rec_nk = rec_nk; aa.final_lo = m_finallo;
+	aa.yo = d_yo; aa.sym = sy; aa.rec_nk = rec_nk; aa.final_lo = m_finallo;
 	if (nH == 0) HIPCHK(hipEventRecord(B.ev[2], st));
 	HIPCHK(hipEventRecord(B.ev[3], st));
 	launch_ac2(aa, nc, st);

@@ -61,6 +61,7 @@ __device__ __forceinline__ int x3_clz32(uint32_t v) { return __clz((int)v); }   
 #define X3_LDS static
 
 struct uint2 { uint32_t x, y; };
+struct uint4 { uint32_t x, y, z, w; };
 struct x3emu_dim3 { unsigned x, y, z; x3emu_dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 typedef x3emu_dim3 dim3;
 
