@@ -256,16 +256,18 @@ __device__ static void x3_ac2_body(const X3Ac2Args &a)
 #ifndef X3_EMU
 	/* constant address space: a uniform load from it is an s_load_dwordx4 (scalar cache), not a vector load + 4 readfirstlane.
 	 * The symbols were written by an EARLIER kernel, so the scalar cache (invalidated at kernel start) is coherent with them. */
-	typedef const uint4 __attribute__((address_space(4))) x3_cuint4;
-	x3_cuint4 *sym = (x3_cuint4 *)(uintptr_t)(a.sym + y0);
+	typedef uint32_t x3_u32x4 __attribute__((ext_vector_type(4)));
+	typedef const x3_u32x4 __attribute__((address_space(4))) x3_csym;
+	x3_csym *sym = (x3_csym *)(uintptr_t)(a.sym + y0);
 #else
+	typedef uint4 x3_u32x4;
 	const uint4 *sym = a.sym + y0;
 #endif
 	uint2 *__restrict__ recs = (uint2 *)a.rec_nk + y0;
 	uint32_t lo = 0, R = 0x80000000u; /* ac_init, ac.c:35-41: [0, 0x7FFFFFFF] */
-	uint4 cur = sym[0]; /* Y >= 1: every stream codes E_EOF */
+	x3_u32x4 cur = sym[0]; /* Y >= 1: every stream codes E_EOF */
 	for (uint32_t i = 0; i < Y; i++) {
-		const uint4 nxt = sym[i + 1 < Y ? i + 1 : i];
+		const x3_u32x4 nxt = sym[i + 1 < Y ? i + 1 : i];
 		const uint32_t step = (uint32_t)(((uint64_t)R * cur.z) >> cur.w);
 		const uint32_t nlo = lo + step * cur.x, sf = step * cur.y, nhi = nlo + sf - 1;
 		const uint32_t n = (uint32_t)x3_clz32(nlo ^ nhi) - 1;
