@@ -33,7 +33,7 @@ enum {
 	X3H_E_INTERNAL    = -7  /* a device-side workspace bound was violated (bug)                   */
 };
 
-#define X3H_MAX_CHUNK ((size_t)1 << 28) /* one stream <= 256 MiB (32-bit positions / pool offsets on the device) */
+#define X3H_MAX_CHUNK ((size_t)1 << 27) /* one stream <= 128 MiB: keeps every model total < 2^28, which the coder kernel relies on */
 
 /* The tunables the reference keeps in file-scope globals.  Defaults: x3h_default_params().
  *   window_bytes    set_forward_window()   backend.c:8-18   (CLI -w N means N*1024, x3.c:503)

@@ -226,7 +226,7 @@ __device__ static void x3_modes_body(const X3ModesArgs &a)
 struct X3Ac2Args {
 	const uint32_t *yo;                   /* per chunk: first symbol (nc+1) */
 	const uint4 *sym;                     /* per symbol: {cum, freq, magic multiplier, shift} */
-	uint32_t *rec_nk;                     /* out per symbol: {n | k<<8, lo before the shift (its top n bits are the emitted bits)} as uint2 */
+	uint32_t *rec_nk;                     /* out per symbol: {lo, hi} after narrowing, before the renormalisation shift, as uint2 */
 	uint32_t *final_lo;                   /* out per chunk */
 };
 
@@ -249,6 +249,23 @@ __device__ static __forceinline__ uint4 x3_make_symbol(uint32_t cum, uint32_t fr
  * lo and hi are equal, or differ by the quarter E3 subtracts from both).  clz(0) == 32 makes the formulas cover lo == hi
  * (n = 31, k = 0) and the all-E3 case (n = 0, k = 30) without branches: a taken branch costs a lone wave ~40 cycles.
  */
+/* one symbol of the chain; records (lo, hi) after narrowing, before the shift: the emit stage derives n and k from them */
+#define X3_AC2_STEP(L)                                                                                         \
+	{                                                                                                          \
+		const uint32_t cum = x3_readlane_u32(q.x, (L)), fq = x3_readlane_u32(q.y, (L));                        \
+		const uint32_t m = x3_readlane_u32(q.z, (L)), msh = x3_readlane_u32(q.w, (L));                         \
+		const uint32_t step = (uint32_t)(((uint64_t)R * m) >> msh);                                            \
+		const uint32_t nlo = lo + step * cum, sf = step * fq, nhi = nlo + sf - 1;                              \
+		const uint32_t n = (uint32_t)__builtin_clz(nlo ^ nhi) - 1;                                             \
+		const uint32_t y = ((((nhi | ~nlo) << n) | ~(0xFFFFFFFFu << n)) & 0x3FFFFFFFu);                        \
+		const uint32_t sh = n + (uint32_t)__builtin_clz(y) - 2;                                                \
+		lo = (nlo << sh) & 0x3FFFFFFFu;                                                                        \
+		R = sf << sh;                                                                                          \
+		uint2 rv;                                                                                              \
+		rv.x = nlo; rv.y = nhi;                                                                                \
+		recs[(L)] = rv; /* every lane stores the same (uniform) record: one 8-byte write, no exec masking */   \
+	}
+
 __device__ static void x3_ac2_body(const X3Ac2Args &a)
 {
 	const uint32_t c = blockIdx.x, lane = x3_lane();
@@ -256,26 +273,18 @@ __device__ static void x3_ac2_body(const X3Ac2Args &a)
 	uint32_t lo = 0, R = 0x80000000u; /* ac_init, ac.c:35-41: [0, 0x7FFFFFFF] */
 	for (uint32_t base = 0; base < Y; base += X3_WAVE) {
 		/* 64 symbols per round: one coalesced 16-byte load per lane, then v_readlane feeds the scalar chain.
-		 * (Measured alternative: s_load_dwordx4 per symbol through the scalar cache -- 17 % slower, its latency lands on the chain.) */
+		 * (Measured alternative: s_load_dwordx4 per symbol through the scalar cache -- 17 % slower, its latency lands on the chain.)
+		 * nlo != nhi and y != 0 always: either would need a model total > 2^28, and a stream is at most 2^27 bytes (X3H_MAX_CHUNK),
+		 * so no clz(0) guard is needed.  Two symbols per trip halve the loop overhead and the taken-branch penalty. */
 		const uint4 q = a.sym[y0 + (base + lane < Y ? base + lane : Y - 1)];
-		const uint32_t cnt = Y - base < X3_WAVE ? Y - base : X3_WAVE;
+		const uint32_t cnt = x3_uniform(Y - base < X3_WAVE ? Y - base : X3_WAVE);
 		uint2 *recs = (uint2 *)a.rec_nk + (y0 + base);
-#pragma unroll 2
-		for (uint32_t l = 0; l < cnt; l++) {
-			const uint32_t cum = x3_readlane_u32(q.x, l), fq = x3_readlane_u32(q.y, l);
-			const uint32_t m = x3_readlane_u32(q.z, l), msh = x3_readlane_u32(q.w, l);
-			const uint32_t step = (uint32_t)(((uint64_t)R * m) >> msh);
-			const uint32_t nlo = lo + step * cum, sf = step * fq, nhi = nlo + sf - 1;
-			const uint32_t n = (uint32_t)x3_clz32(nlo ^ nhi) - 1;
-			const uint32_t y = ((((nhi | ~nlo) << n) | ~(0xFFFFFFFFu << n)) & 0x3FFFFFFFu);
-			const uint32_t k = (uint32_t)x3_clz32(y) - 2;
-			const uint32_t sh = n + k;
-			lo = (nlo << sh) & 0x3FFFFFFFu;
-			R = sf << sh;
-			uint2 rv;
-			rv.x = n | (k << 8); rv.y = nlo;
-			recs[l] = rv; /* every lane stores the same (uniform) record: one 8-byte write, no exec masking, no select */
+		uint32_t l = 0;
+		for (; l + 2 <= cnt; l += 2) {
+			X3_AC2_STEP(l)
+			X3_AC2_STEP(l + 1)
 		}
+		if (l < cnt) X3_AC2_STEP(l)
 	}
 	if (lane == 0) a.final_lo[c] = lo;
 }
@@ -293,6 +302,15 @@ static void launch_modes(const X3ModesArgs &a, uint32_t nchunks, hipStream_t) { 
 static void launch_ac2(const X3Ac2Args &a, uint32_t nchunks, hipStream_t) { x3emu_launch(ac2_tramp, (void *)&a, dim3(nchunks), dim3(X3_WAVE)); }
 static inline uint32_t x3_brev32(uint32_t v) { uint32_t r = 0; for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i); return r; }
 #endif
+
+/* E1/E2 count n and E3 count k of a narrowed interval (ac.c:49-74 in closed form; see x3_ac2_body) */
+__device__ static __forceinline__ uint32_t x3_rec_n(uint32_t nlo, uint32_t nhi) { return (uint32_t)x3_clz32(nlo ^ nhi) - 1; }
+__device__ static __forceinline__ uint32_t x3_rec_k(uint32_t nlo, uint32_t nhi)
+{
+	const uint32_t n = x3_rec_n(nlo, nhi);
+	const uint32_t y = ((((nhi | ~nlo) << n) | ~(0xFFFFFFFFu << n)) & 0x3FFFFFFFu);
+	return (uint32_t)x3_clz32(y) - 2;
+}
 
 /* OR `nbits` (<= 32) bits of `val` into the little-endian 32-bit word stream at bit position `bitpos` (bio.c:49-72 layout) */
 __device__ static __forceinline__ void x3_or_bits(uint32_t *out32, uint32_t capw, uint64_t bitpos, uint32_t val, uint32_t nbits)
@@ -733,16 +751,16 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	 * bits written by symbol i = n + pending before it (when n >= 1): first bit, the pending bits inverted, the other n-1 bits */
 	uint32_t *kk = Yv[5], *rv = Yv[6], *Kex = Yv[7], *LE = Yv[8], *len = Yv[9], *pos = Yv[10], *pend = Yv[11];
 	x3_foreach(nY, st, X3_LAMBDA(size_t i) {
-		const uint32_t nk = rec_nk[2 * i];
+		const uint32_t rl = rec_nk[2 * i], rh = rec_nk[2 * i + 1];
 		const uint32_t c = find_chunk(d_yo, nc, (uint32_t)i);
-		kk[i] = nk >> 8;
-		rv[i] = ((nk & 0xFF) >= 1 || i == d_yo[c]) ? (uint32_t)i + 1 : 0u;
+		kk[i] = x3_rec_k(rl, rh);
+		rv[i] = (x3_rec_n(rl, rh) >= 1 || i == d_yo[c]) ? (uint32_t)i + 1 : 0u;
 	});
 	CHK(x3p_excl_scan(B.tmp, kk, Kex, nY, st));
 	CHK(x3p_incl_max_scan(B.tmp, rv, LE, nY, st));
 	x3_foreach(nY, st, X3_LAMBDA(size_t i) { pend[i] = Kex[i + 1] - Kex[LE[i] - 1]; });
 	x3_foreach(nY, st, X3_LAMBDA(size_t i) {
-		const uint32_t n = rec_nk[2 * i] & 0xFF;
+		const uint32_t n = x3_rec_n(rec_nk[2 * i], rec_nk[2 * i + 1]);
 		const uint32_t c = find_chunk(d_yo, nc, (uint32_t)i);
 		len[i] = n >= 1 ? n + (i == d_yo[c] ? 0u : pend[i - 1]) : 0u;
 	});
@@ -755,9 +773,9 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		const uint32_t c = find_chunk(d_yo, nc, (uint32_t)i);
 		uint32_t *out32 = (uint32_t *)(d_out + d_chunks[c].out_off);
 		const uint32_t capw = (uint32_t)(d_chunks[c].out_cap / 4);
-		const uint32_t n = rec_nk[2 * i] & 0xFF, pd = ln - n;
+		const uint32_t n = x3_rec_n(rec_nk[2 * i], rec_nk[2 * i + 1]), pd = ln - n;
 		const uint64_t bp = pos[i] - pos[d_yo[c]];
-		const uint32_t rev = x3_brev32(rec_nk[2 * i + 1] << 1) & (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1)); /* bit j = j-th emitted bit = bit 30-j of lo */
+		const uint32_t rev = x3_brev32(rec_nk[2 * i] << 1) & (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1)); /* bit j = j-th emitted bit = bit 30-j of lo */
 		if (!pd) x3_or_bits(out32, capw, bp, rev, n);
 		else {
 			x3_or_bits(out32, capw, bp, rev & 1u, 1);
