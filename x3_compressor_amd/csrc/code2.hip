@@ -275,16 +275,18 @@ __device__ static void x3_ac2_body(const X3Ac2Args &a)
 		/* 64 symbols per round: one coalesced 16-byte load per lane, then v_readlane feeds the scalar chain.
 		 * (Measured alternative: s_load_dwordx4 per symbol through the scalar cache -- 17 % slower, its latency lands on the chain.)
 		 * nlo != nhi and y != 0 always: either would need a model total > 2^28, and a stream is at most 2^27 bytes (X3H_MAX_CHUNK),
-		 * so no clz(0) guard is needed.  Two symbols per trip halve the loop overhead and the taken-branch penalty. */
+		 * so no clz(0) guard is needed.  Four symbols per trip amortise the loop overhead and the taken-branch penalty. */
 		const uint4 q = a.sym[y0 + (base + lane < Y ? base + lane : Y - 1)];
 		const uint32_t cnt = x3_uniform(Y - base < X3_WAVE ? Y - base : X3_WAVE);
 		uint2 *recs = (uint2 *)a.rec_nk + (y0 + base);
 		uint32_t l = 0;
-		for (; l + 2 <= cnt; l += 2) {
+		for (; l + 4 <= cnt; l += 4) {
 			X3_AC2_STEP(l)
 			X3_AC2_STEP(l + 1)
+			X3_AC2_STEP(l + 2)
+			X3_AC2_STEP(l + 3)
 		}
-		if (l < cnt) X3_AC2_STEP(l)
+		for (; l < cnt; l++) X3_AC2_STEP(l)
 	}
 	if (lane == 0) a.final_lo[c] = lo;
 }

@@ -48,7 +48,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 	X3_LDS uint32_t sE[PBL];
 	X3_LDS uint8_t sM[PB];
 	X3_LDS uint2 sN[PB]; /* the parse step at a cached position: .x = tag of the hit element, .y = 0x80 | L0 for a hit, else the new fragment's length (one 64-bit LDS read per step) */
-	X3_LDS uint16_t sJ[4][PB]; /* jump tables by pointer doubling: sJ[r][i] = (cached index after up to 2^r consecutive hits from i) | (hits taken << 12) */
+	X3_LDS uint32_t sJ[6][PB]; /* jump tables by pointer doubling: sJ[r][i] = (cached index after up to 2^r consecutive hits from i) | (hits taken << 12) */
 	X3_LDS uint16_t sAi[PB];   /* anchors of the current walk: cached index where a stride of hits starts ... */
 	X3_LDS uint32_t sAt[PB];   /* ... and the token index of its first hit */
 	X3_LDS ParseShared S;
@@ -160,15 +160,15 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 			/* jump tables: a miss, the block end and the input end are absorbing (0 hits taken) */
 			for (uint32_t i = first + tid; i < PB; i += X3_PARSE_THREADS) {
 				const uint32_t st = sN[i].y;
-				sJ[0][i] = (uint16_t)((blk + i < n && (st & 0x80u)) ? ((i + (st & 0x7Fu)) | (1u << 12)) : i);
+				sJ[0][i] = (blk + i < n && (st & 0x80u)) ? ((i + (st & 0x7Fu)) | (1u << 12)) : i;
 			}
-			for (uint32_t r = 1; r < 4; r++) {
+			for (uint32_t r = 1; r < 6; r++) {
 				__syncthreads();
 				for (uint32_t i = first + tid; i < PB; i += X3_PARSE_THREADS) {
 					const uint32_t e1 = sJ[r - 1][i];
 					uint32_t pos = e1 & 0xFFFu, cnt = e1 >> 12;
 					if (pos < PB && pos >= first) { const uint32_t e2 = sJ[r - 1][pos]; pos = e2 & 0xFFFu; cnt += e2 >> 12; }
-					sJ[r][i] = (uint16_t)(pos | (cnt << 12));
+					sJ[r][i] = pos | (cnt << 12);
 				}
 			}
 		}
@@ -188,9 +188,9 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 				if (p >= n) { out_flag = FLAG_DONE; break; }
 				const uint32_t idx = p - blk;
 				if (idx >= PB) { out_flag = FLAG_REFILL; break; }
-				const uint32_t jmp = x3_uniform(sJ[3][idx]);
+				const uint32_t jmp = x3_uniform(sJ[5][idx]);
 				const uint32_t cnt = jmp >> 12;
-				if (cnt) { /* up to 8 dictionary hits in one lookup; their tokens are written by the expansion phase */
+				if (cnt) { /* up to 32 dictionary hits in one lookup; their tokens are written by the expansion phase */
 					sAi[na] = (uint16_t)idx;
 					sAt[na] = ntok;
 					na++;
@@ -254,12 +254,14 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 		}
 		__syncthreads();
 		{
-			/* ---- expansion: anchor a covers cnt <= 8 consecutive hits; thread (a, t) finds the t-th one through the 1/2/4 tables ---- */
+			/* ---- expansion: anchor a covers cnt <= 32 consecutive hits; thread (a, t) finds the t-th one through the 1/2/4/8/16 tables ---- */
 			const uint32_t na = S.nanchor;
-			for (uint32_t w = tid; w < na * 8; w += X3_PARSE_THREADS) {
-				const uint32_t an = w >> 3, t = w & 7;
+			for (uint32_t w = tid; w < na * 32; w += X3_PARSE_THREADS) {
+				const uint32_t an = w >> 5, t = w & 31;
 				uint32_t i = sAi[an];
-				if (t < (uint32_t)(sJ[3][i] >> 12)) {
+				if (t < (sJ[5][i] >> 12)) {
+					if (t & 16) i = sJ[4][i] & 0xFFFu;
+					if (t & 8) i = sJ[3][i] & 0xFFFu;
 					if (t & 4) i = sJ[2][i] & 0xFFFu;
 					if (t & 2) i = sJ[1][i] & 0xFFFu;
 					if (t & 1) i = sJ[0][i] & 0xFFFu;
