@@ -119,11 +119,24 @@ __device__ static __forceinline__ void x3_modes_loop(const X3ModesArgs &a, uint3
 {
 	uint32_t E0 = 1024, E1 = 1024, E2 = 1, nidx = 0; /* model_events freqs (x3.c:239-241), IDX1 uses so far */
 	const uint64_t below = ((uint64_t)1 << lane) - 1;
+	/* features of the next block are fetched while this block is decided (a lone wave cannot hide the load latency otherwise) */
+	uint32_t nf0, nt0, nf1, nt1, nr, nd, ns;
+	{
+		const bool in0 = lane < H;
+		const uint32_t g0 = h0 + lane;
+		nf0 = in0 ? a.f0[g0] : 0; nt0 = in0 ? a.t0[g0] : 1; nf1 = in0 ? a.f1[g0] : 0; nt1 = in0 ? a.t1[g0] : 1;
+		nr = in0 ? a.rank[g0] : 0; nd = in0 ? a.dk[g0] : 1; ns = in0 ? a.step[g0] : 0;
+	}
 	for (uint32_t base = 0; base < H; base += X3_WAVE) {
 		const uint32_t g = h0 + base + lane;
 		const bool in = base + lane < H;
-		const uint32_t vf0 = in ? a.f0[g] : 0, vt0 = in ? a.t0[g] : 1, vf1 = in ? a.f1[g] : 0, vt1 = in ? a.t1[g] : 1;
-		const uint32_t vr = in ? a.rank[g] : 0, vd = in ? a.dk[g] : 1, vs = in ? a.step[g] : 0;
+		const uint32_t vf0 = nf0, vt0 = nt0, vf1 = nf1, vt1 = nt1, vr = nr, vd = nd, vs = ns;
+		{
+			const bool inn = base + X3_WAVE + lane < H;
+			const uint32_t gn = g + X3_WAVE;
+			nf0 = inn ? a.f0[gn] : 0; nt0 = inn ? a.t0[gn] : 1; nf1 = inn ? a.f1[gn] : 0; nt1 = inn ? a.t1[gn] : 1;
+			nr = inn ? a.rank[gn] : 0; nd = inn ? a.dk[gn] : 1; ns = inn ? a.step[gn] : 0;
+		}
 		const float q0 = vf0 ? (float)vf0 / (float)vt0 : 0.f; /* (float)freq / (float)total of the context item; 0 == absent */
 		const float q1 = vf1 ? (float)vf1 / (float)vt1 : 0.f;
 		const float ftot = (float)(2051u + vs); /* model_events.total: 2051 + one per earlier step */
@@ -271,12 +284,14 @@ __device__ static void x3_ac2_body(const X3Ac2Args &a)
 	const uint32_t c = blockIdx.x, lane = x3_lane();
 	const uint32_t y0 = x3_uniform(a.yo[c]), Y = x3_uniform(a.yo[c + 1]) - y0;
 	uint32_t lo = 0, R = 0x80000000u; /* ac_init, ac.c:35-41: [0, 0x7FFFFFFF] */
+	uint4 qnext = a.sym[y0 + (lane < Y ? lane : Y - 1)];
 	for (uint32_t base = 0; base < Y; base += X3_WAVE) {
-		/* 64 symbols per round: one coalesced 16-byte load per lane, then v_readlane feeds the scalar chain.
+		/* 64 symbols per round: one coalesced 16-byte load per lane (issued one round ahead), then v_readlane feeds the scalar chain.
 		 * (Measured alternative: s_load_dwordx4 per symbol through the scalar cache -- 17 % slower, its latency lands on the chain.)
 		 * nlo != nhi and y != 0 always: either would need a model total > 2^28, and a stream is at most 2^27 bytes (X3H_MAX_CHUNK),
 		 * so no clz(0) guard is needed.  Four symbols per trip amortise the loop overhead and the taken-branch penalty. */
-		const uint4 q = a.sym[y0 + (base + lane < Y ? base + lane : Y - 1)];
+		const uint4 q = qnext;
+		{ const uint32_t nb = base + X3_WAVE + lane; qnext = a.sym[y0 + (nb < Y ? nb : Y - 1)]; } /* next round's operands: in flight during this round */
 		const uint32_t cnt = x3_uniform(Y - base < X3_WAVE ? Y - base : X3_WAVE);
 		uint2 *recs = (uint2 *)a.rec_nk + (y0 + base);
 		uint32_t l = 0;
