@@ -276,11 +276,12 @@ __device__ static __forceinline__ uint4 x3_make_symbol(uint32_t cum, uint32_t fr
 		R = sf << sh;                                                                                          \
 		uint2 rv;                                                                                              \
 		rv.x = nlo; rv.y = nhi;                                                                                \
-		recs[(L)] = rv; /* every lane stores the same (uniform) record: one 8-byte write, no exec masking */   \
+		srec[(L)] = rv; /* every lane writes the same (uniform) record to LDS: no exec masking, no select */      \
 	}
 
 __device__ static void x3_ac2_body(const X3Ac2Args &a)
 {
+	X3_LDS uint2 srec[X3_WAVE]; /* the round's records; written to HBM once per round, coalesced (keeps the vector-memory queue free for the operand prefetch) */
 	const uint32_t c = blockIdx.x, lane = x3_lane();
 	const uint32_t y0 = x3_uniform(a.yo[c]), Y = x3_uniform(a.yo[c + 1]) - y0;
 	uint32_t lo = 0, R = 0x80000000u; /* ac_init, ac.c:35-41: [0, 0x7FFFFFFF] */
@@ -302,6 +303,9 @@ __device__ static void x3_ac2_body(const X3Ac2Args &a)
 			X3_AC2_STEP(l + 3)
 		}
 		for (; l < cnt; l++) X3_AC2_STEP(l)
+		x3_wave_sync();
+		if (lane < cnt) recs[lane] = srec[lane];
+		x3_wave_sync();
 	}
 	if (lane == 0) a.final_lo[c] = lo;
 }
