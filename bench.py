@@ -175,7 +175,7 @@ def main():
         }
         if chunked:
             line["chunked_same_bytes"] = chunked
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:  # the CPU baseline is a rank-0, N=1 leg only
             cb = cpu_baseline(data, args.w, args.t, args.cpu_sample)
             ref_out = cb.pop("out")
             # same run, same bytes: the GPU stream of the sample must equal the CPU reference's

@@ -109,8 +109,8 @@ extern "C" int x3h_ctx_create(x3h_ctx **out, int device)
 extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 {
 	if (!c) return;
-	hipSetDevice(c->device);
-	if (c->stream) hipStreamSynchronize(c->stream);
+	(void)hipSetDevice(c->device);
+	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	DevBuf *bufs[] = { &c->pad, &c->m, &c->dict_pos, &c->dict_len, &c->ht, &c->tok_pos, &c->tok_info, &c->tok_hb, &c->tok_nb, &c->tok_mb, &c->chunks, &c->presult,
 		               &c->c2.tmp, &c->c2.offs, &c->c2.chunkmeta, &c->c2.idxfreq, &c->c2.hsym, &c->c2.maxred, &c->c2.pp[0], &c->c2.pp[1], &c->c2.pp[2], &c->c2.pp[3],
 		               &c->cresult, &c->mtf, &c->idxfreq, &c->ctx1, &c->ctx0, &c->items, &c->pkey, &c->pval, &c->out, &c->counts, &c->din, &c->dchunks };
@@ -121,8 +121,8 @@ extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 	c->s2.misc.release();
 	for (DevBuf &b : c->c2.y) b.release();
 	for (DevBuf &b : c->c2.ms) b.release();
-	for (int i = 0; i < 6; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
-	if (c->stream) hipStreamDestroy(c->stream);
+	for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+	if (c->stream) (void)hipStreamDestroy(c->stream);
 	delete c;
 }
 
@@ -330,11 +330,11 @@ static int run(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage upto
 			stats->steps += c->hparse[(size_t)i].ntok;
 		}
 		float ms = 0;
-		hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); stats->ms_copy = ms;
-		hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); stats->ms_scan = ms;
-		hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); stats->ms_parse = ms;
-		hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); stats->ms_code = ms;
-		hipEventElapsedTime(&ms, c->ev[0], c->ev[5]); stats->ms_total = ms;
+		(void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); stats->ms_copy = ms;
+		(void)hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); stats->ms_scan = ms;
+		(void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); stats->ms_parse = ms;
+		(void)hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); stats->ms_code = ms;
+		(void)hipEventElapsedTime(&ms, c->ev[0], c->ev[5]); stats->ms_total = ms;
 		if (!c->code_v1 && c->c2.ev[4]) {
 			(void)hipEventElapsedTime(&ms, c->c2.ev[0], c->c2.ev[1]); stats->ms_features = ms;
 			(void)hipEventElapsedTime(&ms, c->c2.ev[1], c->c2.ev[2]); stats->ms_modes = ms;
