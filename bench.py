@@ -138,7 +138,7 @@ def main():
         W = args.w * 1024
         # Algorithmic bytes per launch of each kernel family (what the algorithm must move):
         kernels = {
-            "x3_ac2_kernel": {"ms": ms["ms_coder"], "alg_bytes": Y * (12 + 8)},          # symbol triple in, {n|k, lo} record out
+            "x3_ac2_kernel": {"ms": ms["ms_coder"], "alg_bytes": Y * (16 + 8)},          # {cum, freq, magic, shift} in, {lo, hi} record out
             "x3_modes_kernel": {"ms": ms["ms_modes"], "alg_bytes": H * (7 * 4 + 4)},      # 7 feature words in, mode out
             "x3_parse_kernel": {"ms": ms["ms_parse"], "alg_bytes": 2 * N + 4 * S},        # bytes + m[] in, one token word out
             "scan (sort + lookup + x3_walk_kernel)": {"ms": ms["ms_scan"], "alg_bytes": S * W + N + comp},  # S*W + N + C
