@@ -23,6 +23,10 @@
 #define PBL (PB + 32)       /* positions with cached L/E: filters look 31 ahead              */
 #define PBB (PB + 32 + 32)  /* bytes staged: a 32-byte compare at the last cached position   */
 
+#define X3_LDS_HT_LOG2 11u
+#define X3_LDS_HT (1u << X3_LDS_HT_LOG2) /* the mirror is used while the table has at most this many slots ... */
+#define X3_LDS_DICT (X3_LDS_HT / 2)      /* ... i.e. at most this many elements */
+
 #define FNV_OFF 2166136261u
 #define FNV_MUL 16777619u
 
@@ -51,6 +55,10 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 	X3_LDS uint32_t sJ[6][PB]; /* jump tables by pointer doubling: sJ[r][i] = (cached index after up to 2^r consecutive hits from i) | (hits taken << 12) */
 	X3_LDS uint16_t sAi[PB];   /* anchors of the current walk: cached index where a stride of hits starts ... */
 	X3_LDS uint32_t sAt[PB];   /* ... and the token index of its first hit */
+	/* LDS mirror of the dictionary while it is small (the usual case at large -t): hash table, element position / length */
+	X3_LDS uint16_t sHT[X3_LDS_HT];
+	X3_LDS uint32_t sDpos[X3_LDS_DICT];
+	X3_LDS uint8_t sDlen[X3_LDS_DICT];
 	X3_LDS ParseShared S;
 
 	const X3Chunk ck = a.chunks[blockIdx.x];
@@ -69,6 +77,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 		S.flag = n ? FLAG_REFILL : FLAG_DONE; S.ntok = 0; S.hits = 0; S.rebuild = 0; S.mbytes = 0; S.nanchor = 0;
 	}
 	for (uint32_t i = tid; i < (1u << (X3_HT_LOG2_MIN < ck.ht_log2_max ? X3_HT_LOG2_MIN : ck.ht_log2_max)); i += X3_PARSE_THREADS) ht[i] = 0;
+	for (uint32_t i = tid; i < X3_LDS_HT; i += X3_PARSE_THREADS) sHT[i] = 0;
 	__syncthreads();
 
 	uint64_t cyc_fill = 0, cyc_patch = 0, cyc_table = 0, cyc_walk = 0, t_prev = x3_clock();
@@ -88,13 +97,24 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 					h = (h ^ sb[i + l - 1]) * FNV_MUL;
 					if (!((lenmask >> (l - 1)) & 1)) continue;
 					uint32_t slot = ht_slot(h, l, hlog);
-					for (uint32_t e = ht[slot]; e != 0; slot = (slot + 1) & hmask, e = ht[slot]) {
-						const uint32_t tag = e - 1;
-						if (dlen[tag] != l) continue;
-						const uint8_t *ds = b + dpos[tag];
-						uint32_t k = 0;
-						while (k < l && ds[k] == sb[i + k]) k++;
-						if (k == l) { best = l; btag = tag; break; }
+					if (hlog <= X3_LDS_HT_LOG2) { /* wave-uniform: the whole dictionary is mirrored in LDS */
+						for (uint32_t e = sHT[slot]; e != 0; slot = (slot + 1) & hmask, e = sHT[slot]) {
+							const uint32_t tag = e - 1;
+							if (sDlen[tag] != l) continue;
+							const uint8_t *ds = b + sDpos[tag];
+							uint32_t k = 0;
+							while (k < l && ds[k] == sb[i + k]) k++;
+							if (k == l) { best = l; btag = tag; break; }
+						}
+					} else {
+						for (uint32_t e = ht[slot]; e != 0; slot = (slot + 1) & hmask, e = ht[slot]) {
+							const uint32_t tag = e - 1;
+							if (dlen[tag] != l) continue;
+							const uint8_t *ds = b + dpos[tag];
+							uint32_t k = 0;
+							while (k < l && ds[k] == sb[i + k]) k++;
+							if (k == l) { best = l; btag = tag; break; }
+						}
 					}
 				}
 				sL[i] = (uint8_t)best;
@@ -115,6 +135,10 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 					for (uint32_t k = 0; k < l; k++) h = (h ^ ds[k]) * FNV_MUL;
 					uint32_t slot = ht_slot(h, l, hlog);
 					while (atomicCAS(&ht[slot], 0u, t + 1) != 0u) slot = (slot + 1) & hmask;
+				}
+				if (hlog <= X3_LDS_HT_LOG2) { /* same content as the global table (identical probe order is not needed: exact lookups) */
+					__syncthreads();
+					for (uint32_t i = tid; i <= hmask; i += X3_PARSE_THREADS) sHT[i] = (uint16_t)ht[i];
 				}
 			}
 			const uint32_t first = S.p - blk; /* positions before the parse pointer are never read again */
@@ -227,6 +251,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 					if (lane == 0) {
 						dpos[ntag] = p;
 						dlen[ntag] = (uint8_t)len;
+						if (ntag < X3_LDS_DICT) { sDpos[ntag] = p; sDlen[ntag] = (uint8_t)len; }
 						if (!rebuild) {
 							uint32_t h = FNV_OFF;
 							for (uint32_t k = 0; k < len; k++) h = (h ^ sb[idx + k]) * FNV_MUL;
@@ -234,6 +259,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 							uint32_t slot = ht_slot(h, len, hlog);
 							while (ht[slot] != 0) slot = (slot + 1) & hmask;
 							ht[slot] = ntag + 1;
+							if (hlog <= X3_LDS_HT_LOG2) sHT[slot] = (uint16_t)(ntag + 1);
 						}
 						S.new_pos = p; S.new_len = len; S.new_tag = ntag; S.rebuild = rebuild;
 					}
