@@ -70,7 +70,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    distributed = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched by torch.distributed.run (any world size)
+    if distributed:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
@@ -85,12 +86,12 @@ def main():
 
     def step():
         lens, st = ctx.compress_chunks_dev(d_in.data_ptr(), offsets, prm, d_out.data_ptr(), stride)
-        if world > 1:  # the one exchange step of the path: finished streams -> rank 0 over RCCL/xGMI
+        if distributed:  # the one exchange step of the path: finished streams -> rank 0 over RCCL/xGMI
             xdist.gather_device_streams(d_out, stride, lens)
         return int(lens[0]), st
 
     def barrier():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -105,7 +106,7 @@ def main():
             acc[k] += getattr(st, k)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -185,7 +186,7 @@ def main():
             cb["value"] = round(cb["value"], 5)
             line["cpu_baseline"] = cb
         print(json.dumps(line))
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 
