@@ -193,3 +193,41 @@ def test_large_dictionary_60k_elements(gpu, oracle):
     assert got == want, f"first differing byte {first_diff(np.frombuffer(got, np.uint8), np.frombuffer(want, np.uint8))}"
     assert gpu.last_stats.dict_elems == st.dict_elems
     assert gpu.decompress(got, len(data)) == data
+
+
+# ---- BASELINE configs 3 and 5 at (near) full shape: size-independent properties ----------------------------------------------
+SILESIA_SIZES = [10192446, 51220480, 9970564, 33553445, 6152192, 10085684, 6627202, 21606400, 7251944, 41458703, 8474240, 5345280]
+
+
+def _mr_like(n, seed=55):
+    rng = np.random.default_rng(seed)
+    x = np.cumsum(rng.integers(-6, 7, n // 2 + 1), dtype=np.int64)
+    return ((x - x.min()) % 4096).astype("<u2").tobytes()[:n]
+
+
+def test_config3_shape_twelve_streams_w256_t1024(gpu):
+    """12 independent streams with the Silesia size profile (1/16 scale, mixed content), -w 256 -t 1024, one batch:
+    every stream decodes back to its input on the GPU, and a stream of the batch equals its standalone compression."""
+    sizes = [s // 16 for s in SILESIA_SIZES]
+    parts = []
+    for i, n in enumerate(sizes):
+        if i % 3 == 0: parts.append(synth.english_like(n, seed=100 + i).tobytes())
+        elif i % 3 == 1: parts.append(synth.zipf_bytes(n, offset=7919 * i).tobytes())
+        else: parts.append(_mr_like(n, seed=i))
+    data = b"".join(parts)
+    offs = np.cumsum([0] + sizes)
+    prm = _lib.make_params(w_kib=256, t=1024)
+    streams = gpu.compress_chunks(data, offs, prm)
+    assert all(len(s) % 4 == 0 and len(s) > 0 for s in streams)
+    back = gpu.decompress_chunks(streams, sizes)
+    assert [len(b) for b in back] == sizes and b"".join(back) == data
+    assert gpu.compress(parts[4], prm) == streams[4]
+
+
+def test_config5_full_size_mr_like_round_trip_w512_t4096(gpu):
+    """config 5: 9 970 564 bytes (size of Silesia 'mr'), 16-bit image-like samples, -w 512 -t 4096: compress + decompress on the GPU."""
+    data = _mr_like(9970564)
+    stream = gpu.compress(data, _lib.make_params(w_kib=512, t=4096))
+    st = gpu.last_stats
+    assert len(stream) % 4 == 0 and sum(list(st.events)[:4]) == st.steps
+    assert gpu.decompress(stream, len(data)) == data
