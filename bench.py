@@ -132,6 +132,14 @@ def main():
         chunked = {"chunks": len(coff) - 1, "chunk_bytes": cb, "value": round(args.bytes / cdt / 1e6, 3), "unit": "MB/s",
                    "ms": round(cdt * 1e3, 3), "ratio": round(args.bytes / float(clens.sum()), 4),
                    "stage_ms": {"scan": round(cst.ms_scan, 3), "parse": round(cst.ms_parse, 3), "code": round(cst.ms_code, 3)}}
+        # decoder (x3.c:285-353): the same chunk streams decoded as one batch (host buffers in/out; kernel time reported)
+        hout = d_cout.cpu().numpy()
+        cstreams = [hout[i * cstride:i * cstride + int(clens[i])].tobytes() for i in range(len(coff) - 1)]
+        caps = [int(coff[i + 1] - coff[i]) for i in range(len(coff) - 1)]
+        back = ctx.decompress_chunks(cstreams, caps)
+        dst = ctx.last_stats
+        chunked["decode"] = {"kernel_ms": round(dst.ms_code, 3), "value": round(args.bytes / (dst.ms_code * 1e-3) / 1e6, 3), "unit": "MB/s",
+                             "round_trip_ok": bool(b"".join(back) == data.tobytes())}
         del d_cout
 
     if rank == 0:
