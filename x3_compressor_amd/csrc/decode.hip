@@ -104,6 +104,10 @@ __device__ static uint32_t find_in_ctx(const X3CtxHdr h, const uint64_t *pool, u
 	return 0xFFFFFFFFu;
 }
 
+#ifndef X3_DEC_LDS
+#define X3_DEC_LDS 16384u /* dictionary elements whose recency list + index-model frequencies live in LDS (2 x 64 KiB) */
+#endif
+
 #define DFNV_OFF 2166136261u
 #define DFNV_MUL 16777619u
 
@@ -117,6 +121,10 @@ __device__ static __forceinline__ uint32_t dht_slot(uint32_t h, uint32_t len, ui
 
 __device__ static void x3_decode_body(const X3DecArgs &a)
 {
+	/* the two tables every step sweeps (move-to-front list, model_index1 frequencies) start in LDS and migrate to their global
+	 * arrays only if the stream's dictionary outgrows X3_DEC_LDS elements */
+	X3_LDS uint32_t s_mtf[X3_DEC_LDS];
+	X3_LDS uint32_t s_idx[X3_DEC_LDS];
 	const X3DecChunk ck = a.chunks[blockIdx.x];
 	const uint32_t lane = x3_lane();
 	uint8_t *out = a.out + ck.out_off;
@@ -124,7 +132,8 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 	uint8_t *dlen = a.dict_len + ck.tag_off;
 	uint32_t *ht = a.ht + ck.ht_off;
 	const uint32_t hlog = ck.ht_log2, hmask = (1u << hlog) - 1;
-	uint32_t *mtf = a.mtf + ck.tag_off, *idxfreq = a.idxfreq + ck.tag_off;
+	uint32_t *gmtf = a.mtf + ck.tag_off, *gidx = a.idxfreq + ck.tag_off;
+	uint32_t *mtf = s_mtf, *idxfreq = s_idx;
 	X3CtxHdr *ctx1 = a.ctx1 + ck.tag_off, *ctx0 = a.ctx0 + ck.ctx0_off;
 	uint64_t *pool = a.items + ck.item_off;
 	uint64_t *pkey = a.pair_key + ck.pair_off;
@@ -217,6 +226,11 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 			}
 			x3_wave_sync();
 			if (!dup) { /* x3.c:310-317 */
+				if (D == X3_DEC_LDS && mtf == s_mtf) { /* outgrew LDS: continue in global memory */
+					for (uint32_t i = lane; i < D; i += X3_WAVE) { gmtf[i] = s_mtf[i]; gidx[i] = s_idx[i]; }
+					x3_wave_sync();
+					mtf = gmtf; idxfreq = gidx;
+				}
 				if (lane == 0) { dpos[D] = p; dlen[D] = (uint8_t)len; ht[slot] = D + 1; }
 				mtf_to_front(mtf, D, D, lane);
 				if (lane == 0) idxfreq[D] = 1;
