@@ -113,9 +113,10 @@ class X3Context:
         self.last_stats: Stats | None = None
 
     def close(self):
-        if getattr(self, "_h", None) and self._h.value:
-            self.lib.x3h_ctx_destroy(self._h)
-            self._h = C.c_void_p()
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            self.lib.x3h_ctx_destroy(h)
+            self._h = None
 
     __del__ = close
 

@@ -53,15 +53,19 @@ static int csb_run(X3Code2Bufs &B, hipStream_t st, size_t n, int bits, uint32_t 
 	if (!n) return X3H_OK;
 	uint32_t *key2 = scratch[0], *org = scratch[1], *org2 = scratch[2], *bs2 = scratch[3], *be2 = scratch[4];
 	uint32_t *cnt = scratch[5], *cnt2 = scratch[6], *z = scratch[7], *Z = scratch[8];
-	x3_foreach(n, st, X3_LAMBDA(size_t i) { org[i] = (uint32_t)i; cnt[i] = 0; });
+	if (bits < 1) bits = 1;
+	{
+		const uint32_t *k = key;
+		const int b0 = bits - 1;
+		x3_foreach(n, st, X3_LAMBDA(size_t i) { org[i] = (uint32_t)i; cnt[i] = 0; z[i] = ((k[i] >> b0) & 1u) ^ 1u; });
+	}
 	for (int b = bits - 1; b >= 0; b--) {
-		{
-			const uint32_t *k = key;
-			x3_foreach(n, st, X3_LAMBDA(size_t i) { z[i] = ((k[i] >> b) & 1u) ^ 1u; });
-		}
 		CHK(x3p_excl_scan(B.tmp, z, Z, n, st));
 		{
+			/* stable partition of every bucket by bit b; an element with the bit set has every zero-bit element that precedes it in
+			 * its bucket as a "smaller before".  The flags of the next level are written at the element's new place on the way. */
 			const uint32_t *k = key, *o = org, *s_ = bs, *e_ = be, *c = cnt, *Zc = Z;
+			uint32_t *zn = z;
 			x3_foreach(n, st, X3_LAMBDA(size_t i) {
 				const uint32_t s = s_[i], e = e_[i];
 				const uint32_t zb = Zc[i] - Zc[s], zc = Zc[e] - Zc[s];
@@ -70,6 +74,7 @@ static int csb_run(X3Code2Bufs &B, hipStream_t st, size_t n, int bits, uint32_t 
 				if (!((kv >> b) & 1u)) { d = s + zb; nbs = s; nbe = s + zc; }
 				else { d = s + zc + ((uint32_t)i - s - zb); nbs = s + zc; nbe = e; cv += zb; }
 				key2[d] = kv; org2[d] = o[i]; bs2[d] = nbs; be2[d] = nbe; cnt2[d] = cv;
+				if (b > 0) zn[d] = ((kv >> (b - 1)) & 1u) ^ 1u; /* safe in place: Z (the scan of z) is what this level reads */
 			});
 		}
 		uint32_t *t;
@@ -547,17 +552,18 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 				const uint32_t kv = (i > 0 && ks[i - 1] == ks[i]) ? vs[i - 1] + 1 : 0u;
 				key[ev] = kv;
 			});
+			/* keys relative to the stream (0 = first touch, else previous touch + 1): the bit depth follows the largest stream, not the batch */
 			x3_foreach(nE, st, X3_LAMBDA(size_t i) {
 				const uint32_t c = find_chunk(d_eo, nc, (uint32_t)i);
-				keyc[i] = key[i]; bs[i] = d_eo[c]; be[i] = d_eo[c + 1];
+				const uint32_t kl = key[i] ? key[i] - d_eo[c] : 0u;
+				key[i] = kl; keyc[i] = kl; bs[i] = d_eo[c]; be[i] = d_eo[c + 1];
 			});
-			CHK(csb_run(B, st, nE, bits_for(nE + 1), keyc, bs, be, cnt, T + 8));
+			uint64_t maxE = 1;
+			for (uint32_t c = 0; c < nc; c++) { const uint64_t ec = (uint64_t)h_parsed[c].hits + h_parsed[c].dict_elems; if (ec > maxE) maxE = ec; }
+			CHK(csb_run(B, st, nE, bits_for(maxE + 1), keyc, bs, be, cnt, T + 8));
 			x3_foreach(nE, st, X3_LAMBDA(size_t i) {
 				const uint32_t gh = e_hit[i];
-				if (gh != NONE32) {
-					const uint32_t c = find_chunk(d_eo, nc, (uint32_t)i);
-					h_rank[gh] = cnt[i] - (key[i] - d_eo[c]);
-				}
+				if (gh != NONE32) h_rank[gh] = cnt[i] - key[i]; /* #{earlier touches with an older previous touch} - (previous touch + 1) */
 			});
 		}
 
