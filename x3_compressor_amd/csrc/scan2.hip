@@ -6,9 +6,9 @@
  * where count_i(p) = #{ s in [p+1, p+W-33] : bytes p..p+i equal bytes s..s+i } (backend.c:62-74).
  * count_i(p) >= K  <=>  the K-th NEXT OCCURRENCE of the (i+1)-gram at p lies inside the window.  So:
  *   1. sort all positions of the (zero padded) batch by their 1-, 2-, 3- and 4-gram with a stable radix sort: inside a class
- *      the positions are ascending, and R_l[p] is p's index in list S_l;
- *   2. levels i = 0..3 are O(1): look at S_{i+1}[R_{i+1}[p] + K] -- same gram and still <= p+W-33 ?  (count_0 itself is only
- *      needed when it is <= T: a binary search over at most T+1 list entries);
+ *      the positions are ascending;
+ *   2. levels i = 0..3 are O(1): entry j of list l is position p; look at entry j+K -- same gram and still <= p+W-33 ?
+ *      (count_0 itself is only needed when it is <= T: a binary search over at most T+1 list entries);
  *   3. only positions whose 4-gram already repeats K times in their window ("active") go deeper: one wavefront per active
  *      position sweeps the candidates of its 4-gram class that lie in the window -- ONE LANE PER CANDIDATE, coalesced reads of
  *      the class list, a 32-byte look-ahead of p broadcast from LDS -- and builds count_4..31 with ballot/popcount.
@@ -34,7 +34,8 @@ __device__ static __forceinline__ uint32_t load_gram(const uint8_t *b, uint64_t 
 
 struct X3WalkArgs {
 	const uint8_t *bytes;
-	const uint32_t *S4, *R4;     /* positions sorted by 4-gram; inverse */
+	const uint32_t *S4;          /* positions sorted by 4-gram */
+	const uint32_t *active_j;    /* index of each active position in S4 */
 	const uint32_t *active;      /* positions to walk */
 	const uint32_t *active_k;    /* their K */
 	const uint32_t *nactive;
@@ -62,7 +63,7 @@ __device__ static void x3_walk_body(const X3WalkArgs &a)
 #pragma unroll
 	for (int i = 0; i < 28; i++) cnt[i] = 0;
 	uint32_t done = 0;
-	for (uint32_t base = a.R4[p] + 1; base < a.total && !done; base += X3_WAVE) {
+	for (uint32_t base = a.active_j[idx] + 1; base < a.total && !done; base += X3_WAVE) {
 		const uint32_t j = base + lane;
 		uint32_t s = j < a.total ? a.S4[j] : NONE32;
 		uint32_t lcp = 0;
@@ -115,7 +116,11 @@ static void launch_walk(const X3WalkArgs &a, uint32_t nact_upper, hipStream_t)
 }
 #endif
 
-/* m[] for every position of every chunk.  d_bytes/d_m use the padded layout (X3Chunk::byte_off), `total` = padded bytes. */
+/* m[] for every position of every chunk.  d_bytes/d_m use the padded layout (X3Chunk::byte_off), `total` = padded bytes.
+ * All passes run over the SORTED lists: entry j of list l is position S_l[j]; its class neighbours are the adjacent entries
+ * (the sorted key array says where the class ends), so "K-th next occurrence inside the window" is  S_l[j+K] <= p + W-33
+ * with equal keys -- sequential reads of the list plus one random read/write of a per-position state word {K, m}.
+ * Padding positions are processed like any other (their results are never read). */
 int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, const X3Chunk *h_chunks, const X3Chunk *d_chunks,
                    const uint8_t *d_bytes, uint8_t *d_m, uint64_t total, uint32_t window, int32_t T)
 {
@@ -124,89 +129,72 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 	const size_t P = (size_t)total;
 	const uint32_t ncand = window > X3_MAXLEN + 1 ? window - X3_MAXLEN - 1 : 0;
 	uint64_t nsum = 0;
-	std::vector<uint32_t> po(nc + 1); /* real (unpadded) positions, for the per-position kernels */
-	for (uint32_t c = 0; c < nc; c++) { po[c] = (uint32_t)nsum; nsum += h_chunks[c].len; }
-	po[nc] = (uint32_t)nsum;
-	const size_t N = (size_t)nsum;
-	if (T <= 0 || ncand == 0 || N == 0) { /* backend.c:76,99: no threshold can be met -> length 1 everywhere */
+	for (uint32_t c = 0; c < nc; c++) nsum += h_chunks[c].len;
+	if (T <= 0 || ncand == 0 || nsum == 0) { /* backend.c:76,99: no threshold can be met -> length 1 everywhere */
 		HIPCHK(hipMemsetAsync(d_m, 0, P, st));
 		return X3H_OK;
 	}
-	for (int i = 0; i < 12; i++) CHK(B.a[i].reserve((P + 8) * 4));
-	CHK(B.misc.reserve((size_t)(nc + 1) * 4 + 64));
-	uint32_t *S[5], *R[5];
-	for (int l = 1; l <= 4; l++) { S[l] = B.a[2 * (l - 1)].as<uint32_t>(); R[l] = B.a[2 * (l - 1) + 1].as<uint32_t>(); }
-	uint32_t *keys = B.a[8].as<uint32_t>(), *iota = B.a[9].as<uint32_t>(), *ks = B.a[10].as<uint32_t>(), *act = B.a[11].as<uint32_t>();
-	uint32_t *d_po = B.misc.as<uint32_t>(), *d_nact = d_po + (nc + 1);
-	HIPCHK(hipMemcpyAsync(d_po, po.data(), (nc + 1) * 4, hipMemcpyHostToDevice, st));
+	for (int i = 0; i < 8; i++) CHK(B.a[i].reserve((P + 8) * 4));
+	CHK(B.misc.reserve(64));
+	uint32_t *keys = B.a[0].as<uint32_t>(), *iota = B.a[1].as<uint32_t>(), *ks = B.a[2].as<uint32_t>(), *S = B.a[3].as<uint32_t>();
+	uint32_t *state = B.a[4].as<uint32_t>(); /* per position: K in bits 0..15 (K <= T+1), m in bits 16..23 */
+	uint32_t *act = B.a[5].as<uint32_t>(), *act_k = B.a[6].as<uint32_t>(), *act_j = B.a[7].as<uint32_t>();
+	uint32_t *d_nact = B.misc.as<uint32_t>();
 	HIPCHK(hipMemsetAsync(d_nact, 0, 4, st));
+	const uint32_t Tu = (uint32_t)T > 0xFFFEu ? 0xFFFEu : (uint32_t)T, Pn = (uint32_t)P;
+	if ((uint32_t)T > 0xFFFEu) return X3H_E_ARG; /* K is kept in 16 bits */
 
-	/* ---- 1. positions sorted by l-gram, l = 1..4 (stable: ascending positions inside a class), and the inverse ---- */
 	x3_foreach(P, st, X3_LAMBDA(size_t q) { iota[q] = (uint32_t)q; });
 	for (uint32_t l = 1; l <= 4; l++) {
-		uint32_t *Sl = S[l], *Rl = R[l];
+		/* positions sorted by l-gram (stable: ascending positions inside a class) */
 		x3_foreach(P, st, X3_LAMBDA(size_t q) { keys[q] = load_gram(d_bytes, q, l); });
-		CHK(x3p_sort_pairs(tmp, keys, ks, iota, Sl, P, 8 * (int)l, st));
-		x3_foreach(P, st, X3_LAMBDA(size_t j) { Rl[Sl[j]] = (uint32_t)j; });
+		CHK(x3p_sort_pairs(tmp, keys, ks, iota, S, P, 8 * (int)l, st));
+		if (l == 1) {
+			/* K = min(T+1, count_0): is the (T+1)-th next occurrence of the byte inside the window?  else count them (binary search) */
+			x3_foreach(P, st, X3_LAMBDA(size_t j) {
+				const uint32_t p = S[j], kj = ks[j];
+				const uint64_t wend = (uint64_t)p + ncand;
+				const uint64_t u = (uint64_t)j + Tu + 1;
+				uint32_t K;
+				if (u < Pn && ks[u] == kj && S[u] <= wend) K = Tu + 1;
+				else {
+					uint32_t a = 0, bnd = Tu; /* predicate true at a */
+					if ((uint64_t)j + bnd >= Pn) bnd = Pn - 1 - (uint32_t)j;
+					while (a < bnd) {
+						const uint32_t mid = (a + bnd + 1) >> 1;
+						if (ks[j + mid] == kj && S[j + mid] <= wend) a = mid; else bnd = mid - 1;
+					}
+					K = a; /* == count_0 */
+				}
+				state[p] = K; /* m = 0 */
+			});
+		} else {
+			x3_foreach(P, st, X3_LAMBDA(size_t j) {
+				const uint32_t p = S[j];
+				const uint32_t sv = state[p], K = sv & 0xFFFFu, m = sv >> 16;
+				if (K < 2 || m != l - 2) return; /* count_0 < 2, or the previous level already failed */
+				const uint64_t u = (uint64_t)j + K;
+				if (u < Pn && ks[u] == ks[j] && S[u] <= (uint64_t)p + ncand) {
+					state[p] = K | ((l - 1) << 16);
+					if (l == 4) { /* count_3 >= K: deeper levels need the candidates themselves -- unless p is padding (never read) */
+						uint32_t lo = 0, hi = nc;
+						while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (d_chunks[mid].byte_off <= p) lo = mid; else hi = mid; }
+						if (p - (uint32_t)d_chunks[lo].byte_off >= d_chunks[lo].len) return;
+						const uint32_t slot = atomicAdd(d_nact, 1u);
+						act[slot] = p; act_k[slot] = K; act_j[slot] = (uint32_t)j;
+					}
+				}
+			});
+		}
 	}
+	x3_foreach(P, st, X3_LAMBDA(size_t q) { d_m[q] = (uint8_t)(state[q] >> 16); });
 
-	/* ---- 2. per position: K, then levels 0..3 by K-th-next-occurrence lookups; deeper candidates are queued ---- */
-	const uint32_t *S1 = S[1], *R1 = R[1], *S2 = S[2], *R2 = R[2], *S3 = S[3], *R3 = R[3], *S4 = S[4], *R4 = R[4];
-	uint32_t *act_k = ks; /* the sorted-key scratch is dead now */
-	const uint32_t Tu = (uint32_t)T, Pn = (uint32_t)P;
-	x3_foreach(N, st, X3_LAMBDA(size_t gi) {
-		uint32_t lo = 0, hi = nc; /* chunk of this position */
-		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (d_po[mid] <= (uint32_t)gi) lo = mid; else hi = mid; }
-		const uint64_t p64 = d_chunks[lo].byte_off + ((uint32_t)gi - d_po[lo]);
-		const uint32_t p = (uint32_t)p64;
-		const uint64_t wend = p64 + ncand; /* last candidate position (backend.c:66: s < p + W - 32) */
-		const uint32_t b0 = d_bytes[p];
-		/* K = min(T+1, count_0) */
-		const uint32_t j1 = R1[p];
-		uint32_t K;
-		{
-			const uint64_t u = (uint64_t)j1 + Tu + 1;
-			if (u < Pn && S1[u] <= wend && d_bytes[S1[u]] == b0) K = Tu + 1;
-			else { /* count_0 <= T: largest u in [j1, j1+T] still in class and window */
-				uint32_t a = 0, bnd = Tu; /* predicate true at a */
-				if ((uint64_t)j1 + bnd >= Pn) bnd = Pn - 1 - j1;
-				while (a < bnd) {
-					const uint32_t mid = (a + bnd + 1) >> 1;
-					const uint32_t s = S1[j1 + mid];
-					if (s <= wend && d_bytes[s] == b0) a = mid; else bnd = mid - 1;
-				}
-				K = a; /* == count_0 */
-			}
-		}
-		uint32_t m = 0;
-		bool deeper = false;
-		if (K >= 2) {
-			const uint32_t g4 = load_gram(d_bytes, p, 4);
-			uint64_t u = (uint64_t)R2[p] + K;
-			if (u < Pn && S2[u] <= wend && load_gram(d_bytes, S2[u], 2) == (g4 & 0xFFFFu)) {
-				m = 1;
-				u = (uint64_t)R3[p] + K;
-				if (u < Pn && S3[u] <= wend && load_gram(d_bytes, S3[u], 3) == (g4 & 0xFFFFFFu)) {
-					m = 2;
-					u = (uint64_t)R4[p] + K;
-					if (u < Pn && S4[u] <= wend && load_gram(d_bytes, S4[u], 4) == g4) { m = 3; deeper = true; }
-				}
-			}
-		}
-		d_m[p] = (uint8_t)m;
-		if (deeper) {
-			const uint32_t slot = atomicAdd(d_nact, 1u);
-			act[slot] = p;
-			act_k[slot] = K;
-		}
-	});
-
-	/* ---- 3. active positions: one wavefront each over the in-window candidates of its 4-gram class ---- */
+	/* active positions: one wavefront each over the in-window candidates of its 4-gram class (S still holds list 4) */
 	uint32_t nact = 0;
 	HIPCHK(hipMemcpyAsync(&nact, d_nact, 4, hipMemcpyDeviceToHost, st));
 	HIPCHK(hipStreamSynchronize(st));
 	X3WalkArgs wa;
-	wa.bytes = d_bytes; wa.S4 = S4; wa.R4 = R4; wa.active = act; wa.active_k = act_k; wa.nactive = d_nact; wa.m = d_m;
+	wa.bytes = d_bytes; wa.S4 = S; wa.active_j = act_j; wa.active = act; wa.active_k = act_k; wa.nactive = d_nact; wa.m = d_m;
 	wa.total = Pn; wa.ncand = ncand;
 	launch_walk(wa, nact, st);
 	HIPCHK(hipGetLastError());
