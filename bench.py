@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=256 * 1024)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--chunks", type=int, default=64, help="also report the same bytes as N independent chunks in one batch (0/1: skip)")
+    ap.add_argument("--many-chunks-mib", type=int, default=64, help="also report a batch of this many MiB cut into 256 KiB chunks (0: skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -142,6 +143,28 @@ def main():
                              "round_trip_ok": bool(b"".join(back) == data.tobytes())}
         del d_cout
 
+    many = None
+    if rank == 0 and world == 1 and args.many_chunks_mib > 0:
+        # aggregate figure: many independent streams in ONE batch (chunks of 256 KiB, the text tiled -- streams are independent, so
+        # repeated content costs what fresh content costs).  Bounded by the parallel sort/scan phases, not by the serial chains.
+        mtot, mcb = args.many_chunks_mib << 20, 256 << 10
+        mdata = np.tile(data[:8 << 20], mtot // (8 << 20) + 1)[:mtot]
+        d_min = torch.from_numpy(mdata).to(dev)
+        moff = np.arange(0, mtot + 1, mcb, dtype=np.uint64)
+        mstride = (mcb + (mcb >> 1) + 4096 + 3) & ~3
+        d_mout = torch.empty(mstride * (len(moff) - 1), dtype=torch.uint8, device=dev)
+        ctx.compress_chunks_dev(d_min.data_ptr(), moff, prm, d_mout.data_ptr(), mstride)  # warm-up (allocations)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        mlens, mst = ctx.compress_chunks_dev(d_min.data_ptr(), moff, prm, d_mout.data_ptr(), mstride)
+        torch.cuda.synchronize()
+        mdt = time.perf_counter() - t1
+        many = {"chunks": len(moff) - 1, "chunk_bytes": mcb, "total_bytes": mtot, "value": round(mtot / mdt / 1e6, 2), "unit": "MB/s",
+                "ms": round(mdt * 1e3, 2), "ratio": round(mtot / float(mlens.sum()), 4),
+                "stage_ms": {"scan": round(mst.ms_scan, 2), "parse": round(mst.ms_parse, 2), "features": round(mst.ms_features, 2),
+                             "modes": round(mst.ms_modes, 2), "coder": round(mst.ms_coder, 2), "emit": round(mst.ms_emit, 2)}}
+        del d_min, d_mout
+
     if rank == 0:
         S, H, Y, comp, N = int(st.steps), int(sum(list(st.events)[:3])), int(st.coded_symbols), out_len, args.bytes
         W = args.w * 1024
@@ -184,6 +207,8 @@ def main():
         }
         if chunked:
             line["chunked_same_bytes"] = chunked
+        if many:
+            line["many_chunks_batch"] = many
         if not args.no_cpu and world == 1:  # the CPU baseline is a rank-0, N=1 leg only
             cb = cpu_baseline(data, args.w, args.t, args.cpu_sample)
             ref_out = cb.pop("out")
