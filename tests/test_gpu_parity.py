@@ -231,3 +231,12 @@ def test_config5_full_size_mr_like_round_trip_w512_t4096(gpu):
     st = gpu.last_stats
     assert len(stream) % 4 == 0 and sum(list(st.events)[:4]) == st.steps
     assert gpu.decompress(stream, len(data)) == data
+
+
+def test_huge_t_and_zero_window(gpu, oracle):
+    """-t far above any count (K = count_0 then) and -w 0 (no candidates at all; the reference reads out of bounds there)."""
+    data = synth.english_like(30_000).tobytes()
+    for kw in (dict(w_kib=4, t=1_000_000), dict(w_kib=4, t=70_000)):
+        assert gpu.compress(data, _lib.make_params(**kw)) == oracle.compress(data, oracle_lib.params(**kw))
+    z = gpu.compress(data, _lib.make_params(w_kib=0, t=15))
+    assert gpu.decompress(z, len(data)) == data and np.all(gpu.scan_m(data, _lib.make_params(w_kib=0, t=15)) == 0)

@@ -190,7 +190,7 @@ static int run(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage upto
 	x3h_params dp;
 	if (!prm_in) { x3h_default_params(&dp); prm_in = &dp; }
 	const x3h_params prm = *prm_in;
-	if (prm.window_bytes > (1u << 30)) return X3H_E_ARG;
+	if (prm.window_bytes > (1u << 24)) return X3H_E_ARG; /* -w up to 16384 (KiB) */
 	HIPCHK(hipSetDevice(c->device));
 	const int nc = io.nchunks;
 	uint64_t max_len = 0;

@@ -137,12 +137,13 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 	for (int i = 0; i < 8; i++) CHK(B.a[i].reserve((P + 8) * 4));
 	CHK(B.misc.reserve(64));
 	uint32_t *keys = B.a[0].as<uint32_t>(), *iota = B.a[1].as<uint32_t>(), *ks = B.a[2].as<uint32_t>(), *S = B.a[3].as<uint32_t>();
-	uint32_t *state = B.a[4].as<uint32_t>(); /* per position: K in bits 0..15 (K <= T+1), m in bits 16..23 */
+	uint32_t *state = B.a[4].as<uint32_t>(); /* per position: K in bits 0..23 (K <= count_0 <= W-33 < 2^24), m in bits 24..28 */
 	uint32_t *act = B.a[5].as<uint32_t>(), *act_k = B.a[6].as<uint32_t>(), *act_j = B.a[7].as<uint32_t>();
 	uint32_t *d_nact = B.misc.as<uint32_t>();
 	HIPCHK(hipMemsetAsync(d_nact, 0, 4, st));
-	const uint32_t Tu = (uint32_t)T > 0xFFFEu ? 0xFFFEu : (uint32_t)T, Pn = (uint32_t)P;
-	if ((uint32_t)T > 0xFFFEu) return X3H_E_ARG; /* K is kept in 16 bits */
+	if (window > (1u << 24)) return X3H_E_ARG; /* K is kept in 24 bits */
+	/* K = min(T+1, count_0) and count_0 <= ncand: any T >= ncand behaves like T = ncand */
+	const uint32_t Tu = (uint32_t)T > ncand ? ncand : (uint32_t)T, Pn = (uint32_t)P;
 
 	x3_foreach(P, st, X3_LAMBDA(size_t q) { iota[q] = (uint32_t)q; });
 	for (uint32_t l = 1; l <= 4; l++) {
@@ -171,11 +172,11 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 		} else {
 			x3_foreach(P, st, X3_LAMBDA(size_t j) {
 				const uint32_t p = S[j];
-				const uint32_t sv = state[p], K = sv & 0xFFFFu, m = sv >> 16;
+				const uint32_t sv = state[p], K = sv & 0xFFFFFFu, m = sv >> 24;
 				if (K < 2 || m != l - 2) return; /* count_0 < 2, or the previous level already failed */
 				const uint64_t u = (uint64_t)j + K;
 				if (u < Pn && ks[u] == ks[j] && S[u] <= (uint64_t)p + ncand) {
-					state[p] = K | ((l - 1) << 16);
+					state[p] = K | ((l - 1) << 24);
 					if (l == 4) { /* count_3 >= K: deeper levels need the candidates themselves -- unless p is padding (never read) */
 						uint32_t lo = 0, hi = nc;
 						while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (d_chunks[mid].byte_off <= p) lo = mid; else hi = mid; }
@@ -187,7 +188,7 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 			});
 		}
 	}
-	x3_foreach(P, st, X3_LAMBDA(size_t q) { d_m[q] = (uint8_t)(state[q] >> 16); });
+	x3_foreach(P, st, X3_LAMBDA(size_t q) { d_m[q] = (uint8_t)(state[q] >> 24); });
 
 	/* active positions: one wavefront each over the in-window candidates of its 4-gram class (S still holds list 4) */
 	uint32_t nact = 0;
