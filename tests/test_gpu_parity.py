@@ -237,6 +237,7 @@ def test_huge_t_and_zero_window(gpu, oracle):
     """-t far above any count (K = count_0 then) and -w 0 (no candidates at all; the reference reads out of bounds there)."""
     data = synth.english_like(30_000).tobytes()
     for kw in (dict(w_kib=4, t=1_000_000), dict(w_kib=4, t=70_000)):
-        assert gpu.compress(data, _lib.make_params(**kw)) == oracle.compress(data, oracle_lib.params(**kw))
+        oprm = oracle_lib.params(**kw)  # (the faithful selection loops tc = T..1 like backend.c:76: use the oracle's closed-form path here)
+        assert gpu.compress(data, _lib.make_params(**kw)) == oracle.compress(data, oprm, via_m=oracle.scan_m(data, oprm))
     z = gpu.compress(data, _lib.make_params(w_kib=0, t=15))
     assert gpu.decompress(z, len(data)) == data and np.all(gpu.scan_m(data, _lib.make_params(w_kib=0, t=15)) == 0)
