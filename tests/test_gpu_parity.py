@@ -241,3 +241,18 @@ def test_huge_t_and_zero_window(gpu, oracle):
         assert gpu.compress(data, _lib.make_params(**kw)) == oracle.compress(data, oprm, via_m=oracle.scan_m(data, oprm))
     z = gpu.compress(data, _lib.make_params(w_kib=0, t=15))
     assert gpu.decompress(z, len(data)) == data and np.all(gpu.scan_m(data, _lib.make_params(w_kib=0, t=15)) == 0)
+
+
+def test_sub_batching_is_transparent(gpu, monkeypatch):
+    """Batches above X3H_BATCH_BYTES are coded as consecutive sub-batches; streams are independent, so nothing may change."""
+    data = synth.english_like(300_000).tobytes()
+    cuts = [0, 50_000, 50_000, 120_000, 200_000, 299_999, 300_000]
+    prm = _lib.make_params(w_kib=8, t=16)
+    whole = gpu.compress_chunks(data, cuts, prm)
+    monkeypatch.setenv("X3H_BATCH_BYTES", "100000")
+    small = _lib.X3Context(0)
+    try:
+        assert small.compress_chunks(data, cuts, prm) == whole
+        assert small.last_stats.steps == gpu.last_stats.steps
+    finally:
+        small.close()

@@ -35,6 +35,7 @@ struct x3h_ctx {
 	X3Code2Bufs c2;
 	X3Scan2Bufs s2;
 	int code_v1 = 0, scan_v1 = 0;
+	uint64_t batch_bytes = (uint64_t)1 << 30;
 	uint64_t pad_total = 0;
 	DevBuf mtf, idxfreq, ctx1, ctx0, items, pkey, pval, out, counts;
 	DevBuf din, dchunks; /* decoder: input streams, stream table */
@@ -99,6 +100,7 @@ extern "C" int x3h_ctx_create(x3h_ctx **out, int device)
 	c->device = device;
 	{ const char *e = getenv("X3H_CODE_V1"); c->code_v1 = e && *e && *e != '0'; }
 	{ const char *e = getenv("X3H_SCAN_V1"); c->scan_v1 = e && *e && *e != '0'; }
+	{ const char *e = getenv("X3H_BATCH_BYTES"); if (e && atoll(e) > 0) c->batch_bytes = (uint64_t)atoll(e); }
 	if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return X3H_E_HIP; }
 	for (int i = 0; i < 6; i++)
 		if (hipEventCreate(&c->ev[i]) != hipSuccess) { x3h_ctx_destroy(c); return X3H_E_HIP; }
@@ -184,7 +186,7 @@ static int stage_inputs(x3h_ctx *c, const x3h_params *prm, const RunIO &io, uint
 	return X3H_OK;
 }
 
-static int run(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage upto, x3h_stats *stats)
+static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage upto, x3h_stats *stats)
 {
 	if (!c || !io.offsets || io.nchunks <= 0 || (!io.src && io.offsets[io.nchunks] != io.offsets[0])) return X3H_E_ARG;
 	x3h_params dp;
@@ -344,6 +346,39 @@ static int run(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage upto
 		}
 	}
 	return rc;
+}
+
+/* Workspace is ~150 bytes per input byte, so very large batches are coded as consecutive sub-batches of at most `batch_bytes`
+ * input bytes (X3H_BATCH_BYTES, default 1 GiB ~ 160 GB of HBM): chunks of a sub-batch still run concurrently, streams are
+ * independent, so the output is identical to the unsplit run. */
+static int run(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage upto, x3h_stats *stats)
+{
+	if (!c || !io.offsets || io.nchunks <= 0) return X3H_E_ARG;
+	const uint64_t limit = c->batch_bytes;
+	const uint64_t total = io.offsets[io.nchunks] - io.offsets[0];
+	if (upto != STAGE_CODE || total <= limit || io.nchunks == 1) return run_one(c, prm_in, io, upto, stats);
+	x3h_stats acc, part;
+	memset(&acc, 0, sizeof acc);
+	int first = 0;
+	while (first < io.nchunks) {
+		int last = first + 1;
+		while (last < io.nchunks && io.offsets[last + 1] - io.offsets[first] <= limit) last++;
+		RunIO sub = io;
+		sub.offsets = io.offsets + first;
+		sub.nchunks = last - first;
+		sub.dst = io.dst ? io.dst + (uint64_t)first * io.dst_stride : nullptr;
+		sub.out_lens = io.out_lens ? io.out_lens + first : nullptr;
+		CHK(run_one(c, prm_in, sub, upto, stats ? &part : nullptr));
+		if (stats) {
+			for (int e = 0; e < 5; e++) acc.events[e] += part.events[e];
+			acc.dict_elems += part.dict_elems; acc.ctx0_entries += part.ctx0_entries; acc.steps += part.steps; acc.coded_symbols += part.coded_symbols;
+			acc.ms_total += part.ms_total; acc.ms_scan += part.ms_scan; acc.ms_parse += part.ms_parse; acc.ms_code += part.ms_code; acc.ms_copy += part.ms_copy;
+			acc.ms_features += part.ms_features; acc.ms_modes += part.ms_modes; acc.ms_coder += part.ms_coder; acc.ms_emit += part.ms_emit;
+		}
+		first = last;
+	}
+	if (stats) *stats = acc;
+	return X3H_OK;
 }
 
 /* ------------------------------------------------------------------------------------------------------------ */
