@@ -53,14 +53,7 @@ __device__ static void dec_narrow(Dec &d, BitReader &r, uint32_t step, uint32_t 
 	}
 }
 
-__device__ static __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane)
-{
-	for (unsigned d = 1; d < X3_WAVE; d <<= 1) {
-		const uint32_t u = x3_shfl_up_u32(v, d);
-		if (lane >= d) v += u;
-	}
-	return v;
-}
+__device__ static __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) { (void)lane; return x3_wave_incl_scan_u32(v); }
 
 /* find the symbol of a frequency array (global memory, `count` entries) that holds `value`; returns 0xFFFFFFFF if none */
 __device__ static uint32_t find_in_array(const uint32_t *freq, uint32_t count, uint32_t value, uint32_t lane, uint32_t &cum_out, uint32_t &fq_out)

@@ -36,6 +36,20 @@ __device__ __forceinline__ uint32_t x3_readlane_u32(uint32_t v, uint32_t lane_un
 __device__ __forceinline__ uint32_t x3_writelane_u32(uint32_t old, uint32_t val, uint32_t lane_uniform) { return x3_lane() == lane_uniform ? val : old; }
 __device__ __forceinline__ uint32_t x3_shfl_up_u32(uint32_t v, unsigned d) { return (uint32_t)__shfl_up((int)v, d, X3_WAVE); }
 __device__ __forceinline__ uint32_t x3_shfl_xor_u32(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, X3_WAVE); }
+/* inclusive prefix sum / total over the 64 lanes with DPP row shifts + row broadcasts (six VALU adds; the same sequence LLVM's
+ * atomic optimizer emits for gfx9) instead of six ds_bpermute round trips */
+__device__ __forceinline__ uint32_t x3_wave_incl_scan_u32(uint32_t v)
+{
+	int x = (int)v;
+	x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false); /* row_shr:1 */
+	x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false); /* row_shr:2 */
+	x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false); /* row_shr:4 */
+	x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false); /* row_shr:8 */
+	x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false); /* row_bcast:15 -> rows 1,3 */
+	x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false); /* row_bcast:31 -> rows 2,3 */
+	return (uint32_t)x;
+}
+__device__ __forceinline__ uint32_t x3_wave_sum_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)x3_wave_incl_scan_u32(v), 63); }
 /* Orders this wave's earlier LDS/global accesses before its later ones when different lanes touch the same
  * address (the compiler only tracks per-lane dependencies). */
 __device__ __forceinline__ void x3_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
@@ -81,6 +95,13 @@ static inline uint32_t x3_readlane_u32(uint32_t v, uint32_t lane_uniform) { retu
 static inline uint32_t x3_writelane_u32(uint32_t old, uint32_t val, uint32_t lane_uniform) { return x3_lane() == lane_uniform ? val : old; }
 static inline uint32_t x3_shfl_up_u32(uint32_t v, unsigned d) { int l = (int)x3_lane(); return x3emu_shfl(v, l >= (int)d ? l - (int)d : l); }
 static inline uint32_t x3_shfl_xor_u32(uint32_t v, int m) { return x3emu_shfl(v, (int)x3_lane() ^ m); }
+static inline uint32_t x3_wave_incl_scan_u32(uint32_t v)
+{
+	const int l = (int)x3_lane();
+	for (int d = 1; d < X3_WAVE; d <<= 1) { const uint32_t u = x3emu_shfl(v, l >= d ? l - d : l); if (l >= d) v += u; }
+	return v;
+}
+static inline uint32_t x3_wave_sum_u32(uint32_t v) { return x3emu_shfl(x3_wave_incl_scan_u32(v), X3_WAVE - 1); }
 static inline void x3_wave_sync() { (void)x3emu_ballot(0); }
 static inline uint64_t x3_clock() { return 0; }
 static inline int x3_popc64(uint64_t v) { return __builtin_popcountll(v); }

@@ -7,11 +7,7 @@
 #define X3_TABLES_H
 #include "x3_kernels.h"
 
-__device__ static __forceinline__ uint32_t wave_sum(uint32_t v)
-{
-	for (int m = 32; m >= 1; m >>= 1) v += x3_shfl_xor_u32(v, m);
-	return v;
-}
+__device__ static __forceinline__ uint32_t wave_sum(uint32_t v) { return x3_wave_sum_u32(v); }
 
 struct CtxQ { uint32_t found, pos, freq, cum; };
 
