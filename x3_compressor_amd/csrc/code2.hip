@@ -404,7 +404,7 @@ static int ctx_stats(X3Code2Bufs &B, hipStream_t st, size_t nH, int gbits, int t
 		key[i] = p;
 		bs[i] = gsA[i];
 		be[i] = gend[gsA[i]];
-		if (p) atomicMax(dmax, p);
+		if (p > __atomic_load_n(dmax, __ATOMIC_RELAXED)) atomicMax(dmax, p); /* the running maximum rises O(log) times: almost no hit reaches the atomic */
 	});
 	uint32_t hmax = 0;
 	HIPCHK(hipMemcpyAsync(&hmax, dmax, 4, hipMemcpyDeviceToHost, st));
