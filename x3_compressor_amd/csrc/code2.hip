@@ -261,59 +261,113 @@ __device__ static __forceinline__ uint4 x3_make_symbol(uint32_t cum, uint32_t fr
 	return q;
 }
 
-/* The serial chain, state (lo, range):  step = range / total;  lo += step*cum;  range = step*freq;  then E1/E2 (ac.c:49-67) shift out
- * the n leading bits on which lo and hi = lo+range-1 agree and E3 (ac.c:70-74) the k positions below the top bit where lo has 1
- * and hi has 0 -- both are left shifts, applied at once, and they simply scale the range: range <<= n+k (the shifted-out bits of
- * lo and hi are equal, or differ by the quarter E3 subtracts from both).  clz(0) == 32 makes the formulas cover lo == hi
- * (n = 31, k = 0) and the all-E3 case (n = 0, k = 30) without branches: a taken branch costs a lone wave ~40 cycles.
+/* The serial chain, state (lo, R = range):  step = R / total;  nlo = lo + step*cum;  sf = step*freq;  nhi = nlo + sf - 1;  then the
+ * renormalisation of ac.c:46-75.  E1/E2 zoom into the lower/upper half and E3 into the middle half of the current window, so after s
+ * shifts in total the window is SOME [j*h, (j+2)*h) with h = 2^(30-s), and the loops stop exactly when no window of the next level
+ * holds [nlo, nhi].  That happens at t = 30 - s with (nhi >> t) - (nlo >> t) <= 1 no longer satisfiable one level down, i.e. with
+ * D = nhi - nlo = sf - 1 and b = its top bit:  s = clz(D) - 1 - carry, where carry = the carry into bit b of nlo + D == NOT bit b of
+ * (nlo ^ nhi)  (bit b of D is 1).  Both kinds of shift are left shifts that scale the range: lo' = (nlo << s) mod 2^30, R' = sf << s.
+ * One clz, one bit test and a subtract-with-borrow replace the E1/E2/E3 loops: 17 scalar instructions per symbol in all.
+ * Nothing is written to the bit stream here: the record (nlo, nhi) goes out, and the emit stage derives n (E1/E2 count), k (E3
+ * count), the mScale bookkeeping and the bit placement from the records with prefix sums.
+ * D != 0 always: sf >= step >= 2^29 / total, and a model total stays < 2^28 (a stream is at most 2^27 bytes, X3H_MAX_CHUNK).
  */
-/* one symbol of the chain; records (lo, hi) after narrowing, before the shift: the emit stage derives n and k from them */
-#define X3_AC2_STEP(L)                                                                                         \
-	{                                                                                                          \
-		const uint32_t cum = x3_readlane_u32(q.x, (L)), fq = x3_readlane_u32(q.y, (L));                        \
-		const uint32_t m = x3_readlane_u32(q.z, (L)), msh = x3_readlane_u32(q.w, (L));                         \
-		const uint32_t step = (uint32_t)(((uint64_t)R * m) >> msh);                                            \
-		const uint32_t nlo = lo + step * cum, sf = step * fq, nhi = nlo + sf - 1;                              \
-		const uint32_t n = (uint32_t)__builtin_clz(nlo ^ nhi) - 1;                                             \
-		const uint32_t y = ((((nhi | ~nlo) << n) | ~(0xFFFFFFFFu << n)) & 0x3FFFFFFFu);                        \
-		const uint32_t sh = n + (uint32_t)__builtin_clz(y) - 2;                                                \
-		lo = (nlo << sh) & 0x3FFFFFFFu;                                                                        \
-		R = sf << sh;                                                                                          \
-		uint2 rv;                                                                                              \
-		rv.x = nlo; rv.y = nhi;                                                                                \
-		srec[(L)] = rv; /* every lane writes the same (uniform) record to LDS: no exec masking, no select */      \
+#ifndef X3_EMU
+/* Everything on the chain lives in SGPRs.  Operands arrive by s_load_dwordx16 (4 symbols per load, 8 symbols = one "group" per
+ * ping-pong register set, fetched one group ahead of their use), records leave by s_store_dwordx2 through the scalar data cache
+ * (written back once at the end): no VALU, no LDS and no v_readlane on the chain.  A vector load per 512 symbols touches the
+ * operand lines far ahead of the scalar loads, so those hit in L2.  Scalar memory returns out of order, so the only usable wait is
+ * lgkmcnt(0); the load of the NEXT group is therefore issued right after the wait for the current one.
+ * The asm blocks carry the in-flight registers as "+s" operands so the compiler keeps them pinned and orders their uses behind the wait. */
+typedef uint32_t x3_u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t x3_u32x4 __attribute__((ext_vector_type(4)));
+
+#define X3_AC2_SYM(Q, J, OFF)                                                                                                   \
+	{                                                                                                                           \
+		const uint32_t cum = (Q)[4 * (J)], fq = (Q)[4 * (J) + 1], m = (Q)[4 * (J) + 2], msh = (Q)[4 * (J) + 3];                 \
+		const uint32_t step = (uint32_t)(((uint64_t)R * m) >> msh);                                                             \
+		const uint32_t nlo = lo + step * cum, sf = step * fq, D = sf - 1, nhi = nlo + D;                                        \
+		const uint32_t cz = (uint32_t)__builtin_clz(D), x = nlo ^ nhi, t = 31u - cz;                                            \
+		uint32_t sh;                                                                                                            \
+		asm("s_bitcmp0_b32 %1, %2\n\ts_subb_u32 %0, %3, 1" : "=s"(sh) : "s"(x), "s"(t), "s"(cz) : "scc");                      \
+		const uint64_t rec = ((uint64_t)nhi << 32) | nlo;                                                                       \
+		asm volatile("s_store_dwordx2 %0, %1, %2" : : "s"(rec), "s"(recp), "n"(OFF) : "memory");                               \
+		lo = (nlo << sh) & 0x3FFFFFFFu;                                                                                         \
+		R = sf << sh;                                                                                                           \
 	}
+#define X3_AC2_GROUP(Q0, Q1)                                                                                                    \
+	X3_AC2_SYM(Q0, 0, 0) X3_AC2_SYM(Q0, 1, 8) X3_AC2_SYM(Q0, 2, 16) X3_AC2_SYM(Q0, 3, 24)                                       \
+	X3_AC2_SYM(Q1, 0, 32) X3_AC2_SYM(Q1, 1, 40) X3_AC2_SYM(Q1, 2, 48) X3_AC2_SYM(Q1, 3, 56)
+/* wait for everything in flight (the group about to be used included), then start the loads of the group after it */
+#define X3_AC2_FETCH(N0, N1, C0, C1, PTR)                                                                                       \
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40"                           \
+	             : "=&s"(N0), "=&s"(N1), "+s"(C0), "+s"(C1) : "s"(PTR) : "memory")
 
 __device__ static void x3_ac2_body(const X3Ac2Args &a)
 {
-	X3_LDS uint2 srec[X3_WAVE]; /* the round's records; written to HBM once per round, coalesced (keeps the vector-memory queue free for the operand prefetch) */
 	const uint32_t c = blockIdx.x, lane = x3_lane();
 	const uint32_t y0 = x3_uniform(a.yo[c]), Y = x3_uniform(a.yo[c + 1]) - y0;
 	uint32_t lo = 0, R = 0x80000000u; /* ac_init, ac.c:35-41: [0, 0x7FFFFFFF] */
-	uint4 qnext = a.sym[y0 + (lane < Y ? lane : Y - 1)];
-	for (uint32_t base = 0; base < Y; base += X3_WAVE) {
-		/* 64 symbols per round: one coalesced 16-byte load per lane (issued one round ahead), then v_readlane feeds the scalar chain.
-		 * (Measured alternative: s_load_dwordx4 per symbol through the scalar cache -- 17 % slower, its latency lands on the chain.)
-		 * nlo != nhi and y != 0 always: either would need a model total > 2^28, and a stream is at most 2^27 bytes (X3H_MAX_CHUNK),
-		 * so no clz(0) guard is needed.  Four symbols per trip amortise the loop overhead and the taken-branch penalty. */
-		const uint4 q = qnext;
-		{ const uint32_t nb = base + X3_WAVE + lane; qnext = a.sym[y0 + (nb < Y ? nb : Y - 1)]; } /* next round's operands: in flight during this round */
-		const uint32_t cnt = x3_uniform(Y - base < X3_WAVE ? Y - base : X3_WAVE);
-		uint2 *recs = (uint2 *)a.rec_nk + (y0 + base);
-		uint32_t l = 0;
-		for (; l + 4 <= cnt; l += 4) {
-			X3_AC2_STEP(l)
-			X3_AC2_STEP(l + 1)
-			X3_AC2_STEP(l + 2)
-			X3_AC2_STEP(l + 3)
+	const uint64_t symp = (uint64_t)(a.sym + y0);
+	uint64_t recp = (uint64_t)((uint2 *)a.rec_nk + y0);
+	const uint32_t G = Y >> 3; /* whole groups of 8 symbols */
+	const uint32_t lastoff = (G ? G - 1 : 0) * 128u;
+	if (G) {
+		x3_u32x16 A0, A1, B0, B1;
+		uint32_t dummy = 0; /* destination of the L2-warming loads: kept live to the end so its register is never reused under a load in flight */
+		asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(A0), "=&s"(A1) : "s"(symp) : "memory");
+		for (uint32_t g = 0; g < G; g += 2) {
+			if ((g & 63u) == 0) { /* every 512 symbols: pull the operand lines of symbols [g*8+512, g*8+1024) towards L2 (result unused) */
+				uint64_t pf = symp + (uint64_t)(g + 64) * 128u + lane * 128u;
+				const uint64_t pfmax = symp + (uint64_t)lastoff;
+				pf = pf < pfmax ? pf : pfmax;
+				asm volatile("s_waitcnt vmcnt(0)\n\tglobal_load_dword %0, %1, off" : "+v"(dummy) : "v"(pf) : "memory");
+			}
+			{
+				const uint32_t o = (g + 1) * 128u;
+				X3_AC2_FETCH(B0, B1, A0, A1, symp + (o < lastoff ? o : lastoff));
+			}
+			X3_AC2_GROUP(A0, A1)
+			recp += 64;
+			if (g + 1 >= G) break;
+			{
+				const uint32_t o = (g + 2) * 128u;
+				X3_AC2_FETCH(A0, A1, B0, B1, symp + (o < lastoff ? o : lastoff));
+			}
+			X3_AC2_GROUP(B0, B1)
+			recp += 64;
 		}
-		for (; l < cnt; l++) X3_AC2_STEP(l)
-		x3_wave_sync();
-		if (lane < cnt) recs[lane] = srec[lane];
-		x3_wave_sync();
+		asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : : "v"(dummy) : "memory"); /* the last (clamped) prefetches */
+	}
+	for (uint32_t y = G << 3; y < Y; y++) { /* < 8 leftover symbols */
+		x3_u32x4 Q;
+		asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(Q) : "s"(symp + (uint64_t)y * 16u) : "memory");
+		X3_AC2_SYM(Q, 0, 0)
+		recp += 8;
+	}
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" : : : "memory"); /* records: scalar cache -> L2 */
+	if (lane == 0) a.final_lo[c] = lo;
+}
+#else
+/* functional restatement of the same formulas for the CPU emulator build (tests only) */
+__device__ static void x3_ac2_body(const X3Ac2Args &a)
+{
+	const uint32_t c = blockIdx.x, lane = x3_lane();
+	const uint32_t y0 = a.yo[c], Y = a.yo[c + 1] - y0;
+	uint32_t lo = 0, R = 0x80000000u;
+	for (uint32_t y = 0; y < Y; y++) {
+		const uint4 q = a.sym[y0 + y];
+		const uint32_t step = (uint32_t)(((uint64_t)R * q.z) >> q.w);
+		const uint32_t nlo = lo + step * q.x, sf = step * q.y, D = sf - 1, nhi = nlo + D;
+		const uint32_t cz = (uint32_t)x3_clz32(D), t = 31u - cz;
+		const uint32_t sh = cz - 1 - ((((nlo ^ nhi) >> t) & 1u) ^ 1u);
+		if (lane == 0) { a.rec_nk[2 * (size_t)(y0 + y)] = nlo; a.rec_nk[2 * (size_t)(y0 + y) + 1] = nhi; }
+		lo = (nlo << sh) & 0x3FFFFFFFu;
+		R = sf << sh;
 	}
 	if (lane == 0) a.final_lo[c] = lo;
 }
+#endif
 
 #ifndef X3_EMU
 __global__ void __launch_bounds__(X3_WAVE) x3_modes_kernel(X3ModesArgs a) { x3_modes_body(a); }
