@@ -272,81 +272,101 @@ __device__ static __forceinline__ uint4 x3_make_symbol(uint32_t cum, uint32_t fr
  * count), the mScale bookkeeping and the bit placement from the records with prefix sums.
  * D != 0 always: sf >= step >= 2^29 / total, and a model total stays < 2^28 (a stream is at most 2^27 bytes, X3H_MAX_CHUNK).
  */
+#define X3_SYM_PAD 72 /* readable operand entries behind the last symbol (the chain fetches one group of 8 ahead) */
 #ifndef X3_EMU
 /* Everything on the chain lives in SGPRs.  Operands arrive by s_load_dwordx16 (4 symbols per load, 8 symbols = one "group" per
- * ping-pong register set, fetched one group ahead of their use), records leave by s_store_dwordx2 through the scalar data cache
- * (written back once at the end): no VALU, no LDS and no v_readlane on the chain.  A vector load per 512 symbols touches the
- * operand lines far ahead of the scalar loads, so those hit in L2.  Scalar memory returns out of order, so the only usable wait is
- * lgkmcnt(0); the load of the NEXT group is therefore issued right after the wait for the current one.
- * The asm blocks carry the in-flight registers as "+s" operands so the compiler keeps them pinned and orders their uses behind the wait. */
+ * ping-pong register set, fetched one group ahead of their use), records leave by s_store_dwordx4 (two records) through the scalar
+ * data cache (written back once at the end): no VALU, no LDS and no v_readlane on the chain.  A vector load per 512 symbols touches
+ * the operand lines far ahead of the scalar loads, so those hit in L2.  Scalar memory returns out of order, so the only usable wait
+ * is lgkmcnt(0); the load of the NEXT group is therefore issued right after the wait for the current one.  The asm blocks carry the
+ * in-flight registers as "+s" operands so the compiler keeps them pinned and orders their uses behind the wait.
+ * The operand array has X3_SYM_PAD readable entries behind the last symbol, so the fetch one group ahead needs no clamping.
+ * lo is NOT reduced mod 2^30 after the shift: the two stray bits (30, 31) never reach a bit the chain looks at (they cancel in
+ * nlo ^ nhi at bit 30, the only place they could matter) and are shifted out or stay put; the records carry them along and
+ * x3_rec_fix (parallel, emit stage) removes them again: 15 instructions per symbol + 0.5 for the store. */
 typedef uint32_t x3_u32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t x3_u32x4 __attribute__((ext_vector_type(4)));
 
-#define X3_AC2_SYM(Q, J, OFF)                                                                                                   \
+#define X3_AC2_SYM(Q, J, NLO, NHI)                                                                                              \
 	{                                                                                                                           \
 		const uint32_t cum = (Q)[4 * (J)], fq = (Q)[4 * (J) + 1], m = (Q)[4 * (J) + 2], msh = (Q)[4 * (J) + 3];                 \
 		const uint32_t step = (uint32_t)(((uint64_t)R * m) >> msh);                                                             \
-		const uint32_t nlo = lo + step * cum, sf = step * fq, D = sf - 1, nhi = nlo + D;                                        \
-		const uint32_t cz = (uint32_t)__builtin_clz(D), x = nlo ^ nhi, t = 31u - cz;                                            \
+		const uint32_t sf = step * fq, D = sf - 1;                                                                              \
+		NLO = lo + step * cum;                                                                                                  \
+		NHI = NLO + D;                                                                                                          \
+		const uint32_t cz = (uint32_t)__builtin_clz(D), x = NLO ^ NHI, t = 31u - cz;                                            \
 		uint32_t sh;                                                                                                            \
 		asm("s_bitcmp0_b32 %1, %2\n\ts_subb_u32 %0, %3, 1" : "=s"(sh) : "s"(x), "s"(t), "s"(cz) : "scc");                      \
-		const uint64_t rec = ((uint64_t)nhi << 32) | nlo;                                                                       \
-		asm volatile("s_store_dwordx2 %0, %1, %2" : : "s"(rec), "s"(recp), "n"(OFF) : "memory");                               \
-		lo = (nlo << sh) & 0x3FFFFFFFu;                                                                                         \
+		lo = NLO << sh;                                                                                                         \
 		R = sf << sh;                                                                                                           \
 	}
-#define X3_AC2_GROUP(Q0, Q1)                                                                                                    \
-	X3_AC2_SYM(Q0, 0, 0) X3_AC2_SYM(Q0, 1, 8) X3_AC2_SYM(Q0, 2, 16) X3_AC2_SYM(Q0, 3, 24)                                       \
-	X3_AC2_SYM(Q1, 0, 32) X3_AC2_SYM(Q1, 1, 40) X3_AC2_SYM(Q1, 2, 48) X3_AC2_SYM(Q1, 3, 56)
+#define X3_AC2_PAIR(Q, J, OFF)                                                                                                  \
+	{                                                                                                                           \
+		x3_u32x4 rr;                                                                                                            \
+		X3_AC2_SYM(Q, J, rr[0], rr[1])                                                                                          \
+		X3_AC2_SYM(Q, (J) + 1, rr[2], rr[3])                                                                                    \
+		asm volatile("s_store_dwordx4 %0, %1, %2" : : "s"(rr), "s"(recp), "n"(OFF) : "memory");                                \
+	}
+#define X3_AC2_GROUP(Q0, Q1, OFF)                                                                                               \
+	X3_AC2_PAIR(Q0, 0, (OFF)) X3_AC2_PAIR(Q0, 2, (OFF) + 16) X3_AC2_PAIR(Q1, 0, (OFF) + 32) X3_AC2_PAIR(Q1, 2, (OFF) + 48)
 /* wait for everything in flight (the group about to be used included), then start the loads of the group after it */
-#define X3_AC2_FETCH(N0, N1, C0, C1, PTR)                                                                                       \
-	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40"                           \
-	             : "=&s"(N0), "=&s"(N1), "+s"(C0), "+s"(C1) : "s"(PTR) : "memory")
+#define X3_AC2_FETCH(N0, N1, C0, C1, OFF)                                                                                       \
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_load_dwordx16 %0, %4, %5\n\ts_load_dwordx16 %1, %4, %5+0x40"                         \
+	             : "=&s"(N0), "=&s"(N1), "+s"(C0), "+s"(C1) : "s"(symp), "n"(OFF) : "memory")
 
 __device__ static void x3_ac2_body(const X3Ac2Args &a)
 {
 	const uint32_t c = blockIdx.x, lane = x3_lane();
 	const uint32_t y0 = x3_uniform(a.yo[c]), Y = x3_uniform(a.yo[c + 1]) - y0;
 	uint32_t lo = 0, R = 0x80000000u; /* ac_init, ac.c:35-41: [0, 0x7FFFFFFF] */
-	const uint64_t symp = (uint64_t)(a.sym + y0);
+	uint64_t symp = (uint64_t)(a.sym + y0);
 	uint64_t recp = (uint64_t)((uint2 *)a.rec_nk + y0);
 	const uint32_t G = Y >> 3; /* whole groups of 8 symbols */
-	const uint32_t lastoff = (G ? G - 1 : 0) * 128u;
 	if (G) {
 		x3_u32x16 A0, A1, B0, B1;
 		uint32_t dummy = 0; /* destination of the L2-warming loads: kept live to the end so its register is never reused under a load in flight */
+		const uint64_t pfmax = symp + (uint64_t)Y * 16u;
 		asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(A0), "=&s"(A1) : "s"(symp) : "memory");
-		for (uint32_t g = 0; g < G; g += 2) {
-			if ((g & 63u) == 0) { /* every 512 symbols: pull the operand lines of symbols [g*8+512, g*8+1024) towards L2 (result unused) */
-				uint64_t pf = symp + (uint64_t)(g + 64) * 128u + lane * 128u;
-				const uint64_t pfmax = symp + (uint64_t)lastoff;
+		uint32_t g = 0;
+		for (; g + 4 <= G; g += 4) { /* 32 symbols per trip */
+			if ((g & 63u) == 0) { /* every 512 symbols: pull the operand lines of symbols [+512, +1024) towards L2 (result unused) */
+				uint64_t pf = symp + 64u * 128u + lane * 128u;
 				pf = pf < pfmax ? pf : pfmax;
 				asm volatile("s_waitcnt vmcnt(0)\n\tglobal_load_dword %0, %1, off" : "+v"(dummy) : "v"(pf) : "memory");
 			}
-			{
-				const uint32_t o = (g + 1) * 128u;
-				X3_AC2_FETCH(B0, B1, A0, A1, symp + (o < lastoff ? o : lastoff));
-			}
-			X3_AC2_GROUP(A0, A1)
-			recp += 64;
-			if (g + 1 >= G) break;
-			{
-				const uint32_t o = (g + 2) * 128u;
-				X3_AC2_FETCH(A0, A1, B0, B1, symp + (o < lastoff ? o : lastoff));
-			}
-			X3_AC2_GROUP(B0, B1)
+			X3_AC2_FETCH(B0, B1, A0, A1, 128);
+			X3_AC2_GROUP(A0, A1, 0)
+			X3_AC2_FETCH(A0, A1, B0, B1, 256);
+			X3_AC2_GROUP(B0, B1, 64)
+			X3_AC2_FETCH(B0, B1, A0, A1, 384);
+			X3_AC2_GROUP(A0, A1, 128)
+			X3_AC2_FETCH(A0, A1, B0, B1, 512);
+			X3_AC2_GROUP(B0, B1, 192)
+			symp += 512;
+			recp += 256;
+		}
+		for (; g < G; g++) { /* < 4 leftover groups; A holds the current one */
+			X3_AC2_FETCH(B0, B1, A0, A1, 128);
+			X3_AC2_GROUP(A0, A1, 0)
+			asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(B0), "+s"(B1) : : "memory"); /* landed: only now may the registers be copied */
+			A0 = B0; A1 = B1;
+			symp += 128;
 			recp += 64;
 		}
-		asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : : "v"(dummy) : "memory"); /* the last (clamped) prefetches */
+		asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : : "v"(dummy) : "memory"); /* the last prefetches */
 	}
 	for (uint32_t y = G << 3; y < Y; y++) { /* < 8 leftover symbols */
 		x3_u32x4 Q;
-		asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(Q) : "s"(symp + (uint64_t)y * 16u) : "memory");
-		X3_AC2_SYM(Q, 0, 0)
+		uint32_t nlo, nhi;
+		asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(Q) : "s"(symp) : "memory");
+		X3_AC2_SYM(Q, 0, nlo, nhi)
+		const uint64_t rec = ((uint64_t)nhi << 32) | nlo;
+		asm volatile("s_store_dwordx2 %0, %1, 0x0" : : "s"(rec), "s"(recp) : "memory");
+		symp += 16;
 		recp += 8;
 	}
 	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" : : : "memory"); /* records: scalar cache -> L2 */
-	if (lane == 0) a.final_lo[c] = lo;
+	if (lane == 0) a.final_lo[c] = lo & 0x3FFFFFFFu;
 }
 #else
 /* functional restatement of the same formulas for the CPU emulator build (tests only) */
@@ -362,10 +382,10 @@ __device__ static void x3_ac2_body(const X3Ac2Args &a)
 		const uint32_t cz = (uint32_t)x3_clz32(D), t = 31u - cz;
 		const uint32_t sh = cz - 1 - ((((nlo ^ nhi) >> t) & 1u) ^ 1u);
 		if (lane == 0) { a.rec_nk[2 * (size_t)(y0 + y)] = nlo; a.rec_nk[2 * (size_t)(y0 + y) + 1] = nhi; }
-		lo = (nlo << sh) & 0x3FFFFFFFu;
+		lo = nlo << sh; /* not reduced mod 2^30, like the device chain: x3_rec_fix removes the stray bits from the records */
 		R = sf << sh;
 	}
-	if (lane == 0) a.final_lo[c] = lo;
+	if (lane == 0) a.final_lo[c] = lo & 0x3FFFFFFFu;
 }
 #endif
 
@@ -390,6 +410,15 @@ __device__ static __forceinline__ uint32_t x3_rec_k(uint32_t nlo, uint32_t nhi)
 	const uint32_t n = x3_rec_n(nlo, nhi);
 	const uint32_t y = ((((nhi | ~nlo) << n) | ~(0xFFFFFFFFu << n)) & 0x3FFFFFFFu);
 	return (uint32_t)x3_clz32(y) - 2;
+}
+
+/* The chain keeps lo unreduced, so a record (nlo, nhi) carries the two stray top bits of the state it started from:
+ * lo_before = (previous nlo) << (previous shift) as the chain computed it; its bits 30..31 are what has to come off both words. */
+__device__ static __forceinline__ uint32_t x3_rec_stray(uint32_t pl, uint32_t ph)
+{
+	const uint32_t D = ph - pl, cz = (uint32_t)x3_clz32(D), t = 31u - cz;
+	const uint32_t sh = cz - 1 - ((((pl ^ ph) >> t) & 1u) ^ 1u);
+	return (pl << sh) & 0xC0000000u;
 }
 
 /* OR `nbits` (<= 32) bits of `val` into the little-endian 32-bit word stream at bit position `bitpos` (bio.c:49-72 layout) */
@@ -787,7 +816,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 
 	/* ---- the coded symbols, in coding order: symbol index of step k = 2k + (new-fragment bytes before k) ---- */
 	uint32_t *Yv[12];
-	for (int i = 0; i < 12; i++) { CHK(B.y[i].reserve((nY + 4) * (i == 0 ? 16 : i == 3 ? 8 : 4))); Yv[i] = B.y[i].as<uint32_t>(); }
+	for (int i = 0; i < 12; i++) { CHK(B.y[i].reserve((nY + (i == 0 ? X3_SYM_PAD : 4)) * (i == 0 ? 16 : i == 3 ? 8 : 4))); Yv[i] = B.y[i].as<uint32_t>(); }
 	uint4 *sy = (uint4 *)Yv[0]; /* {cum, freq, magic, shift} per symbol */
 	uint32_t *rec_nk = Yv[3]; /* 2 words per symbol */
 	x3_foreach(nS, st, X3_LAMBDA(size_t gs) {
@@ -831,6 +860,16 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	 * pending after symbol i  = sum of k over (last symbol that shifted out bits (n>=1) or stream start .. i]
 	 * bits written by symbol i = n + pending before it (when n >= 1): first bit, the pending bits inverted, the other n-1 bits */
 	uint32_t *kk = Yv[5], *rv = Yv[6], *Kex = Yv[7], *LE = Yv[8], *len = Yv[9], *pos = Yv[10], *pend = Yv[11];
+	uint32_t *rec_fx = Yv[0]; /* the operand array is dead now: the records with the stray bits removed go there */
+	{
+		const uint32_t *rg = rec_nk;
+		x3_foreach(nY, st, X3_LAMBDA(size_t i) {
+			const uint32_t c = find_chunk(d_yo, nc, (uint32_t)i);
+			const uint32_t g2 = i == d_yo[c] ? 0u : x3_rec_stray(rg[2 * i - 2], rg[2 * i - 1]);
+			rec_fx[2 * i] = rg[2 * i] - g2; rec_fx[2 * i + 1] = rg[2 * i + 1] - g2;
+		});
+		rec_nk = rec_fx;
+	}
 	x3_foreach(nY, st, X3_LAMBDA(size_t i) {
 		const uint32_t rl = rec_nk[2 * i], rh = rec_nk[2 * i + 1];
 		const uint32_t c = find_chunk(d_yo, nc, (uint32_t)i);
