@@ -64,6 +64,8 @@ typedef struct x3h_stats {
 	double   ms_coder;      /* K3: x3_ac2_kernel (arithmetic-coder interval recurrence, ac.c:46-85)      */
 	double   ms_emit;       /* K3: symbol assembly + bit emission                                        */
 	uint64_t coded_symbols; /* arithmetic-coder symbols (ac_encode calls) of the batch                   */
+	int64_t  mode_iters;    /* K3: fixed-point iterations of the mode choice (0: the serial kernel decided;  */
+	                        /*     < 0: no fixed point within the cap, the serial kernel ran after all)       */
 } x3h_stats;
 
 typedef struct x3h_ctx x3h_ctx; /* one per GPU: device, stream, growable workspace */

@@ -343,6 +343,7 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 			(void)hipEventElapsedTime(&ms, c->c2.ev[3], c->c2.ev[4]); stats->ms_coder = ms;
 			stats->ms_emit = stats->ms_code - stats->ms_features - stats->ms_modes - stats->ms_coder;
 			stats->coded_symbols = c->c2.last.symbols;
+			stats->mode_iters = c->c2.last.mode_iters;
 		}
 	}
 	return rc;
@@ -373,7 +374,7 @@ static int run(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage upto
 			for (int e = 0; e < 5; e++) acc.events[e] += part.events[e];
 			acc.dict_elems += part.dict_elems; acc.ctx0_entries += part.ctx0_entries; acc.steps += part.steps; acc.coded_symbols += part.coded_symbols;
 			acc.ms_total += part.ms_total; acc.ms_scan += part.ms_scan; acc.ms_parse += part.ms_parse; acc.ms_code += part.ms_code; acc.ms_copy += part.ms_copy;
-			acc.ms_features += part.ms_features; acc.ms_modes += part.ms_modes; acc.ms_coder += part.ms_coder; acc.ms_emit += part.ms_emit;
+			acc.ms_features += part.ms_features; acc.ms_modes += part.ms_modes; acc.ms_coder += part.ms_coder; acc.ms_emit += part.ms_emit; acc.mode_iters += part.mode_iters;
 		}
 		first = last;
 	}

@@ -498,6 +498,86 @@ static int ctx_stats(X3Code2Bufs &B, hipStream_t st, size_t nH, int gbits, int t
 }
 
 /* ============================================================================================================
+ * the mode choice as a FIXED-POINT ITERATION (alternative to serial pass 1 when a batch has few, long streams).
+ * mode_i = F_i(mode_0 .. mode_{i-1}): the decision of x3.c:152-172 at hit i reads model_events (three counters = counts of the
+ * earlier modes) and model_index1 (freq of the hit's rank = 1 + earlier IDX1-coded hits with that rank; total = elements + earlier
+ * IDX1 hits).  Given ANY candidate sequence M, all those counters are prefix sums over M, and F(M) is evaluated for every hit at
+ * once with the reference's exact float expression.  F is causal, so if M is right on [0, k) then F(M) is right on [0, k]; the
+ * reference's sequence is the only fixed point, and M == F(M) proves M is it.  Decisions are insensitive to small counter errors,
+ * so the correct prefix grows by large jumps: a handful of chip-wide iterations replace a 5.7 M-step serial chain.
+ * Not converged within max_iter (adversarial input): the caller runs the serial kernel instead.
+ * T: 17 temporaries of nH+1 words. */
+static int modes_fixed_point(X3Code2Bufs &B, hipStream_t st, size_t nH, uint32_t nc, const uint32_t *d_ho, int rbits,
+                             const uint32_t *f0, const uint32_t *t0, const uint32_t *f1, const uint32_t *t1, const uint32_t *h_rank,
+                             const uint32_t *h_dk, const uint32_t *h_step, uint32_t *mode, uint32_t *const *T, int max_iter,
+                             int *iters, bool *converged)
+{
+	uint32_t *iota = T[0], *ks = T[1], *Rv = T[2], *hf = T[3], *segstart = T[4], *inv = T[5], *segI = T[6], *q0b = T[7], *q1b = T[8];
+	uint32_t *lo_ = T[9], *z0 = T[10], *z1 = T[11], *ziS = T[12], *c0s = T[13], *c1s = T[14], *ciS = T[15], *Mn = T[16];
+	uint32_t *d_flag = B.maxred.as<uint32_t>() + 4;
+	*converged = false;
+	*iters = 0;
+	/* hits ordered by (rank, stream, time): a run = the hits that share one model_index1 symbol */
+	x3_foreach(nH, st, X3_LAMBDA(size_t i) { iota[i] = (uint32_t)i; });
+	CHK(x3p_sort_pairs(B.tmp, h_rank, ks, iota, Rv, nH, rbits, st));
+	x3_foreach(nH, st, X3_LAMBDA(size_t j) {
+		const bool head = j == 0 || ks[j - 1] != ks[j] || find_chunk(d_ho, nc, Rv[j - 1]) != find_chunk(d_ho, nc, Rv[j]);
+		hf[j] = head ? (uint32_t)j : 0u;
+	});
+	CHK(x3p_incl_max_scan(B.tmp, hf, segstart, nH, st));
+	x3_foreach(nH, st, X3_LAMBDA(size_t j) { inv[Rv[j]] = (uint32_t)j; segI[Rv[j]] = segstart[j]; });
+	/* per-hit constants + the starting guess (the better context, if the tag is in one) */
+	uint32_t *M = mode;
+	x3_foreach(nH, st, X3_LAMBDA(size_t i) {
+		const uint32_t vf0 = f0[i], vf1 = f1[i];
+		const float q0 = vf0 ? (float)vf0 / (float)t0[i] : 0.f, q1 = vf1 ? (float)vf1 / (float)t1[i] : 0.f;
+		q0b[i] = __float_as_uint(q0); q1b[i] = __float_as_uint(q1);
+		lo_[i] = d_ho[find_chunk(d_ho, nc, (uint32_t)i)];
+		const uint32_t m = (vf1 && q1 >= q0) ? X3_E_CTX1 : vf0 ? X3_E_CTX0 : X3_E_IDX1;
+		M[i] = m;
+		z0[i] = m == X3_E_CTX0; z1[i] = m == X3_E_CTX1; ziS[inv[i]] = m == X3_E_IDX1;
+	});
+	for (int it = 0; it < max_iter; it++) {
+		CHK(x3p_excl_scan(B.tmp, z0, c0s, nH, st));
+		CHK(x3p_excl_scan(B.tmp, z1, c1s, nH, st));
+		CHK(x3p_excl_scan(B.tmp, ziS, ciS, nH, st));
+		HIPCHK(hipMemsetAsync(d_flag, 0, 4, st));
+		{
+			const uint32_t *Mc = M;
+			uint32_t *Mo = Mn;
+			x3_foreach(nH, st, X3_LAMBDA(size_t i) {
+				const uint32_t lo = lo_[i], hb = (uint32_t)i - lo;
+				const uint32_t n0 = c0s[i] - c0s[lo], n1 = c1s[i] - c1s[lo], n2 = hb - n0 - n1; /* earlier CTX0 / CTX1 / IDX1 hits of the stream */
+				const uint32_t e0 = 1024u + n0, e1 = 1024u + n1, e2 = 1u + n2;              /* model_events freqs, x3.c:239-241 + inc_model per hit */
+				const uint32_t tot = 2051u + h_step[i], itot = h_dk[i] + n2;
+				const uint32_t rf = 1u + ciS[inv[i]] - ciS[segI[i]];
+				const float ftot = (float)tot;
+				const uint32_t p0 = __float_as_uint(((float)e0 / ftot) * __uint_as_float(q0b[i]));
+				const uint32_t p1 = __float_as_uint(((float)e1 / ftot) * __uint_as_float(q1b[i]));
+				const uint32_t pi = __float_as_uint(((float)e2 / ftot) * ((float)rf / (float)itot));
+				uint32_t md = X3_E_IDX1, best = pi; /* x3.c:162-172 (floats >= +0 compare like their bit patterns) */
+				if (p0 > best) { md = X3_E_CTX0; best = p0; }
+				if (p1 > best) md = X3_E_CTX1;
+				if (md != Mc[i]) *d_flag = 1u;
+				Mo[i] = md;
+				z0[i] = md == X3_E_CTX0; z1[i] = md == X3_E_CTX1; ziS[inv[i]] = md == X3_E_IDX1;
+			});
+		}
+		{ uint32_t *t = M; M = Mn; Mn = t; }
+		uint32_t changed = 1;
+		HIPCHK(hipMemcpyAsync(&changed, d_flag, 4, hipMemcpyDeviceToHost, st));
+		HIPCHK(hipStreamSynchronize(st));
+		*iters = it + 1;
+		if (!changed) { *converged = true; break; }
+	}
+	if (*converged && M != mode) {
+		const uint32_t *Mc = M;
+		x3_foreach(nH, st, X3_LAMBDA(size_t i) { mode[i] = Mc[i]; });
+	}
+	return X3H_OK;
+}
+
+/* ============================================================================================================
  * K2 post-pass: the parse walker only emits one word per step (tag or fragment length); positions and the running
  * counts the coding stage indexes with are prefix sums over that list.
  *   tok_pos = sum of earlier step lengths (dict_len of the tag / fragment length)      (x3.c:394,422: p += len)
@@ -703,12 +783,26 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	x3_foreach(nD + 1, st, X3_LAMBDA(size_t i) { idxf[i] = 1; });
 	HIPCHK(hipEventRecord(B.ev[1], st));
 	if (nH > 0) {
-		X3ModesArgs ma;
-		ma.parsed = d_parsed; ma.ho = d_ho; ma.dof = d_dof;
-		ma.f0 = f0; ma.t0 = t0; ma.f1 = f1; ma.t1 = t1; ma.rank = h_rank; ma.dk = h_dk; ma.step = h_step;
-		ma.idxfreq = idxf; ma.mode = mode;
-		launch_modes(ma, nc, st);
-		HIPCHK(hipGetLastError());
+		uint64_t maxH = 0, maxDk = 1;
+		for (uint32_t c = 0; c < nc; c++) { if (h_parsed[c].hits > maxH) maxH = h_parsed[c].hits; if (h_parsed[c].dict_elems > maxDk) maxDk = h_parsed[c].dict_elems; }
+		/* the serial kernel costs ~11.5 ns per hit of the longest stream (streams run side by side); an iteration of the fixed-point
+		 * form streams ~60 B per hit of the whole batch and a dozen of them are typical: pick the cheaper (X3H_MODES=serial|fixed overrides) */
+		bool fixed = (double)maxH * 11.5e-9 > 2.0 * (double)nH * 0.45e-9 + 1e-3, done = false;
+		if (const char *e = getenv("X3H_MODES")) fixed = e[0] == 'f';
+		B.last.mode_iters = 0;
+		if (fixed) {
+			int iters = 0;
+			CHK(modes_fixed_point(B, st, nH, nc, d_ho, bits_for(maxDk), f0, t0, f1, t1, h_rank, h_dk, h_step, mode, T, 256, &iters, &done));
+			B.last.mode_iters = done ? iters : -iters;
+		}
+		if (!done) {
+			X3ModesArgs ma;
+			ma.parsed = d_parsed; ma.ho = d_ho; ma.dof = d_dof;
+			ma.f0 = f0; ma.t0 = t0; ma.f1 = f1; ma.t1 = t1; ma.rank = h_rank; ma.dk = h_dk; ma.step = h_step;
+			ma.idxfreq = idxf; ma.mode = mode;
+			launch_modes(ma, nc, st);
+			HIPCHK(hipGetLastError());
+		}
 		HIPCHK(hipEventRecord(B.ev[2], st));
 
 		/* ---- model_events / model_index1 state at every hit, recovered from the modes by prefix sums ---- */

@@ -23,6 +23,16 @@ int x3p_sort_pairs(DevBuf &tmp, const uint32_t *kin, uint32_t *kout, const uint3
 	return X3H_OK;
 }
 
+int x3p_sort_pairs_bits(DevBuf &tmp, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, int begin_bit, int end_bit, hipStream_t st)
+{
+	if (!n) return X3H_OK;
+	size_t need = 0;
+	HIPCHK(rocprim::radix_sort_pairs(nullptr, need, kin, kout, vin, vout, n, (unsigned)begin_bit, (unsigned)end_bit, st));
+	CHK(tmp.reserve(need));
+	HIPCHK(rocprim::radix_sort_pairs(tmp.p, need, kin, kout, vin, vout, n, (unsigned)begin_bit, (unsigned)end_bit, st));
+	return X3H_OK;
+}
+
 int x3p_excl_scan(DevBuf &tmp, const uint32_t *in, uint32_t *out, size_t n, hipStream_t st)
 {
 	size_t need = 0;
@@ -52,6 +62,18 @@ int x3p_sort_pairs(DevBuf &, const uint32_t *kin, uint32_t *kout, const uint32_t
 	std::vector<size_t> idx(n);
 	for (size_t i = 0; i < n; i++) idx[i] = i;
 	std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return (kin[x] & mask) < (kin[y] & mask); });
+	std::vector<uint32_t> k(n), v(n);
+	for (size_t i = 0; i < n; i++) { k[i] = kin[idx[i]]; v[i] = vin[idx[i]]; }
+	for (size_t i = 0; i < n; i++) { kout[i] = k[i]; vout[i] = v[i]; }
+	return X3H_OK;
+}
+
+int x3p_sort_pairs_bits(DevBuf &, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, int begin_bit, int end_bit, hipStream_t)
+{
+	const uint32_t mask = (end_bit - begin_bit) >= 32 ? 0xFFFFFFFFu : ((1u << (end_bit - begin_bit)) - 1);
+	std::vector<size_t> idx(n);
+	for (size_t i = 0; i < n; i++) idx[i] = i;
+	std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return ((kin[x] >> begin_bit) & mask) < ((kin[y] >> begin_bit) & mask); });
 	std::vector<uint32_t> k(n), v(n);
 	for (size_t i = 0; i < n; i++) { k[i] = kin[idx[i]]; v[i] = vin[idx[i]]; }
 	for (size_t i = 0; i < n; i++) { kout[i] = k[i]; vout[i] = v[i]; }

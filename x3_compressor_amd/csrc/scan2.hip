@@ -6,7 +6,9 @@
  * where count_i(p) = #{ s in [p+1, p+W-33] : bytes p..p+i equal bytes s..s+i } (backend.c:62-74).
  * count_i(p) >= K  <=>  the K-th NEXT OCCURRENCE of the (i+1)-gram at p lies inside the window.  So:
  *   1. sort all positions of the (zero padded) batch by their 1-, 2-, 3- and 4-gram with a stable radix sort: inside a class
- *      the positions are ascending;
+ *      the positions are ascending.  The four orders are the four successive 8-bit passes of ONE LSD radix sort: element q
+ *      carries the key byte[q] | byte[q-1] << 8 | byte[q-2] << 16 | byte[q-3] << 24; after pass l the list is ordered by the low
+ *      l key bytes, i.e. by the l-gram that STARTS at p = q-(l-1), with q (hence p) ascending inside a class;
  *   2. levels i = 0..3 are O(1): entry j of list l is position p; look at entry j+K -- same gram and still <= p+W-33 ?
  *      (count_0 itself is only needed when it is <= T: a binary search over at most T+1 list entries);
  *   3. only positions whose 4-gram already repeats K times in their window ("active") go deeper: one wavefront per active
@@ -34,7 +36,7 @@ __device__ static __forceinline__ uint32_t load_gram(const uint8_t *b, uint64_t 
 
 struct X3WalkArgs {
 	const uint8_t *bytes;
-	const uint32_t *S4;          /* positions sorted by 4-gram */
+	const uint32_t *S4;          /* list 4: element q stands for position q - 3 */
 	const uint32_t *active_j;    /* index of each active position in S4 */
 	const uint32_t *active;      /* positions to walk */
 	const uint32_t *active_k;    /* their K */
@@ -65,7 +67,7 @@ __device__ static void x3_walk_body(const X3WalkArgs &a)
 	uint32_t done = 0;
 	for (uint32_t base = a.active_j[idx] + 1; base < a.total && !done; base += X3_WAVE) {
 		const uint32_t j = base + lane;
-		uint32_t s = j < a.total ? a.S4[j] : NONE32;
+		uint32_t s = j < a.total ? a.S4[j] - 3u : NONE32; /* q < 3 wraps to a huge value: fails the window test like any out-of-class entry */
 		uint32_t lcp = 0;
 		bool inwin = false;
 		if (s != NONE32 && s <= wend) {
@@ -136,7 +138,7 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 	}
 	for (int i = 0; i < 8; i++) CHK(B.a[i].reserve((P + 8) * 4));
 	CHK(B.misc.reserve(64));
-	uint32_t *keys = B.a[0].as<uint32_t>(), *iota = B.a[1].as<uint32_t>(), *ks = B.a[2].as<uint32_t>(), *S = B.a[3].as<uint32_t>();
+	uint32_t *keys = B.a[0].as<uint32_t>(), *iota = B.a[1].as<uint32_t>();
 	uint32_t *state = B.a[4].as<uint32_t>(); /* per position: K in bits 0..23 (K <= count_0 <= W-33 < 2^24), m in bits 24..28 */
 	uint32_t *act = B.a[5].as<uint32_t>(), *act_k = B.a[6].as<uint32_t>(), *act_j = B.a[7].as<uint32_t>();
 	uint32_t *d_nact = B.misc.as<uint32_t>();
@@ -145,25 +147,34 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 	/* K = min(T+1, count_0) and count_0 <= ncand: any T >= ncand behaves like T = ncand */
 	const uint32_t Tu = (uint32_t)T > ncand ? ncand : (uint32_t)T, Pn = (uint32_t)P;
 
-	x3_foreach(P, st, X3_LAMBDA(size_t q) { iota[q] = (uint32_t)q; });
+	/* element q: key = the four bytes ENDING at q (bytes before the buffer read as 0), value = q */
+	x3_foreach(P, st, X3_LAMBDA(size_t q) {
+		iota[q] = (uint32_t)q;
+		keys[q] = q >= 3 ? __builtin_bswap32(load_gram(d_bytes, q - 3, 4)) : __builtin_bswap32(load_gram(d_bytes, 0, 4) << (8 * (3 - (uint32_t)q)));
+	});
+	uint32_t *kin = keys, *vin = iota, *ks = B.a[2].as<uint32_t>(), *S = B.a[3].as<uint32_t>();
 	for (uint32_t l = 1; l <= 4; l++) {
-		/* positions sorted by l-gram (stable: ascending positions inside a class) */
-		x3_foreach(P, st, X3_LAMBDA(size_t q) { keys[q] = load_gram(d_bytes, q, l); });
-		CHK(x3p_sort_pairs(tmp, keys, ks, iota, S, P, 8 * (int)l, st));
+		/* pass l of the LSD sort: the list is now ordered by the l-gram starting at p = q-(l-1) (stable: ascending positions inside a class) */
+		/* (rocPRIM 4.2's small-input merge path builds its digit mask with 1 << end_bit, which is wrong for end_bit == 32: below its
+		 * switch-over the last pass is a full-key stable sort of the pass-3 list instead -- the same order, and the cost does not matter there) */
+		if (l == 4 && P <= ((size_t)8 << 20)) CHK(x3p_sort_pairs(tmp, kin, ks, vin, S, P, 32, st));
+		else CHK(x3p_sort_pairs_bits(tmp, kin, ks, vin, S, P, 8 * ((int)l - 1), 8 * (int)l, st));
+		const uint32_t msk = l >= 4 ? 0xFFFFFFFFu : ((1u << (8 * l)) - 1), back = l - 1;
+		const uint32_t *ksc = ks, *Sc = S;
 		if (l == 1) {
 			/* K = min(T+1, count_0): is the (T+1)-th next occurrence of the byte inside the window?  else count them (binary search) */
 			x3_foreach(P, st, X3_LAMBDA(size_t j) {
-				const uint32_t p = S[j], kj = ks[j];
+				const uint32_t p = Sc[j], kj = ksc[j] & msk;
 				const uint64_t wend = (uint64_t)p + ncand;
 				const uint64_t u = (uint64_t)j + Tu + 1;
 				uint32_t K;
-				if (u < Pn && ks[u] == kj && S[u] <= wend) K = Tu + 1;
+				if (u < Pn && (ksc[u] & msk) == kj && Sc[u] <= wend) K = Tu + 1;
 				else {
 					uint32_t a = 0, bnd = Tu; /* predicate true at a */
 					if ((uint64_t)j + bnd >= Pn) bnd = Pn - 1 - (uint32_t)j;
 					while (a < bnd) {
 						const uint32_t mid = (a + bnd + 1) >> 1;
-						if (ks[j + mid] == kj && S[j + mid] <= wend) a = mid; else bnd = mid - 1;
+						if ((ksc[j + mid] & msk) == kj && Sc[j + mid] <= wend) a = mid; else bnd = mid - 1;
 					}
 					K = a; /* == count_0 */
 				}
@@ -171,11 +182,13 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 			});
 		} else {
 			x3_foreach(P, st, X3_LAMBDA(size_t j) {
-				const uint32_t p = S[j];
+				const uint32_t q = Sc[j];
+				if (q < back) return; /* the l-gram would start before the buffer */
+				const uint32_t p = q - back;
 				const uint32_t sv = state[p], K = sv & 0xFFFFFFu, m = sv >> 24;
 				if (K < 2 || m != l - 2) return; /* count_0 < 2, or the previous level already failed */
 				const uint64_t u = (uint64_t)j + K;
-				if (u < Pn && ks[u] == ks[j] && S[u] <= (uint64_t)p + ncand) {
+				if (u < Pn && ((ksc[u] ^ ksc[j]) & msk) == 0 && (uint64_t)Sc[u] <= (uint64_t)q + ncand) { /* both sides carry the same +back */
 					state[p] = K | ((l - 1) << 24);
 					if (l == 4) { /* count_3 >= K: deeper levels need the candidates themselves -- unless p is padding (never read) */
 						uint32_t lo = 0, hi = nc;
@@ -187,7 +200,11 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 				}
 			});
 		}
+		uint32_t *t;
+		t = kin; kin = ks; ks = t;
+		t = vin; vin = S; S = t;
 	}
+	S = vin; /* list 4 (the last pass's output) */
 	x3_foreach(P, st, X3_LAMBDA(size_t q) { d_m[q] = (uint8_t)(state[q] >> 24); });
 
 	/* active positions: one wavefront each over the in-window candidates of its 4-gram class (S still holds list 4) */

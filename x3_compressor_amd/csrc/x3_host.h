@@ -63,6 +63,8 @@ template <class F> static inline void x3_foreach(size_t n, hipStream_t, F f) { f
 /* ---- library primitives (prims.hip) ---------------------------------------------------------------------- */
 /* stable LSD radix sort on key bits [0,bits) */
 int x3p_sort_pairs(DevBuf &tmp, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, int bits, hipStream_t st);
+/* one stable pass on key bits [begin_bit, end_bit) only */
+int x3p_sort_pairs_bits(DevBuf &tmp, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, int begin_bit, int end_bit, hipStream_t st);
 /* out[i] = sum in[0..i) for i in [0,n]; `in` must have n+1 readable entries (in[n] is ignored), out n+1 writable */
 int x3p_excl_scan(DevBuf &tmp, const uint32_t *in, uint32_t *out, size_t n, hipStream_t st);
 /* out[i] = max in[0..i] */
@@ -74,14 +76,14 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
                    const uint8_t *d_bytes, uint8_t *d_m, uint64_t total, uint32_t window, int32_t T);
 
 /* ---- v2 coding stage (code2.hip) ------------------------------------------------------------------------- */
-struct X3Code2Stats { double ms_features, ms_modes, ms_coder, ms_emit; uint64_t symbols; };
+struct X3Code2Stats { double ms_features, ms_modes, ms_coder, ms_emit; uint64_t symbols; int mode_iters; /* fixed-point iterations of the mode choice (0: serial kernel, < 0: not converged, serial kernel ran) */ };
 
 struct X3Code2Bufs {
 	DevBuf tmp, offs, chunkmeta;
 	DevBuf a[48]; /* u32 work arrays of max(hits, events)+4 entries */
 	DevBuf idxfreq, hsym, maxred;
 	hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
-	X3Code2Stats last = { 0, 0, 0, 0, 0 };
+	X3Code2Stats last = { 0, 0, 0, 0, 0, 0 };
 	DevBuf y[12]; /* u32 arrays over coded symbols */
 	DevBuf pp[4]; /* token post-pass temporaries */
 	DevBuf ms[16]; /* u32 arrays over new-fragment lengths / bytes */
