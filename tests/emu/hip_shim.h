@@ -28,5 +28,11 @@ static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; 
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new x3emu_event(); return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); e->t = t.tv_sec * 1e3 + t.tv_nsec * 1e-6; return hipSuccess; }
+static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+enum { hipHostMallocMapped = 2, hipHostMallocCoherent = 0x40000000 };
+static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { *d = h; return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
 #endif

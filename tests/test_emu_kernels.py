@@ -64,3 +64,46 @@ def test_emulated_decoder_errors(emu, golden):
     with pytest.raises(_lib.X3Error) as e:
         emu.decompress(b"\x12\x34\x56\x78" * 50, 1000)
     assert e.value.status == -4
+
+
+# ---- alternative schedules of the same computation: must not change a bit -------------------------------------------------------
+@pytest.fixture()
+def emu_env(monkeypatch):
+    """an emulator context created under the given environment (the library reads its switches at context creation / call time)"""
+    subprocess.run(["make", "-C", os.path.join(HERE, "emu")], check=True, capture_output=True)
+    made = []
+
+    def make(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = _lib.X3Context(0, library=EMU_SO)
+        made.append(ctx)
+        return ctx
+    yield make
+    for c in made:
+        c.close()
+
+
+PIPE_CASES = [
+    ("tiny", b"ab", dict()),
+    ("abra", b"abracadabra" * 30, dict(w_kib=1, t=2)),
+    ("english", synth.english_like(9000).tobytes(), dict(w_kib=2, t=8)),
+    ("zipf", synth.zipf_bytes(4000).tobytes(), dict(w_kib=1, t=2)),
+    ("zeros", bytes(3000), dict(w_kib=1, t=15)),
+]
+
+
+@pytest.mark.parametrize("name,data,kw", PIPE_CASES, ids=[c[0] for c in PIPE_CASES])
+def test_emulated_pipelined_single_stream(emu_env, oracle, name, data, kw):
+    """api.hip run_pipelined: the coding stage of growing prefixes (parse checkpoints at 2/8/26/62 %) + segment-wise coder."""
+    ctx = emu_env(X3H_PIPE_MIN="1")
+    assert ctx.compress(data, _lib.make_params(**kw)) == oracle.compress(data, oracle_lib.params(**kw))
+
+
+@pytest.mark.parametrize("pipe", ["0", "1"])
+def test_emulated_fixed_point_modes(emu_env, oracle, pipe):
+    """code2.hip modes_fixed_point (forced): the mode sequence as the fixed point of a chip-wide iteration."""
+    ctx = emu_env(X3H_MODES="fixed", X3H_PIPE_MIN=pipe)
+    data, kw = synth.english_like(20000).tobytes(), dict(w_kib=4, t=8)
+    assert ctx.compress(data, _lib.make_params(**kw)) == oracle.compress(data, oracle_lib.params(**kw))
+    assert ctx.last_stats.mode_iters > 0

@@ -256,3 +256,38 @@ def test_sub_batching_is_transparent(gpu, monkeypatch):
         assert small.last_stats.steps == gpu.last_stats.steps
     finally:
         small.close()
+
+
+# ---- alternative schedules of the same computation (single-stream pipelining, fixed-point mode choice) ------------------------
+@pytest.fixture()
+def gpu_env(monkeypatch):
+    made = []
+
+    def make(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = _lib.X3Context(0)
+        made.append(ctx)
+        return ctx
+    yield make
+    for c in made:
+        c.close()
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_pipelined_stream_equals_reference_golden(gpu_env, golden, name):
+    """every golden stream again with the pipelined schedule forced (X3H_PIPE_MIN=1: parse checkpoints, prefix-wise coding stage,
+    segment-wise coder on its own HIP stream) and the fixed-point mode choice forced"""
+    ctx = gpu_env(X3H_PIPE_MIN="1", X3H_MODES="fixed")
+    c = golden[name]
+    assert ctx.compress(c["data"], _lib.params_from_args(c["args"])) == c["expect"]
+
+
+@pytest.mark.parametrize("env", [dict(X3H_PIPE_MIN="0", X3H_MODES="serial"), dict(X3H_PIPE_MIN="0", X3H_MODES="fixed"),
+                                 dict(X3H_PIPE_MIN="1", X3H_MODES="serial")], ids=["classic-serial", "classic-fixed", "pipelined-serial"])
+def test_schedules_agree_on_a_long_stream(gpu, gpu_env, env):
+    """3 MiB of text, -w 64 -t 256: the default schedule (pipelined, cost-model choice of the mode pass) against the forced others"""
+    data = synth.english_like(3 << 20, seed=77).tobytes()
+    prm = _lib.make_params(w_kib=64, t=256)
+    want = gpu.compress(data, prm)
+    assert gpu_env(**env).compress(data, prm) == want

@@ -35,6 +35,13 @@ struct x3h_ctx {
 	X3Code2Bufs c2;
 	X3Scan2Bufs s2;
 	int code_v1 = 0, scan_v1 = 0;
+	/* single-stream pipelining (run_pipelined): the parse on its own stream publishes checkpoints, the coding stage of every prefix
+	 * runs while the parse continues, the coder recurrence of a segment on a third stream */
+	uint64_t pipe_min = (uint64_t)1 << 20; /* streams at least this long are pipelined (X3H_PIPE_MIN; 0: never) */
+	hipStream_t s_parse = nullptr, s_coder = nullptr;
+	hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr, ev_ready = nullptr, ev_cb[X3_MAX_CKPT + 1] = {}, ev_ce[X3_MAX_CKPT + 1] = {};
+	X3ParseCkpt *ckpt = nullptr; /* host-mapped */
+	DevBuf coder_state, prefix_result;
 	uint64_t batch_bytes = (uint64_t)1 << 30;
 	uint64_t pad_total = 0;
 	DevBuf mtf, idxfreq, ctx1, ctx0, items, pkey, pval, out, counts;
@@ -101,6 +108,7 @@ extern "C" int x3h_ctx_create(x3h_ctx **out, int device)
 	{ const char *e = getenv("X3H_CODE_V1"); c->code_v1 = e && *e && *e != '0'; }
 	{ const char *e = getenv("X3H_SCAN_V1"); c->scan_v1 = e && *e && *e != '0'; }
 	{ const char *e = getenv("X3H_BATCH_BYTES"); if (e && atoll(e) > 0) c->batch_bytes = (uint64_t)atoll(e); }
+	{ const char *e = getenv("X3H_PIPE_MIN"); if (e && *e) c->pipe_min = (uint64_t)atoll(e); }
 	if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return X3H_E_HIP; }
 	for (int i = 0; i < 6; i++)
 		if (hipEventCreate(&c->ev[i]) != hipSuccess) { x3h_ctx_destroy(c); return X3H_E_HIP; }
@@ -117,6 +125,13 @@ extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 		               &c->c2.tmp, &c->c2.offs, &c->c2.chunkmeta, &c->c2.idxfreq, &c->c2.hsym, &c->c2.maxred, &c->c2.pp[0], &c->c2.pp[1], &c->c2.pp[2], &c->c2.pp[3],
 		               &c->cresult, &c->mtf, &c->idxfreq, &c->ctx1, &c->ctx0, &c->items, &c->pkey, &c->pval, &c->out, &c->counts, &c->din, &c->dchunks };
 	for (DevBuf *b : bufs) b->release();
+	c->coder_state.release(); c->prefix_result.release();
+	if (c->ckpt) (void)hipHostFree((void *)c->ckpt);
+	if (c->s_parse) (void)hipStreamDestroy(c->s_parse);
+	if (c->s_coder) (void)hipStreamDestroy(c->s_coder);
+	hipEvent_t pev[] = { c->ev_p0, c->ev_p1, c->ev_ready };
+	for (hipEvent_t e : pev) if (e) (void)hipEventDestroy(e);
+	for (int i = 0; i <= X3_MAX_CKPT; i++) { if (c->ev_cb[i]) (void)hipEventDestroy(c->ev_cb[i]); if (c->ev_ce[i]) (void)hipEventDestroy(c->ev_ce[i]); }
 	for (int i = 0; i < 5; i++) if (c->c2.ev[i]) (void)hipEventDestroy(c->c2.ev[i]);
 	for (DevBuf &b : c->c2.a) b.release();
 	for (DevBuf &b : c->s2.a) b.release();
@@ -186,6 +201,118 @@ static int stage_inputs(x3h_ctx *c, const x3h_params *prm, const RunIO &io, uint
 	return X3H_OK;
 }
 
+/* ------------------------------------------------------------------------------------------------------------
+ * K2 + K3 of ONE long stream, pipelined.  The stages of a single stream are chains (parse: one workgroup; coder: one wavefront), but
+ * they are DIFFERENT chains: the parse never reads coder state (parse.hip), and everything between them is prefix-causal counting
+ * (code2.hip).  So the parse runs on its own HIP stream and publishes a checkpoint when it crosses 2 %, 8 %, 26 % and 62 % of the
+ * input; for every checkpoint the host runs the coding stage of that PREFIX (features and modes recomputed chip-wide, new symbols
+ * assembled) and queues the recurrence of the new symbols on a third stream.  The recurrence is ~3x slower per byte than the parse,
+ * so after the first 2 % it never waits: a step costs about scan + coder instead of scan + parse + features + modes + coder.
+ * Results are bit-identical by construction (same kernels, same order of symbols; only WHEN they run changes).
+ * ------------------------------------------------------------------------------------------------------------ */
+struct PipeStats { double ms_parse = 0, ms_features = 0, ms_modes = 0, ms_coder = 0; long long mode_iters = 0; };
+
+static int pipe_setup(x3h_ctx *c)
+{
+	if (c->s_parse) return X3H_OK;
+	HIPCHK(hipStreamCreate(&c->s_parse));
+	HIPCHK(hipStreamCreate(&c->s_coder));
+	HIPCHK(hipEventCreate(&c->ev_p0)); HIPCHK(hipEventCreate(&c->ev_p1)); HIPCHK(hipEventCreate(&c->ev_ready));
+	for (int i = 0; i <= X3_MAX_CKPT; i++) { HIPCHK(hipEventCreate(&c->ev_cb[i])); HIPCHK(hipEventCreate(&c->ev_ce[i])); }
+	HIPCHK(hipHostMalloc((void **)&c->ckpt, sizeof(X3ParseCkpt) * X3_MAX_CKPT, hipHostMallocMapped | hipHostMallocCoherent));
+	CHK(c->coder_state.reserve(64));
+	CHK(c->prefix_result.reserve(sizeof(X3ParseResult)));
+	return X3H_OK;
+}
+
+static int run_pipelined(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, uint32_t *tok_pos, uint32_t *tok_hb, uint32_t *tok_nb, uint32_t *tok_mb,
+                         uint8_t *d_out, PipeStats *ps)
+{
+	CHK(pipe_setup(c));
+	const uint32_t n = c->hchunks[0].len;
+	static const double marks[] = { 0.02, 0.08, 0.26, 0.62 };
+	pa.nckpt = 0;
+	for (double f : marks) { const uint32_t q = (uint32_t)((double)n * f); if (q > 0 && q < n && pa.nckpt < X3_MAX_CKPT) pa.ckpt_pos[pa.nckpt++] = q; }
+	memset((void *)c->ckpt, 0, sizeof(X3ParseCkpt) * X3_MAX_CKPT);
+	void *dck = nullptr;
+	HIPCHK(hipHostGetDevicePointer(&dck, (void *)c->ckpt, 0));
+	pa.ckpt = (X3ParseCkpt *)dck;
+	/* the parse starts behind the scan (main stream) and runs on its own stream from here on */
+	HIPCHK(hipEventRecord(c->ev_ready, c->stream));
+	HIPCHK(hipStreamWaitEvent(c->s_parse, c->ev_ready, 0));
+	HIPCHK(hipEventRecord(c->ev_p0, c->s_parse));
+	x3k_launch_parse(&pa, 1, c->s_parse);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(c->ev_p1, c->s_parse));
+	const uint32_t init_state[2] = { 0u, 0x80000000u }; /* ac_init, ac.c:35-41 */
+	HIPCHK(hipMemcpyAsync(c->coder_state.p, init_state, 8, hipMemcpyHostToDevice, c->stream));
+
+	X3CodeSeg seg;
+	memset(&seg, 0, sizeof(seg));
+	seg.coder_stream = c->s_coder; seg.ev_ready = c->ev_ready; seg.coder_state = c->coder_state.as<uint32_t>();
+	seg.res_bytes = n;
+	uint32_t next = 0;
+	int nseg = 0;
+	bool parse_done = false;
+	for (;;) {
+		X3ParseResult pr;
+		memset(&pr, 0, sizeof(pr));
+		bool have = false, final = false;
+		/* newest checkpoint not consumed yet (a long step may skip marks; the emulator's parse has finished by now, so the test build
+		 * takes them oldest first to walk through every segment) */
+#ifndef X3_EMU
+		for (uint32_t k = pa.nckpt; k-- > next;)
+#else
+		for (uint32_t k = next; k < pa.nckpt; k++)
+#endif
+			if (c->ckpt[k].seq == k + 1) {
+				pr.ntok = c->ckpt[k].ntok; pr.hits = c->ckpt[k].hits; pr.dict_elems = c->ckpt[k].dict_elems; pr.miss_bytes = c->ckpt[k].miss_bytes;
+				if (!seg.res_steps) { /* first look at the stream: size the workspace for all of it (x1.3; linear growth overestimates D) */
+					const double sc = 1.3 * (double)n / (double)(c->ckpt[k].p ? c->ckpt[k].p : 1);
+					seg.res_steps = (size_t)(pr.ntok * sc) + 4096; seg.res_hits = (size_t)(pr.hits * sc) + 4096;
+					seg.res_elems = (size_t)(pr.dict_elems * sc) + 4096; seg.res_mbytes = (size_t)(pr.miss_bytes * sc) + 4096;
+					if (seg.res_steps > (size_t)n + 16) seg.res_steps = (size_t)n + 16;
+					if (seg.res_hits > (size_t)n + 16) seg.res_hits = (size_t)n + 16;
+					if (seg.res_elems > (size_t)n + 16) seg.res_elems = (size_t)n + 16;
+					if (seg.res_mbytes > (size_t)n + 16) seg.res_mbytes = (size_t)n + 16;
+				}
+				next = k + 1; have = true;
+				break;
+			}
+		if (!have) {
+			if (!parse_done && hipEventQuery(c->ev_p1) == hipSuccess) parse_done = true;
+			if (!parse_done) continue; /* spin: the wait is a few ms at most and a checkpoint should be picked up at once */
+			/* the whole stream is parsed: final call with the kernel's own result */
+			HIPCHK(hipStreamSynchronize(c->s_parse));
+			c->hparse.resize(1);
+			HIPCHK(hipMemcpyAsync(c->hparse.data(), c->presult.p, sizeof(X3ParseResult), hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(hipStreamSynchronize(c->stream));
+			pr = c->hparse[0];
+			final = true;
+		}
+		seg.final = final;
+		seg.ev_coder_begin = c->ev_cb[nseg]; seg.ev_coder_end = c->ev_ce[nseg];
+		HIPCHK(hipMemcpyAsync(c->prefix_result.p, &pr, sizeof(pr), hipMemcpyHostToDevice, c->stream));
+		const X3ParseResult *d_pr = c->prefix_result.as<X3ParseResult>();
+		CHK(x3_token_postpass(c->c2, c->stream, 1, c->hchunks.data(), c->chunks.as<X3Chunk>(), d_pr, pa.tok_info, pa.dict_len,
+		                      tok_pos, tok_hb, tok_nb, tok_mb, pr.ntok ? pr.ntok : 1));
+		CHK(x3_code_v2_run(c->c2, c->stream, 1, c->hchunks.data(), c->chunks.as<X3Chunk>(), &pr, d_pr, d_bytes, tok_pos, pa.tok_info,
+		                   tok_hb, tok_nb, tok_mb, d_out, c->cresult.as<X3CodeResult>(), &seg));
+		nseg++;
+		HIPCHK(hipStreamSynchronize(c->stream)); /* this stream only: the coder and the parse keep running */
+		float ms = 0;
+		(void)hipEventElapsedTime(&ms, c->c2.ev[0], c->c2.ev[1]); ps->ms_features += ms;
+		(void)hipEventElapsedTime(&ms, c->c2.ev[1], c->c2.ev[2]); ps->ms_modes += ms;
+		ps->mode_iters += c->c2.last.mode_iters;
+		if (final) break;
+	}
+	HIPCHK(hipStreamSynchronize(c->s_coder));
+	float ms = 0;
+	(void)hipEventElapsedTime(&ms, c->ev_p0, c->ev_p1); ps->ms_parse = ms;
+	for (int i = 0; i < nseg; i++) { (void)hipEventElapsedTime(&ms, c->ev_cb[i], c->ev_ce[i]); ps->ms_coder += ms; }
+	return X3H_OK;
+}
+
 static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage upto, x3h_stats *stats)
 {
 	if (!c || !io.offsets || io.nchunks <= 0 || (!io.src && io.offsets[io.nchunks] != io.offsets[0])) return X3H_E_ARG;
@@ -225,7 +352,9 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 	if (upto == STAGE_SCAN) { HIPCHK(hipStreamSynchronize(c->stream)); return X3H_OK; }
 
 	/* ---- K2 ---- */
+	const bool pipe = upto == STAGE_CODE && !c->code_v1 && nc == 1 && c->pipe_min && c->hchunks[0].len >= c->pipe_min;
 	X3ParseArgs pa;
+	pa.ckpt = nullptr; pa.nckpt = 0;
 	pa.bytes = sa.bytes; pa.chunks = sa.chunks; pa.m = sa.m;
 	pa.dict_pos = c->dict_pos.as<uint32_t>(); pa.dict_len = c->dict_len.as<uint8_t>();
 	pa.ht = c->ht.as<uint32_t>();
@@ -233,17 +362,22 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 	uint32_t *tok_pos = c->tok_pos.as<uint32_t>(), *tok_hb = c->tok_hb.as<uint32_t>(), *tok_nb = c->tok_nb.as<uint32_t>(), *tok_mb = c->tok_mb.as<uint32_t>();
 	pa.result = c->presult.as<X3ParseResult>();
 	pa.factor1 = prm.factor1; pa.factor2 = prm.factor2; pa.nl_mode = prm.nl_mode;
-	x3k_launch_parse(&pa, (uint32_t)nc, c->stream);
-	HIPCHK(hipGetLastError());
-	CHK(x3_token_postpass(c->c2, c->stream, nc, c->hchunks.data(), c->chunks.as<X3Chunk>(), pa.result, pa.tok_info, pa.dict_len,
-	                      tok_pos, tok_hb, tok_nb, tok_mb));
-	HIPCHK(hipEventRecord(c->ev[3], c->stream));
-	c->hparse.resize((size_t)nc);
-	HIPCHK(hipMemcpyAsync(c->hparse.data(), c->presult.p, (size_t)nc * sizeof(X3ParseResult), hipMemcpyDeviceToHost, c->stream));
-	HIPCHK(hipStreamSynchronize(c->stream));
-	if (getenv("X3H_DEBUG")) for (int i = 0; i < nc && i < 4; i++) { const X3ParseResult &r = c->hparse[(size_t)i];
-		fprintf(stderr, "[x3h] chunk %d: steps %u hits %u D %u missbytes %u | parse kcycles: fill %u patch %u table %u walk %u\n", i, r.ntok, r.hits, r.dict_elems, r.miss_bytes, r.kcyc_fill, r.kcyc_patch, r._r0, r.kcyc_walk); }
-	if (upto == STAGE_PARSE) return X3H_OK;
+	if (!pipe) {
+		x3k_launch_parse(&pa, (uint32_t)nc, c->stream);
+		HIPCHK(hipGetLastError());
+		CHK(x3_token_postpass(c->c2, c->stream, nc, c->hchunks.data(), c->chunks.as<X3Chunk>(), pa.result, pa.tok_info, pa.dict_len,
+		                      tok_pos, tok_hb, tok_nb, tok_mb));
+		HIPCHK(hipEventRecord(c->ev[3], c->stream));
+		c->hparse.resize((size_t)nc);
+		HIPCHK(hipMemcpyAsync(c->hparse.data(), c->presult.p, (size_t)nc * sizeof(X3ParseResult), hipMemcpyDeviceToHost, c->stream));
+		HIPCHK(hipStreamSynchronize(c->stream));
+		if (getenv("X3H_DEBUG")) for (int i = 0; i < nc && i < 4; i++) { const X3ParseResult &r = c->hparse[(size_t)i];
+			fprintf(stderr, "[x3h] chunk %d: steps %u hits %u D %u missbytes %u | parse kcycles: fill %u patch %u table %u walk %u\n", i, r.ntok, r.hits, r.dict_elems, r.miss_bytes, r.kcyc_fill, r.kcyc_patch, r._r0, r.kcyc_walk); }
+		if (upto == STAGE_PARSE) return X3H_OK;
+	} else {
+		HIPCHK(hipEventRecord(c->ev[3], c->stream)); /* the parse overlaps the coding stage (run_pipelined): its time is reported from its own events */
+		c->hparse.assign(1, X3ParseResult());
+	}
 
 	/* ---- K3 workspace from the exact D / hits of every chunk ---- */
 	uint64_t toff = 0, c0off = 0, ioff = 0, poff = 0, ooff = 0;
@@ -275,7 +409,10 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 	uint8_t *d_out = io.dst_dev ? io.dst : c->out.as<uint8_t>();
 	HIPCHK(hipMemcpyAsync(c->chunks.p, c->hchunks.data(), (size_t)nc * sizeof(X3Chunk), hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipEventRecord(c->ev[4], c->stream));
-	if (!c->code_v1) {
+	PipeStats ps;
+	if (pipe) {
+		CHK(run_pipelined(c, pa, sa.bytes, tok_pos, tok_hb, tok_nb, tok_mb, d_out, &ps));
+	} else if (!c->code_v1) {
 		/* v2: parallel feature extraction (sorts / scans / count-smaller-before) + two thin serial passes (code2.hip) */
 		CHK(x3_code_v2_run(c->c2, c->stream, nc, c->hchunks.data(), c->chunks.as<X3Chunk>(), c->hparse.data(), pa.result,
 		                   sa.bytes, tok_pos, pa.tok_info, tok_hb, tok_nb, tok_mb, d_out, c->cresult.as<X3CodeResult>()));
@@ -337,13 +474,17 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 		(void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); stats->ms_parse = ms;
 		(void)hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); stats->ms_code = ms;
 		(void)hipEventElapsedTime(&ms, c->ev[0], c->ev[5]); stats->ms_total = ms;
-		if (!c->code_v1 && c->c2.ev[4]) {
+		if (!pipe && !c->code_v1 && c->c2.ev[4]) {
 			(void)hipEventElapsedTime(&ms, c->c2.ev[0], c->c2.ev[1]); stats->ms_features = ms;
 			(void)hipEventElapsedTime(&ms, c->c2.ev[1], c->c2.ev[2]); stats->ms_modes = ms;
 			(void)hipEventElapsedTime(&ms, c->c2.ev[3], c->c2.ev[4]); stats->ms_coder = ms;
 			stats->ms_emit = stats->ms_code - stats->ms_features - stats->ms_modes - stats->ms_coder;
 			stats->coded_symbols = c->c2.last.symbols;
 			stats->mode_iters = c->c2.last.mode_iters;
+		}
+		if (pipe) { /* overlapped stages: each from its own events (their sum exceeds ms_total) */
+			stats->ms_parse = ps.ms_parse; stats->ms_features = ps.ms_features; stats->ms_modes = ps.ms_modes; stats->ms_coder = ps.ms_coder;
+			stats->ms_emit = 0; stats->mode_iters = ps.mode_iters; stats->coded_symbols = c->c2.last.symbols;
 		}
 	}
 	return rc;

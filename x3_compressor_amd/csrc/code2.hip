@@ -246,6 +246,8 @@ struct X3Ac2Args {
 	const uint4 *sym;                     /* per symbol: {cum, freq, magic multiplier, shift} */
 	uint32_t *rec_nk;                     /* out per symbol: {lo, hi} after narrowing, before the renormalisation shift, as uint2 */
 	uint32_t *final_lo;                   /* out per chunk */
+	uint32_t *seg_state;                  /* nullptr: whole streams.  Else ONE stream, symbols [seg_begin, seg_end): {lo, R} in / out */
+	uint32_t seg_begin, seg_end;
 };
 
 /* range / total as a multiply-shift (Granlund-Montgomery, N = 31): L = ceil(log2 total), m = ceil(2^(31+L)/total) < 2^32,
@@ -317,8 +319,9 @@ typedef uint32_t x3_u32x4 __attribute__((ext_vector_type(4)));
 __device__ static void x3_ac2_body(const X3Ac2Args &a)
 {
 	const uint32_t c = blockIdx.x, lane = x3_lane();
-	const uint32_t y0 = x3_uniform(a.yo[c]), Y = x3_uniform(a.yo[c + 1]) - y0;
-	uint32_t lo = 0, R = 0x80000000u; /* ac_init, ac.c:35-41: [0, 0x7FFFFFFF] */
+	uint32_t y0, Y, lo = 0, R = 0x80000000u; /* ac_init, ac.c:35-41: [0, 0x7FFFFFFF] */
+	if (a.seg_state) { y0 = a.seg_begin; Y = a.seg_end - a.seg_begin; lo = x3_uniform(a.seg_state[0]); R = x3_uniform(a.seg_state[1]); }
+	else { y0 = x3_uniform(a.yo[c]); Y = x3_uniform(a.yo[c + 1]) - y0; }
 	uint64_t symp = (uint64_t)(a.sym + y0);
 	uint64_t recp = (uint64_t)((uint2 *)a.rec_nk + y0);
 	const uint32_t G = Y >> 3; /* whole groups of 8 symbols */
@@ -366,15 +369,20 @@ __device__ static void x3_ac2_body(const X3Ac2Args &a)
 		recp += 8;
 	}
 	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" : : : "memory"); /* records: scalar cache -> L2 */
-	if (lane == 0) a.final_lo[c] = lo & 0x3FFFFFFFu;
+	if (lane == 0) {
+		a.final_lo[c] = lo & 0x3FFFFFFFu;
+		if (a.seg_state) { a.seg_state[0] = lo; a.seg_state[1] = R; } /* lo as the chain holds it (stray bits included): the next segment continues it */
+	}
 }
 #else
 /* functional restatement of the same formulas for the CPU emulator build (tests only) */
 __device__ static void x3_ac2_body(const X3Ac2Args &a)
 {
 	const uint32_t c = blockIdx.x, lane = x3_lane();
-	const uint32_t y0 = a.yo[c], Y = a.yo[c + 1] - y0;
-	uint32_t lo = 0, R = 0x80000000u;
+	uint32_t y0, Y, lo = 0, R = 0x80000000u;
+	if (a.seg_state) { y0 = a.seg_begin; Y = a.seg_end - a.seg_begin; lo = a.seg_state[0]; R = a.seg_state[1]; }
+	else { y0 = a.yo[c]; Y = a.yo[c + 1] - y0; }
+	x3_wave_sync();
 	for (uint32_t y = 0; y < Y; y++) {
 		const uint4 q = a.sym[y0 + y];
 		const uint32_t step = (uint32_t)(((uint64_t)R * q.z) >> q.w);
@@ -385,7 +393,11 @@ __device__ static void x3_ac2_body(const X3Ac2Args &a)
 		lo = nlo << sh; /* not reduced mod 2^30, like the device chain: x3_rec_fix removes the stray bits from the records */
 		R = sf << sh;
 	}
-	if (lane == 0) a.final_lo[c] = lo & 0x3FFFFFFFu;
+	x3_wave_sync();
+	if (lane == 0) {
+		a.final_lo[c] = lo & 0x3FFFFFFFu;
+		if (a.seg_state) { a.seg_state[0] = lo; a.seg_state[1] = R; }
+	}
 }
 #endif
 
@@ -585,7 +597,7 @@ static int modes_fixed_point(X3Code2Bufs &B, hipStream_t st, size_t nH, uint32_t
  * ============================================================================================================ */
 int x3_token_postpass(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h_chunks, const X3Chunk *d_chunks,
                       const X3ParseResult *d_parsed, const uint32_t *tok_info, const uint8_t *dict_len,
-                      uint32_t *tok_pos, uint32_t *tok_hb, uint32_t *tok_nb, uint32_t *tok_mb)
+                      uint32_t *tok_pos, uint32_t *tok_hb, uint32_t *tok_nb, uint32_t *tok_mb, size_t prefix_tokens)
 {
 	const uint32_t nc = (uint32_t)nchunks;
 	std::vector<uint32_t> eo(nc + 1);
@@ -593,11 +605,11 @@ int x3_token_postpass(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk
 	for (uint32_t c = 0; c < nc; c++) { eo[c] = (uint32_t)h_chunks[c].elem_off; tot = h_chunks[c].elem_off + h_chunks[c].len + 16; }
 	if (tot >= (1ull << 31)) return X3H_E_ARG;
 	eo[nc] = (uint32_t)tot;
-	const size_t n = tot;
+	const size_t n = (prefix_tokens && nc == 1 && prefix_tokens + 4 < tot) ? prefix_tokens + 4 : (size_t)tot; /* one stream, tokens parsed so far */
 	CHK(B.offs.reserve((size_t)(nc + 1) * 8 * 4));
 	uint32_t *d_eo = B.offs.as<uint32_t>() + (size_t)(nc + 1) * 7;
 	HIPCHK(hipMemcpyAsync(d_eo, eo.data(), (nc + 1) * 4, hipMemcpyHostToDevice, st));
-	for (int i = 0; i < 4; i++) CHK(B.pp[i].reserve((n + 4) * 4));
+	for (int i = 0; i < 4; i++) CHK(B.pp[i].reserve(((size_t)tot + 4) * 4)); /* full size even for a prefix: no reallocation between prefix calls */
 	uint32_t *vh = B.pp[0].as<uint32_t>(), *vn = B.pp[1].as<uint32_t>(), *vm = B.pp[2].as<uint32_t>(), *vl = B.pp[3].as<uint32_t>();
 	x3_foreach(n, st, X3_LAMBDA(size_t i) {
 		const uint32_t c = find_chunk(d_eo, nc, (uint32_t)i);
@@ -632,9 +644,11 @@ int x3_token_postpass(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk
 int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h_chunks, const X3Chunk *d_chunks,
                    const X3ParseResult *h_parsed, const X3ParseResult *d_parsed,
                    const uint8_t *d_bytes, const uint32_t *tok_pos, const uint32_t *tok_info, const uint32_t *tok_hb,
-                   const uint32_t *tok_nb, const uint32_t *tok_mb, uint8_t *d_out, X3CodeResult *d_result)
+                   const uint32_t *tok_nb, const uint32_t *tok_mb, uint8_t *d_out, X3CodeResult *d_result, X3CodeSeg *seg)
 {
 	const uint32_t nc = (uint32_t)nchunks;
+	if (seg && nc != 1) return X3H_E_ARG;
+	const bool final = !seg || seg->final;
 	for (int i = 0; i < 5; i++) if (!B.ev[i]) HIPCHK(hipEventCreate(&B.ev[i]));
 	HIPCHK(hipEventRecord(B.ev[0], st));
 	/* ---- index spaces: steps, hits, MTF events (hits + inserted elements), tags ---- */
@@ -644,7 +658,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		so[c] = (uint32_t)s; ho[c] = (uint32_t)h; eo[c] = (uint32_t)e; dof[c] = (uint32_t)d; mo[c] = (uint32_t)mi; bo[c] = (uint32_t)by; yo[c] = (uint32_t)y;
 		s += h_parsed[c].ntok; h += h_parsed[c].hits; e += (uint64_t)h_parsed[c].hits + h_parsed[c].dict_elems; d += h_parsed[c].dict_elems;
 		mi += h_parsed[c].ntok - h_parsed[c].hits; by += h_parsed[c].miss_bytes;
-		y += 2ull * h_parsed[c].ntok + h_parsed[c].miss_bytes + 1; /* two symbols per step, one per new-fragment byte, E_EOF */
+		y += 2ull * h_parsed[c].ntok + h_parsed[c].miss_bytes + (final ? 1 : 0); /* two symbols per step, one per new-fragment byte, E_EOF */
 	}
 	if (s >= (1ull << 31) || e >= (1ull << 31) || y >= (1ull << 31)) return X3H_E_ARG; /* one batch: < 2^31 coded symbols */
 	so[nc] = (uint32_t)s; ho[nc] = (uint32_t)h; eo[nc] = (uint32_t)e; dof[nc] = (uint32_t)d; mo[nc] = (uint32_t)mi; bo[nc] = (uint32_t)by; yo[nc] = (uint32_t)y;
@@ -652,6 +666,17 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	size_t nA = nE > nH ? nE : nH;
 	if (nM > nA) nA = nM;
 	if (nB > nA) nA = nB;
+	size_t nDres = nD, nYres = nY, nMSres = (nM > nB ? nM : nB);
+	if (seg) { /* a growing prefix: size everything for the estimated whole stream (a reallocation would wait for the running parse / coder) */
+		if (seg->res_hits + seg->res_elems > nA) nA = seg->res_hits + seg->res_elems;
+		if (seg->res_mbytes > nA) nA = seg->res_mbytes;
+		if (seg->res_steps > nA) nA = seg->res_steps;
+		if (seg->res_elems > nDres) nDres = seg->res_elems;
+		nYres = 3 * seg->res_bytes + 8; /* the operand and record arrays persist from call to call: their hard upper bound */
+		if (seg->res_mbytes > nMSres) nMSres = seg->res_mbytes;
+		if (seg->res_steps > nMSres) nMSres = seg->res_steps;
+		CHK(B.tmp.reserve(24 * nA + ((size_t)8 << 20)));
+	}
 	nA += 4;
 
 	CHK(B.offs.reserve((size_t)(nc + 1) * 8 * 4));
@@ -667,7 +692,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	CHK(B.chunkmeta.reserve((size_t)nc * 10 * 4 + 64));
 	uint32_t *m_pairbase = B.chunkmeta.as<uint32_t>(), *m_npairs = m_pairbase + nc, *m_first00 = m_npairs + nc, *m_ord00 = m_first00 + nc;
 	CHK(B.maxred.reserve(64));
-	CHK(B.idxfreq.reserve((nD + 4) * 4));
+	CHK(B.idxfreq.reserve((nDres + 4) * 4));
 	const int NARR = 48;
 	static_assert(sizeof(B.a) / sizeof(B.a[0]) >= 48, "work arrays");
 	uint32_t *A[NARR];
@@ -872,7 +897,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 
 	/* ---- new fragments: model_match_size (32 symbols) and model_chars (256 symbols) are adaptive order-0 models
 	 *      (x3.c:259-267): cum_freq = symbol + #{earlier smaller}, freq = 1 + #{earlier equal}, total = alphabet + index ---- */
-	const size_t nMS = (nM > nB ? nM : nB) + 4;
+	const size_t nMS = nMSres + 4;
 	uint32_t *Q[16];
 	for (int i = 0; i < 16; i++) { CHK(B.ms[i].reserve(nMS * 4)); Q[i] = B.ms[i].as<uint32_t>(); }
 	uint32_t *lval = Q[0], *lsm = Q[1], *leq = Q[2], *bval = Q[3], *bsm = Q[4], *beq = Q[5];
@@ -910,12 +935,18 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 
 	/* ---- the coded symbols, in coding order: symbol index of step k = 2k + (new-fragment bytes before k) ---- */
 	uint32_t *Yv[12];
-	for (int i = 0; i < 12; i++) { CHK(B.y[i].reserve((nY + (i == 0 ? X3_SYM_PAD : 4)) * (i == 0 ? 16 : i == 3 ? 8 : 4))); Yv[i] = B.y[i].as<uint32_t>(); }
+	for (int i = 0; i < 12; i++) {
+		const size_t ny = (i == 0 || i == 3) ? nYres : (final ? nY : 0); /* the emit arrays are only needed by the final call */
+		CHK(B.y[i].reserve((ny + (i == 0 ? X3_SYM_PAD : 4)) * (i == 0 ? 16 : i == 3 ? 8 : 4)));
+		Yv[i] = B.y[i].as<uint32_t>();
+	}
+	const uint32_t steps_done = seg ? seg->steps_done : 0u;
 	uint4 *sy = (uint4 *)Yv[0]; /* {cum, freq, magic, shift} per symbol */
 	uint32_t *rec_nk = Yv[3]; /* 2 words per symbol */
 	x3_foreach(nS, st, X3_LAMBDA(size_t gs) {
 		const uint32_t c = find_chunk(d_so, nc, (uint32_t)gs);
 		const uint32_t k = (uint32_t)gs - d_so[c];
+		if (k < steps_done) return; /* assembled by an earlier prefix call (the coder may be reading it right now) */
 		const uint64_t base = d_chunks[c].elem_off;
 		const uint32_t info = tok_info[base + k], hb = tok_hb[base + k], mb = tok_mb[base + k];
 		uint32_t yi = d_yo[c] + 2 * k + mb;
@@ -936,7 +967,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 			}
 		}
 	});
-	x3_foreach(nc, st, X3_LAMBDA(size_t c) { /* E_EOF, x3.c:432-433 */
+	if (final) x3_foreach(nc, st, X3_LAMBDA(size_t c) { /* E_EOF, x3.c:432-433 */
 		const uint32_t yi = d_yo[c + 1] - 1, evtotal = 2051u + d_parsed[c].ntok;
 		sy[yi] = x3_make_symbol(evtotal - 1, 1, evtotal);
 	});
@@ -944,11 +975,26 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	/* ---- serial pass 2: interval recurrence ---- */
 	X3Ac2Args aa;
 	aa.yo = d_yo; aa.sym = sy; aa.rec_nk = rec_nk; aa.final_lo = m_finallo;
+	aa.seg_state = nullptr; aa.seg_begin = aa.seg_end = 0;
 	if (nH == 0) HIPCHK(hipEventRecord(B.ev[2], st));
-	HIPCHK(hipEventRecord(B.ev[3], st));
-	launch_ac2(aa, nc, st);
-	HIPCHK(hipGetLastError());
-	HIPCHK(hipEventRecord(B.ev[4], st));
+	if (!seg) {
+		HIPCHK(hipEventRecord(B.ev[3], st));
+		launch_ac2(aa, nc, st);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipEventRecord(B.ev[4], st));
+	} else {
+		/* the new symbols [y_done, nY) go to the coder stream; this (feature) stream carries on with the next prefix */
+		aa.seg_state = seg->coder_state; aa.seg_begin = seg->y_done; aa.seg_end = (uint32_t)nY;
+		HIPCHK(hipEventRecord(seg->ev_ready, st));
+		HIPCHK(hipStreamWaitEvent(seg->coder_stream, seg->ev_ready, 0));
+		HIPCHK(hipEventRecord(seg->ev_coder_begin, seg->coder_stream));
+		if (aa.seg_end > aa.seg_begin) { launch_ac2(aa, 1, seg->coder_stream); HIPCHK(hipGetLastError()); }
+		HIPCHK(hipEventRecord(seg->ev_coder_end, seg->coder_stream));
+		seg->steps_done = (uint32_t)nS; seg->y_done = (uint32_t)nY;
+		B.last.symbols = nY;
+		if (!final) return X3H_OK;
+		HIPCHK(hipStreamWaitEvent(st, seg->ev_coder_end, 0)); /* emission needs every record */
+	}
 
 	/* ---- bit emission (ac.c:49-67 put_bit + mScale, bio.c:49-72) as prefix sums over the records ----
 	 * pending after symbol i  = sum of k over (last symbol that shifted out bits (n>=1) or stream start .. i]

@@ -58,7 +58,7 @@ __device__ static __forceinline__ bool x3_eq_bytes(const uint8_t *b, uint32_t gp
 /* state shared by the workgroup */
 struct ParseShared {
 	uint32_t p, blk, D, lenmask, hlog, flag, ntok, hits, mbytes;
-	uint32_t new_pos, new_len, new_tag, rebuild, nanchor;
+	uint32_t new_pos, new_len, new_tag, rebuild, nanchor, nck;
 };
 enum { FLAG_REFILL = 1, FLAG_PATCH = 2, FLAG_DONE = 3 };
 
@@ -91,7 +91,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 
 	if (tid == 0) {
 		S.p = 0; S.blk = 0; S.D = 0; S.lenmask = 0; S.hlog = X3_HT_LOG2_MIN < ck.ht_log2_max ? X3_HT_LOG2_MIN : ck.ht_log2_max;
-		S.flag = n ? FLAG_REFILL : FLAG_DONE; S.ntok = 0; S.hits = 0; S.rebuild = 0; S.mbytes = 0; S.nanchor = 0;
+		S.flag = n ? FLAG_REFILL : FLAG_DONE; S.ntok = 0; S.hits = 0; S.rebuild = 0; S.mbytes = 0; S.nanchor = 0; S.nck = 0;
 	}
 	for (uint32_t i = tid; i < (1u << (X3_HT_LOG2_MIN < ck.ht_log2_max ? X3_HT_LOG2_MIN : ck.ht_log2_max)); i += X3_PARSE_THREADS) ht[i] = 0;
 	for (uint32_t i = tid; i < X3_LDS_HT; i += X3_PARSE_THREADS) sHT[i] = 0;
@@ -308,6 +308,23 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 		}
 		__syncthreads();
 		{ const uint64_t t = x3_clock(); cyc_walk += t - t_prev; t_prev = t; }
+		if (a.ckpt && blockIdx.x == 0 && S.nck < a.nckpt && S.p >= a.ckpt_pos[S.nck] && S.flag != FLAG_DONE) { /* uniform: S is stable between barriers */
+			/* every token below S.ntok (and dict_len of every element) has been stored by SOME thread of this workgroup: each
+			 * thread releases its own stores to device scope, then one thread publishes the counters to the host */
+			__threadfence();
+			__syncthreads();
+			if (tid == 0) {
+				uint32_t k = S.nck;
+				while (k + 1 < a.nckpt && S.p >= a.ckpt_pos[k + 1]) k++; /* a long step may cross several marks: publish the last one only */
+				X3ParseCkpt *ck = a.ckpt + k;
+				ck->p = S.p; ck->ntok = S.ntok; ck->hits = S.hits; ck->dict_elems = S.D; ck->miss_bytes = S.mbytes;
+				__threadfence_system();
+				ck->seq = k + 1;
+				__threadfence_system();
+				S.nck = k + 1;
+			}
+			__syncthreads();
+		}
 	}
 
 	if (tid == 0) {

@@ -116,6 +116,7 @@ template <typename T> static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v
 template <typename T> static inline T atomicCAS(T *p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}
+static inline void __threadfence_system() {}
 
 /* run `fn(arg)` as a kernel: grid x block fibers, blocks one after another */
 void x3emu_launch(void (*fn)(void *), void *arg, dim3 grid, dim3 block);

@@ -92,11 +92,23 @@ struct X3Code2Bufs {
 
 int x3_token_postpass(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h_chunks, const X3Chunk *d_chunks,
                       const X3ParseResult *d_parsed, const uint32_t *tok_info, const uint8_t *dict_len,
-                      uint32_t *tok_pos, uint32_t *tok_hb, uint32_t *tok_nb, uint32_t *tok_mb);
+                      uint32_t *tok_pos, uint32_t *tok_hb, uint32_t *tok_nb, uint32_t *tok_mb, size_t prefix_tokens = 0);
+
+/* Coding a GROWING PREFIX of one stream while its parse is still running (api.hip, single-stream pipelining): every call recomputes
+ * the (parallel) features of the whole prefix, assembles only the symbols of the new steps and queues the coder recurrence for
+ * them on its own stream, so the recurrence of one segment overlaps the parse and the feature passes of the next. */
+struct X3CodeSeg {
+	bool final;                  /* the prefix is the whole stream: E_EOF, flush and bit emission happen in this call           */
+	uint32_t steps_done, y_done; /* steps / symbols already handed to the coder by earlier calls (updated by the call)          */
+	hipStream_t coder_stream;
+	hipEvent_t ev_ready, ev_coder_begin, ev_coder_end; /* symbols assembled (feature stream); around the recurrence (coder stream) */
+	uint32_t *coder_state;       /* device: {lo, R} carried from segment to segment; {0, 0x80000000} before the first           */
+	size_t res_steps, res_hits, res_elems, res_mbytes, res_bytes; /* sizing estimates for the whole stream: nothing is reallocated while other streams run */
+};
 
 int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h_chunks, const X3Chunk *d_chunks,
                    const X3ParseResult *h_parsed, const X3ParseResult *d_parsed,
                    const uint8_t *d_bytes, const uint32_t *tok_pos, const uint32_t *tok_info, const uint32_t *tok_hb,
-                   const uint32_t *tok_nb, const uint32_t *tok_mb, uint8_t *d_out, X3CodeResult *d_result);
+                   const uint32_t *tok_nb, const uint32_t *tok_mb, uint8_t *d_out, X3CodeResult *d_result, X3CodeSeg *seg = nullptr);
 
 #endif /* X3_HOST_H */
