@@ -41,7 +41,7 @@ struct x3h_ctx {
 	hipStream_t s_parse = nullptr, s_coder = nullptr;
 	hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr, ev_ready = nullptr, ev_cb[X3_MAX_CKPT + 1] = {}, ev_ce[X3_MAX_CKPT + 1] = {};
 	X3ParseCkpt *ckpt = nullptr; /* host-mapped */
-	DevBuf coder_state, prefix_result;
+	DevBuf coder_state, prefix_result, srcoff;
 	uint64_t batch_bytes = (uint64_t)1 << 30;
 	uint64_t pad_total = 0;
 	DevBuf mtf, idxfreq, ctx1, ctx0, items, pkey, pval, out, counts;
@@ -125,7 +125,7 @@ extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 		               &c->c2.tmp, &c->c2.offs, &c->c2.chunkmeta, &c->c2.idxfreq, &c->c2.hsym, &c->c2.maxred, &c->c2.pp[0], &c->c2.pp[1], &c->c2.pp[2], &c->c2.pp[3],
 		               &c->cresult, &c->mtf, &c->idxfreq, &c->ctx1, &c->ctx0, &c->items, &c->pkey, &c->pval, &c->out, &c->counts, &c->din, &c->dchunks };
 	for (DevBuf *b : bufs) b->release();
-	c->coder_state.release(); c->prefix_result.release();
+	c->coder_state.release(); c->prefix_result.release(); c->srcoff.release();
 	if (c->ckpt) (void)hipHostFree((void *)c->ckpt);
 	if (c->s_parse) (void)hipStreamDestroy(c->s_parse);
 	if (c->s_coder) (void)hipStreamDestroy(c->s_coder);
@@ -137,6 +137,7 @@ extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 	for (DevBuf &b : c->s2.a) b.release();
 	c->s2.misc.release();
 	for (DevBuf &b : c->c2.y) b.release();
+	c->c2.yraw.release();
 	for (DevBuf &b : c->c2.ms) b.release();
 	for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
 	if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -191,13 +192,34 @@ static int stage_inputs(x3h_ctx *c, const x3h_params *prm, const RunIO &io, uint
 	CHK(c->cresult.reserve((size_t)nc * sizeof(X3CodeResult)));
 
 	HIPCHK(hipMemsetAsync(c->pad.p, 0, boff + 256, c->stream));
+	HIPCHK(hipMemcpyAsync(c->chunks.p, c->hchunks.data(), (size_t)nc * sizeof(X3Chunk), hipMemcpyHostToDevice, c->stream));
+	if (io.src_dev && nc > 4) {
+		/* device-resident batch: one launch moves every chunk into its padded slot (a copy call per chunk costs more in launches than in bytes) */
+		CHK(c->srcoff.reserve((size_t)(nc + 1) * 8));
+		HIPCHK(hipMemcpyAsync(c->srcoff.p, io.offsets, (size_t)(nc + 1) * 8, hipMemcpyHostToDevice, c->stream));
+		const uint64_t *so = c->srcoff.as<uint64_t>();
+		const X3Chunk *dck = c->chunks.as<X3Chunk>();
+		const uint8_t *src = io.src;
+		uint8_t *pad = c->pad.as<uint8_t>();
+		const uint64_t per = (max_len + 15) / 16;
+		x3_foreach((size_t)(per * (uint64_t)nc), c->stream, X3_LAMBDA(size_t i) {
+			const uint32_t ci = (uint32_t)(i / per);
+			const uint64_t o = (uint64_t)(i % per) * 16, len = dck[ci].len;
+			if (o >= len) return;
+			const uint8_t *s = src + so[ci] + o;
+			uint8_t *d = pad + dck[ci].byte_off + o; /* 16-byte aligned: slots are 256-byte aligned */
+			const uint32_t nb = len - o >= 16 ? 16u : (uint32_t)(len - o);
+			if (nb == 16 && (((uintptr_t)s) & 15) == 0) { *(uint4 *)d = *(const uint4 *)s; return; }
+			for (uint32_t k = 0; k < nb; k++) d[k] = s[k];
+		});
+		return X3H_OK;
+	}
 	for (int i = 0; i < nc; i++) {
 		const X3Chunk &k = c->hchunks[(size_t)i];
 		if (!k.len) continue;
 		HIPCHK(hipMemcpyAsync(c->pad.as<uint8_t>() + k.byte_off, io.src + io.offsets[i], k.len,
 		                      io.src_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
 	}
-	HIPCHK(hipMemcpyAsync(c->chunks.p, c->hchunks.data(), (size_t)nc * sizeof(X3Chunk), hipMemcpyHostToDevice, c->stream));
 	return X3H_OK;
 }
 

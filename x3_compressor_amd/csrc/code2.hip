@@ -250,16 +250,21 @@ struct X3Ac2Args {
 	uint32_t seg_begin, seg_end;
 };
 
-/* range / total as a multiply-shift (Granlund-Montgomery, N = 31): L = ceil(log2 total), m = ceil(2^(31+L)/total) < 2^32,
- * floor(range*m / 2^(31+L)) == floor(range/total) for every range <= 2^31 because m*total - 2^(31+L) < total <= 2^L.
+/* range / total as a multiply-shift (Granlund-Montgomery, N = 31): L = ceil(log2 total) >= 1, m = ceil(2^(31+L)/total) in [2^31, 2^32),
+ * floor(range*m / 2^(31+L)) == floor(range/total) for every range <= 2^31 because m*total - 2^(31+L) < total <= 2^L.  The chain takes the
+ * high product word (s_mul_hi_u32) and shifts it by L-1: two instructions.  total == 1 (a context or index model with a single symbol of
+ * frequency 1) would need m = 2^32 -- but such a symbol is a NO-OP for the coder (step = range, the interval does not change, nothing is
+ * renormalised): it is marked (w = X3_SYM_NOOP) and dropped from the chain's input by the compaction pass of x3_code_v2_run.
  * Computed per symbol by the parallel assembly kernels, off the serial chain. */
+#define X3_SYM_NOOP 0xFFFFFFFFu
 __device__ static __forceinline__ uint4 x3_make_symbol(uint32_t cum, uint32_t freq, uint32_t total)
 {
-	const uint32_t L = total <= 1 ? 0u : 32u - (uint32_t)x3_clz32(total - 1);
 	uint4 q;
 	q.x = cum; q.y = freq;
+	if (total <= 1) { q.z = 0; q.w = X3_SYM_NOOP; return q; }
+	const uint32_t L = 32u - (uint32_t)x3_clz32(total - 1);
 	q.z = (uint32_t)((((uint64_t)1 << (31 + L)) + total - 1) / total);
-	q.w = 31 + L;
+	q.w = L - 1;
 	return q;
 }
 
@@ -285,14 +290,14 @@ __device__ static __forceinline__ uint4 x3_make_symbol(uint32_t cum, uint32_t fr
  * The operand array has X3_SYM_PAD readable entries behind the last symbol, so the fetch one group ahead needs no clamping.
  * lo is NOT reduced mod 2^30 after the shift: the two stray bits (30, 31) never reach a bit the chain looks at (they cancel in
  * nlo ^ nhi at bit 30, the only place they could matter) and are shifted out or stay put; the records carry them along and
- * x3_rec_fix (parallel, emit stage) removes them again: 15 instructions per symbol + 0.5 for the store. */
+ * x3_rec_fix (parallel, emit stage) removes them again: 14 instructions per symbol + 0.5 for the store. */
 typedef uint32_t x3_u32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t x3_u32x4 __attribute__((ext_vector_type(4)));
 
 #define X3_AC2_SYM(Q, J, NLO, NHI)                                                                                              \
 	{                                                                                                                           \
 		const uint32_t cum = (Q)[4 * (J)], fq = (Q)[4 * (J) + 1], m = (Q)[4 * (J) + 2], msh = (Q)[4 * (J) + 3];                 \
-		const uint32_t step = (uint32_t)(((uint64_t)R * m) >> msh);                                                             \
+		const uint32_t step = (uint32_t)(((uint64_t)R * m) >> 32) >> msh;                                                       \
 		const uint32_t sf = step * fq, D = sf - 1;                                                                              \
 		NLO = lo + step * cum;                                                                                                  \
 		NHI = NLO + D;                                                                                                          \
@@ -385,7 +390,7 @@ __device__ static void x3_ac2_body(const X3Ac2Args &a)
 	x3_wave_sync();
 	for (uint32_t y = 0; y < Y; y++) {
 		const uint4 q = a.sym[y0 + y];
-		const uint32_t step = (uint32_t)(((uint64_t)R * q.z) >> q.w);
+		const uint32_t step = (uint32_t)(((uint64_t)R * q.z) >> 32) >> q.w;
 		const uint32_t nlo = lo + step * q.x, sf = step * q.y, D = sf - 1, nhi = nlo + D;
 		const uint32_t cz = (uint32_t)x3_clz32(D), t = 31u - cz;
 		const uint32_t sh = cz - 1 - ((((nlo ^ nhi) >> t) & 1u) ^ 1u);
@@ -606,7 +611,7 @@ int x3_token_postpass(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk
 	if (tot >= (1ull << 31)) return X3H_E_ARG;
 	eo[nc] = (uint32_t)tot;
 	const size_t n = (prefix_tokens && nc == 1 && prefix_tokens + 4 < tot) ? prefix_tokens + 4 : (size_t)tot; /* one stream, tokens parsed so far */
-	CHK(B.offs.reserve((size_t)(nc + 1) * 8 * 4));
+	CHK(B.offs.reserve((size_t)(nc + 1) * 9 * 4));
 	uint32_t *d_eo = B.offs.as<uint32_t>() + (size_t)(nc + 1) * 7;
 	HIPCHK(hipMemcpyAsync(d_eo, eo.data(), (nc + 1) * 4, hipMemcpyHostToDevice, st));
 	for (int i = 0; i < 4; i++) CHK(B.pp[i].reserve(((size_t)tot + 4) * 4)); /* full size even for a prefix: no reallocation between prefix calls */
@@ -679,9 +684,10 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	}
 	nA += 4;
 
-	CHK(B.offs.reserve((size_t)(nc + 1) * 8 * 4));
+	CHK(B.offs.reserve((size_t)(nc + 1) * 9 * 4));
 	uint32_t *d_so = B.offs.as<uint32_t>(), *d_ho = d_so + (nc + 1), *d_eo = d_ho + (nc + 1), *d_dof = d_eo + (nc + 1);
 	uint32_t *d_mo = d_dof + (nc + 1), *d_bo = d_mo + (nc + 1), *d_yo = d_bo + (nc + 1);
+	uint32_t *d_yoc = d_so + (size_t)(nc + 1) * 8; /* symbol offsets after the no-op symbols are dropped (slot 7 belongs to the token post-pass) */
 	HIPCHK(hipMemcpyAsync(d_mo, mo.data(), (nc + 1) * 4, hipMemcpyHostToDevice, st));
 	HIPCHK(hipMemcpyAsync(d_bo, bo.data(), (nc + 1) * 4, hipMemcpyHostToDevice, st));
 	HIPCHK(hipMemcpyAsync(d_yo, yo.data(), (nc + 1) * 4, hipMemcpyHostToDevice, st));
@@ -936,10 +942,12 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	/* ---- the coded symbols, in coding order: symbol index of step k = 2k + (new-fragment bytes before k) ---- */
 	uint32_t *Yv[12];
 	for (int i = 0; i < 12; i++) {
-		const size_t ny = (i == 0 || i == 3) ? nYres : (final ? nY : 0); /* the emit arrays are only needed by the final call */
+		const size_t ny = (i == 0 || i == 3) ? nYres : ((final || i == 5 || i == 6) ? nY : 0); /* the emit arrays are only needed by the final call; 5, 6 also serve the compaction */
 		CHK(B.y[i].reserve((ny + (i == 0 ? X3_SYM_PAD : 4)) * (i == 0 ? 16 : i == 3 ? 8 : 4)));
 		Yv[i] = B.y[i].as<uint32_t>();
 	}
+	CHK(B.yraw.reserve((nYres + 4) * 16));
+	uint4 *syr = B.yraw.as<uint4>(); /* every symbol at its closed-form index (no-ops included) */
 	const uint32_t steps_done = seg ? seg->steps_done : 0u;
 	uint4 *sy = (uint4 *)Yv[0]; /* {cum, freq, magic, shift} per symbol */
 	uint32_t *rec_nk = Yv[3]; /* 2 words per symbol */
@@ -954,27 +962,41 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		if (!(info & X3_TOK_MISS)) {
 			const uint32_t gh = d_ho[c] + hb, m = mode[gh], e0 = pe0[gh], e1 = pe1[gh];
 			const uint32_t e2 = 2049u + hb - e0 - e1; /* every hit bumps exactly one of the three */
-			sy[yi] = x3_make_symbol(m == X3_E_CTX0 ? 0u : m == X3_E_CTX1 ? e0 : e0 + e1, m == X3_E_CTX0 ? e0 : m == X3_E_CTX1 ? e1 : e2, evtotal);
-			sy[yi + 1] = x3_make_symbol(hs_cum[gh], hs_freq[gh], hs_tot[gh]);
+			syr[yi] = x3_make_symbol(m == X3_E_CTX0 ? 0u : m == X3_E_CTX1 ? e0 : e0 + e1, m == X3_E_CTX0 ? e0 : m == X3_E_CTX1 ? e1 : e2, evtotal);
+			syr[yi + 1] = x3_make_symbol(hs_cum[gh], hs_freq[gh], hs_tot[gh]);
 		} else {
 			const uint32_t len = info & 0x3Fu, mk = k - hb; /* mk = new fragments before this one */
-			sy[yi] = x3_make_symbol(2049u + hb, 1u + mk, evtotal); /* E_NEW */
+			syr[yi] = x3_make_symbol(2049u + hb, 1u + mk, evtotal); /* E_NEW */
 			const uint32_t gm = d_mo[c] + mk;
-			sy[yi + 1] = x3_make_symbol((len - 1) + lsm[gm], 1u + leq[gm], 32u + mk);
+			syr[yi + 1] = x3_make_symbol((len - 1) + lsm[gm], 1u + leq[gm], 32u + mk);
 			for (uint32_t j = 0; j < len; j++) {
 				const uint32_t gb = d_bo[c] + mb + j;
-				sy[yi + 2 + j] = x3_make_symbol(bval[gb] + bsm[gb], 1u + beq[gb], 256u + mb + j);
+				syr[yi + 2 + j] = x3_make_symbol(bval[gb] + bsm[gb], 1u + beq[gb], 256u + mb + j);
 			}
 		}
 	});
 	if (final) x3_foreach(nc, st, X3_LAMBDA(size_t c) { /* E_EOF, x3.c:432-433 */
 		const uint32_t yi = d_yo[c + 1] - 1, evtotal = 2051u + d_parsed[c].ntok;
-		sy[yi] = x3_make_symbol(evtotal - 1, 1, evtotal);
+		syr[yi] = x3_make_symbol(evtotal - 1, 1, evtotal);
 	});
+
+	/* ---- drop the no-op symbols (total == 1): the chain's input is the compacted list, everything downstream (records, emission)
+	 *      lives in compacted symbol indices.  A prefix of the raw list compacts to a prefix of the compacted list. ---- */
+	uint32_t *kf = Yv[5], *Pk = Yv[6];
+	const uint32_t y_raw_done = seg ? seg->y_raw_done : 0u;
+	x3_foreach(nY, st, X3_LAMBDA(size_t y) { kf[y] = syr[y].w != X3_SYM_NOOP ? 1u : 0u; });
+	CHK(x3p_excl_scan(B.tmp, kf, Pk, nY, st));
+	x3_foreach(nY, st, X3_LAMBDA(size_t y) { if (y >= y_raw_done && kf[y]) sy[Pk[y]] = syr[y]; });
+	x3_foreach(nc + 1, st, X3_LAMBDA(size_t c) { d_yoc[c] = Pk[d_yo[c]]; });
+	uint32_t nYc32 = 0;
+	HIPCHK(hipMemcpyAsync(&nYc32, Pk + nY, 4, hipMemcpyDeviceToHost, st));
+	HIPCHK(hipStreamSynchronize(st));
+	const size_t nYraw = nY;
+	const size_t nYc = nYc32;
 
 	/* ---- serial pass 2: interval recurrence ---- */
 	X3Ac2Args aa;
-	aa.yo = d_yo; aa.sym = sy; aa.rec_nk = rec_nk; aa.final_lo = m_finallo;
+	aa.yo = d_yoc; aa.sym = sy; aa.rec_nk = rec_nk; aa.final_lo = m_finallo;
 	aa.seg_state = nullptr; aa.seg_begin = aa.seg_end = 0;
 	if (nH == 0) HIPCHK(hipEventRecord(B.ev[2], st));
 	if (!seg) {
@@ -984,14 +1006,14 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		HIPCHK(hipEventRecord(B.ev[4], st));
 	} else {
 		/* the new symbols [y_done, nY) go to the coder stream; this (feature) stream carries on with the next prefix */
-		aa.seg_state = seg->coder_state; aa.seg_begin = seg->y_done; aa.seg_end = (uint32_t)nY;
+		aa.seg_state = seg->coder_state; aa.seg_begin = seg->y_done; aa.seg_end = (uint32_t)nYc;
 		HIPCHK(hipEventRecord(seg->ev_ready, st));
 		HIPCHK(hipStreamWaitEvent(seg->coder_stream, seg->ev_ready, 0));
 		HIPCHK(hipEventRecord(seg->ev_coder_begin, seg->coder_stream));
 		if (aa.seg_end > aa.seg_begin) { launch_ac2(aa, 1, seg->coder_stream); HIPCHK(hipGetLastError()); }
 		HIPCHK(hipEventRecord(seg->ev_coder_end, seg->coder_stream));
-		seg->steps_done = (uint32_t)nS; seg->y_done = (uint32_t)nY;
-		B.last.symbols = nY;
+		seg->steps_done = (uint32_t)nS; seg->y_done = (uint32_t)nYc; seg->y_raw_done = (uint32_t)nYraw;
+		B.last.symbols = nYraw;
 		if (!final) return X3H_OK;
 		HIPCHK(hipStreamWaitEvent(st, seg->ev_coder_end, 0)); /* emission needs every record */
 	}
@@ -1003,38 +1025,49 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	uint32_t *rec_fx = Yv[0]; /* the operand array is dead now: the records with the stray bits removed go there */
 	{
 		const uint32_t *rg = rec_nk;
-		x3_foreach(nY, st, X3_LAMBDA(size_t i) {
-			const uint32_t c = find_chunk(d_yo, nc, (uint32_t)i);
-			const uint32_t g2 = i == d_yo[c] ? 0u : x3_rec_stray(rg[2 * i - 2], rg[2 * i - 1]);
+		x3_foreach(nYc, st, X3_LAMBDA(size_t i) {
+			const uint32_t c = find_chunk(d_yoc, nc, (uint32_t)i);
+			const uint32_t g2 = i == d_yoc[c] ? 0u : x3_rec_stray(rg[2 * i - 2], rg[2 * i - 1]);
 			rec_fx[2 * i] = rg[2 * i] - g2; rec_fx[2 * i + 1] = rg[2 * i + 1] - g2;
 		});
 		rec_nk = rec_fx;
 	}
-	x3_foreach(nY, st, X3_LAMBDA(size_t i) {
+	x3_foreach(nYc, st, X3_LAMBDA(size_t i) {
 		const uint32_t rl = rec_nk[2 * i], rh = rec_nk[2 * i + 1];
-		const uint32_t c = find_chunk(d_yo, nc, (uint32_t)i);
+		const uint32_t c = find_chunk(d_yoc, nc, (uint32_t)i);
 		kk[i] = x3_rec_k(rl, rh);
-		rv[i] = (x3_rec_n(rl, rh) >= 1 || i == d_yo[c]) ? (uint32_t)i + 1 : 0u;
+		rv[i] = (x3_rec_n(rl, rh) >= 1 || i == d_yoc[c]) ? (uint32_t)i + 1 : 0u;
 	});
-	CHK(x3p_excl_scan(B.tmp, kk, Kex, nY, st));
-	CHK(x3p_incl_max_scan(B.tmp, rv, LE, nY, st));
-	x3_foreach(nY, st, X3_LAMBDA(size_t i) { pend[i] = Kex[i + 1] - Kex[LE[i] - 1]; });
-	x3_foreach(nY, st, X3_LAMBDA(size_t i) {
+	CHK(x3p_excl_scan(B.tmp, kk, Kex, nYc, st));
+	CHK(x3p_incl_max_scan(B.tmp, rv, LE, nYc, st));
+	x3_foreach(nYc, st, X3_LAMBDA(size_t i) { pend[i] = Kex[i + 1] - Kex[LE[i] - 1]; });
+	x3_foreach(nYc, st, X3_LAMBDA(size_t i) {
 		const uint32_t n = x3_rec_n(rec_nk[2 * i], rec_nk[2 * i + 1]);
-		const uint32_t c = find_chunk(d_yo, nc, (uint32_t)i);
-		len[i] = n >= 1 ? n + (i == d_yo[c] ? 0u : pend[i - 1]) : 0u;
+		const uint32_t c = find_chunk(d_yoc, nc, (uint32_t)i);
+		len[i] = n >= 1 ? n + (i == d_yoc[c] ? 0u : pend[i - 1]) : 0u;
 	});
-	CHK(x3p_excl_scan(B.tmp, len, pos, nY, st));
-	for (uint32_t c = 0; c < nc; c++) /* the stream is assembled with ORs */
-		if (h_chunks[c].out_cap) HIPCHK(hipMemsetAsync(d_out + h_chunks[c].out_off, 0, h_chunks[c].out_cap, st));
-	x3_foreach(nY, st, X3_LAMBDA(size_t i) {
+	CHK(x3p_excl_scan(B.tmp, len, pos, nYc, st));
+	{ /* the stream is assembled with ORs: zero every chunk's slot (one launch for the batch; out_off and out_cap are multiples of 4) */
+		uint64_t maxcap = 0;
+		for (uint32_t c = 0; c < nc; c++) if (h_chunks[c].out_cap > maxcap) maxcap = h_chunks[c].out_cap;
+		const uint64_t per = (maxcap + 15) / 16;
+		x3_foreach((size_t)(per * nc), st, X3_LAMBDA(size_t i) {
+			const uint32_t c = (uint32_t)(i / per);
+			const uint64_t o = (uint64_t)(i % per) * 16, cap = d_chunks[c].out_cap;
+			if (o >= cap) return;
+			uint32_t *w = (uint32_t *)(d_out + d_chunks[c].out_off + o);
+			const uint32_t nw = cap - o >= 16 ? 4u : (uint32_t)((cap - o) / 4);
+			for (uint32_t k = 0; k < nw; k++) w[k] = 0;
+		});
+	}
+	x3_foreach(nYc, st, X3_LAMBDA(size_t i) {
 		const uint32_t ln = len[i];
 		if (!ln) return;
-		const uint32_t c = find_chunk(d_yo, nc, (uint32_t)i);
+		const uint32_t c = find_chunk(d_yoc, nc, (uint32_t)i);
 		uint32_t *out32 = (uint32_t *)(d_out + d_chunks[c].out_off);
 		const uint32_t capw = (uint32_t)(d_chunks[c].out_cap / 4);
 		const uint32_t n = x3_rec_n(rec_nk[2 * i], rec_nk[2 * i + 1]), pd = ln - n;
-		const uint64_t bp = pos[i] - pos[d_yo[c]];
+		const uint64_t bp = pos[i] - pos[d_yoc[c]];
 		const uint32_t rev = x3_brev32(rec_nk[2 * i] << 1) & (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1)); /* bit j = j-th emitted bit = bit 30-j of lo */
 		if (!pd) x3_or_bits(out32, capw, bp, rev, n);
 		else {
@@ -1046,8 +1079,8 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	x3_foreach(nc, st, X3_LAMBDA(size_t c) { /* ac_encode_flush (ac.c:115-126) + bio_close (bio.c:105-112) + result */
 		uint32_t *out32 = (uint32_t *)(d_out + d_chunks[c].out_off);
 		const uint32_t capw = (uint32_t)(d_chunks[c].out_cap / 4);
-		const uint32_t last = d_yo[c + 1] - 1;
-		uint64_t nbits = pos[d_yo[c + 1]] - pos[d_yo[c]];
+		const uint32_t last = d_yoc[c + 1] - 1;
+		uint64_t nbits = pos[d_yoc[c + 1]] - pos[d_yoc[c]];
 		if (m_finallo[c] < 0x20000000u) {
 			x3_or_run(out32, capw, nbits + 1, 1u, pend[last] + 1); /* '0' then mScale+1 ones */
 			nbits += 2 + (uint64_t)pend[last];
@@ -1064,6 +1097,6 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		d_result[c] = r;
 	});
 	(void)tok_nb;
-	B.last.symbols = nY;
+	B.last.symbols = nYraw;
 	return X3H_OK;
 }

@@ -85,6 +85,7 @@ struct X3Code2Bufs {
 	hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
 	X3Code2Stats last = { 0, 0, 0, 0, 0, 0 };
 	DevBuf y[12]; /* u32 arrays over coded symbols */
+	DevBuf yraw;  /* symbol operands before the no-op symbols are dropped */
 	DevBuf pp[4]; /* token post-pass temporaries */
 	DevBuf ms[16]; /* u32 arrays over new-fragment lengths / bytes */
 };
@@ -99,7 +100,7 @@ int x3_token_postpass(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk
  * them on its own stream, so the recurrence of one segment overlaps the parse and the feature passes of the next. */
 struct X3CodeSeg {
 	bool final;                  /* the prefix is the whole stream: E_EOF, flush and bit emission happen in this call           */
-	uint32_t steps_done, y_done; /* steps / symbols already handed to the coder by earlier calls (updated by the call)          */
+	uint32_t steps_done, y_done, y_raw_done; /* steps / chain symbols / symbols incl. no-ops already handed on by earlier calls (updated by the call) */
 	hipStream_t coder_stream;
 	hipEvent_t ev_ready, ev_coder_begin, ev_coder_end; /* symbols assembled (feature stream); around the recurrence (coder stream) */
 	uint32_t *coder_state;       /* device: {lo, R} carried from segment to segment; {0, 0x80000000} before the first           */
