@@ -66,6 +66,9 @@ typedef struct x3h_stats {
 	uint64_t coded_symbols; /* arithmetic-coder symbols (ac_encode calls) of the batch                   */
 	int64_t  mode_iters;    /* K3: fixed-point iterations of the mode choice (0: the serial kernel decided;  */
 	                        /*     < 0: no fixed point within the cap, the serial kernel ran after all)       */
+	uint64_t chain_symbols; /* symbols the coder recurrence processed (coded_symbols minus the no-op ones)   */
+	uint64_t pipelined;     /* 1: single-stream schedule with overlapped stages (ms_parse, ms_features,      */
+	                        /*    ms_modes, ms_coder are then per-stage sums that overlap inside ms_total)    */
 } x3h_stats;
 
 typedef struct x3h_ctx x3h_ctx; /* one per GPU: device, stream, growable workspace */

@@ -503,10 +503,12 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 			stats->ms_emit = stats->ms_code - stats->ms_features - stats->ms_modes - stats->ms_coder;
 			stats->coded_symbols = c->c2.last.symbols;
 			stats->mode_iters = c->c2.last.mode_iters;
+			stats->chain_symbols = c->c2.last.chain_symbols;
 		}
 		if (pipe) { /* overlapped stages: each from its own events (their sum exceeds ms_total) */
 			stats->ms_parse = ps.ms_parse; stats->ms_features = ps.ms_features; stats->ms_modes = ps.ms_modes; stats->ms_coder = ps.ms_coder;
 			stats->ms_emit = 0; stats->mode_iters = ps.mode_iters; stats->coded_symbols = c->c2.last.symbols;
+			stats->chain_symbols = c->c2.last.chain_symbols; stats->pipelined = 1;
 		}
 	}
 	return rc;
@@ -537,7 +539,7 @@ static int run(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage upto
 			for (int e = 0; e < 5; e++) acc.events[e] += part.events[e];
 			acc.dict_elems += part.dict_elems; acc.ctx0_entries += part.ctx0_entries; acc.steps += part.steps; acc.coded_symbols += part.coded_symbols;
 			acc.ms_total += part.ms_total; acc.ms_scan += part.ms_scan; acc.ms_parse += part.ms_parse; acc.ms_code += part.ms_code; acc.ms_copy += part.ms_copy;
-			acc.ms_features += part.ms_features; acc.ms_modes += part.ms_modes; acc.ms_coder += part.ms_coder; acc.ms_emit += part.ms_emit; acc.mode_iters += part.mode_iters;
+			acc.ms_features += part.ms_features; acc.ms_modes += part.ms_modes; acc.ms_coder += part.ms_coder; acc.ms_emit += part.ms_emit; acc.mode_iters += part.mode_iters; acc.chain_symbols += part.chain_symbols; acc.pipelined |= part.pipelined;
 		}
 		first = last;
 	}

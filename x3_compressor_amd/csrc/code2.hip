@@ -1013,7 +1013,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		if (aa.seg_end > aa.seg_begin) { launch_ac2(aa, 1, seg->coder_stream); HIPCHK(hipGetLastError()); }
 		HIPCHK(hipEventRecord(seg->ev_coder_end, seg->coder_stream));
 		seg->steps_done = (uint32_t)nS; seg->y_done = (uint32_t)nYc; seg->y_raw_done = (uint32_t)nYraw;
-		B.last.symbols = nYraw;
+		B.last.symbols = nYraw; B.last.chain_symbols = nYc;
 		if (!final) return X3H_OK;
 		HIPCHK(hipStreamWaitEvent(st, seg->ev_coder_end, 0)); /* emission needs every record */
 	}
@@ -1097,6 +1097,6 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		d_result[c] = r;
 	});
 	(void)tok_nb;
-	B.last.symbols = nYraw;
+	B.last.symbols = nYraw; B.last.chain_symbols = nYc;
 	return X3H_OK;
 }

@@ -70,15 +70,15 @@ __device__ static void x3_walk_body(const X3WalkArgs &a)
 		uint32_t s = j < a.total ? a.S4[j] - 3u : NONE32; /* q < 3 wraps to a huge value: fails the window test like any out-of-class entry */
 		uint32_t lcp = 0;
 		bool inwin = false;
-		if (s != NONE32 && s <= wend) {
-			if (load_gram(b, s, 4) == g) {
-				inwin = true;
-				lcp = 32;
-#pragma unroll
-				for (int k = 7; k >= 1; k--) {
-					const uint32_t x = load_gram(b, (uint64_t)s + 4 * k, 4) ^ look[wv][k];
-					if (x) lcp = 4 * k + ((uint32_t)x3_ctz32(x) >> 3);
-				}
+		if (s != NONE32 && s <= wend && load_gram(b, s, 4) == g) { inwin = true; lcp = 4; }
+		/* extend word by word while some lane still matches everything so far (typical common prefixes are short: one or two rounds
+		 * instead of seven unconditional gram loads per candidate) */
+		for (uint32_t k = 1; k < 8; k++) {
+			const bool alive = inwin && lcp == 4 * k;
+			if (!x3_ballot(alive)) break;
+			if (alive) {
+				const uint32_t x = load_gram(b, (uint64_t)s + 4 * k, 4) ^ look[wv][k];
+				lcp = x ? 4 * k + ((uint32_t)x3_ctz32(x) >> 3) : 4 * k + 4;
 			}
 		}
 		const uint64_t inm = x3_ballot(inwin);

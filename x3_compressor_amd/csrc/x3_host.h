@@ -76,14 +76,14 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
                    const uint8_t *d_bytes, uint8_t *d_m, uint64_t total, uint32_t window, int32_t T);
 
 /* ---- v2 coding stage (code2.hip) ------------------------------------------------------------------------- */
-struct X3Code2Stats { double ms_features, ms_modes, ms_coder, ms_emit; uint64_t symbols; int mode_iters; /* fixed-point iterations of the mode choice (0: serial kernel, < 0: not converged, serial kernel ran) */ };
+struct X3Code2Stats { double ms_features, ms_modes, ms_coder, ms_emit; uint64_t symbols, chain_symbols; int mode_iters; /* fixed-point iterations of the mode choice (0: serial kernel, < 0: not converged, serial kernel ran) */ };
 
 struct X3Code2Bufs {
 	DevBuf tmp, offs, chunkmeta;
 	DevBuf a[48]; /* u32 work arrays of max(hits, events)+4 entries */
 	DevBuf idxfreq, hsym, maxred;
 	hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
-	X3Code2Stats last = { 0, 0, 0, 0, 0, 0 };
+	X3Code2Stats last = { 0, 0, 0, 0, 0, 0, 0 };
 	DevBuf y[12]; /* u32 arrays over coded symbols */
 	DevBuf yraw;  /* symbol operands before the no-op symbols are dropped */
 	DevBuf pp[4]; /* token post-pass temporaries */
