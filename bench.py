@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=256 * 1024)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--chunks", type=int, default=64, help="also report the same bytes as N independent chunks in one batch (0/1: skip)")
-    ap.add_argument("--many-chunks-mib", type=int, default=64, help="also report a batch of this many MiB cut into 256 KiB chunks (0: skip)")
+    ap.add_argument("--many-chunks-mib", type=int, default=256, help="also report a batch of this many MiB cut into 256 KiB chunks (0: skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -184,10 +184,10 @@ def main():
         dom = max((k for k in kernels if kernels[k]["alg_bytes"]), key=lambda k: kernels[k]["ms"])
         traffic, traffic_src = None, None
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(pmc_path):  # HBM bytes per launch from separate rocprofv3 --pmc passes of this same command
+        if os.path.exists(pmc_path):  # HBM bytes from separate rocprofv3 --pmc passes of this same command (tools/pmc_agg.py), summed over the kernel's launches of one step
             pmc = json.load(open(pmc_path))
             if dom in pmc.get("kernels", {}):
-                traffic, traffic_src = pmc["kernels"][dom]["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
+                traffic, traffic_src = pmc["kernels"][dom]["hbm_bytes_per_step"], "profiles/r01_pmc_traffic.json (per step = all launches of the kernel; algorithmic_bytes likewise)"
         path_bytes = S * W + N + comp  # the path's algorithmic bytes B_alg = S*W + N + C
         line = {
             "metric": "compress MB/s + ratio, Silesia 'dickens' -w 64 -t 256, at 1/2/4/8 MI355X",

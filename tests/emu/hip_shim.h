@@ -7,7 +7,7 @@
 #include <time.h>
 
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorOutOfMemory = 2 };
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorNotReady = 600 };
 typedef void *hipStream_t;
 struct x3emu_event { double t; };
 typedef x3emu_event *hipEvent_t;

@@ -247,10 +247,23 @@ static int pipe_setup(x3h_ctx *c)
 	return X3H_OK;
 }
 
+static int run_pipelined_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, uint32_t *tok_pos, uint32_t *tok_hb, uint32_t *tok_nb, uint32_t *tok_mb,
+                              uint8_t *d_out, PipeStats *ps);
+
 static int run_pipelined(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, uint32_t *tok_pos, uint32_t *tok_hb, uint32_t *tok_nb, uint32_t *tok_mb,
                          uint8_t *d_out, PipeStats *ps)
 {
 	CHK(pipe_setup(c));
+	const int rc = run_pipelined_body(c, pa, d_bytes, tok_pos, tok_hb, tok_nb, tok_mb, d_out, ps);
+	if (rc != X3H_OK) { /* never return with the parse or a coder segment still running on the side streams */
+		(void)hipStreamSynchronize(c->s_parse); (void)hipStreamSynchronize(c->s_coder); (void)hipStreamSynchronize(c->stream);
+	}
+	return rc;
+}
+
+static int run_pipelined_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, uint32_t *tok_pos, uint32_t *tok_hb, uint32_t *tok_nb, uint32_t *tok_mb,
+                              uint8_t *d_out, PipeStats *ps)
+{
 	const uint32_t n = c->hchunks[0].len;
 	static const double marks[] = { 0.02, 0.08, 0.26, 0.62 };
 	pa.nckpt = 0;
@@ -302,8 +315,12 @@ static int run_pipelined(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, ui
 				break;
 			}
 		if (!have) {
-			if (!parse_done && hipEventQuery(c->ev_p1) == hipSuccess) parse_done = true;
-			if (!parse_done) continue; /* spin: the wait is a few ms at most and a checkpoint should be picked up at once */
+			if (!parse_done) {
+				const hipError_t q = hipEventQuery(c->ev_p1);
+				if (q == hipSuccess) parse_done = true;
+				else if (q != hipErrorNotReady) { x3_last_hip = (int)q; return X3H_E_HIP; } /* the parse kernel faulted: do not spin on it */
+			}
+			if (!parse_done) continue; /* spin: a checkpoint should be picked up at once (the waits are milliseconds) */
 			/* the whole stream is parsed: final call with the kernel's own result */
 			HIPCHK(hipStreamSynchronize(c->s_parse));
 			c->hparse.resize(1);
