@@ -275,22 +275,25 @@ __device__ static __forceinline__ uint4 x3_make_symbol(uint32_t cum, uint32_t fr
  * D = nhi - nlo = sf - 1 and b = its top bit:  s = clz(D) - 1 - carry, where carry = the carry into bit b of nlo + D == NOT bit b of
  * (nlo ^ nhi)  (bit b of D is 1).  Both kinds of shift are left shifts that scale the range: lo' = (nlo << s) mod 2^30, R' = sf << s.
  * One clz, one bit test and a subtract-with-borrow replace the E1/E2/E3 loops: 17 scalar instructions per symbol in all.
- * Nothing is written to the bit stream here: the record (nlo, nhi) goes out, and the emit stage derives n (E1/E2 count), k (E3
- * count), the mScale bookkeeping and the bit placement from the records with prefix sums.
+ * Nothing is written to the bit stream here, not even a record per symbol: the chain stores its STATE (lo, R) once per group of
+ * X3_AC2_G = 8 symbols (at the slot of the group's first symbol); the emit stage re-runs the eight steps of every group in parallel
+ * (x3_expand_records) to get the per-symbol intervals (nlo, nhi), and derives n (E1/E2 count), k (E3 count), the mScale bookkeeping
+ * and the bit placement from those with prefix sums.  (A record store per symbol pair cost the chain 7 %.)
  * D != 0 always: sf >= step >= 2^29 / total, and a model total stays < 2^28 (a stream is at most 2^27 bytes, X3H_MAX_CHUNK).
  */
+#define X3_AC2_G 8u   /* symbols per stored chain state */
 #define X3_SYM_PAD 72 /* readable operand entries behind the last symbol (the chain fetches one group of 8 ahead) */
 #ifndef X3_EMU
 /* Everything on the chain lives in SGPRs.  Operands arrive by s_load_dwordx16 (4 symbols per load, 8 symbols = one "group" per
- * ping-pong register set, fetched one group ahead of their use), records leave by s_store_dwordx4 (two records) through the scalar
+ * ping-pong register set, fetched one group ahead of their use), the state leaves by one s_store_dwordx2 per group through the scalar
  * data cache (written back once at the end): no VALU, no LDS and no v_readlane on the chain.  A vector load per 512 symbols touches
  * the operand lines far ahead of the scalar loads, so those hit in L2.  Scalar memory returns out of order, so the only usable wait
  * is lgkmcnt(0); the load of the NEXT group is therefore issued right after the wait for the current one.  The asm blocks carry the
  * in-flight registers as "+s" operands so the compiler keeps them pinned and orders their uses behind the wait.
  * The operand array has X3_SYM_PAD readable entries behind the last symbol, so the fetch one group ahead needs no clamping.
  * lo is NOT reduced mod 2^30 after the shift: the two stray bits (30, 31) never reach a bit the chain looks at (they cancel in
- * nlo ^ nhi at bit 30, the only place they could matter) and are shifted out or stay put; the records carry them along and
- * x3_rec_fix (parallel, emit stage) removes them again: 14 instructions per symbol + 0.5 for the store. */
+ * nlo ^ nhi at bit 30, the only place they could matter) and are shifted out or stay put; x3_expand_records re-runs the chain with
+ * the same unreduced lo and takes the stray bits off the intervals it writes: 14 instructions per symbol + 1/8 store. */
 typedef uint32_t x3_u32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t x3_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -307,15 +310,19 @@ typedef uint32_t x3_u32x4 __attribute__((ext_vector_type(4)));
 		lo = NLO << sh;                                                                                                         \
 		R = sf << sh;                                                                                                           \
 	}
-#define X3_AC2_PAIR(Q, J, OFF)                                                                                                  \
+#define X3_AC2_STATE(OFF)                                                                                                       \
 	{                                                                                                                           \
-		x3_u32x4 rr;                                                                                                            \
-		X3_AC2_SYM(Q, J, rr[0], rr[1])                                                                                          \
-		X3_AC2_SYM(Q, (J) + 1, rr[2], rr[3])                                                                                    \
-		asm volatile("s_store_dwordx4 %0, %1, %2" : : "s"(rr), "s"(recp), "n"(OFF) : "memory");                                \
+		const uint64_t stt = ((uint64_t)R << 32) | lo;                                                                          \
+		asm volatile("s_store_dwordx2 %0, %1, %2" : : "s"(stt), "s"(recp), "n"(OFF) : "memory");                               \
 	}
 #define X3_AC2_GROUP(Q0, Q1, OFF)                                                                                               \
-	X3_AC2_PAIR(Q0, 0, (OFF)) X3_AC2_PAIR(Q0, 2, (OFF) + 16) X3_AC2_PAIR(Q1, 0, (OFF) + 32) X3_AC2_PAIR(Q1, 2, (OFF) + 48)
+	{                                                                                                                           \
+		uint32_t nl_, nh_;                                                                                                      \
+		X3_AC2_STATE(OFF)                                                                                                       \
+		X3_AC2_SYM(Q0, 0, nl_, nh_) X3_AC2_SYM(Q0, 1, nl_, nh_) X3_AC2_SYM(Q0, 2, nl_, nh_) X3_AC2_SYM(Q0, 3, nl_, nh_)          \
+		X3_AC2_SYM(Q1, 0, nl_, nh_) X3_AC2_SYM(Q1, 1, nl_, nh_) X3_AC2_SYM(Q1, 2, nl_, nh_) X3_AC2_SYM(Q1, 3, nl_, nh_)          \
+		(void)nl_; (void)nh_;                                                                                                   \
+	}
 /* wait for everything in flight (the group about to be used included), then start the loads of the group after it */
 #define X3_AC2_FETCH(N0, N1, C0, C1, OFF)                                                                                       \
 	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_load_dwordx16 %0, %4, %5\n\ts_load_dwordx16 %1, %4, %5+0x40"                         \
@@ -363,15 +370,14 @@ __device__ static void x3_ac2_body(const X3Ac2Args &a)
 		}
 		asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : : "v"(dummy) : "memory"); /* the last prefetches */
 	}
+	if ((G << 3) < Y) X3_AC2_STATE(0) /* the (shorter) last group */
 	for (uint32_t y = G << 3; y < Y; y++) { /* < 8 leftover symbols */
 		x3_u32x4 Q;
 		uint32_t nlo, nhi;
 		asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(Q) : "s"(symp) : "memory");
 		X3_AC2_SYM(Q, 0, nlo, nhi)
-		const uint64_t rec = ((uint64_t)nhi << 32) | nlo;
-		asm volatile("s_store_dwordx2 %0, %1, 0x0" : : "s"(rec), "s"(recp) : "memory");
+		(void)nlo; (void)nhi;
 		symp += 16;
-		recp += 8;
 	}
 	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" : : : "memory"); /* records: scalar cache -> L2 */
 	if (lane == 0) {
@@ -394,8 +400,8 @@ __device__ static void x3_ac2_body(const X3Ac2Args &a)
 		const uint32_t nlo = lo + step * q.x, sf = step * q.y, D = sf - 1, nhi = nlo + D;
 		const uint32_t cz = (uint32_t)x3_clz32(D), t = 31u - cz;
 		const uint32_t sh = cz - 1 - ((((nlo ^ nhi) >> t) & 1u) ^ 1u);
-		if (lane == 0) { a.rec_nk[2 * (size_t)(y0 + y)] = nlo; a.rec_nk[2 * (size_t)(y0 + y) + 1] = nhi; }
-		lo = nlo << sh; /* not reduced mod 2^30, like the device chain: x3_rec_fix removes the stray bits from the records */
+		if (lane == 0 && (y % X3_AC2_G) == 0) { a.rec_nk[2 * (size_t)(y0 + y)] = lo; a.rec_nk[2 * (size_t)(y0 + y) + 1] = R; } /* the state before the group */
+		lo = nlo << sh; /* not reduced mod 2^30, like the device chain */
 		R = sf << sh;
 	}
 	x3_wave_sync();
@@ -429,13 +435,20 @@ __device__ static __forceinline__ uint32_t x3_rec_k(uint32_t nlo, uint32_t nhi)
 	return (uint32_t)x3_clz32(y) - 2;
 }
 
-/* The chain keeps lo unreduced, so a record (nlo, nhi) carries the two stray top bits of the state it started from:
- * lo_before = (previous nlo) << (previous shift) as the chain computed it; its bits 30..31 are what has to come off both words. */
-__device__ static __forceinline__ uint32_t x3_rec_stray(uint32_t pl, uint32_t ph)
+/* One step of the coder chain exactly as x3_ac2_kernel takes it (lo unreduced), for the parallel re-run of a group: returns the
+ * narrowed interval with the stray top bits of lo removed, advances (lo, R). */
+__device__ static __forceinline__ uint2 x3_chain_step(uint32_t &lo, uint32_t &R, const uint4 q)
 {
-	const uint32_t D = ph - pl, cz = (uint32_t)x3_clz32(D), t = 31u - cz;
-	const uint32_t sh = cz - 1 - ((((pl ^ ph) >> t) & 1u) ^ 1u);
-	return (pl << sh) & 0xC0000000u;
+	const uint32_t step = (uint32_t)(((uint64_t)R * q.z) >> 32) >> q.w;
+	const uint32_t nlo = lo + step * q.x, sf = step * q.y, D = sf - 1, nhi = nlo + D;
+	const uint32_t cz = (uint32_t)x3_clz32(D), t = 31u - cz;
+	const uint32_t sh = cz - 1 - ((((nlo ^ nhi) >> t) & 1u) ^ 1u);
+	const uint32_t stray = lo & 0xC0000000u;
+	uint2 r;
+	r.x = nlo - stray; r.y = nhi - stray;
+	lo = nlo << sh;
+	R = sf << sh;
+	return r;
 }
 
 /* OR `nbits` (<= 32) bits of `val` into the little-endian 32-bit word stream at bit position `bitpos` (bio.c:49-72 layout) */
@@ -1006,13 +1019,15 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		HIPCHK(hipEventRecord(B.ev[4], st));
 	} else {
 		/* the new symbols [y_done, nY) go to the coder stream; this (feature) stream carries on with the next prefix */
-		aa.seg_state = seg->coder_state; aa.seg_begin = seg->y_done; aa.seg_end = (uint32_t)nYc;
+		/* a non-final segment ends on a group boundary (the stream starts at symbol 0): the few symbols left over go with the next one */
+		const uint32_t seg_end = final ? (uint32_t)nYc : (uint32_t)nYc - (uint32_t)nYc % X3_AC2_G;
+		aa.seg_state = seg->coder_state; aa.seg_begin = seg->y_done; aa.seg_end = seg_end > seg->y_done ? seg_end : seg->y_done;
 		HIPCHK(hipEventRecord(seg->ev_ready, st));
 		HIPCHK(hipStreamWaitEvent(seg->coder_stream, seg->ev_ready, 0));
 		HIPCHK(hipEventRecord(seg->ev_coder_begin, seg->coder_stream));
 		if (aa.seg_end > aa.seg_begin) { launch_ac2(aa, 1, seg->coder_stream); HIPCHK(hipGetLastError()); }
 		HIPCHK(hipEventRecord(seg->ev_coder_end, seg->coder_stream));
-		seg->steps_done = (uint32_t)nS; seg->y_done = (uint32_t)nYc; seg->y_raw_done = (uint32_t)nYraw;
+		seg->steps_done = (uint32_t)nS; seg->y_done = aa.seg_end; seg->y_raw_done = (uint32_t)nYraw;
 		B.last.symbols = nYraw; B.last.chain_symbols = nYc;
 		if (!final) return X3H_OK;
 		HIPCHK(hipStreamWaitEvent(st, seg->ev_coder_end, 0)); /* emission needs every record */
@@ -1022,13 +1037,20 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	 * pending after symbol i  = sum of k over (last symbol that shifted out bits (n>=1) or stream start .. i]
 	 * bits written by symbol i = n + pending before it (when n >= 1): first bit, the pending bits inverted, the other n-1 bits */
 	uint32_t *kk = Yv[5], *rv = Yv[6], *Kex = Yv[7], *LE = Yv[8], *len = Yv[9], *pos = Yv[10], *pend = Yv[11];
-	uint32_t *rec_fx = Yv[0]; /* the operand array is dead now: the records with the stray bits removed go there */
+	uint32_t *rec_fx = (uint32_t *)syr; /* the uncompacted operand array is dead now: the per-symbol intervals go there */
 	{
-		const uint32_t *rg = rec_nk;
+		/* x3_expand_records: the chain left its state at the first symbol of every group of X3_AC2_G; one thread re-runs each group */
+		const uint32_t *stt = rec_nk;
+		const uint4 *syc = sy;
 		x3_foreach(nYc, st, X3_LAMBDA(size_t i) {
 			const uint32_t c = find_chunk(d_yoc, nc, (uint32_t)i);
-			const uint32_t g2 = i == d_yoc[c] ? 0u : x3_rec_stray(rg[2 * i - 2], rg[2 * i - 1]);
-			rec_fx[2 * i] = rg[2 * i] - g2; rec_fx[2 * i + 1] = rg[2 * i + 1] - g2;
+			if (((uint32_t)i - d_yoc[c]) % X3_AC2_G) return;
+			uint32_t lo = stt[2 * i], R = stt[2 * i + 1];
+			const uint32_t end = d_yoc[c + 1], cnt = end - (uint32_t)i < X3_AC2_G ? end - (uint32_t)i : X3_AC2_G;
+			for (uint32_t j = 0; j < cnt; j++) {
+				const uint2 r = x3_chain_step(lo, R, syc[i + j]);
+				rec_fx[2 * (i + j)] = r.x; rec_fx[2 * (i + j) + 1] = r.y;
+			}
 		});
 		rec_nk = rec_fx;
 	}
