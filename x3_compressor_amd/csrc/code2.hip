@@ -46,35 +46,92 @@ __device__ static __forceinline__ uint32_t find_chunk(const uint32_t *off, uint3
 /* ============================================================================================================
  * CSB: cnt_out[i] = #{ j < i : bucket(j) == bucket(i) and key[j] < key[i] }, buckets = contiguous ranges [bs[i], be[i]).
  * key/bs/be are clobbered.  scratch: 9 arrays of n+1 u32.
+ *
+ * MSB-first stable partition, TWO key bits per level (wavelet-tree construction, radix 4).  An element of digit d has every
+ * earlier element of its bucket with a smaller digit as a "smaller before".  The per-digit prefix counts are not full-size scans:
+ * a counting kernel writes, per element, its exclusive digit counts INSIDE its block of 1024 positions (3 x 10 bits in one word)
+ * plus three totals per block; the block totals are scanned (a tiny array) and  Z_d(x) = blockbase_d[x >> 10] + field_d(packed[x]).
+ * Per two key bits an element costs one 4-byte read + one 4-byte write (count) and 24 B in / 20 B out (partition), against
+ * ~128 B with one scanned flag array per bit: the levels run at HBM speed, so fewer bytes is the only way to make them faster.
  * ============================================================================================================ */
+#define X3_CSB_BLK 1024u
+struct X3CsbCountArgs { const uint32_t *key; uint32_t *packed, *tot; uint32_t n, shift, dmask, nblk; };
+
+__device__ static void x3_csb_count_body(const X3CsbCountArgs &a)
+{
+	X3_LDS uint32_t wtot[X3_CSB_BLK / X3_WAVE][3];
+	const uint32_t tid = threadIdx.x, lane = x3_lane(), wave = tid / X3_WAVE;
+	const uint32_t i = blockIdx.x * X3_CSB_BLK + tid;
+	const uint32_t d = i < a.n ? (a.key[i] >> a.shift) & a.dmask : 3u; /* positions >= n count for no digit */
+	const uint64_t below = ((uint64_t)1 << lane) - 1;
+	uint32_t e[3];
+#pragma unroll
+	for (uint32_t dd = 0; dd < 3; dd++) {
+		const uint64_t m = x3_ballot(d == dd);
+		e[dd] = (uint32_t)x3_popc64(m & below);
+		if (lane == 0) wtot[wave][dd] = (uint32_t)x3_popc64(m);
+	}
+	__syncthreads();
+#pragma unroll
+	for (uint32_t dd = 0; dd < 3; dd++) {
+		uint32_t acc = 0;
+		for (uint32_t w = 0; w < wave; w++) acc += wtot[w][dd];
+		e[dd] += acc;
+	}
+	if (i <= a.n) a.packed[i] = e[0] | e[1] << 10 | e[2] << 20; /* exclusive counts inside the block: <= 1023 each */
+	if (tid == X3_CSB_BLK - 1) {
+#pragma unroll
+		for (uint32_t dd = 0; dd < 3; dd++) a.tot[dd * a.nblk + blockIdx.x] = e[dd] + (d == dd ? 1u : 0u);
+	}
+}
+
+#ifndef X3_EMU
+__global__ void __launch_bounds__(X3_CSB_BLK) x3_csb_count_kernel(X3CsbCountArgs a) { x3_csb_count_body(a); }
+static void launch_csb_count(const X3CsbCountArgs &a, hipStream_t st) { hipLaunchKernelGGL(x3_csb_count_kernel, dim3(a.nblk), dim3(X3_CSB_BLK), 0, st, a); }
+#else
+static void csb_count_tramp(void *p) { x3_csb_count_body(*(const X3CsbCountArgs *)p); }
+static void launch_csb_count(const X3CsbCountArgs &a, hipStream_t) { x3emu_launch(csb_count_tramp, (void *)&a, dim3(a.nblk), dim3(X3_CSB_BLK)); }
+#endif
+
 static int csb_run(X3Code2Bufs &B, hipStream_t st, size_t n, int bits, uint32_t *key, uint32_t *bs, uint32_t *be,
                    uint32_t *cnt_out, uint32_t *const *scratch)
 {
 	if (!n) return X3H_OK;
 	uint32_t *key2 = scratch[0], *org = scratch[1], *org2 = scratch[2], *bs2 = scratch[3], *be2 = scratch[4];
-	uint32_t *cnt = scratch[5], *cnt2 = scratch[6], *z = scratch[7], *Z = scratch[8];
+	uint32_t *cnt = scratch[5], *cnt2 = scratch[6], *packed = scratch[7];
 	if (bits < 1) bits = 1;
-	{
-		const uint32_t *k = key;
-		const int b0 = bits - 1;
-		x3_foreach(n, st, X3_LAMBDA(size_t i) { org[i] = (uint32_t)i; cnt[i] = 0; z[i] = ((k[i] >> b0) & 1u) ^ 1u; });
-	}
-	for (int b = bits - 1; b >= 0; b--) {
-		CHK(x3p_excl_scan(B.tmp, z, Z, n, st));
+	const uint32_t nblk = (uint32_t)((n + 1 + X3_CSB_BLK - 1) / X3_CSB_BLK);
+	CHK(B.csbsmall.reserve(((size_t)3 * nblk + 8) * 2 * 4));
+	uint32_t *tot = B.csbsmall.as<uint32_t>(), *S = tot + (size_t)3 * nblk + 4;
+	x3_foreach(n, st, X3_LAMBDA(size_t i) { org[i] = (uint32_t)i; cnt[i] = 0; });
+	for (int hi = bits; hi > 0;) {
+		const int w = (hi & 1) ? 1 : 2; /* an odd bit count starts with a one-bit level */
+		const uint32_t shift = (uint32_t)(hi - w), dmask = (1u << w) - 1;
+		hi -= w;
+		X3CsbCountArgs ca;
+		ca.key = key; ca.packed = packed; ca.tot = tot; ca.n = (uint32_t)n; ca.shift = shift; ca.dmask = dmask; ca.nblk = nblk;
+		launch_csb_count(ca, st);
+		HIPCHK(hipGetLastError());
+		CHK(x3p_excl_scan(B.tmp, tot, S, (size_t)3 * nblk, st)); /* one scan over [digit 0 blocks | digit 1 blocks | digit 2 blocks] */
 		{
-			/* stable partition of every bucket by bit b; an element with the bit set has every zero-bit element that precedes it in
-			 * its bucket as a "smaller before".  The flags of the next level are written at the element's new place on the way. */
-			const uint32_t *k = key, *o = org, *s_ = bs, *e_ = be, *c = cnt, *Zc = Z;
-			uint32_t *zn = z;
+			const uint32_t *k = key, *o = org, *s_ = bs, *e_ = be, *c = cnt, *pk = packed, *Sc = S;
 			x3_foreach(n, st, X3_LAMBDA(size_t i) {
-				const uint32_t s = s_[i], e = e_[i];
-				const uint32_t zb = Zc[i] - Zc[s], zc = Zc[e] - Zc[s];
-				const uint32_t kv = k[i];
-				uint32_t d, nbs, nbe, cv = c[i];
-				if (!((kv >> b) & 1u)) { d = s + zb; nbs = s; nbe = s + zc; }
-				else { d = s + zc + ((uint32_t)i - s - zb); nbs = s + zc; nbe = e; cv += zb; }
-				key2[d] = kv; org2[d] = o[i]; bs2[d] = nbs; be2[d] = nbe; cnt2[d] = cv;
-				if (b > 0) zn[d] = ((kv >> (b - 1)) & 1u) ^ 1u; /* safe in place: Z (the scan of z) is what this level reads */
+				const uint32_t s = s_[i], e = e_[i], kv = k[i], d = (kv >> shift) & dmask;
+				const uint32_t pi = pk[i], ps = pk[s], pe = pk[e];
+				const uint32_t bi = (uint32_t)i / X3_CSB_BLK, bsb = s / X3_CSB_BLK, beb = e / X3_CSB_BLK;
+				uint32_t zb[3], zc[3];
+#pragma unroll
+				for (uint32_t dd = 0; dd < 3; dd++) {
+					const uint32_t zs = Sc[dd * nblk + bsb] + ((ps >> (10 * dd)) & 1023u);
+					zb[dd] = Sc[dd * nblk + bi] + ((pi >> (10 * dd)) & 1023u) - zs;  /* digit dd before i in the bucket */
+					zc[dd] = Sc[dd * nblk + beb] + ((pe >> (10 * dd)) & 1023u) - zs; /* digit dd in the bucket */
+				}
+				uint32_t dst, nbs, nbe, cv = c[i];
+				if (d == 0) { nbs = s; nbe = s + zc[0]; dst = s + zb[0]; }
+				else if (d == 1) { nbs = s + zc[0]; nbe = nbs + zc[1]; dst = nbs + zb[1]; cv += zb[0]; }
+				else if (d == 2) { nbs = s + zc[0] + zc[1]; nbe = nbs + zc[2]; dst = nbs + zb[2]; cv += zb[0] + zb[1]; }
+				else { nbs = s + zc[0] + zc[1] + zc[2]; nbe = e; dst = nbs + ((uint32_t)i - s - zb[0] - zb[1] - zb[2]); cv += zb[0] + zb[1] + zb[2]; }
+				key2[dst] = kv; org2[dst] = o[i]; bs2[dst] = nbs; be2[dst] = nbe; cnt2[dst] = cv;
 			});
 		}
 		uint32_t *t;
@@ -712,6 +769,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	uint32_t *m_pairbase = B.chunkmeta.as<uint32_t>(), *m_npairs = m_pairbase + nc, *m_first00 = m_npairs + nc, *m_ord00 = m_first00 + nc;
 	CHK(B.maxred.reserve(64));
 	CHK(B.idxfreq.reserve((nDres + 4) * 4));
+	CHK(B.csbsmall.reserve(((size_t)3 * ((nA + 1) / X3_CSB_BLK + 2) + 8) * 2 * 4)); /* block totals of csb_run, sized once for every call */
 	const int NARR = 48;
 	static_assert(sizeof(B.a) / sizeof(B.a[0]) >= 48, "work arrays");
 	uint32_t *A[NARR];

@@ -81,7 +81,7 @@ struct X3Code2Stats { double ms_features, ms_modes, ms_coder, ms_emit; uint64_t 
 struct X3Code2Bufs {
 	DevBuf tmp, offs, chunkmeta;
 	DevBuf a[48]; /* u32 work arrays of max(hits, events)+4 entries */
-	DevBuf idxfreq, hsym, maxred;
+	DevBuf idxfreq, hsym, maxred, csbsmall;
 	hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
 	X3Code2Stats last = { 0, 0, 0, 0, 0, 0, 0 };
 	DevBuf y[12]; /* u32 arrays over coded symbols */
