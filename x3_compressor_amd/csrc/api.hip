@@ -37,7 +37,7 @@ struct x3h_ctx {
 	int code_v1 = 0, scan_v1 = 0;
 	/* single-stream pipelining (run_pipelined): the parse on its own stream publishes checkpoints, the coding stage of every prefix
 	 * runs while the parse continues, the coder recurrence of a segment on a third stream */
-	uint64_t pipe_min = (uint64_t)1 << 20; /* streams at least this long are pipelined (X3H_PIPE_MIN; 0: never) */
+	uint64_t pipe_min = (uint64_t)256 << 10; /* streams at least this long are pipelined (X3H_PIPE_MIN; 0: never): measured faster from 256 KiB up */
 	hipStream_t s_parse = nullptr, s_coder = nullptr;
 	hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr, ev_ready = nullptr, ev_cb[X3_MAX_CKPT + 1] = {}, ev_ce[X3_MAX_CKPT + 1] = {};
 	X3ParseCkpt *ckpt = nullptr; /* host-mapped */
