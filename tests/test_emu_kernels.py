@@ -107,3 +107,17 @@ def test_emulated_fixed_point_modes(emu_env, oracle, pipe):
     data, kw = synth.english_like(20000).tobytes(), dict(w_kib=4, t=8)
     assert ctx.compress(data, _lib.make_params(**kw)) == oracle.compress(data, oracle_lib.params(**kw))
     assert ctx.last_stats.mode_iters > 0
+
+
+def test_emulated_pipelined_several_streams(emu_env, oracle):
+    """run_pipelined with a batch: ragged streams (an empty and a 2-byte one among them), per-stream checkpoints, per-stream coder segments
+    in the operand / state rings, gather into the final symbol layout"""
+    ctx = emu_env(X3H_PIPE_MIN="1")
+    kw = dict(w_kib=2, t=8)
+    parts = [synth.english_like(9000).tobytes(), b"", synth.zipf_bytes(3000).tobytes(), b"ab", synth.english_like(20000, seed=5).tobytes(), bytes(2500)]
+    data = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    off = np.cumsum([0] + [len(p) for p in parts]).astype(np.uint64)
+    streams = ctx.compress_chunks(data, off, _lib.make_params(**kw))
+    assert ctx.last_stats.pipelined == 1
+    for p, got in zip(parts, streams):
+        assert got == oracle.compress(p, oracle_lib.params(**kw))

@@ -291,3 +291,22 @@ def test_schedules_agree_on_a_long_stream(gpu, gpu_env, env):
     prm = _lib.make_params(w_kib=64, t=256)
     want = gpu.compress(data, prm)
     assert gpu_env(**env).compress(data, prm) == want
+
+
+def test_pipelined_batch_of_long_streams(gpu, gpu_env):
+    """a batch of a few long ragged streams (pipelined by default) == the same streams coded one by one with the sequential schedule;
+    + a batch above X3H_PIPE_STREAMS falls back to stage-after-stage"""
+    sizes = [700_000, 0, 1_300_000, 5, 400_000, 2_000_000]
+    text = synth.english_like(sum(sizes), seed=99)
+    zipf = synth.zipf_bytes(1_300_000)
+    off = np.cumsum([0] + sizes).astype(np.uint64)
+    data = text.copy()
+    data[int(off[2]):int(off[3])] = zipf
+    prm = _lib.make_params(w_kib=64, t=256)
+    streams = gpu.compress_chunks(data, off, prm)
+    assert gpu.last_stats.pipelined == 1
+    seq = gpu_env(X3H_PIPE_MIN="0")
+    for i in range(len(sizes)):
+        assert streams[i] == seq.compress(data[int(off[i]):int(off[i + 1])].tobytes(), prm), f"stream {i}"
+    few = gpu_env(X3H_PIPE_STREAMS="2")
+    assert few.compress_chunks(data, off, prm) == streams and few.last_stats.pipelined == 0

@@ -37,11 +37,14 @@ struct x3h_ctx {
 	int code_v1 = 0, scan_v1 = 0;
 	/* single-stream pipelining (run_pipelined): the parse on its own stream publishes checkpoints, the coding stage of every prefix
 	 * runs while the parse continues, the coder recurrence of a segment on a third stream */
+	int pipe_max_streams = 32; /* X3H_PIPE_STREAMS */
 	uint64_t pipe_min = (uint64_t)256 << 10; /* streams at least this long are pipelined (X3H_PIPE_MIN; 0: never): measured faster from 256 KiB up */
 	hipStream_t s_parse = nullptr, s_coder = nullptr;
 	hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr, ev_ready = nullptr, ev_cb[X3_MAX_CKPT + 1] = {}, ev_ce[X3_MAX_CKPT + 1] = {};
-	X3ParseCkpt *ckpt = nullptr; /* host-mapped */
-	DevBuf coder_state, prefix_result, srcoff;
+	X3ParseCkpt *ckpt = nullptr; /* host-mapped, X3_CKPT_SLOTS per stream */
+	uint32_t ckpt_cap = 0;
+	X3CodeSeg seg;
+	DevBuf coder_state, prefix_result, srcoff, ckpt_pos;
 	uint64_t batch_bytes = (uint64_t)1 << 30;
 	uint64_t pad_total = 0;
 	DevBuf mtf, idxfreq, ctx1, ctx0, items, pkey, pval, out, counts;
@@ -109,6 +112,7 @@ extern "C" int x3h_ctx_create(x3h_ctx **out, int device)
 	{ const char *e = getenv("X3H_SCAN_V1"); c->scan_v1 = e && *e && *e != '0'; }
 	{ const char *e = getenv("X3H_BATCH_BYTES"); if (e && atoll(e) > 0) c->batch_bytes = (uint64_t)atoll(e); }
 	{ const char *e = getenv("X3H_PIPE_MIN"); if (e && *e) c->pipe_min = (uint64_t)atoll(e); }
+	{ const char *e = getenv("X3H_PIPE_STREAMS"); if (e && *e) c->pipe_max_streams = atoi(e); }
 	if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return X3H_E_HIP; }
 	for (int i = 0; i < 6; i++)
 		if (hipEventCreate(&c->ev[i]) != hipSuccess) { x3h_ctx_destroy(c); return X3H_E_HIP; }
@@ -125,7 +129,8 @@ extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 		               &c->c2.tmp, &c->c2.offs, &c->c2.chunkmeta, &c->c2.idxfreq, &c->c2.hsym, &c->c2.maxred, &c->c2.pp[0], &c->c2.pp[1], &c->c2.pp[2], &c->c2.pp[3],
 		               &c->cresult, &c->mtf, &c->idxfreq, &c->ctx1, &c->ctx0, &c->items, &c->pkey, &c->pval, &c->out, &c->counts, &c->din, &c->dchunks };
 	for (DevBuf *b : bufs) b->release();
-	c->coder_state.release(); c->prefix_result.release(); c->srcoff.release();
+	c->coder_state.release(); c->prefix_result.release(); c->srcoff.release(); c->ckpt_pos.release(); c->seg.meta.release();
+	c->c2.yfin.release(); c->c2.yfinrec.release();
 	if (c->ckpt) (void)hipHostFree((void *)c->ckpt);
 	if (c->s_parse) (void)hipStreamDestroy(c->s_parse);
 	if (c->s_coder) (void)hipStreamDestroy(c->s_coder);
@@ -241,9 +246,6 @@ static int pipe_setup(x3h_ctx *c)
 	HIPCHK(hipStreamCreate(&c->s_coder));
 	HIPCHK(hipEventCreate(&c->ev_p0)); HIPCHK(hipEventCreate(&c->ev_p1)); HIPCHK(hipEventCreate(&c->ev_ready));
 	for (int i = 0; i <= X3_MAX_CKPT; i++) { HIPCHK(hipEventCreate(&c->ev_cb[i])); HIPCHK(hipEventCreate(&c->ev_ce[i])); }
-	HIPCHK(hipHostMalloc((void **)&c->ckpt, sizeof(X3ParseCkpt) * X3_MAX_CKPT, hipHostMallocMapped | hipHostMallocCoherent));
-	CHK(c->coder_state.reserve(64));
-	CHK(c->prefix_result.reserve(sizeof(X3ParseResult)));
 	return X3H_OK;
 }
 
@@ -264,78 +266,121 @@ static int run_pipelined(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, ui
 static int run_pipelined_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, uint32_t *tok_pos, uint32_t *tok_hb, uint32_t *tok_nb, uint32_t *tok_mb,
                               uint8_t *d_out, PipeStats *ps)
 {
-	const uint32_t n = c->hchunks[0].len;
+	const uint32_t nc = (uint32_t)c->hchunks.size();
 	static const double marks[] = { 0.02, 0.08, 0.26, 0.62 };
-	pa.nckpt = 0;
-	for (double f : marks) { const uint32_t q = (uint32_t)((double)n * f); if (q > 0 && q < n && pa.nckpt < X3_MAX_CKPT) pa.ckpt_pos[pa.nckpt++] = q; }
-	memset((void *)c->ckpt, 0, sizeof(X3ParseCkpt) * X3_MAX_CKPT);
+	const uint32_t nmarks = (uint32_t)(sizeof(marks) / sizeof(marks[0]));
+	/* checkpoint memory (host-mapped) and the marks of every stream */
+	if (c->ckpt_cap < nc) {
+		if (c->ckpt) (void)hipHostFree((void *)c->ckpt);
+		c->ckpt = nullptr; c->ckpt_cap = 0;
+		HIPCHK(hipHostMalloc((void **)&c->ckpt, sizeof(X3ParseCkpt) * X3_CKPT_SLOTS * nc, hipHostMallocMapped | hipHostMallocCoherent));
+		c->ckpt_cap = nc;
+	}
+	memset((void *)c->ckpt, 0, sizeof(X3ParseCkpt) * X3_CKPT_SLOTS * nc);
+	std::vector<uint32_t> pos((size_t)nc * X3_MAX_CKPT, 0xFFFFFFFFu);
+	uint64_t nsum = 0;
+	for (uint32_t i = 0; i < nc; i++) {
+		const uint32_t n = c->hchunks[i].len;
+		nsum += n;
+		for (uint32_t k = 0; k < nmarks; k++) { const uint32_t q = (uint32_t)((double)n * marks[k]); if (q > 0 && q < n) pos[(size_t)i * X3_MAX_CKPT + k] = q; }
+	}
+	CHK(c->ckpt_pos.reserve(pos.size() * 4));
+	HIPCHK(hipMemcpyAsync(c->ckpt_pos.p, pos.data(), pos.size() * 4, hipMemcpyHostToDevice, c->stream));
+	CHK(c->coder_state.reserve((size_t)nc * 8));
+	CHK(c->prefix_result.reserve((size_t)nc * sizeof(X3ParseResult)));
+	std::vector<uint32_t> init((size_t)nc * 2);
+	for (uint32_t i = 0; i < nc; i++) { init[2 * i] = 0u; init[2 * i + 1] = 0x80000000u; } /* ac_init, ac.c:35-41 */
+	HIPCHK(hipMemcpyAsync(c->coder_state.p, init.data(), init.size() * 4, hipMemcpyHostToDevice, c->stream));
 	void *dck = nullptr;
 	HIPCHK(hipHostGetDevicePointer(&dck, (void *)c->ckpt, 0));
-	pa.ckpt = (X3ParseCkpt *)dck;
+	pa.ckpt = (X3ParseCkpt *)dck; pa.ckpt_pos = c->ckpt_pos.as<uint32_t>(); pa.nckpt = nmarks;
 	/* the parse starts behind the scan (main stream) and runs on its own stream from here on */
 	HIPCHK(hipEventRecord(c->ev_ready, c->stream));
 	HIPCHK(hipStreamWaitEvent(c->s_parse, c->ev_ready, 0));
 	HIPCHK(hipEventRecord(c->ev_p0, c->s_parse));
-	x3k_launch_parse(&pa, 1, c->s_parse);
+	x3k_launch_parse(&pa, nc, c->s_parse);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(c->ev_p1, c->s_parse));
-	const uint32_t init_state[2] = { 0u, 0x80000000u }; /* ac_init, ac.c:35-41 */
-	HIPCHK(hipMemcpyAsync(c->coder_state.p, init_state, 8, hipMemcpyHostToDevice, c->stream));
 
-	X3CodeSeg seg;
-	memset(&seg, 0, sizeof(seg));
-	seg.coder_stream = c->s_coder; seg.ev_ready = c->ev_ready; seg.coder_state = c->coder_state.as<uint32_t>();
-	seg.res_bytes = n;
-	uint32_t next = 0;
-	int nseg = 0;
+	X3CodeSeg &seg = c->seg;
+	seg.final = false; seg.coder_stream = c->s_coder; seg.ev_ready = c->ev_ready; seg.coder_state = c->coder_state.as<uint32_t>();
+	seg.y_done.assign(nc, 0u); seg.ring_top = 0; seg.calls.clear();
+	seg.res_steps = seg.res_hits = seg.res_elems = seg.res_mbytes = 0; seg.res_bytes = (size_t)nsum;
+	std::vector<X3ParseResult> pr(nc);
+	std::vector<int> avail(nc, -1); /* newest record seen per stream: -1 none, mark index, X3_MAX_CKPT = done */
+	int next = 0, nseg = 0;
 	bool parse_done = false;
 	for (;;) {
-		X3ParseResult pr;
-		memset(&pr, 0, sizeof(pr));
-		bool have = false, final = false;
-		/* newest checkpoint not consumed yet (a long step may skip marks; the emulator's parse has finished by now, so the test build
-		 * takes them oldest first to walk through every segment) */
+		/* newest record of every stream (a long step may skip marks); a prefix call is due when EVERY stream has passed the next mark */
+		int lowest = X3_MAX_CKPT;
+		for (uint32_t i = 0; i < nc; i++) {
+			const X3ParseCkpt *ck = c->ckpt + (size_t)i * X3_CKPT_SLOTS;
+			if (avail[i] < X3_MAX_CKPT) {
+				int best = avail[i];
+				if (ck[X3_MAX_CKPT].seq == X3_MAX_CKPT + 1) best = X3_MAX_CKPT;
+				else
 #ifndef X3_EMU
-		for (uint32_t k = pa.nckpt; k-- > next;)
+					for (int k = (int)nmarks - 1; k > avail[i]; k--) { if (ck[k].seq == (uint32_t)k + 1) { best = k; break; } }
 #else
-		for (uint32_t k = next; k < pa.nckpt; k++)
+					for (int k = avail[i] + 1; k < (int)nmarks; k++) { if (ck[k].seq == (uint32_t)k + 1) { best = k; if (k >= next) break; } } /* the emulator's parse has finished by now: walk through every mark */
 #endif
-			if (c->ckpt[k].seq == k + 1) {
-				pr.ntok = c->ckpt[k].ntok; pr.hits = c->ckpt[k].hits; pr.dict_elems = c->ckpt[k].dict_elems; pr.miss_bytes = c->ckpt[k].miss_bytes;
-				if (!seg.res_steps) { /* first look at the stream: size the workspace for all of it (x1.3; linear growth overestimates D) */
-					const double sc = 1.3 * (double)n / (double)(c->ckpt[k].p ? c->ckpt[k].p : 1);
-					seg.res_steps = (size_t)(pr.ntok * sc) + 4096; seg.res_hits = (size_t)(pr.hits * sc) + 4096;
-					seg.res_elems = (size_t)(pr.dict_elems * sc) + 4096; seg.res_mbytes = (size_t)(pr.miss_bytes * sc) + 4096;
-					if (seg.res_steps > (size_t)n + 16) seg.res_steps = (size_t)n + 16;
-					if (seg.res_hits > (size_t)n + 16) seg.res_hits = (size_t)n + 16;
-					if (seg.res_elems > (size_t)n + 16) seg.res_elems = (size_t)n + 16;
-					if (seg.res_mbytes > (size_t)n + 16) seg.res_mbytes = (size_t)n + 16;
+				if (best != avail[i]) {
+					avail[i] = best;
+					pr[i] = X3ParseResult();
+					pr[i].ntok = ck[best].ntok; pr[i].hits = ck[best].hits; pr[i].dict_elems = ck[best].dict_elems; pr[i].miss_bytes = ck[best].miss_bytes;
+					pr[i]._r0 = ck[best].p; /* (scratch) parse position of the record */
 				}
-				next = k + 1; have = true;
-				break;
 			}
-		if (!have) {
+			if (avail[i] < lowest) lowest = avail[i];
+		}
+		bool final = false;
+#ifdef X3_EMU
+		if (lowest == X3_MAX_CKPT && next < (int)nmarks) { /* test build: every stream is done already -- still take the marks one by one */
+			lowest = next;
+			for (uint32_t i = 0; i < nc; i++) {
+				const X3ParseCkpt *ck = c->ckpt + (size_t)i * X3_CKPT_SLOTS;
+				int k = next; while (k < (int)nmarks && ck[k].seq != (uint32_t)k + 1) k++;
+				const int use = k < (int)nmarks ? k : X3_MAX_CKPT;
+				pr[i] = X3ParseResult();
+				pr[i].ntok = ck[use].ntok; pr[i].hits = ck[use].hits; pr[i].dict_elems = ck[use].dict_elems; pr[i].miss_bytes = ck[use].miss_bytes; pr[i]._r0 = ck[use].p;
+			}
+		}
+#endif
+		if (lowest == X3_MAX_CKPT) {
+			/* every stream is parsed: final call with the kernel's own results */
+			HIPCHK(hipStreamSynchronize(c->s_parse));
+			c->hparse.resize(nc);
+			HIPCHK(hipMemcpyAsync(c->hparse.data(), c->presult.p, (size_t)nc * sizeof(X3ParseResult), hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(hipStreamSynchronize(c->stream));
+			pr = c->hparse;
+			final = true;
+		} else if (lowest < next) {
 			if (!parse_done) {
 				const hipError_t q = hipEventQuery(c->ev_p1);
-				if (q == hipSuccess) parse_done = true;
+				if (q == hipSuccess) parse_done = true; /* the done records are (about to be) visible */
 				else if (q != hipErrorNotReady) { x3_last_hip = (int)q; return X3H_E_HIP; } /* the parse kernel faulted: do not spin on it */
 			}
-			if (!parse_done) continue; /* spin: a checkpoint should be picked up at once (the waits are milliseconds) */
-			/* the whole stream is parsed: final call with the kernel's own result */
-			HIPCHK(hipStreamSynchronize(c->s_parse));
-			c->hparse.resize(1);
-			HIPCHK(hipMemcpyAsync(c->hparse.data(), c->presult.p, sizeof(X3ParseResult), hipMemcpyDeviceToHost, c->stream));
-			HIPCHK(hipStreamSynchronize(c->stream));
-			pr = c->hparse[0];
-			final = true;
+			continue; /* spin: a checkpoint should be picked up at once (the waits are milliseconds) */
 		}
+		if (!seg.res_steps) { /* first look at the streams: size the workspace for all of them (x1.3; linear growth overestimates D) */
+			double st_ = 0, hi_ = 0, el_ = 0, mb_ = 0;
+			for (uint32_t i = 0; i < nc; i++) {
+				const double sc = 1.3 * (double)c->hchunks[i].len / (double)(pr[i]._r0 ? pr[i]._r0 : 1);
+				st_ += pr[i].ntok * sc + 1024; hi_ += pr[i].hits * sc + 1024; el_ += pr[i].dict_elems * sc + 1024; mb_ += pr[i].miss_bytes * sc + 1024;
+			}
+			const double cap = (double)nsum + 16.0 * nc;
+			seg.res_steps = (size_t)(st_ < cap ? st_ : cap); seg.res_hits = (size_t)(hi_ < cap ? hi_ : cap);
+			seg.res_elems = (size_t)(el_ < cap ? el_ : cap); seg.res_mbytes = (size_t)(mb_ < cap ? mb_ : cap);
+		}
+		next = lowest + 1;
+		for (uint32_t i = 0; i < nc; i++) pr[i]._r0 = 0;
 		seg.final = final;
 		seg.ev_coder_begin = c->ev_cb[nseg]; seg.ev_coder_end = c->ev_ce[nseg];
-		HIPCHK(hipMemcpyAsync(c->prefix_result.p, &pr, sizeof(pr), hipMemcpyHostToDevice, c->stream));
+		HIPCHK(hipMemcpyAsync(c->prefix_result.p, pr.data(), (size_t)nc * sizeof(X3ParseResult), hipMemcpyHostToDevice, c->stream));
 		const X3ParseResult *d_pr = c->prefix_result.as<X3ParseResult>();
-		CHK(x3_token_postpass(c->c2, c->stream, 1, c->hchunks.data(), c->chunks.as<X3Chunk>(), d_pr, pa.tok_info, pa.dict_len,
-		                      tok_pos, tok_hb, tok_nb, tok_mb, pr.ntok ? pr.ntok : 1));
-		CHK(x3_code_v2_run(c->c2, c->stream, 1, c->hchunks.data(), c->chunks.as<X3Chunk>(), &pr, d_pr, d_bytes, tok_pos, pa.tok_info,
+		CHK(x3_token_postpass(c->c2, c->stream, (int)nc, c->hchunks.data(), c->chunks.as<X3Chunk>(), d_pr, pa.tok_info, pa.dict_len,
+		                      tok_pos, tok_hb, tok_nb, tok_mb, nc == 1 ? (pr[0].ntok ? pr[0].ntok : 1) : 0));
+		CHK(x3_code_v2_run(c->c2, c->stream, (int)nc, c->hchunks.data(), c->chunks.as<X3Chunk>(), pr.data(), d_pr, d_bytes, tok_pos, pa.tok_info,
 		                   tok_hb, tok_nb, tok_mb, d_out, c->cresult.as<X3CodeResult>(), &seg));
 		nseg++;
 		HIPCHK(hipStreamSynchronize(c->stream)); /* this stream only: the coder and the parse keep running */
@@ -391,7 +436,8 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 	if (upto == STAGE_SCAN) { HIPCHK(hipStreamSynchronize(c->stream)); return X3H_OK; }
 
 	/* ---- K2 ---- */
-	const bool pipe = upto == STAGE_CODE && !c->code_v1 && nc == 1 && c->pipe_min && c->hchunks[0].len >= c->pipe_min;
+	/* pipelined schedule: a few long streams (the serial chains dominate); many short ones run stage after stage (the chip-wide passes dominate) */
+	const bool pipe = upto == STAGE_CODE && !c->code_v1 && nc <= c->pipe_max_streams && c->pipe_min && max_len >= c->pipe_min;
 	X3ParseArgs pa;
 	pa.ckpt = nullptr; pa.nckpt = 0;
 	pa.bytes = sa.bytes; pa.chunks = sa.chunks; pa.m = sa.m;
@@ -415,7 +461,7 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 		if (upto == STAGE_PARSE) return X3H_OK;
 	} else {
 		HIPCHK(hipEventRecord(c->ev[3], c->stream)); /* the parse overlaps the coding stage (run_pipelined): its time is reported from its own events */
-		c->hparse.assign(1, X3ParseResult());
+		c->hparse.assign((size_t)nc, X3ParseResult());
 	}
 
 	/* ---- K3 workspace from the exact D / hits of every chunk ---- */

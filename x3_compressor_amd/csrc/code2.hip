@@ -303,8 +303,8 @@ struct X3Ac2Args {
 	const uint4 *sym;                     /* per symbol: {cum, freq, magic multiplier, shift} */
 	uint32_t *rec_nk;                     /* out per symbol: {lo, hi} after narrowing, before the renormalisation shift, as uint2 */
 	uint32_t *final_lo;                   /* out per chunk */
-	uint32_t *seg_state;                  /* nullptr: whole streams.  Else ONE stream, symbols [seg_begin, seg_end): {lo, R} in / out */
-	uint32_t seg_begin, seg_end;
+	const uint32_t *seg_off, *seg_len;    /* nullptr: whole streams (yo).  Else per stream: first symbol (ring coordinate) and count of this segment */
+	uint32_t *seg_state;                  /* ... and {lo, R} per stream, in / out */
 };
 
 /* range / total as a multiply-shift (Granlund-Montgomery, N = 31): L = ceil(log2 total) >= 1, m = ceil(2^(31+L)/total) in [2^31, 2^32),
@@ -389,7 +389,7 @@ __device__ static void x3_ac2_body(const X3Ac2Args &a)
 {
 	const uint32_t c = blockIdx.x, lane = x3_lane();
 	uint32_t y0, Y, lo = 0, R = 0x80000000u; /* ac_init, ac.c:35-41: [0, 0x7FFFFFFF] */
-	if (a.seg_state) { y0 = a.seg_begin; Y = a.seg_end - a.seg_begin; lo = x3_uniform(a.seg_state[0]); R = x3_uniform(a.seg_state[1]); }
+	if (a.seg_off) { y0 = x3_uniform(a.seg_off[c]); Y = x3_uniform(a.seg_len[c]); lo = x3_uniform(a.seg_state[2 * c]); R = x3_uniform(a.seg_state[2 * c + 1]); }
 	else { y0 = x3_uniform(a.yo[c]); Y = x3_uniform(a.yo[c + 1]) - y0; }
 	uint64_t symp = (uint64_t)(a.sym + y0);
 	uint64_t recp = (uint64_t)((uint2 *)a.rec_nk + y0);
@@ -439,7 +439,7 @@ __device__ static void x3_ac2_body(const X3Ac2Args &a)
 	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb\n\ts_waitcnt lgkmcnt(0)" : : : "memory"); /* records: scalar cache -> L2 */
 	if (lane == 0) {
 		a.final_lo[c] = lo & 0x3FFFFFFFu;
-		if (a.seg_state) { a.seg_state[0] = lo; a.seg_state[1] = R; } /* lo as the chain holds it (stray bits included): the next segment continues it */
+		if (a.seg_off) { a.seg_state[2 * c] = lo; a.seg_state[2 * c + 1] = R; } /* lo as the chain holds it (stray bits included): the next segment continues it */
 	}
 }
 #else
@@ -448,7 +448,7 @@ __device__ static void x3_ac2_body(const X3Ac2Args &a)
 {
 	const uint32_t c = blockIdx.x, lane = x3_lane();
 	uint32_t y0, Y, lo = 0, R = 0x80000000u;
-	if (a.seg_state) { y0 = a.seg_begin; Y = a.seg_end - a.seg_begin; lo = a.seg_state[0]; R = a.seg_state[1]; }
+	if (a.seg_off) { y0 = a.seg_off[c]; Y = a.seg_len[c]; lo = a.seg_state[2 * c]; R = a.seg_state[2 * c + 1]; }
 	else { y0 = a.yo[c]; Y = a.yo[c + 1] - y0; }
 	x3_wave_sync();
 	for (uint32_t y = 0; y < Y; y++) {
@@ -464,7 +464,7 @@ __device__ static void x3_ac2_body(const X3Ac2Args &a)
 	x3_wave_sync();
 	if (lane == 0) {
 		a.final_lo[c] = lo & 0x3FFFFFFFu;
-		if (a.seg_state) { a.seg_state[0] = lo; a.seg_state[1] = R; }
+		if (a.seg_off) { a.seg_state[2 * c] = lo; a.seg_state[2 * c + 1] = R; }
 	}
 }
 #endif
@@ -722,7 +722,6 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
                    const uint32_t *tok_nb, const uint32_t *tok_mb, uint8_t *d_out, X3CodeResult *d_result, X3CodeSeg *seg)
 {
 	const uint32_t nc = (uint32_t)nchunks;
-	if (seg && nc != 1) return X3H_E_ARG;
 	const bool final = !seg || seg->final;
 	for (int i = 0; i < 5; i++) if (!B.ev[i]) HIPCHK(hipEventCreate(&B.ev[i]));
 	HIPCHK(hipEventRecord(B.ev[0], st));
@@ -747,7 +746,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		if (seg->res_mbytes > nA) nA = seg->res_mbytes;
 		if (seg->res_steps > nA) nA = seg->res_steps;
 		if (seg->res_elems > nDres) nDres = seg->res_elems;
-		nYres = 3 * seg->res_bytes + 8; /* the operand and record arrays persist from call to call: their hard upper bound */
+		nYres = 3 * seg->res_bytes + 8 + (size_t)nc * 8 * (X3_MAX_CKPT + 3); /* the operand / state rings persist from call to call: hard upper bound (+ the < 8 symbols per stream and call that are put twice) */
 		if (seg->res_mbytes > nMSres) nMSres = seg->res_mbytes;
 		if (seg->res_steps > nMSres) nMSres = seg->res_steps;
 		CHK(B.tmp.reserve(24 * nA + ((size_t)8 << 20)));
@@ -1019,13 +1018,11 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	}
 	CHK(B.yraw.reserve((nYres + 4) * 16));
 	uint4 *syr = B.yraw.as<uint4>(); /* every symbol at its closed-form index (no-ops included) */
-	const uint32_t steps_done = seg ? seg->steps_done : 0u;
 	uint4 *sy = (uint4 *)Yv[0]; /* {cum, freq, magic, shift} per symbol */
 	uint32_t *rec_nk = Yv[3]; /* 2 words per symbol */
 	x3_foreach(nS, st, X3_LAMBDA(size_t gs) {
 		const uint32_t c = find_chunk(d_so, nc, (uint32_t)gs);
 		const uint32_t k = (uint32_t)gs - d_so[c];
-		if (k < steps_done) return; /* assembled by an earlier prefix call (the coder may be reading it right now) */
 		const uint64_t base = d_chunks[c].elem_off;
 		const uint32_t info = tok_info[base + k], hb = tok_hb[base + k], mb = tok_mb[base + k];
 		uint32_t yi = d_yo[c] + 2 * k + mb;
@@ -1054,41 +1051,90 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	/* ---- drop the no-op symbols (total == 1): the chain's input is the compacted list, everything downstream (records, emission)
 	 *      lives in compacted symbol indices.  A prefix of the raw list compacts to a prefix of the compacted list. ---- */
 	uint32_t *kf = Yv[5], *Pk = Yv[6];
-	const uint32_t y_raw_done = seg ? seg->y_raw_done : 0u;
 	x3_foreach(nY, st, X3_LAMBDA(size_t y) { kf[y] = syr[y].w != X3_SYM_NOOP ? 1u : 0u; });
 	CHK(x3p_excl_scan(B.tmp, kf, Pk, nY, st));
-	x3_foreach(nY, st, X3_LAMBDA(size_t y) { if (y >= y_raw_done && kf[y]) sy[Pk[y]] = syr[y]; });
 	x3_foreach(nc + 1, st, X3_LAMBDA(size_t c) { d_yoc[c] = Pk[d_yo[c]]; });
-	uint32_t nYc32 = 0;
-	HIPCHK(hipMemcpyAsync(&nYc32, Pk + nY, 4, hipMemcpyDeviceToHost, st));
+	std::vector<uint32_t> yoc(nc + 1);
+	HIPCHK(hipMemcpyAsync(yoc.data(), d_yoc, (nc + 1) * 4, hipMemcpyDeviceToHost, st));
 	HIPCHK(hipStreamSynchronize(st));
 	const size_t nYraw = nY;
-	const size_t nYc = nYc32;
+	const size_t nYc = yoc[nc];
 
 	/* ---- serial pass 2: interval recurrence ---- */
 	X3Ac2Args aa;
 	aa.yo = d_yoc; aa.sym = sy; aa.rec_nk = rec_nk; aa.final_lo = m_finallo;
-	aa.seg_state = nullptr; aa.seg_begin = aa.seg_end = 0;
+	aa.seg_off = aa.seg_len = nullptr; aa.seg_state = nullptr;
 	if (nH == 0) HIPCHK(hipEventRecord(B.ev[2], st));
 	if (!seg) {
+		x3_foreach(nY, st, X3_LAMBDA(size_t y) { if (kf[y]) sy[Pk[y]] = syr[y]; });
 		HIPCHK(hipEventRecord(B.ev[3], st));
 		launch_ac2(aa, nc, st);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipEventRecord(B.ev[4], st));
 	} else {
-		/* the new symbols [y_done, nY) go to the coder stream; this (feature) stream carries on with the next prefix */
-		/* a non-final segment ends on a group boundary (the stream starts at symbol 0): the few symbols left over go with the next one */
-		const uint32_t seg_end = final ? (uint32_t)nYc : (uint32_t)nYc - (uint32_t)nYc % X3_AC2_G;
-		aa.seg_state = seg->coder_state; aa.seg_begin = seg->y_done; aa.seg_end = seg_end > seg->y_done ? seg_end : seg->y_done;
+		/* the NEW chain symbols of every stream go into the ring and to the coder stream; this (feature) stream carries on with the
+		 * next prefix.  A non-final segment ends on a group boundary of its stream: the few symbols left over are put again next time. */
+		if (seg->y_done.size() != nc) seg->y_done.assign(nc, 0u);
+		const size_t kcall = seg->calls.size();
+		if (kcall >= X3_MAX_CKPT + 2) return X3H_E_INTERNAL;
+		seg->calls.emplace_back();
+		X3CodeSegCall &cl = seg->calls.back();
+		cl.base = seg->ring_top; cl.off.resize(nc + 1); cl.len.resize(nc); cl.before.resize(nc);
+		uint64_t acc = 0;
+		for (uint32_t c = 0; c < nc; c++) {
+			const uint32_t cntc = yoc[c + 1] - yoc[c], newc = cntc - seg->y_done[c];
+			cl.off[c] = (uint32_t)(cl.base + acc); cl.before[c] = seg->y_done[c];
+			cl.len[c] = final ? newc : newc - newc % X3_AC2_G;
+			acc += newc;
+		}
+		cl.off[nc] = (uint32_t)(cl.base + acc); cl.total = acc;
+		if (cl.base + acc > nYres) return X3H_E_INTERNAL; /* the ring bound is a hard bound: cannot happen */
+		CHK(seg->meta.reserve((size_t)(X3_MAX_CKPT + 2) * (3 * (size_t)nc + 1) * 4));
+		uint32_t *d_off = seg->meta.as<uint32_t>() + kcall * (3 * (size_t)nc + 1), *d_len = d_off + (nc + 1), *d_before = d_len + nc;
+		HIPCHK(hipMemcpyAsync(d_off, cl.off.data(), (nc + 1) * 4, hipMemcpyHostToDevice, st));
+		HIPCHK(hipMemcpyAsync(d_len, cl.len.data(), nc * 4, hipMemcpyHostToDevice, st));
+		HIPCHK(hipMemcpyAsync(d_before, cl.before.data(), nc * 4, hipMemcpyHostToDevice, st));
+		{
+			const uint32_t *doff = d_off, *dbef = d_before;
+			x3_foreach(nY, st, X3_LAMBDA(size_t y) {
+				if (!kf[y]) return;
+				const uint32_t c = find_chunk(d_yo, nc, (uint32_t)y);
+				const uint32_t r = Pk[y] - d_yoc[c];
+				if (r >= dbef[c]) sy[doff[c] + (r - dbef[c])] = syr[y];
+			});
+		}
+		aa.seg_off = d_off; aa.seg_len = d_len; aa.seg_state = seg->coder_state;
 		HIPCHK(hipEventRecord(seg->ev_ready, st));
 		HIPCHK(hipStreamWaitEvent(seg->coder_stream, seg->ev_ready, 0));
 		HIPCHK(hipEventRecord(seg->ev_coder_begin, seg->coder_stream));
-		if (aa.seg_end > aa.seg_begin) { launch_ac2(aa, 1, seg->coder_stream); HIPCHK(hipGetLastError()); }
+		launch_ac2(aa, nc, seg->coder_stream);
+		HIPCHK(hipGetLastError());
 		HIPCHK(hipEventRecord(seg->ev_coder_end, seg->coder_stream));
-		seg->steps_done = (uint32_t)nS; seg->y_done = aa.seg_end; seg->y_raw_done = (uint32_t)nYraw;
+		for (uint32_t c = 0; c < nc; c++) seg->y_done[c] += cl.len[c];
+		seg->ring_top += acc;
 		B.last.symbols = nYraw; B.last.chain_symbols = nYc;
 		if (!final) return X3H_OK;
-		HIPCHK(hipStreamWaitEvent(st, seg->ev_coder_end, 0)); /* emission needs every record */
+		HIPCHK(hipStreamWaitEvent(st, seg->ev_coder_end, 0)); /* emission needs every chain state */
+		/* final symbol layout: the operands once more (one scatter) and the chain states of every segment gathered from the ring */
+		CHK(B.yfin.reserve((nYc + X3_SYM_PAD) * 16));
+		CHK(B.yfinrec.reserve((nYc + 4) * 8));
+		uint4 *syf = B.yfin.as<uint4>();
+		uint32_t *recf = B.yfinrec.as<uint32_t>();
+		x3_foreach(nY, st, X3_LAMBDA(size_t y) { if (kf[y]) syf[Pk[y]] = syr[y]; });
+		for (size_t k = 0; k < seg->calls.size(); k++) {
+			const X3CodeSegCall &ck = seg->calls[k];
+			if (!ck.total) continue;
+			const uint32_t *koff = seg->meta.as<uint32_t>() + k * (3 * (size_t)nc + 1), *klen = koff + (nc + 1), *kbef = klen + nc;
+			const uint32_t *ring = rec_nk;
+			const uint32_t kbase = (uint32_t)ck.base;
+			x3_foreach((size_t)ck.total, st, X3_LAMBDA(size_t t) {
+				const uint32_t pos = kbase + (uint32_t)t, c = find_chunk(koff, nc, pos), rel = pos - koff[c];
+				if (rel >= klen[c] || rel % X3_AC2_G) return;
+				const size_t dst = (size_t)d_yoc[c] + kbef[c] + rel;
+				recf[2 * dst] = ring[2 * (size_t)pos]; recf[2 * dst + 1] = ring[2 * (size_t)pos + 1];
+			});
+		}
+		sy = syf; rec_nk = recf;
 	}
 
 	/* ---- bit emission (ac.c:49-67 put_bit + mScale, bio.c:49-72) as prefix sums over the records ----

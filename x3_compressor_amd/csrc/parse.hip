@@ -308,15 +308,15 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 		}
 		__syncthreads();
 		{ const uint64_t t = x3_clock(); cyc_walk += t - t_prev; t_prev = t; }
-		if (a.ckpt && blockIdx.x == 0 && S.nck < a.nckpt && S.p >= a.ckpt_pos[S.nck] && S.flag != FLAG_DONE) { /* uniform: S is stable between barriers */
+		if (a.ckpt && S.nck < a.nckpt && S.p >= a.ckpt_pos[blockIdx.x * X3_MAX_CKPT + S.nck] && S.flag != FLAG_DONE) { /* uniform: S is stable between barriers */
 			/* every token below S.ntok (and dict_len of every element) has been stored by SOME thread of this workgroup: each
 			 * thread releases its own stores to device scope, then one thread publishes the counters to the host */
 			__threadfence();
 			__syncthreads();
 			if (tid == 0) {
 				uint32_t k = S.nck;
-				while (k + 1 < a.nckpt && S.p >= a.ckpt_pos[k + 1]) k++; /* a long step may cross several marks: publish the last one only */
-				X3ParseCkpt *ck = a.ckpt + k;
+				while (k + 1 < a.nckpt && S.p >= a.ckpt_pos[blockIdx.x * X3_MAX_CKPT + k + 1]) k++; /* a long step may cross several marks: publish the last one only */
+				X3ParseCkpt *ck = a.ckpt + (size_t)blockIdx.x * X3_CKPT_SLOTS + k;
 				ck->p = S.p; ck->ntok = S.ntok; ck->hits = S.hits; ck->dict_elems = S.D; ck->miss_bytes = S.mbytes;
 				__threadfence_system();
 				ck->seq = k + 1;
@@ -324,6 +324,17 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 				S.nck = k + 1;
 			}
 			__syncthreads();
+		}
+	}
+	if (a.ckpt) { /* the chunk is parsed: its "done" record (the other chunks of the batch may still be running) */
+		__threadfence();
+		__syncthreads();
+		if (tid == 0) {
+			X3ParseCkpt *ck = a.ckpt + (size_t)blockIdx.x * X3_CKPT_SLOTS + X3_MAX_CKPT;
+			ck->p = S.p; ck->ntok = S.ntok; ck->hits = S.hits; ck->dict_elems = S.D; ck->miss_bytes = S.mbytes;
+			__threadfence_system();
+			ck->seq = X3_MAX_CKPT + 1;
+			__threadfence_system();
 		}
 	}
 

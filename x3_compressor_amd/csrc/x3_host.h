@@ -15,6 +15,7 @@
 
 #include <stddef.h>
 #include <stdint.h>
+#include <vector>
 
 extern thread_local int x3_last_hip;
 
@@ -86,6 +87,7 @@ struct X3Code2Bufs {
 	X3Code2Stats last = { 0, 0, 0, 0, 0, 0, 0 };
 	DevBuf y[12]; /* u32 arrays over coded symbols */
 	DevBuf yraw;  /* symbol operands before the no-op symbols are dropped */
+	DevBuf yfin, yfinrec; /* pipelined schedule, final call: operands / chain states gathered into the final symbol layout */
 	DevBuf pp[4]; /* token post-pass temporaries */
 	DevBuf ms[16]; /* u32 arrays over new-fragment lengths / bytes */
 };
@@ -95,16 +97,22 @@ int x3_token_postpass(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk
                       const X3ParseResult *d_parsed, const uint32_t *tok_info, const uint8_t *dict_len,
                       uint32_t *tok_pos, uint32_t *tok_hb, uint32_t *tok_nb, uint32_t *tok_mb, size_t prefix_tokens = 0);
 
-/* Coding a GROWING PREFIX of one stream while its parse is still running (api.hip, single-stream pipelining): every call recomputes
- * the (parallel) features of the whole prefix, assembles only the symbols of the new steps and queues the coder recurrence for
- * them on its own stream, so the recurrence of one segment overlaps the parse and the feature passes of the next. */
+/* Coding GROWING PREFIXES of a few long streams while their parse is still running (api.hip, pipelined schedule): every call
+ * recomputes the (parallel) features of the whole prefixes, puts the operands of the NEW chain symbols of every stream into a ring
+ * (bump-allocated, never moved) and queues the coder recurrence for them on its own HIP stream, so the recurrence of one segment
+ * overlaps the parse and the feature passes of the next.  The final call gathers the chain states of all segments into the final
+ * symbol layout and emits the bit streams. */
+struct X3CodeSegCall { uint64_t base, total; std::vector<uint32_t> off /* nc+1, ring coordinates */, len, before; };
 struct X3CodeSeg {
-	bool final;                  /* the prefix is the whole stream: E_EOF, flush and bit emission happen in this call           */
-	uint32_t steps_done, y_done, y_raw_done; /* steps / chain symbols / symbols incl. no-ops already handed on by earlier calls (updated by the call) */
-	hipStream_t coder_stream;
-	hipEvent_t ev_ready, ev_coder_begin, ev_coder_end; /* symbols assembled (feature stream); around the recurrence (coder stream) */
-	uint32_t *coder_state;       /* device: {lo, R} carried from segment to segment; {0, 0x80000000} before the first           */
-	size_t res_steps, res_hits, res_elems, res_mbytes, res_bytes; /* sizing estimates for the whole stream: nothing is reallocated while other streams run */
+	bool final = false;               /* the prefixes are the whole streams: E_EOF, flush and bit emission happen in this call      */
+	hipStream_t coder_stream = nullptr;
+	hipEvent_t ev_ready = nullptr, ev_coder_begin = nullptr, ev_coder_end = nullptr; /* symbols assembled (feature stream); around the recurrence (coder stream) */
+	uint32_t *coder_state = nullptr;  /* device: {lo, R} per stream, carried from segment to segment; {0, 0x80000000} before the first */
+	std::vector<uint32_t> y_done;     /* per stream: chain symbols already handed to the coder (a multiple of 8 until the final call)  */
+	uint64_t ring_top = 0;            /* bump pointer of the operand / state rings, in symbols                                     */
+	std::vector<X3CodeSegCall> calls; /* what every call put where                                                                 */
+	DevBuf meta;                      /* device copy of (off, len, before) of every call                                           */
+	size_t res_steps = 0, res_hits = 0, res_elems = 0, res_mbytes = 0, res_bytes = 0; /* sizing estimates for the whole batch: nothing is reallocated while other streams run */
 };
 
 int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h_chunks, const X3Chunk *d_chunks,

@@ -72,16 +72,18 @@ struct X3ScanArgs {
 #define X3_PARSE_PB      2048  /* positions whose dictionary matches are cached in LDS            */
 #define X3_HT_LOG2_MIN   10
 
-/* Progress checkpoints of a running parse (single-stream pipelining, api.hip): whenever the parse pointer of chunk 0 crosses
- * pos[k], the kernel makes every token written so far visible device-wide and publishes its counters to host-mapped memory;
- * the host then starts the coding stage of that prefix while the parse continues.  seq is written last (k + 1). */
-#define X3_MAX_CKPT 16
+/* Progress checkpoints of a running parse (pipelined schedule, api.hip): whenever the parse pointer of a chunk crosses one of its
+ * marks, the kernel makes every token of that chunk written so far visible device-wide and publishes the chunk's counters to
+ * host-mapped memory; the host starts the coding stage of the prefixes while the parse continues.  seq is written last (mark + 1).
+ * Slot X3_MAX_CKPT of a chunk is its "done" record (the final counters). */
+#define X3_MAX_CKPT 8
+#define X3_CKPT_SLOTS (X3_MAX_CKPT + 1)
 struct X3ParseCkpt { volatile uint32_t seq, p, ntok, hits, dict_elems, miss_bytes, _r0, _r1; };
 
 struct X3ParseArgs {
-	X3ParseCkpt *ckpt;          /* host-mapped, X3_MAX_CKPT entries; nullptr: no checkpoints                       */
+	X3ParseCkpt *ckpt;          /* host-mapped, X3_CKPT_SLOTS entries per chunk; nullptr: no checkpoints                */
+	const uint32_t *ckpt_pos;   /* device, X3_MAX_CKPT marks per chunk (0xFFFFFFFF: unused)                            */
 	uint32_t nckpt;
-	uint32_t ckpt_pos[X3_MAX_CKPT];
 	const uint8_t *bytes;
 	const X3Chunk *chunks;
 	const uint8_t *m;
