@@ -121,3 +121,10 @@ def test_emulated_pipelined_several_streams(emu_env, oracle):
     assert ctx.last_stats.pipelined == 1
     for p, got in zip(parts, streams):
         assert got == oracle.compress(p, oracle_lib.params(**kw))
+
+
+def test_emulated_csb_count_kernel_body(emu_env, oracle):
+    """the radix-4 count kernel itself (1024-thread workgroups) on the emulator, once; the other tests use its loop equivalent"""
+    ctx = emu_env(X3_EMU_CSB_KERNEL="1")
+    data, kw = synth.english_like(6000).tobytes(), dict(w_kib=2, t=8)
+    assert ctx.compress(data, _lib.make_params(**kw)) == oracle.compress(data, oracle_lib.params(**kw))

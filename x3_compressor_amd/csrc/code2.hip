@@ -89,8 +89,22 @@ __device__ static void x3_csb_count_body(const X3CsbCountArgs &a)
 __global__ void __launch_bounds__(X3_CSB_BLK) x3_csb_count_kernel(X3CsbCountArgs a) { x3_csb_count_body(a); }
 static void launch_csb_count(const X3CsbCountArgs &a, hipStream_t st) { hipLaunchKernelGGL(x3_csb_count_kernel, dim3(a.nblk), dim3(X3_CSB_BLK), 0, st, a); }
 #else
+/* test build: the same counts by a plain loop (1024-fiber workgroups make the CPU suite crawl; X3_EMU_CSB_KERNEL=1 runs the kernel body on the emulator) */
 static void csb_count_tramp(void *p) { x3_csb_count_body(*(const X3CsbCountArgs *)p); }
-static void launch_csb_count(const X3CsbCountArgs &a, hipStream_t) { x3emu_launch(csb_count_tramp, (void *)&a, dim3(a.nblk), dim3(X3_CSB_BLK)); }
+static void launch_csb_count(const X3CsbCountArgs &a, hipStream_t)
+{
+	if (getenv("X3_EMU_CSB_KERNEL")) { x3emu_launch(csb_count_tramp, (void *)&a, dim3(a.nblk), dim3(X3_CSB_BLK)); return; }
+	for (uint32_t b = 0; b < a.nblk; b++) {
+		uint32_t e[3] = { 0, 0, 0 };
+		for (uint32_t t = 0; t < X3_CSB_BLK; t++) {
+			const uint32_t i = b * X3_CSB_BLK + t;
+			if (i <= a.n) a.packed[i] = e[0] | e[1] << 10 | e[2] << 20;
+			const uint32_t d = i < a.n ? (a.key[i] >> a.shift) & a.dmask : 3u;
+			if (d < 3) e[d]++;
+		}
+		for (uint32_t dd = 0; dd < 3; dd++) a.tot[dd * a.nblk + b] = e[dd];
+	}
+}
 #endif
 
 static int csb_run(X3Code2Bufs &B, hipStream_t st, size_t n, int bits, uint32_t *key, uint32_t *bs, uint32_t *be,
