@@ -172,7 +172,7 @@ def main():
         W = args.w * 1024
         # Algorithmic bytes per launch of each kernel family (what the algorithm must move):
         kernels = {
-            "x3_ac2_kernel": {"ms": ms["ms_coder"], "alg_bytes": Yc * (16 + 8)},         # {cum, freq, magic, shift} in, {lo, hi} record out
+            "x3_ac2_kernel": {"ms": ms["ms_coder"], "alg_bytes": Yc * 16 + (Yc + 7) // 8 * 8},  # {cum, freq, magic, shift} in per symbol, one {lo, R} state out per 8 symbols
             "mode choice (fixed-point passes / x3_modes_kernel)": {"ms": ms["ms_modes"], "alg_bytes": H * (7 * 4 + 4)},  # 7 feature words in, mode out (per pass)
             "x3_parse_kernel": {"ms": ms["ms_parse"], "alg_bytes": 2 * N + 4 * S},        # bytes + m[] in, one token word out
             "scan (sort + lookup + x3_walk_kernel)": {"ms": ms["ms_scan"], "alg_bytes": S * W + N + comp},  # S*W + N + C
@@ -205,7 +205,7 @@ def main():
                          "frac": round(kernels[dom]["alg_bytes"] / (kernels[dom]["ms"] * 1e-3) / HBM_PEAK, 7), "traffic": traffic,
                          "traffic_source": traffic_src, "algorithmic_bytes": kernels[dom]["alg_bytes"], "kernel_ms": kernels[dom]["ms"],
                          "launches_per_step": 5 if int(st.pipelined) else 1,
-                         "note": "dominant kernel by time: ONE wavefront's dependent chain per stream, 14.5 scalar instructions per symbol at the 4-cycle single-wave issue rate (~62 cycles/symbol), operands and records through the scalar cache; HBM is the stated bound, not the limiter"},
+                         "note": "dominant kernel by time: ONE wavefront's dependent chain per stream, 14.2 scalar instructions per symbol at the 4-cycle single-wave issue rate, operands and chain states through the scalar cache (the 8-byte state stores cost a 32-byte sector each, hence traffic > algorithmic bytes); HBM is the stated bound, not the limiter"},
             "kernels": kernels,
             "path_roofline": {"algorithmic_bytes": path_bytes, "achieved_GBps": round(path_bytes / (ms_per_step * 1e-3) / 1e9, 2),
                               "frac_of_hbm_peak": round(path_bytes / (ms_per_step * 1e-3) / HBM_PEAK, 5),
