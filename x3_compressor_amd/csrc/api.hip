@@ -729,6 +729,9 @@ extern "C" int x3h_decompress_chunks(x3h_ctx *c, const uint8_t *in, const uint64
 	c->hcode.resize((size_t)nc);
 	HIPCHK(hipMemcpyAsync(c->hcode.data(), c->cresult.p, (size_t)nc * sizeof(X3CodeResult), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
+	if (getenv("X3H_DEBUG")) { const X3CodeResult &r = c->hcode[0];
+		fprintf(stderr, "[x3h] decode stream 0: out %u D %u pairs %u events %u %u %u %u | kcycles (profile builds): event %u symbol %u contexts %u tail %u\n",
+		        r.out_len, r._r, r.pairs, r.events[0], r.events[1], r.events[2], r.events[3], r.events[4], r.events[5], r.events[6], r.events[7]); }
 	int rc = X3H_OK;
 	for (int i = 0; i < nc; i++) {
 		const X3CodeResult &r = c->hcode[(size_t)i];

@@ -9,10 +9,27 @@
  *   dict_get_index_by_tag (dict.c:174-183) -> ballot search of the move-to-front list
  *   dict_query_elem (dict.c:148-157)     -> exact hash lookup; an element is a (pos,len) reference into the OUTPUT
  *   dict_update_costs + qsort            -> move-to-front (x3_tables.h)
+ * The chain is latency-bound (a dozen dependent global loads per step in the naive order), so the loop PREFETCHES the next step's
+ * context state as soon as it is known: the pair looked up / inserted at the end of a hit step (x3.c:213-222) IS the (prev, context1)
+ * pair the next step would look up, so its ordinal is carried over instead of probed again, and both context headers plus the first
+ * 64 items of either list are loaded at the end of a step -- they are in flight while the next event symbol is decoded.
  * Streams of a batch decode concurrently (grid = streams).  The reference's unchecked 64x output buffer (x3.c:621) is
  * replaced by a capacity check (X3_ST_OUT_FULL), malformed input ends in X3_ST_CORRUPT instead of abort() (ac.c:178).
  */
 #include "x3_tables.h"
+
+#ifdef X3_DEC_PROFILE /* experiment builds: cycles per section of the hit path, reported in the unused event slots */
+#define DPROF_T(var) const uint64_t var = x3_clock();
+#define DPROF_ADD(acc, a, b) acc += (b) - (a);
+#else
+#define DPROF_T(var)
+#define DPROF_ADD(acc, a, b)
+#endif
+
+/* The chain's state is wave-uniform, but every value that comes out of a (vector) load looks divergent to the compiler: pinning the
+ * loaded words with readfirstlane keeps the interval arithmetic, the bit reader and the control flow on the scalar unit. */
+__device__ static __forceinline__ uint64_t uni64(uint64_t v) { return ((uint64_t)x3_uniform((uint32_t)(v >> 32)) << 32) | x3_uniform((uint32_t)v); }
+__device__ static __forceinline__ X3CtxHdr uni_hdr(const X3CtxHdr h) { X3CtxHdr r; r.off = x3_uniform(h.off); r.items = x3_uniform(h.items); r.cap = x3_uniform(h.cap); r.total = x3_uniform(h.total); return r; }
 
 struct BitReader { /* bio.c:5-42 */
 	const uint8_t *p, *end;
@@ -23,7 +40,7 @@ __device__ static __forceinline__ uint32_t br_get(BitReader &r)
 {
 	if (r.cnt == 32) {
 		if (r.end - r.p >= 4) { /* bio.c:10,35-39: past the last whole word the reader feeds 0x80000000 */
-			r.acc = (uint32_t)r.p[0] | (uint32_t)r.p[1] << 8 | (uint32_t)r.p[2] << 16 | (uint32_t)r.p[3] << 24;
+			r.acc = x3_uniform((uint32_t)r.p[0] | (uint32_t)r.p[1] << 8 | (uint32_t)r.p[2] << 16 | (uint32_t)r.p[3] << 24);
 			r.p += 4;
 		} else r.acc = 0x80000000u;
 		r.cnt = 0;
@@ -54,16 +71,18 @@ __device__ static void dec_narrow(Dec &d, BitReader &r, uint32_t step, uint32_t 
 }
 
 __device__ static __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) { (void)lane; return x3_wave_incl_scan_u32(v); }
+/* value < incl  with  value = off / step (ac.c:128-131), without dividing:  off < incl * step  (step == 0: never, like a value out of range) */
+__device__ static __forceinline__ bool dec_below(uint32_t off, uint32_t step, uint32_t incl) { return (uint64_t)off < (uint64_t)incl * step; }
 
 /* find the symbol of a frequency array (global memory, `count` entries) that holds `value`; returns 0xFFFFFFFF if none */
-__device__ static uint32_t find_in_array(const uint32_t *freq, uint32_t count, uint32_t value, uint32_t lane, uint32_t &cum_out, uint32_t &fq_out)
+__device__ static uint32_t find_in_array(const uint32_t *freq, uint32_t count, uint32_t off, uint32_t step, uint32_t lane, uint32_t &cum_out, uint32_t &fq_out)
 {
 	uint32_t carry = 0;
 	for (uint32_t base = 0; base < count; base += X3_WAVE) {
 		const uint32_t i = base + lane;
 		const uint32_t fq = i < count ? freq[i] : 0;
 		const uint32_t incl = wave_incl_scan(fq, lane) + carry;
-		const uint64_t mask = x3_ballot(i < count && incl > value);
+		const uint64_t mask = x3_ballot(i < count && dec_below(off, step, incl));
 		if (mask) {
 			const uint32_t l = (uint32_t)x3_ctz64(mask);
 			fq_out = x3_bcast_u32(fq, (int)l);
@@ -76,15 +95,15 @@ __device__ static uint32_t find_in_array(const uint32_t *freq, uint32_t count, u
 }
 
 /* same over a context's item list; returns the list position */
-__device__ static uint32_t find_in_ctx(const X3CtxHdr h, const uint64_t *pool, uint32_t value, uint32_t lane, uint32_t &cum_out, uint32_t &fq_out, uint32_t &tag_out)
+__device__ static uint32_t find_in_ctx(const X3CtxHdr h, const uint64_t *pool, uint32_t off, uint32_t step, uint32_t lane, uint64_t first, uint32_t &cum_out, uint32_t &fq_out, uint32_t &tag_out)
 {
 	uint32_t carry = 0;
 	for (uint32_t base = 0; base < h.items; base += X3_WAVE) {
 		const uint32_t i = base + lane;
-		const uint64_t it = i < h.items ? pool[(uint64_t)h.off + i] : 0;
+		const uint64_t it = base == 0 ? first : (i < h.items ? pool[(uint64_t)h.off + i] : 0); /* items [0, 64) were prefetched with the header */
 		const uint32_t fq = (uint32_t)it;
 		const uint32_t incl = wave_incl_scan(fq, lane) + carry;
-		const uint64_t mask = x3_ballot(i < h.items && incl > value);
+		const uint64_t mask = x3_ballot(i < h.items && dec_below(off, step, incl));
 		if (mask) {
 			const uint32_t l = (uint32_t)x3_ctz64(mask);
 			fq_out = x3_bcast_u32(fq, (int)l);
@@ -95,6 +114,20 @@ __device__ static uint32_t find_in_ctx(const X3CtxHdr h, const uint64_t *pool, u
 		carry = x3_bcast_u32(incl, X3_WAVE - 1);
 	}
 	return 0xFFFFFFFFu;
+}
+
+/* position of `tag` in a context's item list (ctx_query_tag_item, context.c:20-40): all the model update needs -- no frequency sums */
+__device__ static CtxQ ctx_find_tag(const X3CtxHdr h, const uint64_t *pool, uint32_t tag, uint32_t lane, uint64_t first)
+{
+	CtxQ q;
+	q.found = 0; q.pos = 0; q.freq = 0; q.cum = 0;
+	for (uint32_t base = 0; base < h.items; base += X3_WAVE) {
+		const uint32_t i = base + lane;
+		const uint64_t it = base == 0 ? first : (i < h.items ? pool[(uint64_t)h.off + i] : 0);
+		const uint64_t mask = x3_ballot(i < h.items && (uint32_t)(it >> 32) == tag);
+		if (mask) { q.found = 1; q.pos = base + (uint32_t)x3_ctz64(mask); break; }
+	}
+	return q;
 }
 
 #ifndef X3_DEC_LDS
@@ -146,16 +179,23 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 	uint32_t cf0 = 1, cf1 = 1, cf2 = 1, cf3 = 1, cftotal = 256;
 	uint32_t D = 0, idxtotal = 0, npairs = 0, status = X3_ST_OK;
 	uint64_t pool_top = 0;
-	uint32_t prev1 = 0, ctx1tag = 0;
+	uint64_t pc_ev = 0, pc_sym = 0, pc_rank = 0, pc_ctx = 0, pc_tail = 0; (void)pc_ev; (void)pc_sym; (void)pc_rank; (void)pc_ctx; (void)pc_tail;
+	uint32_t ctx1tag = 0; /* context1; the (prev, context1) pair of x3.c:139 is tracked as its ordinal n_c0id */
 	uint32_t p = 0;
+	/* the context state of the NEXT hit step, loaded ahead: ctx0 ordinal (0 when the pair is unknown, x3.c:142-145), both headers, items [0,64) of both lists */
+	uint32_t n_c0id = 0;
+	X3CtxHdr n_h0 = ctx0[0], n_h1 = ctx1[0]; /* both empty at the start (zeroed workspace) */
+	uint64_t n_it0 = 0, n_it1 = 0;
 
 	for (;;) {
+		DPROF_T(t_a)
 		/* ---- the event (x3.c:293-295) ---- */
+		/* ac_decode_target + index_of_value (ac.c:128-131,167-179) without the second division:  (buf-lo)/step < c  <=>  buf-lo < c*step */
 		uint32_t step = (d.hi - d.lo + 1) / evtotal;
-		uint32_t value = step ? (d.buf - d.lo) / step : 0xFFFFFFFFu;
+		const uint32_t off_e = d.buf - d.lo;
 		uint32_t cum = 0, decision = 5;
 		for (uint32_t s = 0; s < 5; s++) {
-			if (value >= cum && value < cum + ev[s]) { decision = s; break; }
+			if ((uint64_t)off_e < (uint64_t)(cum + ev[s]) * step) { decision = s; break; }
 			cum += ev[s];
 		}
 		if (decision == 5) { status = X3_ST_CORRUPT; break; } /* the reference abort()s, ac.c:178 */
@@ -169,9 +209,8 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 			uint32_t len;
 			{
 				step = (d.hi - d.lo + 1) / lftotal;
-				value = step ? (d.buf - d.lo) / step : 0xFFFFFFFFu;
 				const uint32_t incl = wave_incl_scan(lane < 32 ? lf : 0u, lane);
-				const uint64_t mask = x3_ballot(lane < 32 && incl > value);
+				const uint64_t mask = x3_ballot(lane < 32 && dec_below(d.buf - d.lo, step, incl));
 				if (!mask) { status = X3_ST_CORRUPT; break; }
 				const uint32_t l = (uint32_t)x3_ctz64(mask);
 				const uint32_t fq = x3_bcast_u32(lf, (int)l), cl = x3_bcast_u32(incl, (int)l) - fq;
@@ -185,17 +224,17 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 			int bad = 0;
 			for (uint32_t j = 0; j < len; j++) {
 				step = (d.hi - d.lo + 1) / cftotal;
-				value = step ? (d.buf - d.lo) / step : 0xFFFFFFFFu;
+				const uint32_t offb = d.buf - d.lo;
 				const uint32_t s4 = cf0 + cf1 + cf2 + cf3;
 				const uint32_t incl = wave_incl_scan(s4, lane);
-				const uint64_t mask = x3_ballot(incl > value);
+				const uint64_t mask = x3_ballot(dec_below(offb, step, incl));
 				if (!mask) { bad = 1; break; }
 				const uint32_t l = (uint32_t)x3_ctz64(mask);
 				const uint32_t b0 = x3_bcast_u32(cf0, (int)l), b1 = x3_bcast_u32(cf1, (int)l), b2 = x3_bcast_u32(cf2, (int)l), b3 = x3_bcast_u32(cf3, (int)l);
 				uint32_t cl = x3_bcast_u32(incl, (int)l) - (b0 + b1 + b2 + b3), sub, fq;
-				if (value < cl + b0) { sub = 0; fq = b0; }
-				else if (value < cl + b0 + b1) { sub = 1; fq = b1; cl += b0; }
-				else if (value < cl + b0 + b1 + b2) { sub = 2; fq = b2; cl += b0 + b1; }
+				if (dec_below(offb, step, cl + b0)) { sub = 0; fq = b0; }
+				else if (dec_below(offb, step, cl + b0 + b1)) { sub = 1; fq = b1; cl += b0; }
+				else if (dec_below(offb, step, cl + b0 + b1 + b2)) { sub = 2; fq = b2; cl += b0 + b1; }
 				else { sub = 3; fq = b3; cl += b0 + b1 + b2; }
 				dec_narrow(d, br, step, cl, cl + fq);
 				if (lane == l) { if (sub == 0) cf0++; else if (sub == 1) cf1++; else if (sub == 2) cf2++; else cf3++; }
@@ -231,32 +270,38 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 				idxtotal++;
 			}
 			p += len;
-			prev1 = 0; ctx1tag = 0; /* x3.c:321-322 */
+			ctx1tag = 0; /* x3.c:321-322: both contexts reset */
 			x3_wave_sync();
+			{ /* the next hit step's contexts: pair (0, 0) if it is known, else context 0 */
+				const uint64_t key = 1;
+				uint32_t s = pair_slot(key, plog);
+				n_c0id = 0;
+				for (uint64_t kk = uni64(pkey[s]); kk != 0; s = (s + 1) & pmask, kk = uni64(pkey[s]))
+					if (kk == key) { n_c0id = x3_uniform(pval[s]); break; }
+				n_h0 = ctx0[n_c0id]; n_h1 = ctx1[0];
+				n_it0 = lane < n_h0.items ? pool[(uint64_t)n_h0.off + lane] : 0;
+				n_it1 = lane < n_h1.items ? pool[(uint64_t)n_h1.off + lane] : 0;
+			}
 			continue;
 		}
 
 		/* ---- decode_tag, x3.c:58-129 ---- */
+		DPROF_T(t_b)
+		DPROF_ADD(pc_ev, t_a, t_b)
 		if (D == 0) { status = X3_ST_CORRUPT; break; }
 		nev[decision]++;
-		uint32_t c0id = 0;
-		{
-			const uint64_t key = (((uint64_t)prev1 << 32) | ctx1tag) + 1;
-			uint32_t s = pair_slot(key, plog);
-			for (uint64_t kk = pkey[s]; kk != 0; s = (s + 1) & pmask, kk = pkey[s])
-				if (kk == key) { c0id = pval[s]; break; }
-		}
+		const uint32_t c0id = n_c0id;
 		X3CtxHdr *h0p = ctx0 + c0id, *h1p = ctx1 + ctx1tag;
-		const X3CtxHdr h0 = *h0p, h1 = *h1p;
-		uint32_t tag = 0, rank = 0;
+		const X3CtxHdr h0 = uni_hdr(n_h0), h1 = uni_hdr(n_h1); /* pinned here, not where the loads were issued: they stay in flight until now */
+		const uint64_t it0 = n_it0, it1 = n_it1;
+		uint32_t tag = 0, rank = 0, cpos = 0;
 		if (decision == X3_E_IDX1) {
 			step = (d.hi - d.lo + 1) / idxtotal;
-			value = step ? (d.buf - d.lo) / step : 0xFFFFFFFFu;
 			uint32_t cl = 0, fq = 0;
-			rank = find_in_array(idxfreq, D, value, lane, cl, fq);
+			rank = find_in_array(idxfreq, D, d.buf - d.lo, step, lane, cl, fq);
 			if (rank == 0xFFFFFFFFu) { status = X3_ST_CORRUPT; break; }
 			dec_narrow(d, br, step, cl, cl + fq);
-			tag = mtf[rank];
+			tag = x3_uniform(mtf[rank]);
 			x3_wave_sync();
 			if (lane == 0) idxfreq[rank] = fq + 1; /* inc_model(&model_index1, index), x3.c:89 */
 			idxtotal++;
@@ -264,10 +309,10 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 			const X3CtxHdr hc = decision == X3_E_CTX0 ? h0 : h1;
 			if (hc.items == 0 || hc.total == 0) { status = X3_ST_CORRUPT; break; }
 			step = (d.hi - d.lo + 1) / hc.total;
-			value = step ? (d.buf - d.lo) / step : 0xFFFFFFFFu;
 			uint32_t cl = 0, fq = 0;
-			const uint32_t pos = find_in_ctx(hc, pool, value, lane, cl, fq, tag);
+			const uint32_t pos = find_in_ctx(hc, pool, d.buf - d.lo, step, lane, decision == X3_E_CTX0 ? it0 : it1, cl, fq, tag);
 			if (pos == 0xFFFFFFFFu) { status = X3_ST_CORRUPT; break; }
+			cpos = pos;
 			dec_narrow(d, br, step, cl, cl + fq);
 			/* dict_get_index_by_tag (x3.c:79,84) */
 			uint32_t found = 0;
@@ -278,9 +323,12 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 			}
 			if (!found) { status = X3_ST_CORRUPT; break; }
 		}
+		DPROF_T(t_c)
+		DPROF_ADD(pc_sym, t_b, t_c)
 		/* x3.c:99-126: both contexts learn the tag, (context1, tag) becomes a known pair */
-		const CtxQ q0 = ctx_query(h0, pool, tag, lane);
-		const CtxQ q1 = ctx_query(h1, pool, tag, lane);
+		CtxQ q0, q1; /* the context the tag was decoded from already told its list position */
+		if (decision == X3_E_CTX0) { q0.found = 1; q0.pos = cpos; q0.freq = q0.cum = 0; } else q0 = ctx_find_tag(h0, pool, tag, lane, it0);
+		if (decision == X3_E_CTX1) { q1.found = 1; q1.pos = cpos; q1.freq = q1.cum = 0; } else q1 = ctx_find_tag(h1, pool, tag, lane, it1);
 		x3_wave_sync();
 		ctx_touch(h0p, h0, q0, tag, pool, pool_top, ck.item_cap, status, lane);
 		ctx_touch(h1p, h1, q1, tag, pool, pool_top, ck.item_cap, status, lane);
@@ -288,23 +336,31 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 		{
 			const uint64_t key = (((uint64_t)ctx1tag << 32) | tag) + 1;
 			uint32_t s = pair_slot(key, plog);
-			uint64_t kk = pkey[s];
-			while (kk != 0 && kk != key) { s = (s + 1) & pmask; kk = pkey[s]; }
+			uint64_t kk = uni64(pkey[s]);
+			while (kk != 0 && kk != key) { s = (s + 1) & pmask; kk = uni64(pkey[s]); }
 			x3_wave_sync();
 			if (kk == 0) {
 				if (lane == 0) { pkey[s] = key; pval[s] = npairs; }
+				n_c0id = npairs; /* this pair is the (prev, context1) of the next step: its ordinal is the next ctx0 id */
 				npairs++;
-			}
+			} else n_c0id = x3_uniform(pval[s]);
 		}
+		DPROF_T(t_d)
+		DPROF_ADD(pc_ctx, t_c, t_d)
 		/* x3.c:332-348: copy the element, move it to the front */
-		const uint32_t len = dlen[tag], src = dpos[tag];
+		const uint32_t len = x3_uniform(dlen[tag]), src = x3_uniform(dpos[tag]);
 		if ((uint64_t)p + len > cap) { status = X3_ST_OUT_FULL; break; }
 		if (lane < len) out[p + lane] = out[src + lane]; /* len <= 32; src + len <= p */
 		mtf_to_front(mtf, rank, tag, lane);
-		prev1 = ctx1tag;
-		ctx1tag = tag;
+		ctx1tag = tag; /* x3.c:346-347 */
 		p += len;
 		x3_wave_sync();
+		/* the next step's contexts, in flight while its event symbol is decoded (this step's updates are already stored) */
+		n_h0 = ctx0[n_c0id]; n_h1 = ctx1[ctx1tag];
+		n_it0 = lane < n_h0.items ? pool[(uint64_t)n_h0.off + lane] : 0;
+		n_it1 = lane < n_h1.items ? pool[(uint64_t)n_h1.off + lane] : 0;
+		DPROF_T(t_e)
+		DPROF_ADD(pc_tail, t_d, t_e)
 	}
 
 	if (lane == 0) {
@@ -312,6 +368,9 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 		r.out_len = p; r.status = status; r.pairs = npairs; r._r = D;
 		for (int i = 0; i < 4; i++) r.events[i] = nev[i];
 		r.events[4] = r.events[5] = r.events[6] = r.events[7] = 0;
+#ifdef X3_DEC_PROFILE
+		r.events[4] = (uint32_t)(pc_ev >> 10); r.events[5] = (uint32_t)(pc_sym >> 10); r.events[6] = (uint32_t)(pc_ctx >> 10); r.events[7] = (uint32_t)(pc_tail >> 10);
+#endif
 		a.result[blockIdx.x] = r;
 	}
 }

@@ -13,13 +13,14 @@ struct CtxQ { uint32_t found, pos, freq, cum; };
 
 /* one sweep of a context's items: position of `tag`, its freq and the cumulative freq before it
  * (ctx_query_tag_item / ctx_query_tag_index / count_cum_freqs, context.c:20-40,95-133) */
-__device__ static CtxQ ctx_query(const X3CtxHdr h, const uint64_t *pool, uint32_t tag, uint32_t lane)
+__device__ static CtxQ ctx_query(const X3CtxHdr h, const uint64_t *pool, uint32_t tag, uint32_t lane, bool have_first = false, uint64_t first = 0)
 {
+	/* have_first: the caller already holds items [0, 64) of the list (one per lane, 0 beyond the end) -- the decoder prefetches them */
 	CtxQ q;
 	q.found = 0; q.pos = 0; q.freq = 0; q.cum = 0;
 	for (uint32_t base = 0; base < h.items; base += X3_WAVE) {
 		const uint32_t i = base + lane;
-		const uint64_t it = i < h.items ? pool[(uint64_t)h.off + i] : 0;
+		const uint64_t it = (have_first && base == 0) ? first : (i < h.items ? pool[(uint64_t)h.off + i] : 0);
 		const uint32_t fq = (uint32_t)it;
 		const uint64_t mask = x3_ballot(i < h.items && (uint32_t)(it >> 32) == tag);
 		if (mask) {
