@@ -48,7 +48,7 @@ struct x3h_ctx {
 	uint64_t batch_bytes = (uint64_t)1 << 30;
 	uint64_t pad_total = 0;
 	DevBuf mtf, idxfreq, ctx1, ctx0, items, pkey, pval, out, counts;
-	DevBuf din, dchunks; /* decoder: input streams, stream table */
+	DevBuf din, dchunks, items_ord; /* decoder: input streams, stream table, pair ordinal per context item */
 	std::vector<X3Chunk> hchunks;
 	std::vector<X3ParseResult> hparse;
 	std::vector<X3CodeResult> hcode;
@@ -127,7 +127,7 @@ extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	DevBuf *bufs[] = { &c->pad, &c->m, &c->dict_pos, &c->dict_len, &c->ht, &c->tok_pos, &c->tok_info, &c->tok_hb, &c->tok_nb, &c->tok_mb, &c->chunks, &c->presult,
 		               &c->c2.tmp, &c->c2.offs, &c->c2.chunkmeta, &c->c2.idxfreq, &c->c2.hsym, &c->c2.maxred, &c->c2.pp[0], &c->c2.pp[1], &c->c2.pp[2], &c->c2.pp[3],
-		               &c->cresult, &c->mtf, &c->idxfreq, &c->ctx1, &c->ctx0, &c->items, &c->pkey, &c->pval, &c->out, &c->counts, &c->din, &c->dchunks };
+		               &c->cresult, &c->mtf, &c->idxfreq, &c->ctx1, &c->ctx0, &c->items, &c->pkey, &c->pval, &c->out, &c->counts, &c->din, &c->dchunks, &c->items_ord };
 	for (DevBuf *b : bufs) b->release();
 	c->coder_state.release(); c->prefix_result.release(); c->srcoff.release(); c->ckpt_pos.release(); c->seg.meta.release();
 	c->c2.yfin.release(); c->c2.yfinrec.release();
@@ -706,7 +706,7 @@ extern "C" int x3h_decompress_chunks(x3h_ctx *c, const uint8_t *in, const uint64
 	CHK(c->dict_pos.reserve(toff * 4)); CHK(c->dict_len.reserve(toff));
 	CHK(c->mtf.reserve(toff * 4)); CHK(c->idxfreq.reserve(toff * 4));
 	CHK(c->ctx1.reserve(toff * sizeof(X3CtxHdr))); CHK(c->ctx0.reserve(c0off * sizeof(X3CtxHdr)));
-	CHK(c->items.reserve(itoff * 8)); CHK(c->pkey.reserve(poff * 8)); CHK(c->pval.reserve(poff * 4)); CHK(c->ht.reserve(hoff * 4));
+	CHK(c->items.reserve(itoff * 8)); CHK(c->items_ord.reserve(itoff * 4)); CHK(c->ht.reserve(hoff * 4));
 	HIPCHK(hipEventRecord(c->ev[0], c->stream));
 	for (int i = 0; i < nc; i++)
 		if (dk[(size_t)i].in_len)
@@ -714,14 +714,13 @@ extern "C" int x3h_decompress_chunks(x3h_ctx *c, const uint8_t *in, const uint64
 	HIPCHK(hipMemcpyAsync(c->dchunks.p, dk.data(), (size_t)nc * sizeof(X3DecChunk), hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipMemsetAsync(c->ctx1.p, 0, toff * sizeof(X3CtxHdr), c->stream));
 	HIPCHK(hipMemsetAsync(c->ctx0.p, 0, c0off * sizeof(X3CtxHdr), c->stream));
-	HIPCHK(hipMemsetAsync(c->pkey.p, 0, poff * 8, c->stream));
 	HIPCHK(hipMemsetAsync(c->ht.p, 0, hoff * 4, c->stream));
 	X3DecArgs da;
 	da.in = c->din.as<uint8_t>(); da.chunks = c->dchunks.as<X3DecChunk>(); da.out = c->out.as<uint8_t>();
 	da.dict_pos = c->dict_pos.as<uint32_t>(); da.dict_len = c->dict_len.as<uint8_t>(); da.ht = c->ht.as<uint32_t>();
 	da.mtf = c->mtf.as<uint32_t>(); da.idxfreq = c->idxfreq.as<uint32_t>();
 	da.ctx1 = c->ctx1.as<X3CtxHdr>(); da.ctx0 = c->ctx0.as<X3CtxHdr>(); da.items = c->items.as<uint64_t>();
-	da.pair_key = c->pkey.as<uint64_t>(); da.pair_val = c->pval.as<uint32_t>(); da.result = c->cresult.as<X3CodeResult>();
+	da.item_ord = c->items_ord.as<uint32_t>(); da.pair_key = nullptr; da.pair_val = nullptr; da.result = c->cresult.as<X3CodeResult>();
 	HIPCHK(hipEventRecord(c->ev[4], c->stream));
 	x3k_launch_decode(&da, (uint32_t)nc, c->stream);
 	HIPCHK(hipGetLastError());

@@ -11,8 +11,10 @@
  *   dict_update_costs + qsort            -> move-to-front (x3_tables.h)
  * The chain is latency-bound (a dozen dependent global loads per step in the naive order), so the loop PREFETCHES the next step's
  * context state as soon as it is known: the pair looked up / inserted at the end of a hit step (x3.c:213-222) IS the (prev, context1)
- * pair the next step would look up, so its ordinal is carried over instead of probed again, and both context headers plus the first
- * 64 items of either list are loaded at the end of a step -- they are in flight while the next event symbol is decoded.
+ * pair the next step would look up, so its ordinal is carried over instead of looked up again -- and it needs no hash map at all: a
+ * pair (context1, tag) exists exactly when `tag` is in the item list of context1 (x3.c:197-222 add both in the same step), so every
+ * item of a context1 list carries the ordinal of its pair.  Both context headers plus the first 64 items of either list are loaded at
+ * the end of a step: they are in flight while the next event symbol is decoded.
  * Streams of a batch decode concurrently (grid = streams).  The reference's unchecked 64x output buffer (x3.c:621) is
  * replaced by a capacity check (X3_ST_OUT_FULL), malformed input ends in X3_ST_CORRUPT instead of abort() (ac.c:178).
  */
@@ -130,6 +132,29 @@ __device__ static CtxQ ctx_find_tag(const X3CtxHdr h, const uint64_t *pool, uint
 	return q;
 }
 
+/* ctx_touch (x3_tables.h) for a context1 list: a new item also records the ordinal of the pair (context1, tag) it stands for */
+__device__ static void ctx1_touch(X3CtxHdr *hp, X3CtxHdr h, const CtxQ q, uint32_t tag, uint32_t ord, uint64_t *pool, uint32_t *pord,
+                                  uint64_t &pool_top, uint64_t pool_cap, uint32_t &status, uint32_t lane)
+{
+	if (q.found) {
+		if (lane == 0) pool[(uint64_t)h.off + q.pos] += 1;
+	} else {
+		if (h.items == h.cap) {
+			const uint32_t ncap = h.cap ? 2 * h.cap : 2;
+			if (pool_top + ncap > pool_cap) { status = X3_ST_POOL_FULL; return; }
+			const uint32_t noff = (uint32_t)pool_top;
+			pool_top += ncap;
+			for (uint32_t i = lane; i < h.items; i += X3_WAVE) { pool[(uint64_t)noff + i] = pool[(uint64_t)h.off + i]; pord[(uint64_t)noff + i] = pord[(uint64_t)h.off + i]; }
+			h.off = noff;
+			h.cap = ncap;
+		}
+		if (lane == 0) { pool[(uint64_t)h.off + h.items] = ((uint64_t)tag << 32) | 1u; pord[(uint64_t)h.off + h.items] = ord; }
+		h.items++;
+	}
+	h.total++;
+	if (lane == 0) *hp = h;
+}
+
 #ifndef X3_DEC_LDS
 #define X3_DEC_LDS 16384u /* dictionary elements whose recency list + index-model frequencies live in LDS (2 x 64 KiB) */
 #endif
@@ -162,9 +187,7 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 	uint32_t *mtf = s_mtf, *idxfreq = s_idx;
 	X3CtxHdr *ctx1 = a.ctx1 + ck.tag_off, *ctx0 = a.ctx0 + ck.ctx0_off;
 	uint64_t *pool = a.items + ck.item_off;
-	uint64_t *pkey = a.pair_key + ck.pair_off;
-	uint32_t *pval = a.pair_val + ck.pair_off;
-	const uint32_t plog = ck.pair_log2, pmask = (1u << plog) - 1;
+	uint32_t *pord = a.item_ord + ck.item_off;
 	const uint32_t cap = ck.out_cap;
 
 	BitReader br;
@@ -186,6 +209,8 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 	uint32_t n_c0id = 0;
 	X3CtxHdr n_h0 = ctx0[0], n_h1 = ctx1[0]; /* both empty at the start (zeroed workspace) */
 	uint64_t n_it0 = 0, n_it1 = 0;
+	uint32_t n_po1 = 0;               /* ... and the pair ordinals of the context1 items */
+	uint32_t ord00 = 0, have00 = 0;   /* the pair (0, 0): what both contexts are after a new fragment (x3.c:321-322) */
 
 	for (;;) {
 		DPROF_T(t_a)
@@ -272,16 +297,12 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 			p += len;
 			ctx1tag = 0; /* x3.c:321-322: both contexts reset */
 			x3_wave_sync();
-			{ /* the next hit step's contexts: pair (0, 0) if it is known, else context 0 */
-				const uint64_t key = 1;
-				uint32_t s = pair_slot(key, plog);
-				n_c0id = 0;
-				for (uint64_t kk = uni64(pkey[s]); kk != 0; s = (s + 1) & pmask, kk = uni64(pkey[s]))
-					if (kk == key) { n_c0id = x3_uniform(pval[s]); break; }
-				n_h0 = ctx0[n_c0id]; n_h1 = ctx1[0];
-				n_it0 = lane < n_h0.items ? pool[(uint64_t)n_h0.off + lane] : 0;
-				n_it1 = lane < n_h1.items ? pool[(uint64_t)n_h1.off + lane] : 0;
-			}
+			/* the next hit step's contexts: pair (0, 0) if it is known, else context 0 (x3.c:142-145) */
+			n_c0id = have00 ? ord00 : 0u;
+			n_h0 = ctx0[n_c0id]; n_h1 = ctx1[0];
+			n_it0 = lane < n_h0.items ? pool[(uint64_t)n_h0.off + lane] : 0;
+			n_it1 = lane < n_h1.items ? pool[(uint64_t)n_h1.off + lane] : 0;
+			n_po1 = lane < n_h1.items ? pord[(uint64_t)n_h1.off + lane] : 0;
 			continue;
 		}
 
@@ -294,6 +315,7 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 		X3CtxHdr *h0p = ctx0 + c0id, *h1p = ctx1 + ctx1tag;
 		const X3CtxHdr h0 = uni_hdr(n_h0), h1 = uni_hdr(n_h1); /* pinned here, not where the loads were issued: they stay in flight until now */
 		const uint64_t it0 = n_it0, it1 = n_it1;
+		const uint32_t po1 = n_po1;
 		uint32_t tag = 0, rank = 0, cpos = 0;
 		if (decision == X3_E_IDX1) {
 			step = (d.hi - d.lo + 1) / idxtotal;
@@ -330,21 +352,18 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 		if (decision == X3_E_CTX0) { q0.found = 1; q0.pos = cpos; q0.freq = q0.cum = 0; } else q0 = ctx_find_tag(h0, pool, tag, lane, it0);
 		if (decision == X3_E_CTX1) { q1.found = 1; q1.pos = cpos; q1.freq = q1.cum = 0; } else q1 = ctx_find_tag(h1, pool, tag, lane, it1);
 		x3_wave_sync();
-		ctx_touch(h0p, h0, q0, tag, pool, pool_top, ck.item_cap, status, lane);
-		ctx_touch(h1p, h1, q1, tag, pool, pool_top, ck.item_cap, status, lane);
-		if (status != X3_ST_OK) break;
-		{
-			const uint64_t key = (((uint64_t)ctx1tag << 32) | tag) + 1;
-			uint32_t s = pair_slot(key, plog);
-			uint64_t kk = uni64(pkey[s]);
-			while (kk != 0 && kk != key) { s = (s + 1) & pmask; kk = uni64(pkey[s]); }
-			x3_wave_sync();
-			if (kk == 0) {
-				if (lane == 0) { pkey[s] = key; pval[s] = npairs; }
-				n_c0id = npairs; /* this pair is the (prev, context1) of the next step: its ordinal is the next ctx0 id */
-				npairs++;
-			} else n_c0id = x3_uniform(pval[s]);
+		/* the pair (context1, tag) is this step's item in the context1 list -- and the (prev, context1) pair of the NEXT step */
+		uint32_t ord;
+		if (q1.found) ord = q1.pos < X3_WAVE ? x3_readlane_u32(po1, q1.pos) : x3_uniform(pord[(uint64_t)h1.off + q1.pos]);
+		else {
+			ord = npairs;
+			if (ctx1tag == 0 && tag == 0) { ord00 = npairs; have00 = 1; }
+			npairs++;
 		}
+		n_c0id = ord;
+		ctx_touch(h0p, h0, q0, tag, pool, pool_top, ck.item_cap, status, lane);
+		ctx1_touch(h1p, h1, q1, tag, ord, pool, pord, pool_top, ck.item_cap, status, lane);
+		if (status != X3_ST_OK) break;
 		DPROF_T(t_d)
 		DPROF_ADD(pc_ctx, t_c, t_d)
 		/* x3.c:332-348: copy the element, move it to the front */
@@ -359,6 +378,7 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 		n_h0 = ctx0[n_c0id]; n_h1 = ctx1[ctx1tag];
 		n_it0 = lane < n_h0.items ? pool[(uint64_t)n_h0.off + lane] : 0;
 		n_it1 = lane < n_h1.items ? pool[(uint64_t)n_h1.off + lane] : 0;
+		n_po1 = lane < n_h1.items ? pord[(uint64_t)n_h1.off + lane] : 0;
 		DPROF_T(t_e)
 		DPROF_ADD(pc_tail, t_d, t_e)
 	}

@@ -137,6 +137,7 @@ struct X3DecArgs {
 	uint32_t *mtf, *idxfreq;
 	X3CtxHdr *ctx1, *ctx0;
 	uint64_t *items;
+	uint32_t *item_ord;         /* per item slot of a context1 list: the ordinal of the pair (context1, tag) -- replaces the pair map */
 	uint64_t *pair_key;
 	uint32_t *pair_val;
 	X3CodeResult *result;       /* out_len = decoded bytes, _r = dictionary elements                */
