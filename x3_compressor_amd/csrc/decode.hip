@@ -33,43 +33,51 @@
 __device__ static __forceinline__ uint64_t uni64(uint64_t v) { return ((uint64_t)x3_uniform((uint32_t)(v >> 32)) << 32) | x3_uniform((uint32_t)v); }
 __device__ static __forceinline__ X3CtxHdr uni_hdr(const X3CtxHdr h) { X3CtxHdr r; r.off = x3_uniform(h.off); r.items = x3_uniform(h.items); r.cap = x3_uniform(h.cap); r.total = x3_uniform(h.total); return r; }
 
-struct BitReader { /* bio.c:5-42 */
+#ifndef X3_EMU
+__device__ static __forceinline__ uint32_t dec_brev32(uint32_t v) { return __brev(v); }
+#else
+static inline uint32_t dec_brev32(uint32_t v) { uint32_t r = 0; for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i); return r; }
+#endif
+
+struct BitReader { /* bio.c:5-42: bit k of the stream = bit k mod 32 (LSB first) of the little-endian word k / 32 */
 	const uint8_t *p, *end;
-	uint32_t acc, cnt;
+	uint64_t w;   /* unread bits, next one at bit 0 */
+	uint32_t nb;  /* how many */
 };
 
-__device__ static __forceinline__ uint32_t br_get(BitReader &r)
+/* the next n (0..31) bits of the stream, first one most significant -- what n calls of get_bit shifted into mBuffer would leave */
+__device__ static __forceinline__ uint32_t br_take(BitReader &r, uint32_t n)
 {
-	if (r.cnt == 32) {
-		if (r.end - r.p >= 4) { /* bio.c:10,35-39: past the last whole word the reader feeds 0x80000000 */
-			r.acc = x3_uniform((uint32_t)r.p[0] | (uint32_t)r.p[1] << 8 | (uint32_t)r.p[2] << 16 | (uint32_t)r.p[3] << 24);
-			r.p += 4;
-		} else r.acc = 0x80000000u;
-		r.cnt = 0;
+	if (r.nb < n) { /* one more word (bio.c:10,35-39: past the last whole word the reader feeds 0x80000000) */
+		uint32_t nx = 0x80000000u;
+		if (r.end - r.p >= 4) { nx = x3_uniform((uint32_t)r.p[0] | (uint32_t)r.p[1] << 8 | (uint32_t)r.p[2] << 16 | (uint32_t)r.p[3] << 24); r.p += 4; }
+		r.w |= (uint64_t)nx << r.nb;
+		r.nb += 32;
 	}
-	const uint32_t b = r.acc & 1u;
-	r.acc >>= 1;
-	r.cnt++;
-	return b;
+	if (!n) return 0;
+	const uint32_t field = (uint32_t)r.w & (0xFFFFFFFFu >> (32 - n));
+	r.w >>= n;
+	r.nb -= n;
+	return dec_brev32(field) >> (32 - n);
 }
 
 struct Dec { uint32_t lo, hi, buf; };
 
-/* ac_decode_symbol's interval update + ac_decode_scale (ac.c:192-195,142-165) */
-__device__ static void dec_narrow(Dec &d, BitReader &r, uint32_t step, uint32_t cum_lo, uint32_t cum_hi)
+/* ac_decode_symbol's interval update + ac_decode_scale (ac.c:192-195,142-165) in closed form, like the encoder's chain (code2.hip):
+ * all E1/E2/E3 shifts together are  s = clz(D) - 1 - carry  with D = hi - lo after narrowing; lo and the range scale by 2^s, and since
+ * every kind of shift removes the same offset from mBuffer as from mLow,  buffer - low  scales too and takes the s new bits.
+ * false: not an interval a valid stream can produce (the reference would spin in its E1/E2 loop or read garbage). */
+__device__ static __forceinline__ bool dec_narrow(Dec &d, BitReader &r, uint32_t step, uint32_t cum_lo, uint32_t cum_hi)
 {
-	d.hi = d.lo + step * cum_hi - 1;
-	d.lo = d.lo + step * cum_lo;
-	for (;;) {
-		if (d.hi < 0x40000000u) {
-			d.lo = 2 * d.lo; d.hi = 2 * d.hi + 1; d.buf = 2 * d.buf + br_get(r);
-		} else if (d.lo >= 0x40000000u) {
-			d.lo = 2 * (d.lo - 0x40000000u); d.hi = 2 * (d.hi - 0x40000000u) + 1; d.buf = 2 * (d.buf - 0x40000000u) + br_get(r);
-		} else break;
-	}
-	while (d.lo >= 0x20000000u && d.hi < 0x60000000u) {
-		d.lo = 2 * (d.lo - 0x20000000u); d.hi = 2 * (d.hi - 0x20000000u) + 1; d.buf = 2 * (d.buf - 0x20000000u) + br_get(r);
-	}
+	const uint32_t nlo = d.lo + step * cum_lo, nhi = d.lo + step * cum_hi - 1, D = nhi - nlo;
+	if (D == 0 || ((nlo | nhi) >> 31) || nhi < nlo || d.buf < nlo || d.buf > nhi) return false;
+	const uint32_t cz = (uint32_t)x3_clz32(D), t = 31u - cz;
+	const uint32_t sh = cz - 1 - ((((nlo ^ nhi) >> t) & 1u) ^ 1u);
+	const uint32_t lo = (nlo << sh) & 0x3FFFFFFFu;
+	d.buf = lo + ((d.buf - nlo) << sh) + br_take(r, sh);
+	d.hi = lo + ((D + 1) << sh) - 1;
+	d.lo = lo;
+	return true;
 }
 
 __device__ static __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) { (void)lane; return x3_wave_incl_scan_u32(v); }
@@ -191,10 +199,10 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 	const uint32_t cap = ck.out_cap;
 
 	BitReader br;
-	br.p = a.in + ck.in_off; br.end = br.p + ck.in_len; br.acc = 0; br.cnt = 32; /* bio_open(READ), bio.c:14-15 */
+	br.p = a.in + ck.in_off; br.end = br.p + ck.in_len; br.w = 0; br.nb = 0; /* bio_open(READ), bio.c:14-15 */
 	Dec d;
 	d.lo = 0; d.hi = 0x7FFFFFFFu; d.buf = 0; /* ac_init */
-	for (int i = 0; i < 31; i++) d.buf = (d.buf << 1) | br_get(br); /* ac_decode_init, ac.c:133-140 */
+	d.buf = br_take(br, 31); /* ac_decode_init, ac.c:133-140 */
 
 	uint32_t ev[5] = { 1024, 1024, 1, 1, 1 }, evtotal = 2051; /* create(), x3.c:236-244 */
 	uint32_t nev[4] = { 0, 0, 0, 0 };
@@ -224,7 +232,7 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 			cum += ev[s];
 		}
 		if (decision == 5) { status = X3_ST_CORRUPT; break; } /* the reference abort()s, ac.c:178 */
-		dec_narrow(d, br, step, cum, cum + ev[decision]);
+		if (!dec_narrow(d, br, step, cum, cum + ev[decision])) { status = X3_ST_CORRUPT; break; }
 		ev[decision]++; evtotal++;
 		if (decision == X3_E_EOF) break;
 
@@ -239,7 +247,7 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 				if (!mask) { status = X3_ST_CORRUPT; break; }
 				const uint32_t l = (uint32_t)x3_ctz64(mask);
 				const uint32_t fq = x3_bcast_u32(lf, (int)l), cl = x3_bcast_u32(incl, (int)l) - fq;
-				dec_narrow(d, br, step, cl, cl + fq);
+				if (!dec_narrow(d, br, step, cl, cl + fq)) { status = X3_ST_CORRUPT; break; }
 				if (lane == l) lf++;
 				lftotal++;
 				len = l + 1;
@@ -261,7 +269,7 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 				else if (dec_below(offb, step, cl + b0 + b1)) { sub = 1; fq = b1; cl += b0; }
 				else if (dec_below(offb, step, cl + b0 + b1 + b2)) { sub = 2; fq = b2; cl += b0 + b1; }
 				else { sub = 3; fq = b3; cl += b0 + b1 + b2; }
-				dec_narrow(d, br, step, cl, cl + fq);
+				if (!dec_narrow(d, br, step, cl, cl + fq)) { bad = 1; break; }
 				if (lane == l) { if (sub == 0) cf0++; else if (sub == 1) cf1++; else if (sub == 2) cf2++; else cf3++; }
 				cftotal++;
 				const uint32_t ch = 4 * l + sub;
@@ -322,7 +330,7 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 			uint32_t cl = 0, fq = 0;
 			rank = find_in_array(idxfreq, D, d.buf - d.lo, step, lane, cl, fq);
 			if (rank == 0xFFFFFFFFu) { status = X3_ST_CORRUPT; break; }
-			dec_narrow(d, br, step, cl, cl + fq);
+			if (!dec_narrow(d, br, step, cl, cl + fq)) { status = X3_ST_CORRUPT; break; }
 			tag = x3_uniform(mtf[rank]);
 			x3_wave_sync();
 			if (lane == 0) idxfreq[rank] = fq + 1; /* inc_model(&model_index1, index), x3.c:89 */
@@ -335,7 +343,7 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 			const uint32_t pos = find_in_ctx(hc, pool, d.buf - d.lo, step, lane, decision == X3_E_CTX0 ? it0 : it1, cl, fq, tag);
 			if (pos == 0xFFFFFFFFu) { status = X3_ST_CORRUPT; break; }
 			cpos = pos;
-			dec_narrow(d, br, step, cl, cl + fq);
+			if (!dec_narrow(d, br, step, cl, cl + fq)) { status = X3_ST_CORRUPT; break; }
 			/* dict_get_index_by_tag (x3.c:79,84) */
 			uint32_t found = 0;
 			for (uint32_t base = 0; base < D; base += X3_WAVE) {
