@@ -140,23 +140,29 @@ __device__ static CtxQ ctx_find_tag(const X3CtxHdr h, const uint64_t *pool, uint
 	return q;
 }
 
-/* ctx_touch (x3_tables.h) for a context1 list: a new item also records the ordinal of the pair (context1, tag) it stands for */
-__device__ static void ctx1_touch(X3CtxHdr *hp, X3CtxHdr h, const CtxQ q, uint32_t tag, uint32_t ord, uint64_t *pool, uint32_t *pord,
-                                  uint64_t &pool_top, uint64_t pool_cap, uint32_t &status, uint32_t lane)
+/* ctx_touch (x3_tables.h) for the decoder: the lanes already hold items [0, 64) of the list (`first`), so bumping a frequency is a
+ * plain store from the lane that holds the item -- no read-modify-write round trip on the chain.  pord != nullptr: a context1 list,
+ * whose new item also records the ordinal of the pair (context1, tag) it stands for. */
+__device__ static void dec_ctx_touch(X3CtxHdr *hp, X3CtxHdr h, const CtxQ q, uint32_t tag, uint64_t first, uint32_t ord, uint64_t *pool, uint32_t *pord,
+                                     uint64_t &pool_top, uint64_t pool_cap, uint32_t &status, uint32_t lane)
 {
 	if (q.found) {
-		if (lane == 0) pool[(uint64_t)h.off + q.pos] += 1;
+		if (q.pos < X3_WAVE) { if (lane == q.pos) pool[(uint64_t)h.off + q.pos] = first + 1; }
+		else if (lane == 0) pool[(uint64_t)h.off + q.pos] += 1;
 	} else {
 		if (h.items == h.cap) {
 			const uint32_t ncap = h.cap ? 2 * h.cap : 2;
 			if (pool_top + ncap > pool_cap) { status = X3_ST_POOL_FULL; return; }
 			const uint32_t noff = (uint32_t)pool_top;
 			pool_top += ncap;
-			for (uint32_t i = lane; i < h.items; i += X3_WAVE) { pool[(uint64_t)noff + i] = pool[(uint64_t)h.off + i]; pord[(uint64_t)noff + i] = pord[(uint64_t)h.off + i]; }
+			for (uint32_t i = lane; i < h.items; i += X3_WAVE) {
+				pool[(uint64_t)noff + i] = pool[(uint64_t)h.off + i];
+				if (pord) pord[(uint64_t)noff + i] = pord[(uint64_t)h.off + i];
+			}
 			h.off = noff;
 			h.cap = ncap;
 		}
-		if (lane == 0) { pool[(uint64_t)h.off + h.items] = ((uint64_t)tag << 32) | 1u; pord[(uint64_t)h.off + h.items] = ord; }
+		if (lane == 0) { pool[(uint64_t)h.off + h.items] = ((uint64_t)tag << 32) | 1u; if (pord) pord[(uint64_t)h.off + h.items] = ord; }
 		h.items++;
 	}
 	h.total++;
@@ -369,8 +375,8 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 			npairs++;
 		}
 		n_c0id = ord;
-		ctx_touch(h0p, h0, q0, tag, pool, pool_top, ck.item_cap, status, lane);
-		ctx1_touch(h1p, h1, q1, tag, ord, pool, pord, pool_top, ck.item_cap, status, lane);
+		dec_ctx_touch(h0p, h0, q0, tag, it0, 0, pool, nullptr, pool_top, ck.item_cap, status, lane);
+		dec_ctx_touch(h1p, h1, q1, tag, it1, ord, pool, pord, pool_top, ck.item_cap, status, lane);
 		if (status != X3_ST_OK) break;
 		DPROF_T(t_d)
 		DPROF_ADD(pc_ctx, t_c, t_d)
