@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define X3H_ABI_VERSION 1
+#define X3H_ABI_VERSION 2 /* 2: x3h_stats grew (mode_iters, chain_symbols, pipelined) */
 
 /* status codes (the reference abort()s on every error: file.c:9-18, x3.c:515,547,554,583) */
 enum {

@@ -23,6 +23,9 @@ ABI_SYMBOLS = (
 TOK_MISS, TOK_DUP = 0x80000000, 0x40000000
 
 
+ABI_VERSION = 2
+
+
 class Params(C.Structure):
     _fields_ = [("window_bytes", C.c_uint32), ("max_match_count", C.c_int32), ("factor1", C.c_uint32),
                 ("factor2", C.c_uint32), ("nl_mode", C.c_int32)]
@@ -56,6 +59,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib = C.CDLL(path)
     u8p = C.c_void_p
     lib.x3h_abi_version.restype = C.c_int
+    if lib.x3h_abi_version() != ABI_VERSION:  # the Stats layout below mirrors include/x3hip.h of exactly this version
+        raise RuntimeError(f"{path}: ABI version {lib.x3h_abi_version()}, this binding expects {ABI_VERSION} -- rebuild the library")
     lib.x3h_strerror.restype = C.c_char_p
     lib.x3h_strerror.argtypes = [C.c_int]
     lib.x3h_last_hip_error.restype = C.c_int
