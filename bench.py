@@ -164,6 +164,12 @@ def main():
                 "ms": round(mdt * 1e3, 2), "ratio": round(mtot / float(mlens.sum()), 4),
                 "stage_ms": {"scan": round(mst.ms_scan, 2), "parse": round(mst.ms_parse, 2), "features": round(mst.ms_features, 2),
                              "modes": round(mst.ms_modes, 2), "coder": round(mst.ms_coder, 2), "emit": round(mst.ms_emit, 2)}}
+        tpath = os.path.join(ROOT, "profiles", "r01_many_chunks_pmc_traffic.json")
+        if os.path.exists(tpath) and args.many_chunks_mib == 256:  # HBM bytes of this very batch from rocprofv3 --pmc passes (tools/many_chunks_check.py)
+            t = json.load(open(tpath))["total"]
+            many["hbm_traffic"] = {"GB_per_batch": round(t["fetch_GB"] + t["write_GB"], 1), "avg_TBps_over_kernel_time": t["avg_TBps"],
+                                   "frac_of_hbm_peak": round(t["avg_TBps"] * 1e12 / HBM_PEAK, 3), "source": "profiles/r01_many_chunks_pmc_traffic.json",
+                                   "note": "the chip-wide sort / partition / scan passes stream at 3.4-4.7 TB/s; the batch is bound by the BYTES they move (2.7 KB per input byte)"}
         del d_min, d_mout
 
     if rank == 0:
