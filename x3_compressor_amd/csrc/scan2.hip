@@ -139,7 +139,14 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 	for (int i = 0; i < 8; i++) CHK(B.a[i].reserve((P + 8) * 4));
 	CHK(B.misc.reserve(64));
 	uint32_t *keys = B.a[0].as<uint32_t>(), *iota = B.a[1].as<uint32_t>();
-	uint32_t *state = B.a[4].as<uint32_t>(); /* per position: K in bits 0..23 (K <= count_0 <= W-33 < 2^24), m in bits 24..28 */
+	/* K = T+1 for almost every position (its first byte occurs more than T times in its window); the others are marked in a bitmap
+	 * (small enough to stay cached) and only they have an exact K in `kexact`: the level passes below touch no per-position word
+	 * unless they have to, and m[] is written in place (one byte, only when a level passes) */
+	uint32_t *kexact = B.a[4].as<uint32_t>();
+	CHK(B.a[8].reserve((P / 32 + 2) * 4));
+	uint32_t *rare = B.a[8].as<uint32_t>();
+	HIPCHK(hipMemsetAsync(rare, 0, (P / 32 + 2) * 4, st));
+	HIPCHK(hipMemsetAsync(d_m, 0, P, st));
 	uint32_t *act = B.a[5].as<uint32_t>(), *act_k = B.a[6].as<uint32_t>(), *act_j = B.a[7].as<uint32_t>();
 	uint32_t *d_nact = B.misc.as<uint32_t>();
 	HIPCHK(hipMemsetAsync(d_nact, 0, 4, st));
@@ -178,18 +185,29 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 					}
 					K = a; /* == count_0 */
 				}
-				state[p] = K; /* m = 0 */
+				if (K != Tu + 1) { kexact[p] = K; atomicOr(&rare[p >> 5], 1u << (p & 31)); }
 			});
 		} else {
 			x3_foreach(P, st, X3_LAMBDA(size_t j) {
 				const uint32_t q = Sc[j];
 				if (q < back) return; /* the l-gram would start before the buffer */
 				const uint32_t p = q - back;
-				const uint32_t sv = state[p], K = sv & 0xFFFFFFu, m = sv >> 24;
-				if (K < 2 || m != l - 2) return; /* count_0 < 2, or the previous level already failed */
-				const uint64_t u = (uint64_t)j + K;
-				if (u < Pn && ((ksc[u] ^ ksc[j]) & msk) == 0 && (uint64_t)Sc[u] <= (uint64_t)q + ncand) { /* both sides carry the same +back */
-					state[p] = K | ((l - 1) << 24);
+				/* count_{l-1}(p) >= K?  First with K = T+1, from the list alone: if even the (T+1)-th next occurrence is inside the window,
+				 * the level passes whatever K is (K <= T+1).  Only if that fails can a smaller K matter, and only marked positions have one.
+				 * (A level can only pass if the previous one did -- occurrences of the longer gram are occurrences of the shorter -- so the
+				 * levels need not look at each other's result.) */
+				uint32_t K = Tu + 1;
+				uint64_t u = (uint64_t)j + K;
+				bool pass = u < Pn && ((ksc[u] ^ ksc[j]) & msk) == 0 && (uint64_t)Sc[u] <= (uint64_t)q + ncand; /* both sides carry the same +back */
+				if (!pass) {
+					if (!((rare[p >> 5] >> (p & 31)) & 1u)) return;
+					K = kexact[p];
+					if (K < 2) return; /* count_0 < 2 */
+					u = (uint64_t)j + K;
+					pass = u < Pn && ((ksc[u] ^ ksc[j]) & msk) == 0 && (uint64_t)Sc[u] <= (uint64_t)q + ncand;
+				}
+				if (pass) {
+					d_m[p] = (uint8_t)(l - 1);
 					if (l == 4) { /* count_3 >= K: deeper levels need the candidates themselves -- unless p is padding (never read) */
 						uint32_t lo = 0, hi = nc;
 						while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (d_chunks[mid].byte_off <= p) lo = mid; else hi = mid; }
@@ -205,7 +223,6 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 		t = vin; vin = S; S = t;
 	}
 	S = vin; /* list 4 (the last pass's output) */
-	x3_foreach(P, st, X3_LAMBDA(size_t q) { d_m[q] = (uint8_t)(state[q] >> 24); });
 
 	/* active positions: one wavefront each over the in-window candidates of its 4-gram class (S still holds list 4) */
 	uint32_t nact = 0;
