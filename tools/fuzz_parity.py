@@ -1,0 +1,72 @@
+"""Randomised differential test on the GPU: libx3hip.so vs the CPU oracle over random inputs, parameters, batch shapes and schedules.
+usage: fuzz_parity.py [seconds] [seed]   (prints the first mismatch with everything needed to reproduce it; exit code 1)"""
+import os, sys, time
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np
+import oracle_lib
+from x3_compressor_amd import _lib, synth
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+rng = np.random.default_rng(seed)
+orc = oracle_lib.load()
+TEXT = synth.english_like(1 << 20, seed=seed).tobytes()
+ZIPF = synth.zipf_bytes(1 << 20, offset=seed & 0xFFFF).tobytes()
+
+
+def gen(n):
+    kind = int(rng.integers(0, 6))
+    if n == 0: return b""
+    o = int(rng.integers(0, (1 << 20) - n)) if n < (1 << 20) else 0
+    if kind == 0: return TEXT[o:o + n]
+    if kind == 1: return ZIPF[o:o + n]
+    if kind == 2: return bytes(rng.integers(0, 256, n, dtype=np.uint8))
+    if kind == 3: return bytes(rng.integers(0, int(rng.integers(1, 5)), n, dtype=np.uint8))          # tiny alphabet, zero bytes included
+    if kind == 4: p = bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8)); return (p * (n // len(p) + 1))[:n]   # periodic
+    return TEXT[o:o + n // 2] + bytes(n - n // 2)                                                      # text then a run of zeros
+
+
+ctxs = {}
+def ctx_for(env):
+    key = tuple(sorted(env.items()))
+    if key not in ctxs:
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        ctxs[key] = _lib.X3Context(0)
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+    return ctxs[key]
+
+
+ENVS = [dict(), dict(X3H_PIPE_MIN="1"), dict(X3H_PIPE_MIN="1", X3H_MODES="fixed"), dict(X3H_PIPE_MIN="0", X3H_MODES="serial"), dict(X3H_PIPE_MIN="0", X3H_MODES="fixed")]
+t0, cases = time.time(), 0
+while time.time() - t0 < budget:
+    nch = int(rng.choice([1, 1, 1, 2, 3, 7, 40]))
+    sizes = [int(rng.choice([0, 1, 2, 31, 32, 33, 200, 2047, 2048, 2049, 5000, 20000, 70000])) if rng.random() < 0.5 else int(rng.integers(0, 30000)) for _ in range(nch)]
+    w = int(rng.choice([0, 1, 1, 2, 4, 8, 8, 16, 64]))
+    kw = dict(w_kib=w, t=int(rng.choice([0, 1, 2, 3, 8, 15, 16, 64, 256, 5000])), m=int(rng.choice([0, 1, 4, 4, 4, 9])),
+              n=int(rng.choice([0, 0, 0, 1, 2, 5])), x=int(rng.random() < 0.15))
+    if w == 0: continue  # -w 0 reads out of bounds in the reference itself (SURVEY 8a trap 10)
+    parts = [gen(n) for n in sizes]
+    env = ENVS[int(rng.integers(0, len(ENVS)))]
+    ctx = ctx_for(env)
+    prm, oprm = _lib.make_params(**kw), oracle_lib.params(**kw)
+    want = [orc.compress(p, oprm) for p in parts]
+    data = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    off = np.cumsum([0] + sizes).astype(np.uint64)
+    got = ctx.compress_chunks(data, off, prm) if nch > 1 or rng.random() < 0.3 else [ctx.compress(parts[0], prm)]
+    cases += 1
+    for i in range(nch):
+        if got[i] != want[i]:
+            print("MISMATCH: seed", seed, "case", cases, "chunk", i, "sizes", sizes, "params", kw, "env", env, flush=True)
+            sys.exit(1)
+    if rng.random() < 0.3:   # decoder round trip of one stream
+        i = int(rng.integers(0, nch))
+        back = ctx.decompress(got[i], sizes[i] + 8)
+        if back != parts[i]:
+            print("DECODE MISMATCH: seed", seed, "case", cases, "chunk", i, "sizes", sizes, "params", kw, "env", env, flush=True)
+            sys.exit(1)
+    if cases % 25 == 0:
+        print(f"{cases} cases ok, {time.time() - t0:.0f} s", flush=True)
+print(f"fuzz ok: {cases} cases in {time.time() - t0:.0f} s (seed {seed})")
