@@ -305,7 +305,10 @@ static int run_pipelined_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_byte
 	X3CodeSeg &seg = c->seg;
 	seg.final = false; seg.coder_stream = c->s_coder; seg.ev_ready = c->ev_ready; seg.coder_state = c->coder_state.as<uint32_t>();
 	seg.y_done.assign(nc, 0u); seg.ring_top = 0; seg.calls.clear();
-	seg.res_steps = seg.res_hits = seg.res_elems = seg.res_mbytes = 0; seg.res_bytes = (size_t)nsum;
+	/* the workspace is sized ONCE, for the worst case (steps, hits + elements and new-fragment bytes are each <= input bytes): a
+	 * reallocation in mid-flight would wait for the running parse and coder (hipFree synchronises the device), and a token density
+	 * extrapolated from the first 2 % is wrong as soon as the data changes character.  run_one only pipelines batches this fits. */
+	seg.res_steps = seg.res_hits = seg.res_mbytes = seg.res_elems = (size_t)nsum + 16 * (size_t)nc; seg.res_bytes = (size_t)nsum;
 	std::vector<X3ParseResult> pr(nc);
 	std::vector<int> avail(nc, -1); /* newest record seen per stream: -1 none, mark index, X3_MAX_CKPT = done */
 	int next = 0, nseg = 0;
@@ -361,16 +364,6 @@ static int run_pipelined_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_byte
 				else if (q != hipErrorNotReady) { x3_last_hip = (int)q; return X3H_E_HIP; } /* the parse kernel faulted: do not spin on it */
 			}
 			continue; /* spin: a checkpoint should be picked up at once (the waits are milliseconds) */
-		}
-		if (!seg.res_steps) { /* first look at the streams: size the workspace for all of them (x1.3; linear growth overestimates D) */
-			double st_ = 0, hi_ = 0, el_ = 0, mb_ = 0;
-			for (uint32_t i = 0; i < nc; i++) {
-				const double sc = 1.3 * (double)c->hchunks[i].len / (double)(pr[i]._r0 ? pr[i]._r0 : 1);
-				st_ += pr[i].ntok * sc + 1024; hi_ += pr[i].hits * sc + 1024; el_ += pr[i].dict_elems * sc + 1024; mb_ += pr[i].miss_bytes * sc + 1024;
-			}
-			const double cap = (double)nsum + 16.0 * nc;
-			seg.res_steps = (size_t)(st_ < cap ? st_ : cap); seg.res_hits = (size_t)(hi_ < cap ? hi_ : cap);
-			seg.res_elems = (size_t)(el_ < cap ? el_ : cap); seg.res_mbytes = (size_t)(mb_ < cap ? mb_ : cap);
 		}
 		next = lowest + 1;
 		for (uint32_t i = 0; i < nc; i++) pr[i]._r0 = 0;
@@ -437,7 +430,8 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 
 	/* ---- K2 ---- */
 	/* pipelined schedule: a few long streams (the serial chains dominate); many short ones run stage after stage (the chip-wide passes dominate) */
-	const bool pipe = upto == STAGE_CODE && !c->code_v1 && nc <= c->pipe_max_streams && c->pipe_min && max_len >= c->pipe_min;
+	const bool pipe = upto == STAGE_CODE && !c->code_v1 && nc <= c->pipe_max_streams && c->pipe_min && max_len >= c->pipe_min &&
+	                  c->pad_total <= ((uint64_t)320 << 20); /* worst-case workspace of the pipelined schedule: ~330 B per input byte */
 	X3ParseArgs pa;
 	pa.ckpt = nullptr; pa.nckpt = 0;
 	pa.bytes = sa.bytes; pa.chunks = sa.chunks; pa.m = sa.m;

@@ -756,7 +756,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	if (nB > nA) nA = nB;
 	size_t nDres = nD, nYres = nY, nMSres = (nM > nB ? nM : nB);
 	if (seg) { /* a growing prefix: size everything for the estimated whole stream (a reallocation would wait for the running parse / coder) */
-		if (seg->res_hits + seg->res_elems > nA) nA = seg->res_hits + seg->res_elems;
+		/* (hits + elements <= steps: every element was a miss step) */
 		if (seg->res_mbytes > nA) nA = seg->res_mbytes;
 		if (seg->res_steps > nA) nA = seg->res_steps;
 		if (seg->res_elems > nDres) nDres = seg->res_elems;
