@@ -310,3 +310,19 @@ def test_pipelined_batch_of_long_streams(gpu, gpu_env):
         assert streams[i] == seq.compress(data[int(off[i]):int(off[i + 1])].tobytes(), prm), f"stream {i}"
     few = gpu_env(X3H_PIPE_STREAMS="2")
     assert few.compress_chunks(data, off, prm) == streams and few.last_stats.pipelined == 0
+
+
+def test_decode_batch_of_many_streams(gpu):
+    """more than 256 streams select the decoder variant with small LDS tables (ten streams per CU); one stream is rich enough to outgrow
+    them (> 2048 dictionary elements -> its tables migrate to global memory)"""
+    sizes = [3000] * 299 + [400_000]
+    rnd = np.random.default_rng(5)
+    parts = [synth.english_like(3000, seed=100 + i).tobytes() for i in range(299)]
+    parts.append(bytes(rnd.integers(0, 256, 400_000, dtype=np.uint8)))   # random bytes: every step is a new fragment -> thousands of elements
+    data = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    off = np.cumsum([0] + sizes).astype(np.uint64)
+    prm = _lib.make_params(w_kib=8, t=16)
+    streams = gpu.compress_chunks(data, off, prm)
+    assert gpu.last_stats.dict_elems > 2048 + 299
+    back = gpu.decompress_chunks(streams, sizes)
+    assert back == parts

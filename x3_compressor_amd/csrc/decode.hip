@@ -172,6 +172,9 @@ __device__ static void dec_ctx_touch(X3CtxHdr *hp, X3CtxHdr h, const CtxQ q, uin
 #ifndef X3_DEC_LDS
 #define X3_DEC_LDS 16384u /* dictionary elements whose recency list + index-model frequencies live in LDS (2 x 64 KiB) */
 #endif
+#ifndef X3_DEC_LDS_SMALL
+#define X3_DEC_LDS_SMALL 2048u /* ... in batches of many streams: 16 KiB of LDS per stream, so ten streams share a CU instead of one */
+#endif
 
 #define DFNV_OFF 2166136261u
 #define DFNV_MUL 16777619u
@@ -184,12 +187,13 @@ __device__ static __forceinline__ uint32_t dht_slot(uint32_t h, uint32_t len, ui
 	return x >> (32 - hlog);
 }
 
+template <uint32_t NLDS>
 __device__ static void x3_decode_body(const X3DecArgs &a)
 {
 	/* the two tables every step sweeps (move-to-front list, model_index1 frequencies) start in LDS and migrate to their global
-	 * arrays only if the stream's dictionary outgrows X3_DEC_LDS elements */
-	X3_LDS uint32_t s_mtf[X3_DEC_LDS];
-	X3_LDS uint32_t s_idx[X3_DEC_LDS];
+	 * arrays only if the stream's dictionary outgrows NLDS elements */
+	X3_LDS uint32_t s_mtf[NLDS];
+	X3_LDS uint32_t s_idx[NLDS];
 	const X3DecChunk ck = a.chunks[blockIdx.x];
 	const uint32_t lane = x3_lane();
 	uint8_t *out = a.out + ck.out_off;
@@ -297,7 +301,7 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 			}
 			x3_wave_sync();
 			if (!dup) { /* x3.c:310-317 */
-				if (D == X3_DEC_LDS && mtf == s_mtf) { /* outgrew LDS: continue in global memory */
+				if (D == NLDS && mtf == s_mtf) { /* outgrew LDS: continue in global memory */
 					for (uint32_t i = lane; i < D; i += X3_WAVE) { gmtf[i] = s_mtf[i]; gidx[i] = s_idx[i]; }
 					x3_wave_sync();
 					mtf = gmtf; idxfreq = gidx;
@@ -410,13 +414,17 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 }
 
 #ifndef X3_EMU
-__global__ void __launch_bounds__(X3_WAVE) x3_decode_kernel(X3DecArgs a) { x3_decode_body(a); }
+__global__ void __launch_bounds__(X3_WAVE) x3_decode_kernel(X3DecArgs a) { x3_decode_body<X3_DEC_LDS>(a); }
+__global__ void __launch_bounds__(X3_WAVE) x3_decode_many_kernel(X3DecArgs a) { x3_decode_body<X3_DEC_LDS_SMALL>(a); }
 extern "C" void x3k_launch_decode(const X3DecArgs *a, uint32_t nchunks, hipStream_t st)
 {
-	hipLaunchKernelGGL(x3_decode_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, *a);
+	/* one wavefront per stream; the LDS tables decide how many streams share a CU: a few streams get the big tables (no spill to
+	 * global memory up to 16384 elements), a batch that oversubscribes the chip gets small ones (ten streams per CU) */
+	if (nchunks > 256) hipLaunchKernelGGL(x3_decode_many_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, *a);
+	else hipLaunchKernelGGL(x3_decode_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, *a);
 }
 #else
-static void decode_tramp(void *p) { x3_decode_body(*(const X3DecArgs *)p); }
+static void decode_tramp(void *p) { x3_decode_body<X3_DEC_LDS>(*(const X3DecArgs *)p); }
 extern "C" void x3k_launch_decode(const X3DecArgs *a, uint32_t nchunks, void *)
 {
 	x3emu_launch(decode_tramp, (void *)a, dim3(nchunks), dim3(X3_WAVE));
