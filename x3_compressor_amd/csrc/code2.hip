@@ -177,6 +177,9 @@ struct X3ModesArgs {
 #ifndef X3_IDXF_LDS
 #define X3_IDXF_LDS 32768u /* ranks whose model_index1 frequency lives in LDS (128 KiB); beyond that: global memory */
 #endif
+#ifndef X3_IDXF_LDS_SMALL
+#define X3_IDXF_LDS_SMALL 2048u /* ... in batches of many streams: 8 KiB per stream, so the whole batch is resident instead of one stream per CU */
+#endif
 
 /* The mode choice of x3.c:152-172 feeds back through model_events (three counters) and model_index1 (one frequency per
  * rank), so in the reference it is a strictly serial chain.  A lone wavefront executes such a chain at ~5 cycles per
@@ -190,7 +193,7 @@ struct X3ModesArgs {
  *   - the remaining lanes are resolved in order with exact counters (ballot/popcount over the modes decided so far),
  *     using one vector division for the four quotients.
  * Typically only a few percent of the hits need the serial path.  ALL_LDS: every rank fits the LDS table. */
-template <bool ALL_LDS>
+template <bool ALL_LDS, uint32_t NIDX>
 __device__ static __forceinline__ void x3_modes_loop(const X3ModesArgs &a, uint32_t *sidx, uint32_t *scr, uint32_t *idxf, uint32_t H, uint32_t h0, uint32_t lane)
 {
 	uint32_t E0 = 1024, E1 = 1024, E2 = 1, nidx = 0; /* model_events freqs (x3.c:239-241), IDX1 uses so far */
@@ -216,7 +219,7 @@ __device__ static __forceinline__ void x3_modes_loop(const X3ModesArgs &a, uint3
 		const float q0 = vf0 ? (float)vf0 / (float)vt0 : 0.f; /* (float)freq / (float)total of the context item; 0 == absent */
 		const float q1 = vf1 ? (float)vf1 / (float)vt1 : 0.f;
 		const float ftot = (float)(2051u + vs); /* model_events.total: 2051 + one per earlier step */
-		const bool lds_r = ALL_LDS || vr < X3_IDXF_LDS;
+		const bool lds_r = ALL_LDS || vr < NIDX;
 		const uint32_t rfmin = in ? (lds_r ? sidx[lds_r ? vr : 0] : idxf[vr]) : 1;
 		/* same-rank hits in this block (an upper bound is enough: hashed counters, collisions only widen the bracket) */
 		const uint32_t hs = vr & 255u;
@@ -287,18 +290,19 @@ __device__ static __forceinline__ void x3_modes_loop(const X3ModesArgs &a, uint3
 	}
 }
 
+template <uint32_t NIDX>
 __device__ static void x3_modes_body(const X3ModesArgs &a)
 {
-	X3_LDS uint32_t sidx[X3_IDXF_LDS];
+	X3_LDS uint32_t sidx[NIDX];
 	X3_LDS uint32_t scr[256];
 	const uint32_t c = blockIdx.x, lane = x3_lane();
 	const uint32_t H = a.parsed[c].hits, h0 = a.ho[c], Dc = a.parsed[c].dict_elems;
 	uint32_t *idxf = a.idxfreq + a.dof[c];
-	const uint32_t nl = Dc < X3_IDXF_LDS ? Dc : X3_IDXF_LDS;
+	const uint32_t nl = Dc < NIDX ? Dc : NIDX;
 	for (uint32_t i = lane; i < nl; i += X3_WAVE) sidx[i] = 1;
 	x3_wave_sync();
-	if (Dc <= X3_IDXF_LDS) x3_modes_loop<true>(a, sidx, scr, idxf, H, h0, lane);
-	else x3_modes_loop<false>(a, sidx, scr, idxf, H, h0, lane);
+	if (Dc <= NIDX) x3_modes_loop<true, NIDX>(a, sidx, scr, idxf, H, h0, lane);
+	else x3_modes_loop<false, NIDX>(a, sidx, scr, idxf, H, h0, lane);
 }
 
 /* ============================================================================================================
@@ -484,13 +488,19 @@ __device__ static void x3_ac2_body(const X3Ac2Args &a)
 #endif
 
 #ifndef X3_EMU
-__global__ void __launch_bounds__(X3_WAVE) x3_modes_kernel(X3ModesArgs a) { x3_modes_body(a); }
+__global__ void __launch_bounds__(X3_WAVE) x3_modes_kernel(X3ModesArgs a) { x3_modes_body<X3_IDXF_LDS>(a); }
+__global__ void __launch_bounds__(X3_WAVE) x3_modes_many_kernel(X3ModesArgs a) { x3_modes_body<X3_IDXF_LDS_SMALL>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_ac2_kernel(X3Ac2Args a) { x3_ac2_body(a); }
-static void launch_modes(const X3ModesArgs &a, uint32_t nchunks, hipStream_t st) { hipLaunchKernelGGL(x3_modes_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, a); }
+static void launch_modes(const X3ModesArgs &a, uint32_t nchunks, hipStream_t st)
+{
+	/* the LDS table decides how many streams share a CU: a batch that oversubscribes the chip gets the small one */
+	if (nchunks > 256) hipLaunchKernelGGL(x3_modes_many_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, a);
+	else hipLaunchKernelGGL(x3_modes_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, a);
+}
 static void launch_ac2(const X3Ac2Args &a, uint32_t nchunks, hipStream_t st) { hipLaunchKernelGGL(x3_ac2_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, a); }
 __device__ static __forceinline__ uint32_t x3_brev32(uint32_t v) { return __brev(v); }
 #else
-static void modes_tramp(void *p) { x3_modes_body(*(const X3ModesArgs *)p); }
+static void modes_tramp(void *p) { x3_modes_body<X3_IDXF_LDS>(*(const X3ModesArgs *)p); }
 static void ac2_tramp(void *p) { x3_ac2_body(*(const X3Ac2Args *)p); }
 static void launch_modes(const X3ModesArgs &a, uint32_t nchunks, hipStream_t) { x3emu_launch(modes_tramp, (void *)&a, dim3(nchunks), dim3(X3_WAVE)); }
 static void launch_ac2(const X3Ac2Args &a, uint32_t nchunks, hipStream_t) { x3emu_launch(ac2_tramp, (void *)&a, dim3(nchunks), dim3(X3_WAVE)); }
