@@ -326,3 +326,6 @@ def test_decode_batch_of_many_streams(gpu):
     assert gpu.last_stats.dict_elems > 2048 + 299
     back = gpu.decompress_chunks(streams, sizes)
     assert back == parts
+    # the same batch size selects the small-block variants of the parse and mode kernels: their streams == the big variants' (one stream at a time)
+    for i in (0, 150, 299):
+        assert streams[i] == gpu.compress(parts[i], prm), f"stream {i}"

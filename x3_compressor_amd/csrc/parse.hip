@@ -19,9 +19,12 @@
  */
 #include "x3_kernels.h"
 
-#define PB X3_PARSE_PB
-#define PBL (PB + 32)       /* positions with cached L/E: filters look 31 ahead              */
-#define PBB (PB + 32 + 32)  /* bytes staged: a 32-byte compare at the last cached position   */
+/* PB = positions per cached block (template parameter): PBL = PB + 32 positions have a cached L/E (the filters look 31 ahead),
+ * PBB = PB + 64 bytes are staged (a 32-byte compare at the last cached position).  X3_PARSE_PB (2048) for a few streams; a batch
+ * that oversubscribes the chip uses X3_PARSE_PB_SMALL (1024): half the LDS, so two workgroups share a CU. */
+#ifndef X3_PARSE_PB_SMALL
+#define X3_PARSE_PB_SMALL 1024
+#endif
 
 #define X3_LDS_HT_LOG2 11u
 #define X3_LDS_HT (1u << X3_LDS_HT_LOG2) /* the mirror is used while the table has at most this many slots ... */
@@ -62,8 +65,10 @@ struct ParseShared {
 };
 enum { FLAG_REFILL = 1, FLAG_PATCH = 2, FLAG_DONE = 3 };
 
+template <uint32_t PB>
 __device__ static void x3_parse_body(const X3ParseArgs &a)
 {
+	constexpr uint32_t PBL = PB + 32, PBB = PB + 64;
 	X3_LDS uint8_t sb[PBB + 8];
 	X3_LDS uint8_t sL[PBL];
 	X3_LDS uint32_t sE[PBL];
@@ -349,14 +354,16 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 }
 
 #ifndef X3_EMU
-__global__ void __launch_bounds__(X3_PARSE_THREADS) x3_parse_kernel(X3ParseArgs a) { x3_parse_body(a); }
+__global__ void __launch_bounds__(X3_PARSE_THREADS) x3_parse_kernel(X3ParseArgs a) { x3_parse_body<X3_PARSE_PB>(a); }
+__global__ void __launch_bounds__(X3_PARSE_THREADS, 8) x3_parse_many_kernel(X3ParseArgs a) { x3_parse_body<X3_PARSE_PB_SMALL>(a); }
 
 extern "C" void x3k_launch_parse(const X3ParseArgs *a, uint32_t nchunks, hipStream_t st)
 {
-	hipLaunchKernelGGL(x3_parse_kernel, dim3(nchunks), dim3(X3_PARSE_THREADS), 0, st, *a);
+	if (nchunks > 256) hipLaunchKernelGGL(x3_parse_many_kernel, dim3(nchunks), dim3(X3_PARSE_THREADS), 0, st, *a); /* two workgroups per CU */
+	else hipLaunchKernelGGL(x3_parse_kernel, dim3(nchunks), dim3(X3_PARSE_THREADS), 0, st, *a);
 }
 #else
-static void parse_tramp(void *p) { x3_parse_body(*(const X3ParseArgs *)p); }
+static void parse_tramp(void *p) { x3_parse_body<X3_PARSE_PB>(*(const X3ParseArgs *)p); }
 extern "C" void x3k_launch_parse(const X3ParseArgs *a, uint32_t nchunks, void *)
 {
 	x3emu_launch(parse_tramp, (void *)a, dim3(nchunks), dim3(X3_PARSE_THREADS));
