@@ -1,5 +1,6 @@
 /*
- * api.hip -- host side of libx3hip.so: the C ABI of include/x3hip.h on top of the three kernels.
+ * api.hip -- host side of libx3hip.so: the C ABI of include/x3hip.h on top of the three stages (K1 scan2.hip, K2 parse.hip, K3 code2.hip)
+ * and the decoder, plus the two schedules of a compress call (run_one: stage after stage; run_pipelined: overlapped).
  *
  * Data layout in HBM for a batch of independent chunks (streams):
  *   pad    : every chunk copied to a 256-byte aligned slot of  n + W + X3_PAD_EXTRA  bytes, tail zeroed -- the

@@ -12,12 +12,16 @@
  *     whose tag sits at a smaller list position.
  * All of them reduce to stable radix sorts, prefix sums and ONE custom primitive, "count smaller before"
  * (CSB: for every element, how many earlier elements of its bucket have a smaller key), done as an MSB-first stable
- * binary partition (wavelet-tree construction).  These run across the whole chip for all streams of a batch at once.
- * What remains serial per stream is thin:
- *   pass 1 (x3_modes_kernel): the mode choice of x3.c:152-172 -- it feeds back through model_events / model_index1;
- *   [parallel: cum_freq of the IDX1-coded ranks is again a CSB over the IDX1 subset]
- *   pass 2 (x3_ac_kernel)   : the arithmetic coder recurrence + bit output (ac.c:46-85, bio.c:49-72), one symbol triple
- *                             (cum, freq, total) per coded symbol.
+ * radix-4 partition (wavelet-tree construction).  These run across the whole chip for all streams of a batch at once.
+ * What remains per stream is thin:
+ *   the mode choice of x3.c:152-172, which feeds back through model_events / model_index1: either the fixed-point iteration
+ *      modes_fixed_point (chip-wide, for a few long streams) or x3_modes_kernel (one wavefront per stream, for many);
+ *   [parallel: cum_freq of the IDX1-coded ranks is again a CSB over the IDX1 subset; symbol operands; no-op symbols dropped]
+ *   x3_ac2_kernel: the arithmetic-coder interval recurrence (ac.c:46-85) on the scalar unit, one {cum, freq, magic, shift} operand
+ *      per symbol in, one chain state per 8 symbols out;
+ *   [parallel: per-symbol intervals re-derived from the states, bit emission (bio.c:49-72) by prefix sums + an OR-writer].
+ * x3_code_v2_run also serves the pipelined schedule of api.hip: called on growing prefixes (X3CodeSeg), it queues the recurrence of
+ * the new symbols on a separate HIP stream.
  */
 #include "x3_host.h"
 

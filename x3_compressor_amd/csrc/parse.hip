@@ -7,7 +7,7 @@
  * and, unless already present (x3.c:412), appended to the dictionary (tag = insertion ordinal, dict.c:100).
  * The parse never reads model / context / coder state, so it runs ahead of K3 and hands it a token list.
  *
- * MI355X mapping: one 256-thread workgroup per stream.
+ * MI355X mapping: one 1024-thread workgroup per stream.
  *   - dictionary = (pos,len) references into the input (an element IS input bytes) + an exact-match hash table
  *     keyed by (len, bytes) in global memory (L2 resident);
  *   - for a block of X3_PARSE_PB positions the workgroup caches in LDS the longest dictionary match L[q]/tag E[q] of
