@@ -446,7 +446,7 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 		x3k_launch_parse(&pa, (uint32_t)nc, c->stream);
 		HIPCHK(hipGetLastError());
 		CHK(x3_token_postpass(c->c2, c->stream, nc, c->hchunks.data(), c->chunks.as<X3Chunk>(), pa.result, pa.tok_info, pa.dict_len,
-		                      tok_pos, tok_hb, tok_nb, tok_mb));
+		                      tok_pos, tok_hb, tok_nb, tok_mb, 0, c->code_v1 != 0 || upto == STAGE_PARSE));
 		HIPCHK(hipEventRecord(c->ev[3], c->stream));
 		c->hparse.resize((size_t)nc);
 		HIPCHK(hipMemcpyAsync(c->hparse.data(), c->presult.p, (size_t)nc * sizeof(X3ParseResult), hipMemcpyDeviceToHost, c->stream));

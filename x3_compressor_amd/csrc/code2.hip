@@ -700,7 +700,7 @@ static int modes_fixed_point(X3Code2Bufs &B, hipStream_t st, size_t nH, uint32_t
  * ============================================================================================================ */
 int x3_token_postpass(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h_chunks, const X3Chunk *d_chunks,
                       const X3ParseResult *d_parsed, const uint32_t *tok_info, const uint8_t *dict_len,
-                      uint32_t *tok_pos, uint32_t *tok_hb, uint32_t *tok_nb, uint32_t *tok_mb, size_t prefix_tokens)
+                      uint32_t *tok_pos, uint32_t *tok_hb, uint32_t *tok_nb, uint32_t *tok_mb, size_t prefix_tokens, bool rebase)
 {
 	const uint32_t nc = (uint32_t)nchunks;
 	std::vector<uint32_t> eo(nc + 1);
@@ -736,7 +736,7 @@ int x3_token_postpass(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk
 		const uint32_t s = d_eo[c];
 		base[4 * c] = tok_hb[s]; base[4 * c + 1] = tok_nb[s]; base[4 * c + 2] = tok_mb[s]; base[4 * c + 3] = tok_pos[s];
 	});
-	x3_foreach(n, st, X3_LAMBDA(size_t i) {
+	if (rebase) x3_foreach(n, st, X3_LAMBDA(size_t i) {
 		const uint32_t c = find_chunk(d_eo, nc, (uint32_t)i);
 		tok_hb[i] -= base[4 * c]; tok_nb[i] -= base[4 * c + 1]; tok_mb[i] -= base[4 * c + 2]; tok_pos[i] -= base[4 * c + 3];
 	});
@@ -751,6 +751,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 {
 	const uint32_t nc = (uint32_t)nchunks;
 	const bool final = !seg || seg->final;
+	const uint32_t *tokb = B.pp[0].as<uint32_t>(); /* per stream: the token prefix sums {hits, elements, new-fragment bytes, position} at its first token (x3_token_postpass) */
 	for (int i = 0; i < 5; i++) if (!B.ev[i]) HIPCHK(hipEventCreate(&B.ev[i]));
 	HIPCHK(hipEventRecord(B.ev[0], st));
 	/* ---- index spaces: steps, hits, MTF events (hits + inserted elements), tags ---- */
@@ -816,7 +817,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 			const uint32_t c = find_chunk(d_so, nc, (uint32_t)gs);
 			const uint32_t k = (uint32_t)gs - d_so[c];
 			const uint64_t base = d_chunks[c].elem_off;
-			const uint32_t info = tok_info[base + k], hb = tok_hb[base + k], nb = tok_nb[base + k];
+			const uint32_t info = tok_info[base + k], hb = tok_hb[base + k] - tokb[4 * c], nb = tok_nb[base + k] - tokb[4 * c + 1];
 			if (!(info & X3_TOK_MISS)) {
 				const uint32_t gh = d_ho[c] + hb, ev = d_eo[c] + hb + nb;
 				const bool pv = k > 0 && !(tok_info[base + k - 1] & X3_TOK_MISS);
@@ -1011,9 +1012,9 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		const uint64_t base = d_chunks[c].elem_off;
 		const uint32_t info = tok_info[base + k];
 		if (info & X3_TOK_MISS) {
-			const uint32_t len = info & 0x3Fu, hb = tok_hb[base + k], mb = tok_mb[base + k];
+			const uint32_t len = info & 0x3Fu, hb = tok_hb[base + k] - tokb[4 * c], mb = tok_mb[base + k] - tokb[4 * c + 2];
 			lval[d_mo[c] + (k - hb)] = len - 1;
-			const uint8_t *p = d_bytes + d_chunks[c].byte_off + tok_pos[base + k];
+			const uint8_t *p = d_bytes + d_chunks[c].byte_off + (tok_pos[base + k] - tokb[4 * c + 3]);
 			for (uint32_t j = 0; j < len; j++) bval[d_bo[c] + mb + j] = p[j];
 		}
 	});
@@ -1052,7 +1053,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		const uint32_t c = find_chunk(d_so, nc, (uint32_t)gs);
 		const uint32_t k = (uint32_t)gs - d_so[c];
 		const uint64_t base = d_chunks[c].elem_off;
-		const uint32_t info = tok_info[base + k], hb = tok_hb[base + k], mb = tok_mb[base + k];
+		const uint32_t info = tok_info[base + k], hb = tok_hb[base + k] - tokb[4 * c], mb = tok_mb[base + k] - tokb[4 * c + 2];
 		uint32_t yi = d_yo[c] + 2 * k + mb;
 		const uint32_t evtotal = 2051u + k; /* model_events: 1024+1024+1+1+1 (x3.c:236-244), +1 per step */
 		if (!(info & X3_TOK_MISS)) {

@@ -95,7 +95,9 @@ struct X3Code2Bufs {
 
 int x3_token_postpass(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h_chunks, const X3Chunk *d_chunks,
                       const X3ParseResult *d_parsed, const uint32_t *tok_info, const uint8_t *dict_len,
-                      uint32_t *tok_pos, uint32_t *tok_hb, uint32_t *tok_nb, uint32_t *tok_mb, size_t prefix_tokens = 0);
+                      uint32_t *tok_pos, uint32_t *tok_hb, uint32_t *tok_nb, uint32_t *tok_mb, size_t prefix_tokens = 0, bool rebase = false);
+/* (rebase = false: the four arrays stay batch-wide prefix sums and X3Code2Bufs::pp[0] holds, per stream, the four values at its first
+ * token -- x3_code_v2_run subtracts them where it reads; rebase = true rewrites the arrays stream-relative, for the v1 kernel) */
 
 /* Coding GROWING PREFIXES of a few long streams while their parse is still running (api.hip, pipelined schedule): every call
  * recomputes the (parallel) features of the whole prefixes, puts the operands of the NEW chain symbols of every stream into a ring
