@@ -95,11 +95,11 @@ __device__ static uint32_t find_in_array(const uint32_t *freq, uint32_t count, u
 		const uint64_t mask = x3_ballot(i < count && dec_below(off, step, incl));
 		if (mask) {
 			const uint32_t l = (uint32_t)x3_ctz64(mask);
-			fq_out = x3_bcast_u32(fq, (int)l);
-			cum_out = x3_bcast_u32(incl, (int)l) - fq_out;
+			fq_out = x3_readlane_u32(fq, l);
+			cum_out = x3_readlane_u32(incl, l) - fq_out;
 			return base + l;
 		}
-		carry = x3_bcast_u32(incl, X3_WAVE - 1);
+		carry = x3_readlane_u32(incl, X3_WAVE - 1);
 	}
 	return 0xFFFFFFFFu;
 }
@@ -116,12 +116,12 @@ __device__ static uint32_t find_in_ctx(const X3CtxHdr h, const uint64_t *pool, u
 		const uint64_t mask = x3_ballot(i < h.items && dec_below(off, step, incl));
 		if (mask) {
 			const uint32_t l = (uint32_t)x3_ctz64(mask);
-			fq_out = x3_bcast_u32(fq, (int)l);
-			cum_out = x3_bcast_u32(incl, (int)l) - fq_out;
-			tag_out = x3_bcast_u32((uint32_t)(it >> 32), (int)l);
+			fq_out = x3_readlane_u32(fq, l);
+			cum_out = x3_readlane_u32(incl, l) - fq_out;
+			tag_out = x3_readlane_u32((uint32_t)(it >> 32), l);
 			return base + l;
 		}
-		carry = x3_bcast_u32(incl, X3_WAVE - 1);
+		carry = x3_readlane_u32(incl, X3_WAVE - 1);
 	}
 	return 0xFFFFFFFFu;
 }
@@ -256,7 +256,7 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 				const uint64_t mask = x3_ballot(lane < 32 && dec_below(d.buf - d.lo, step, incl));
 				if (!mask) { status = X3_ST_CORRUPT; break; }
 				const uint32_t l = (uint32_t)x3_ctz64(mask);
-				const uint32_t fq = x3_bcast_u32(lf, (int)l), cl = x3_bcast_u32(incl, (int)l) - fq;
+				const uint32_t fq = x3_readlane_u32(lf, l), cl = x3_readlane_u32(incl, l) - fq;
 				if (!dec_narrow(d, br, step, cl, cl + fq)) { status = X3_ST_CORRUPT; break; }
 				if (lane == l) lf++;
 				lftotal++;
@@ -273,8 +273,8 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 				const uint64_t mask = x3_ballot(dec_below(offb, step, incl));
 				if (!mask) { bad = 1; break; }
 				const uint32_t l = (uint32_t)x3_ctz64(mask);
-				const uint32_t b0 = x3_bcast_u32(cf0, (int)l), b1 = x3_bcast_u32(cf1, (int)l), b2 = x3_bcast_u32(cf2, (int)l), b3 = x3_bcast_u32(cf3, (int)l);
-				uint32_t cl = x3_bcast_u32(incl, (int)l) - (b0 + b1 + b2 + b3), sub, fq;
+				const uint32_t b0 = x3_readlane_u32(cf0, l), b1 = x3_readlane_u32(cf1, l), b2 = x3_readlane_u32(cf2, l), b3 = x3_readlane_u32(cf3, l);
+				uint32_t cl = x3_readlane_u32(incl, l) - (b0 + b1 + b2 + b3), sub, fq;
 				if (dec_below(offb, step, cl + b0)) { sub = 0; fq = b0; }
 				else if (dec_below(offb, step, cl + b0 + b1)) { sub = 1; fq = b1; cl += b0; }
 				else if (dec_below(offb, step, cl + b0 + b1 + b2)) { sub = 2; fq = b2; cl += b0 + b1; }
