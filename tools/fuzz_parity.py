@@ -42,8 +42,8 @@ def ctx_for(env):
 ENVS = [dict(), dict(X3H_PIPE_MIN="1"), dict(X3H_PIPE_MIN="1", X3H_MODES="fixed"), dict(X3H_PIPE_MIN="0", X3H_MODES="serial"), dict(X3H_PIPE_MIN="0", X3H_MODES="fixed")]
 t0, cases = time.time(), 0
 while time.time() - t0 < budget:
-    nch = int(rng.choice([1, 1, 1, 2, 3, 7, 40]))
-    sizes = [int(rng.choice([0, 1, 2, 31, 32, 33, 200, 2047, 2048, 2049, 5000, 20000, 70000])) if rng.random() < 0.5 else int(rng.integers(0, 30000)) for _ in range(nch)]
+    nch = int(rng.choice([1, 1, 1, 2, 3, 7, 40, 300]))   # 300: above the switch to the small-LDS kernel variants
+    sizes = [int(rng.integers(0, 3000)) for _ in range(nch)] if nch > 100 else [int(rng.choice([0, 1, 2, 31, 32, 33, 200, 2047, 2048, 2049, 5000, 20000, 70000])) if rng.random() < 0.5 else int(rng.integers(0, 30000)) for _ in range(nch)]
     w = int(rng.choice([0, 1, 1, 2, 4, 8, 8, 16, 64]))
     kw = dict(w_kib=w, t=int(rng.choice([0, 1, 2, 3, 8, 15, 16, 64, 256, 5000])), m=int(rng.choice([0, 1, 4, 4, 4, 9])),
               n=int(rng.choice([0, 0, 0, 1, 2, 5])), x=int(rng.random() < 0.15))
