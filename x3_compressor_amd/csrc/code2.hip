@@ -1170,34 +1170,32 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	 * pending after symbol i  = sum of k over (last symbol that shifted out bits (n>=1) or stream start .. i]
 	 * bits written by symbol i = n + pending before it (when n >= 1): first bit, the pending bits inverted, the other n-1 bits */
 	uint32_t *kk = Yv[5], *rv = Yv[6], *Kex = Yv[7], *LE = Yv[8], *len = Yv[9], *pos = Yv[10], *pend = Yv[11];
-	uint32_t *rec_fx = (uint32_t *)syr; /* the uncompacted operand array is dead now: the per-symbol intervals go there */
+	uint32_t *ebits = (uint32_t *)syr; /* the uncompacted operand array is dead now: one word per symbol goes there: 1 << n | the n bits the symbol shifts out */
 	{
-		/* x3_expand_records: the chain left its state at the first symbol of every group of X3_AC2_G; one thread re-runs each group */
+		/* x3_expand_records: the chain left its state at the first symbol of every group of X3_AC2_G; one thread re-runs each group and
+		 * derives, per symbol, n (E1/E2 shifts) with the n emitted bits, k (E3 shifts) and the "resets the pending count" marker */
 		const uint32_t *stt = rec_nk;
 		const uint4 *syc = sy;
 		x3_foreach(nYc, st, X3_LAMBDA(size_t i) {
 			const uint32_t c = find_chunk(d_yoc, nc, (uint32_t)i);
 			if (((uint32_t)i - d_yoc[c]) % X3_AC2_G) return;
 			uint32_t lo = stt[2 * i], R = stt[2 * i + 1];
-			const uint32_t end = d_yoc[c + 1], cnt = end - (uint32_t)i < X3_AC2_G ? end - (uint32_t)i : X3_AC2_G;
+			const uint32_t first = d_yoc[c], end = d_yoc[c + 1], cnt = end - (uint32_t)i < X3_AC2_G ? end - (uint32_t)i : X3_AC2_G;
 			for (uint32_t j = 0; j < cnt; j++) {
 				const uint2 r = x3_chain_step(lo, R, syc[i + j]);
-				rec_fx[2 * (i + j)] = r.x; rec_fx[2 * (i + j) + 1] = r.y;
+				const uint32_t n = x3_rec_n(r.x, r.y); /* <= 30: the interval has at least two values */
+				const uint32_t rev = x3_brev32(r.x << 1) & ((1u << n) - 1); /* bit j = j-th emitted bit = bit 30-j of lo */
+				ebits[i + j] = (1u << n) | rev;
+				kk[i + j] = x3_rec_k(r.x, r.y);
+				rv[i + j] = (n >= 1 || i + j == first) ? (uint32_t)(i + j) + 1 : 0u;
 			}
 		});
-		rec_nk = rec_fx;
 	}
-	x3_foreach(nYc, st, X3_LAMBDA(size_t i) {
-		const uint32_t rl = rec_nk[2 * i], rh = rec_nk[2 * i + 1];
-		const uint32_t c = find_chunk(d_yoc, nc, (uint32_t)i);
-		kk[i] = x3_rec_k(rl, rh);
-		rv[i] = (x3_rec_n(rl, rh) >= 1 || i == d_yoc[c]) ? (uint32_t)i + 1 : 0u;
-	});
 	CHK(x3p_excl_scan(B.tmp, kk, Kex, nYc, st));
 	CHK(x3p_incl_max_scan(B.tmp, rv, LE, nYc, st));
 	x3_foreach(nYc, st, X3_LAMBDA(size_t i) { pend[i] = Kex[i + 1] - Kex[LE[i] - 1]; });
 	x3_foreach(nYc, st, X3_LAMBDA(size_t i) {
-		const uint32_t n = x3_rec_n(rec_nk[2 * i], rec_nk[2 * i + 1]);
+		const uint32_t n = 31u - (uint32_t)x3_clz32(ebits[i]);
 		const uint32_t c = find_chunk(d_yoc, nc, (uint32_t)i);
 		len[i] = n >= 1 ? n + (i == d_yoc[c] ? 0u : pend[i - 1]) : 0u;
 	});
@@ -1221,9 +1219,9 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		const uint32_t c = find_chunk(d_yoc, nc, (uint32_t)i);
 		uint32_t *out32 = (uint32_t *)(d_out + d_chunks[c].out_off);
 		const uint32_t capw = (uint32_t)(d_chunks[c].out_cap / 4);
-		const uint32_t n = x3_rec_n(rec_nk[2 * i], rec_nk[2 * i + 1]), pd = ln - n;
+		const uint32_t eb = ebits[i], n = 31u - (uint32_t)x3_clz32(eb), pd = ln - n;
 		const uint64_t bp = pos[i] - pos[d_yoc[c]];
-		const uint32_t rev = x3_brev32(rec_nk[2 * i] << 1) & (n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1)); /* bit j = j-th emitted bit = bit 30-j of lo */
+		const uint32_t rev = eb ^ (1u << n);
 		if (!pd) x3_or_bits(out32, capw, bp, rev, n);
 		else {
 			x3_or_bits(out32, capw, bp, rev & 1u, 1);
