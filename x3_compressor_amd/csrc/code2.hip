@@ -1049,40 +1049,57 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	uint4 *syr = B.yraw.as<uint4>(); /* every symbol at its closed-form index (no-ops included) */
 	uint4 *sy = (uint4 *)Yv[0]; /* {cum, freq, magic, shift} per symbol */
 	uint32_t *rec_nk = Yv[3]; /* 2 words per symbol */
+	/* No-op symbols (total == 1, only the tag / index symbol of a hit can be one) are dropped from the chain's input; everything
+	 * downstream (chain states, emission) lives in compacted symbol indices.  Stage-after-stage calls assemble straight into the compacted
+	 * list: nzb[h] = no-op symbols among the hits before h (a scan over the hits).  Prefix calls of the pipelined schedule assemble the
+	 * raw list first: they need the compacted index of every raw symbol to find the NEW ones (a prefix of the raw list compacts to a
+	 * prefix of the compacted list). */
+	uint32_t *nzf = T[3], *nzb = T[4];
+	if (!seg) {
+		HIPCHK(hipMemsetAsync(nzb, 0, 4, st));
+		if (nH > 0) {
+			x3_foreach(nH, st, X3_LAMBDA(size_t gh) { nzf[gh] = hs_tot[gh] <= 1u ? 1u : 0u; });
+			CHK(x3p_excl_scan(B.tmp, nzf, nzb, nH, st));
+		}
+		x3_foreach(nc + 1, st, X3_LAMBDA(size_t c) { d_yoc[c] = d_yo[c] - nzb[d_ho[c]]; });
+	}
+	uint4 *sdst = seg ? syr : sy;
+	const bool direct = !seg;
 	x3_foreach(nS, st, X3_LAMBDA(size_t gs) {
 		const uint32_t c = find_chunk(d_so, nc, (uint32_t)gs);
 		const uint32_t k = (uint32_t)gs - d_so[c];
 		const uint64_t base = d_chunks[c].elem_off;
 		const uint32_t info = tok_info[base + k], hb = tok_hb[base + k] - tokb[4 * c], mb = tok_mb[base + k] - tokb[4 * c + 2];
 		uint32_t yi = d_yo[c] + 2 * k + mb;
+		if (direct) yi -= nzb[d_ho[c] + hb]; /* == d_yoc[c] + 2k + mb - (no-ops among the stream's earlier hits) */
 		const uint32_t evtotal = 2051u + k; /* model_events: 1024+1024+1+1+1 (x3.c:236-244), +1 per step */
 		if (!(info & X3_TOK_MISS)) {
 			const uint32_t gh = d_ho[c] + hb, m = mode[gh], e0 = pe0[gh], e1 = pe1[gh];
 			const uint32_t e2 = 2049u + hb - e0 - e1; /* every hit bumps exactly one of the three */
-			syr[yi] = x3_make_symbol(m == X3_E_CTX0 ? 0u : m == X3_E_CTX1 ? e0 : e0 + e1, m == X3_E_CTX0 ? e0 : m == X3_E_CTX1 ? e1 : e2, evtotal);
-			syr[yi + 1] = x3_make_symbol(hs_cum[gh], hs_freq[gh], hs_tot[gh]);
+			sdst[yi] = x3_make_symbol(m == X3_E_CTX0 ? 0u : m == X3_E_CTX1 ? e0 : e0 + e1, m == X3_E_CTX0 ? e0 : m == X3_E_CTX1 ? e1 : e2, evtotal);
+			if (!direct || hs_tot[gh] > 1u) sdst[yi + 1] = x3_make_symbol(hs_cum[gh], hs_freq[gh], hs_tot[gh]);
 		} else {
 			const uint32_t len = info & 0x3Fu, mk = k - hb; /* mk = new fragments before this one */
-			syr[yi] = x3_make_symbol(2049u + hb, 1u + mk, evtotal); /* E_NEW */
+			sdst[yi] = x3_make_symbol(2049u + hb, 1u + mk, evtotal); /* E_NEW */
 			const uint32_t gm = d_mo[c] + mk;
-			syr[yi + 1] = x3_make_symbol((len - 1) + lsm[gm], 1u + leq[gm], 32u + mk);
+			sdst[yi + 1] = x3_make_symbol((len - 1) + lsm[gm], 1u + leq[gm], 32u + mk);
 			for (uint32_t j = 0; j < len; j++) {
 				const uint32_t gb = d_bo[c] + mb + j;
-				syr[yi + 2 + j] = x3_make_symbol(bval[gb] + bsm[gb], 1u + beq[gb], 256u + mb + j);
+				sdst[yi + 2 + j] = x3_make_symbol(bval[gb] + bsm[gb], 1u + beq[gb], 256u + mb + j);
 			}
 		}
 	});
 	if (final) x3_foreach(nc, st, X3_LAMBDA(size_t c) { /* E_EOF, x3.c:432-433 */
-		const uint32_t yi = d_yo[c + 1] - 1, evtotal = 2051u + d_parsed[c].ntok;
-		syr[yi] = x3_make_symbol(evtotal - 1, 1, evtotal);
+		const uint32_t yi = (direct ? d_yoc[c + 1] : d_yo[c + 1]) - 1, evtotal = 2051u + d_parsed[c].ntok;
+		sdst[yi] = x3_make_symbol(evtotal - 1, 1, evtotal);
 	});
 
-	/* ---- drop the no-op symbols (total == 1): the chain's input is the compacted list, everything downstream (records, emission)
-	 *      lives in compacted symbol indices.  A prefix of the raw list compacts to a prefix of the compacted list. ---- */
 	uint32_t *kf = Yv[5], *Pk = Yv[6];
-	x3_foreach(nY, st, X3_LAMBDA(size_t y) { kf[y] = syr[y].w != X3_SYM_NOOP ? 1u : 0u; });
-	CHK(x3p_excl_scan(B.tmp, kf, Pk, nY, st));
-	x3_foreach(nc + 1, st, X3_LAMBDA(size_t c) { d_yoc[c] = Pk[d_yo[c]]; });
+	if (seg) {
+		x3_foreach(nY, st, X3_LAMBDA(size_t y) { kf[y] = syr[y].w != X3_SYM_NOOP ? 1u : 0u; });
+		CHK(x3p_excl_scan(B.tmp, kf, Pk, nY, st));
+		x3_foreach(nc + 1, st, X3_LAMBDA(size_t c) { d_yoc[c] = Pk[d_yo[c]]; });
+	}
 	std::vector<uint32_t> yoc(nc + 1);
 	HIPCHK(hipMemcpyAsync(yoc.data(), d_yoc, (nc + 1) * 4, hipMemcpyDeviceToHost, st));
 	HIPCHK(hipStreamSynchronize(st));
@@ -1095,7 +1112,6 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	aa.seg_off = aa.seg_len = nullptr; aa.seg_state = nullptr;
 	if (nH == 0) HIPCHK(hipEventRecord(B.ev[2], st));
 	if (!seg) {
-		x3_foreach(nY, st, X3_LAMBDA(size_t y) { if (kf[y]) sy[Pk[y]] = syr[y]; });
 		HIPCHK(hipEventRecord(B.ev[3], st));
 		launch_ac2(aa, nc, st);
 		HIPCHK(hipGetLastError());
