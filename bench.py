@@ -169,7 +169,7 @@ def main():
             t = json.load(open(tpath))["total"]
             many["hbm_traffic"] = {"GB_per_batch": round(t["fetch_GB"] + t["write_GB"], 1), "avg_TBps_over_kernel_time": t["avg_TBps"],
                                    "frac_of_hbm_peak": round(t["avg_TBps"] * 1e12 / HBM_PEAK, 3), "source": "profiles/r01_many_chunks_pmc_traffic.json",
-                                   "note": "the chip-wide sort / partition / scan passes stream at 3.4-5.5 TB/s; the batch is bound by the BYTES they move (2.6 KB per input byte)"}
+                                   "note": "the chip-wide sort / partition / scan passes stream at 3.4-5.5 TB/s; the batch is bound by the BYTES they move (2.4 KB per input byte)"}
         del d_min, d_mout
 
     if rank == 0:
