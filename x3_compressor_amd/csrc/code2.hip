@@ -861,6 +861,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		}
 
 		/* ---- tag-pair ordinals (tag_pair.c) and the ctx0 group of every hit (x3.c:139-147) ---- */
+		uint32_t npairs_total = 0;
 		{
 			uint32_t *iota = T[0], *k1 = T[1], *v1 = T[2], *k2in = T[3], *k2 = T[4], *v2 = T[5], *rsf = T[6], *rs = T[7], *pf = T[8], *P = T[9], *rsflag = T[10];
 			const int tb = bits_for(nD);
@@ -876,6 +877,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 			CHK(x3p_incl_max_scan(B.tmp, rsf, rs, nH, st));
 			x3_foreach(nH, st, X3_LAMBDA(size_t i) { pf[v2[i]] = rsflag[i]; }); /* first occurrence of its pair, in time order */
 			CHK(x3p_excl_scan(B.tmp, pf, P, nH, st));
+			HIPCHK(hipMemcpyAsync(&npairs_total, P + nH, 4, hipMemcpyDeviceToHost, st)); /* read after the next synchronisation point below */
 			x3_foreach(nH, st, X3_LAMBDA(size_t i) { h_pair[v2[i]] = P[v2[rs[i]]]; });
 			x3_foreach(nc, st, X3_LAMBDA(size_t c) {
 				const uint32_t lo = d_ho[c], hi = d_ho[c + 1];
@@ -901,10 +903,11 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 				}
 				G0[gh] = g;
 			});
+			HIPCHK(hipStreamSynchronize(st)); /* npairs_total */
 		}
 
 		/* ---- context statistics ---- */
-		CHK(ctx_stats(B, st, nH, bits_for(nH), bits_for(nD), G0, h_tag, f0, t0, c0, T));
+		CHK(ctx_stats(B, st, nH, bits_for(npairs_total ? npairs_total : 1), bits_for(nD), G0, h_tag, f0, t0, c0, T)); /* ctx0 groups are pair ordinals: sort only as many bits as there are pairs */
 		CHK(ctx_stats(B, st, nH, bits_for(nD), bits_for(nD), h_c1, h_tag, f1, t1, c1, T));
 	}
 
