@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define X3H_ABI_VERSION 2 /* 2: x3h_stats grew (mode_iters, chain_symbols, pipelined) */
+#define X3H_ABI_VERSION 3 /* 2: x3h_stats grew (mode_iters, chain_symbols, pipelined); 3: X3C1 container + multi-device batch entries */
 
 /* status codes (the reference abort()s on every error: file.c:9-18, x3.c:515,547,554,583) */
 enum {
@@ -111,6 +111,41 @@ int x3h_decompress(x3h_ctx *ctx, const uint8_t *in, size_t n, uint8_t *out, size
  * into out[out_offsets[c] .. out_offsets[c+1]) (that span is its capacity); out_lens[c] receives the decoded size. Host pointers. */
 int x3h_decompress_chunks(x3h_ctx *ctx, const uint8_t *in, const uint64_t *in_offsets, int nchunks,
                           uint8_t *out, const uint64_t *out_offsets, uint64_t *out_lens, x3h_stats *stats);
+
+/* ---- independent chunks across several GPUs + the X3C1 chunk container (SURVEY.md 8(b) batch form, 8(e), 8(f).2) --------------
+ * The reference has one stream per file (x3.c:599-611) and no container.  Independent chunks are the only way the path shards
+ * (SURVEY.md 8(e)): chunk c of a batch is coded exactly like `x3 -z` on that chunk alone.  `ctxs[0..ndevices)` are handles on the
+ * GPUs to use (several handles on ONE GPU are allowed); chunks are dealt out in contiguous blocks, device d gets
+ * [d*nchunks/ndevices ...) like BASELINE config 4 (chunk c on GPU c / 16), one host thread per device, no exchange between devices.
+ * Host pointers.  *stats (optional) sums the counters; its ms_* fields are those of the slowest device.                        */
+int x3h_compress_chunks_multi(x3h_ctx *const *ctxs, int ndevices, const x3h_params *prm, const uint8_t *in, const uint64_t *offsets,
+                              int nchunks, uint8_t *out, uint64_t out_stride, uint64_t *out_lens, x3h_stats *stats);
+int x3h_decompress_chunks_multi(x3h_ctx *const *ctxs, int ndevices, const uint8_t *in, const uint64_t *in_offsets, int nchunks,
+                                uint8_t *out, const uint64_t *out_offsets, uint64_t *out_lens, x3h_stats *stats);
+
+/* X3C1 container (little-endian):  "X3C1" | u32 version=1 | u32 window_bytes | i32 max_match_count | u32 factor1 | u32 factor2 |
+ * i32 nl_mode | u32 nchunks | nchunks x { u64 raw_len, u64 comp_len } | the chunk streams back to back.
+ * ONE chunk is never wrapped: it stays the raw x3 code stream of x3.c:603-611, so the CLI remains a drop-in.                  */
+#define X3H_CONTAINER_VERSION 1
+#define X3H_NOT_A_CONTAINER   1 /* x3h_container_probe: no magic -- treat the bytes as one raw x3 stream */
+size_t x3h_container_header_bytes(int nchunks);
+int    x3h_container_write_header(uint8_t *dst, size_t cap, const x3h_params *prm, int nchunks,
+                                  const uint64_t *raw_lens, const uint64_t *comp_lens);
+/* X3H_OK: a well-formed container (prm, *nchunks, *raw_total filled; every length checked against n);
+ * X3H_NOT_A_CONTAINER: no magic;  X3H_E_CORRUPT: magic but a bad version / table / total length.                               */
+int    x3h_container_probe(const uint8_t *blob, size_t n, x3h_params *prm, int *nchunks, uint64_t *raw_total);
+/* after an X3H_OK probe: raw_lens[nchunks], and comp_offsets[nchunks+1] = byte offsets of the chunk streams inside blob        */
+int    x3h_container_table(const uint8_t *blob, size_t n, uint64_t *raw_lens, uint64_t *comp_offsets);
+
+/* Whole files.  x3h_compress_container: cut `in` into chunks of chunk_bytes (the last one shorter), code them on the given
+ * devices and write the container (or, for a single chunk, the raw stream) into out[0..cap).  x3h_container_bound(n, chunk_bytes)
+ * is a sufficient `cap`.  x3h_decompress_container accepts either form; for a raw stream `cap` bounds the output as in
+ * x3h_decompress, for a container X3H_E_OUTPUT_FULL is returned at once when cap < raw_total.                                  */
+size_t x3h_container_bound(size_t n, size_t chunk_bytes);
+int x3h_compress_container(x3h_ctx *const *ctxs, int ndevices, const x3h_params *prm, const uint8_t *in, size_t n, size_t chunk_bytes,
+                           uint8_t *out, size_t cap, size_t *out_len, x3h_stats *stats);
+int x3h_decompress_container(x3h_ctx *const *ctxs, int ndevices, const uint8_t *in, size_t n,
+                             uint8_t *out, size_t cap, size_t *out_len, x3h_stats *stats);
 
 /* Stage-level entry points (kernel parity tests; the seams named in SURVEY.md 8(b)).
  *  x3h_scan_m      : K1 alone.  m_out[p] = max{ i : count[i] > min(T, count[0]-1) } (0 if T<=0 or count[0]<2) with

@@ -43,7 +43,7 @@ def test_library_is_gfx950_only():
 
 
 def test_scalar_entry_points(lib):
-    assert lib.x3h_abi_version() == 2
+    assert lib.x3h_abi_version() == 3
     assert lib.x3h_strerror(0) == b"ok" and b"output" in lib.x3h_strerror(-3)
     assert lib.x3h_compress_bound(0) >= 4 and lib.x3h_compress_bound(1000) >= 2000
     p = _lib.Params()
@@ -69,3 +69,17 @@ def test_missing_library_is_an_error(tmp_path):
 def test_cli_links_only_the_c_abi():
     src = open(os.path.join(ROOT, "x3_compressor_amd", "csrc", "x3_cli.c")).read()
     assert "hip/hip_runtime" not in src and "x3hip.h" in src
+    assert '"zdfkht:w:m:n:xg:"' in src  # the reference's getopt string (x3.c:484) plus the additive -g
+
+
+def test_cli_without_gpu_fails_loudly(tmp_path, lib):
+    """The built CLI runs here too: option parsing and file-name rules work, the hot path refuses to run without a GPU."""
+    if lib.x3h_device_count() > 0:
+        pytest.skip("a GPU is present")
+    exe = os.path.join(ROOT, "x3_compressor_amd", "csrc", "x3")
+    f = tmp_path / "in.txt"
+    f.write_bytes(b"hello hello hello")
+    r = subprocess.run([exe, "-z", str(f)], capture_output=True, text=True)
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr
+    r = subprocess.run([exe, "-h"], capture_output=True, text=True)
+    assert r.returncode == 0 and "--chunk-kib" in r.stderr and "-w NUM" in r.stderr

@@ -128,3 +128,64 @@ def test_emulated_csb_count_kernel_body(emu_env, oracle):
     ctx = emu_env(X3_EMU_CSB_KERNEL="1")
     data, kw = synth.english_like(6000).tobytes(), dict(w_kib=2, t=8)
     assert ctx.compress(data, _lib.make_params(**kw)) == oracle.compress(data, oracle_lib.params(**kw))
+
+
+# ---- chunking behind the C boundary: sub-batches, several handles, X3C1 container (api.hip, x3_container.c) -------------------------
+def test_emulated_sub_batching_by_padded_bytes(emu_env, oracle):
+    """many small chunks under a large window: the sub-batches are cut on the PADDED layout (len + W + slack per chunk), which K1
+    indexes with 32 bits -- not on the input bytes"""
+    kw = dict(w_kib=16, t=8)
+    parts = [synth.english_like(700 + 13 * i, seed=40 + i).tobytes() for i in range(7)] + [b""]
+    data = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    off = np.cumsum([0] + [len(p) for p in parts]).astype(np.uint64)
+    want = [oracle.compress(p, oracle_lib.params(**kw)) for p in parts]
+    ctx = emu_env(X3H_BATCH_PAD_BYTES=str(3 * (16384 + 4096 + 1024)))   # room for two or three padded chunks per sub-batch
+    assert ctx.compress_chunks(data, off, _lib.make_params(**kw)) == want
+    assert ctx.last_stats.steps == sum(len(oracle.trace(p, oracle_lib.params(**kw))[1]) for p in parts)
+
+
+def test_emulated_output_full_in_one_sub_batch_reports_every_length(emu_env):
+    """a sub-batch that does not fit its capacity must not hide the others' results (every out_lens entry is written)"""
+    import ctypes as C
+    ctx = emu_env(X3H_BATCH_BYTES="3000")
+    rnd = np.random.default_rng(3).integers(0, 256, 2500, dtype=np.uint8).tobytes()   # incompressible: needs > 2500 bytes
+    parts = [bytes(2000), rnd, bytes(1500)]
+    data = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    off = np.cumsum([0] + [len(p) for p in parts]).astype(np.uint64)
+    stride, lens, st = 1024, np.full(3, 77, dtype=np.uint64), _lib.Stats()
+    out = np.zeros(stride * 3, dtype=np.uint8)
+    prm = _lib.make_params(w_kib=1, t=4)
+    rc = ctx.lib.x3h_compress_chunks(ctx._h, C.byref(prm), data.ctypes.data, off.ctypes.data, 3, out.ctypes.data, stride, lens.ctypes.data, C.byref(st))
+    assert rc == -3 and lens[0] > 0 and lens[2] > 0 and lens[0] < 100 and lens[2] < 100
+    assert st.steps > 0
+
+
+def test_emulated_container_round_trip_two_handles(emu_env, oracle):
+    """x3h_compress_container / x3h_decompress_container over two handles: chunk c == the oracle's stream of chunk c, one chunk stays raw"""
+    a, b = emu_env(X3H_MULTI_SERIAL="1"), emu_env()
+    kw = dict(w_kib=2, t=8)
+    prm, oprm = _lib.make_params(**kw), oracle_lib.params(**kw)
+    data = synth.english_like(7001).tobytes()
+    blob = _lib.compress_container([a, b], data, prm, 2048)
+    params, chunks = __import__("x3_compressor_amd.container", fromlist=["x"]).unpack(blob)
+    assert params["window_bytes"] == 2048 and params["max_match_count"] == 8 and len(chunks) == 4
+    for i, (raw, s) in enumerate(chunks):
+        assert raw == len(data[i * 2048:(i + 1) * 2048]) and s == oracle.compress(data[i * 2048:(i + 1) * 2048], oprm)
+    assert _lib.decompress_container([a, b], blob, len(data)) == data
+    with pytest.raises(_lib.X3Error) as e:
+        _lib.decompress_container([a], blob, len(data) - 1)
+    assert e.value.status == -3
+    bad = bytearray(blob); bad[-5] ^= 0x40
+    try:
+        assert _lib.decompress_container([a], bytes(bad), len(data)) != data
+    except _lib.X3Error as e2:
+        assert e2.status == -4
+    # one chunk: no frame at all, the reference's raw stream (x3.c:603-611)
+    one = _lib.compress_container([a, b], data[:1500], prm, 2048)
+    assert one == oracle.compress(data[:1500], oprm)
+    assert _lib.decompress_container([a], one, 4096) == data[:1500]
+    assert _lib.compress_container([a], b"", prm, 2048) == oracle.compress(b"", oprm)
+    # chunks over handles directly
+    off = np.array([0, 100, 100, 3000, 7001], dtype=np.uint64)
+    got = _lib.compress_chunks_multi([a, b, a], np.frombuffer(data, np.uint8), off, prm)
+    assert got == [oracle.compress(data[int(off[i]):int(off[i + 1])], oprm) for i in range(4)]

@@ -329,3 +329,46 @@ def test_decode_batch_of_many_streams(gpu):
     # the same batch size selects the small-block variants of the parse and mode kernels: their streams == the big variants' (one stream at a time)
     for i in (0, 150, 299):
         assert streams[i] == gpu.compress(parts[i], prm), f"stream {i}"
+
+
+# ---- chunking behind the C boundary: container, several handles, sub-batches cut on the padded layout ---------------------------------
+def test_container_from_hip_streams(gpu, oracle):
+    """HIP streams -> X3C1 container (x3h_compress_container) -> unpack -> every chunk == the oracle's stream of that chunk ->
+    x3h_decompress_container gives the input back; two handles on GPU 0 working side by side (one host thread each)."""
+    from x3_compressor_amd import container
+    data = synth.english_like(110_000, seed=3).tobytes()
+    kw = dict(w_kib=8, t=16)
+    prm = _lib.make_params(**kw)
+    with _lib.X3Context(0) as second:
+        blob = _lib.compress_container([gpu, second], data, prm, 20_000)
+        params, chunks = container.unpack(blob)
+        assert params["window_bytes"] == 8192 and len(chunks) == 6
+        for i, (raw, s) in enumerate(chunks):
+            part = data[i * 20_000:(i + 1) * 20_000]
+            assert raw == len(part) and s == oracle.compress(part, oracle_lib.params(**kw)), f"chunk {i}"
+        assert _lib.decompress_container([gpu, second], blob, len(data)) == data
+        assert _lib.decompress_container([gpu], blob, len(data)) == data
+        # the same chunks through the multi-handle batch entry, ragged split
+        off = np.array([0, 20_000, 40_000, 40_000, 60_000, 110_000], dtype=np.uint64)
+        got = _lib.compress_chunks_multi([gpu, second], np.frombuffer(data, np.uint8), off, prm)
+        assert got[0] == chunks[0][1] and got[1] == chunks[1][1] and got[3] == chunks[2][1]
+        assert got[2] == oracle.compress(b"", oracle_lib.params(**kw))
+    with pytest.raises(_lib.X3Error) as e:
+        _lib.decompress_container([gpu], blob[:-4], len(data))
+    assert e.value.status == -4
+    with pytest.raises(_lib.X3Error) as e:
+        _lib.decompress_container([gpu], blob, len(data) - 1)
+    assert e.value.status == -3
+
+
+def test_sub_batches_are_cut_on_the_padded_layout(gpu, gpu_env):
+    """many small chunks under a 512 KiB window: every chunk occupies len + W + slack in the padded layout that K1 indexes with 32 bits,
+    so the sub-batch cut must look at that, not at the input bytes (here the limit is lowered to three padded chunks)"""
+    data = synth.english_like(40 * 3000, seed=8)
+    off = np.arange(0, 40 * 3000 + 1, 3000, dtype=np.uint64)
+    prm = _lib.make_params(w_kib=512, t=4096)
+    whole = gpu.compress_chunks(data, off, prm)
+    small = gpu_env(X3H_BATCH_PAD_BYTES=str(3 * ((512 << 10) + 3000 + 4096 + 256)))
+    assert small.compress_chunks(data, off, prm) == whole
+    assert small.last_stats.steps == gpu.last_stats.steps
+    assert whole[7] == gpu.compress(data[7 * 3000:8 * 3000], prm)

@@ -18,12 +18,15 @@ ABI_SYMBOLS = (
     "x3h_abi_version", "x3h_strerror", "x3h_last_hip_error", "x3h_device_count", "x3h_default_params",
     "x3h_compress_bound", "x3h_ctx_create", "x3h_ctx_destroy", "x3h_compress", "x3h_compress_chunks",
     "x3h_compress_chunks_dev", "x3h_decompress", "x3h_decompress_chunks", "x3h_scan_m", "x3h_scan_counts", "x3h_parse",
+    "x3h_compress_chunks_multi", "x3h_decompress_chunks_multi", "x3h_container_header_bytes", "x3h_container_write_header",
+    "x3h_container_probe", "x3h_container_table", "x3h_container_bound", "x3h_compress_container", "x3h_decompress_container",
 )
 
 TOK_MISS, TOK_DUP = 0x80000000, 0x40000000
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
+NOT_A_CONTAINER = 1  # x3h_container_probe: the bytes are one raw x3 stream
 
 
 class Params(C.Structure):
@@ -81,6 +84,19 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.x3h_scan_counts.argtypes = [C.c_void_p, C.POINTER(Params), u8p, C.c_size_t, C.c_void_p]
     lib.x3h_parse.argtypes = [C.c_void_p, C.POINTER(Params), u8p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
                               C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]
+    ctxs = C.POINTER(C.c_void_p)
+    lib.x3h_compress_chunks_multi.argtypes = [ctxs, C.c_int, C.POINTER(Params), u8p, C.c_void_p, C.c_int, u8p, C.c_uint64, C.c_void_p, C.POINTER(Stats)]
+    lib.x3h_decompress_chunks_multi.argtypes = [ctxs, C.c_int, u8p, C.c_void_p, C.c_int, u8p, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+    lib.x3h_container_header_bytes.restype = C.c_size_t
+    lib.x3h_container_header_bytes.argtypes = [C.c_int]
+    lib.x3h_container_bound.restype = C.c_size_t
+    lib.x3h_container_bound.argtypes = [C.c_size_t, C.c_size_t]
+    lib.x3h_container_write_header.argtypes = [u8p, C.c_size_t, C.POINTER(Params), C.c_int, C.c_void_p, C.c_void_p]
+    lib.x3h_container_probe.argtypes = [u8p, C.c_size_t, C.POINTER(Params), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
+    lib.x3h_container_table.argtypes = [u8p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.x3h_compress_container.argtypes = [ctxs, C.c_int, C.POINTER(Params), u8p, C.c_size_t, C.c_size_t, u8p, C.c_size_t,
+                                           C.POINTER(C.c_size_t), C.POINTER(Stats)]
+    lib.x3h_decompress_container.argtypes = [ctxs, C.c_int, u8p, C.c_size_t, u8p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(Stats)]
     return lib
 
 
@@ -215,3 +231,55 @@ class X3Context:
         self._check(self.lib.x3h_parse(self._h, C.byref(prm), a.ctypes.data if a.size else None, a.size, tp.ctypes.data, ti.ctypes.data,
                                        tp.size, C.byref(ntok), C.byref(d)))
         return tp[:ntok.value].copy(), ti[:ntok.value].copy(), int(d.value)
+
+
+# ---- several handles at once: chunks over devices, X3C1 container (include/x3hip.h) ------------------------------------
+def _handles(ctxs):
+    arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    return arr, len(ctxs)
+
+
+def compress_chunks_multi(ctxs: list[X3Context], data, offsets, prm: Params, stride: int | None = None) -> list[bytes]:
+    """x3h_compress_chunks_multi: contiguous blocks of chunks per handle, one host thread per handle."""
+    lib = ctxs[0].lib
+    a = _u8(data)
+    off = np.ascontiguousarray(offsets, dtype=np.uint64)
+    nch = off.size - 1
+    if stride is None:
+        stride = int(lib.x3h_compress_bound(int(np.diff(off.astype(np.int64)).max(initial=0))))
+    stride = (stride + 3) & ~3
+    out = np.empty(stride * nch, dtype=np.uint8)
+    lens = np.zeros(nch, dtype=np.uint64)
+    st = Stats()
+    arr, n = _handles(ctxs)
+    ctxs[0]._check(lib.x3h_compress_chunks_multi(arr, n, C.byref(prm), a.ctypes.data if a.size else None, off.ctypes.data, nch,
+                                                 out.ctypes.data, stride, lens.ctypes.data, C.byref(st)))
+    ctxs[0].last_stats = st
+    return [out[i * stride:i * stride + int(lens[i])].tobytes() for i in range(nch)]
+
+
+def compress_container(ctxs: list[X3Context], data, prm: Params, chunk_bytes: int) -> bytes:
+    """x3h_compress_container: what `x3 -z --chunk-kib N` writes (raw stream if the input is one chunk)."""
+    lib = ctxs[0].lib
+    a = _u8(data)
+    cap = int(lib.x3h_container_bound(a.size, chunk_bytes))
+    out = np.empty(cap, dtype=np.uint8)
+    n_out, st = C.c_size_t(0), Stats()
+    arr, n = _handles(ctxs)
+    ctxs[0]._check(lib.x3h_compress_container(arr, n, C.byref(prm), a.ctypes.data if a.size else None, a.size, chunk_bytes,
+                                              out.ctypes.data, cap, C.byref(n_out), C.byref(st)))
+    ctxs[0].last_stats = st
+    return out[:n_out.value].tobytes()
+
+
+def decompress_container(ctxs: list[X3Context], blob, cap: int) -> bytes:
+    """x3h_decompress_container: an X3C1 container or a raw stream (what `x3 -d` reads)."""
+    lib = ctxs[0].lib
+    a = _u8(blob)
+    out = np.empty(max(cap, 1), dtype=np.uint8)
+    n_out, st = C.c_size_t(0), Stats()
+    arr, n = _handles(ctxs)
+    ctxs[0]._check(lib.x3h_decompress_container(arr, n, a.ctypes.data if a.size else None, a.size, out.ctypes.data, cap,
+                                                C.byref(n_out), C.byref(st)))
+    ctxs[0].last_stats = st
+    return out[:n_out.value].tobytes()

@@ -2,43 +2,64 @@
 
 One chunk  -> the raw x3 code stream, byte-identical to `x3 -z` (no header at all: the CLI stays a drop-in).
 Many chunks -> "X3C1" header, parameter echo, per-chunk (raw_len, comp_len) table, then the chunk streams back-to-back.
-Every chunk is an independent x3 stream (own zero padding, own create() state), so chunk i alone decodes with `x3 -d`.
+Every chunk is an independent x3 stream (own zero padding, own create() state).
+
+The format lives in C (csrc/x3_container.c behind include/x3hip.h: the CLI and `x3h_compress_container` use the same
+code); this module is the ctypes view of those entry points -- host-only functions, no GPU needed.
 """
 from __future__ import annotations
 
-import struct
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
 
 MAGIC = b"X3C1"
-_HDR = struct.Struct("<4sIIiIIiI")  # magic, version, window_bytes, max_match_count, factor1, factor2, nl_mode, nchunks
-_ENT = struct.Struct("<QQ")         # raw_len, comp_len
+_LIB = None
+
+
+def _lib_handle():
+    global _LIB
+    if _LIB is None:
+        _LIB = _lib.load_library()
+    return _LIB
 
 
 def pack(streams: list[bytes], raw_lens: list[int], prm) -> bytes:
     assert len(streams) == len(raw_lens) and len(streams) >= 1
     if len(streams) == 1:
         return bytes(streams[0])
-    head = _HDR.pack(MAGIC, 1, prm.window_bytes, prm.max_match_count, prm.factor1, prm.factor2, prm.nl_mode, len(streams))
-    table = b"".join(_ENT.pack(r, len(s)) for r, s in zip(raw_lens, streams))
-    return head + table + b"".join(streams)
+    lib = _lib_handle()
+    n = len(streams)
+    head = np.empty(int(lib.x3h_container_header_bytes(n)), dtype=np.uint8)
+    raw = np.asarray(raw_lens, dtype=np.uint64)
+    comp = np.asarray([len(s) for s in streams], dtype=np.uint64)
+    rc = lib.x3h_container_write_header(head.ctypes.data, head.size, C.byref(prm), n, raw.ctypes.data, comp.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"x3h_container_write_header: {lib.x3h_strerror(rc).decode()}")
+    return head.tobytes() + b"".join(streams)
 
 
 def unpack(blob: bytes):
-    """-> (params dict or None, [(raw_len or None, stream bytes)])"""
-    if blob[:4] != MAGIC:
+    """-> (params dict or None, [(raw_len or None, stream bytes)]); ValueError on a malformed container."""
+    lib = _lib_handle()
+    a = np.frombuffer(bytes(blob), dtype=np.uint8)
+    prm, nch, raw_total = _lib.Params(), C.c_int(0), C.c_uint64(0)
+    rc = lib.x3h_container_probe(a.ctypes.data if a.size else None, a.size, C.byref(prm), C.byref(nch), C.byref(raw_total))
+    if rc == _lib.NOT_A_CONTAINER:
         return None, [(None, bytes(blob))]
-    magic, ver, w, t, f1, f2, nl, n = _HDR.unpack_from(blob, 0)
-    if ver != 1:
-        raise ValueError(f"unknown container version {ver}")
-    off = _HDR.size
-    ents = [_ENT.unpack_from(blob, off + i * _ENT.size) for i in range(n)]
-    off += n * _ENT.size
-    out = []
-    for raw, comp in ents:
-        out.append((raw, bytes(blob[off:off + comp])))
-        off += comp
-    if off != len(blob):
-        raise ValueError("container length mismatch")
-    return dict(window_bytes=w, max_match_count=t, factor1=f1, factor2=f2, nl_mode=nl), out
+    if rc != 0:
+        raise ValueError(f"malformed X3C1 container: {lib.x3h_strerror(rc).decode()}")
+    n = nch.value
+    raw = np.zeros(n, dtype=np.uint64)
+    off = np.zeros(n + 1, dtype=np.uint64)
+    rc = lib.x3h_container_table(a.ctypes.data, a.size, raw.ctypes.data, off.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"malformed X3C1 container: {lib.x3h_strerror(rc).decode()}")
+    params = dict(window_bytes=prm.window_bytes, max_match_count=prm.max_match_count, factor1=prm.factor1, factor2=prm.factor2,
+                  nl_mode=prm.nl_mode)
+    return params, [(int(raw[i]), bytes(blob[int(off[i]):int(off[i + 1])])) for i in range(n)]
 
 
 def split_offsets(total: int, chunk_bytes: int):

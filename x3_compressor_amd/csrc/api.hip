@@ -22,7 +22,6 @@
 
 extern "C" void x3k_launch_scan(const X3ScanArgs *a, uint32_t max_len, uint32_t nchunks, hipStream_t st);
 extern "C" void x3k_launch_parse(const X3ParseArgs *a, uint32_t nchunks, hipStream_t st);
-extern "C" void x3k_launch_code(const X3CodeArgs *a, uint32_t nchunks, hipStream_t st);
 extern "C" void x3k_launch_decode(const X3DecArgs *a, uint32_t nchunks, hipStream_t st);
 
 thread_local int x3_last_hip = 0;
@@ -35,7 +34,7 @@ struct x3h_ctx {
 	DevBuf pad, m, dict_pos, dict_len, ht, tok_pos, tok_info, tok_hb, tok_nb, tok_mb, chunks, presult, cresult;
 	X3Code2Bufs c2;
 	X3Scan2Bufs s2;
-	int code_v1 = 0, scan_v1 = 0;
+	int scan_v1 = 0;
 	/* single-stream pipelining (run_pipelined): the parse on its own stream publishes checkpoints, the coding stage of every prefix
 	 * runs while the parse continues, the coder recurrence of a segment on a third stream */
 	int pipe_max_streams = 32; /* X3H_PIPE_STREAMS */
@@ -47,6 +46,8 @@ struct x3h_ctx {
 	X3CodeSeg seg;
 	DevBuf coder_state, prefix_result, srcoff, ckpt_pos;
 	uint64_t batch_bytes = (uint64_t)1 << 30;
+	uint64_t dec_batch_bytes = (uint64_t)512 << 20; /* X3H_DEC_BATCH_BYTES */
+	uint64_t batch_pad_bytes = (uint64_t)2 << 30; /* X3H_BATCH_PAD_BYTES: padded layout of one sub-batch (K1 needs < 2^32 - 256) */
 	uint64_t pad_total = 0;
 	DevBuf mtf, idxfreq, ctx1, ctx0, items, pkey, pval, out, counts;
 	DevBuf din, dchunks, items_ord; /* decoder: input streams, stream table, pair ordinal per context item */
@@ -109,9 +110,11 @@ extern "C" int x3h_ctx_create(x3h_ctx **out, int device)
 	x3h_ctx *c = new (std::nothrow) x3h_ctx();
 	if (!c) return X3H_E_NOMEM;
 	c->device = device;
-	{ const char *e = getenv("X3H_CODE_V1"); c->code_v1 = e && *e && *e != '0'; }
 	{ const char *e = getenv("X3H_SCAN_V1"); c->scan_v1 = e && *e && *e != '0'; }
 	{ const char *e = getenv("X3H_BATCH_BYTES"); if (e && atoll(e) > 0) c->batch_bytes = (uint64_t)atoll(e); }
+	{ const char *e = getenv("X3H_DEC_BATCH_BYTES"); if (e && atoll(e) > 0) c->dec_batch_bytes = (uint64_t)atoll(e); }
+	{ const char *e = getenv("X3H_BATCH_PAD_BYTES"); if (e && atoll(e) > 0) c->batch_pad_bytes = (uint64_t)atoll(e); }
+	if (c->batch_pad_bytes > 0xF0000000ull) c->batch_pad_bytes = 0xF0000000ull;
 	{ const char *e = getenv("X3H_PIPE_MIN"); if (e && *e) c->pipe_min = (uint64_t)atoll(e); }
 	{ const char *e = getenv("X3H_PIPE_STREAMS"); if (e && *e) c->pipe_max_streams = atoi(e); }
 	if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return X3H_E_HIP; }
@@ -431,7 +434,7 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 
 	/* ---- K2 ---- */
 	/* pipelined schedule: a few long streams (the serial chains dominate); many short ones run stage after stage (the chip-wide passes dominate) */
-	const bool pipe = upto == STAGE_CODE && !c->code_v1 && nc <= c->pipe_max_streams && c->pipe_min && max_len >= c->pipe_min &&
+	const bool pipe = upto == STAGE_CODE && nc <= c->pipe_max_streams && c->pipe_min && max_len >= c->pipe_min &&
 	                  c->pad_total <= ((uint64_t)320 << 20); /* worst-case workspace of the pipelined schedule: ~330 B per input byte */
 	X3ParseArgs pa;
 	pa.ckpt = nullptr; pa.nckpt = 0;
@@ -446,7 +449,7 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 		x3k_launch_parse(&pa, (uint32_t)nc, c->stream);
 		HIPCHK(hipGetLastError());
 		CHK(x3_token_postpass(c->c2, c->stream, nc, c->hchunks.data(), c->chunks.as<X3Chunk>(), pa.result, pa.tok_info, pa.dict_len,
-		                      tok_pos, tok_hb, tok_nb, tok_mb, 0, c->code_v1 != 0 || upto == STAGE_PARSE));
+		                      tok_pos, tok_hb, tok_nb, tok_mb, 0, upto == STAGE_PARSE));
 		HIPCHK(hipEventRecord(c->ev[3], c->stream));
 		c->hparse.resize((size_t)nc);
 		HIPCHK(hipMemcpyAsync(c->hparse.data(), c->presult.p, (size_t)nc * sizeof(X3ParseResult), hipMemcpyDeviceToHost, c->stream));
@@ -492,33 +495,10 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 	PipeStats ps;
 	if (pipe) {
 		CHK(run_pipelined(c, pa, sa.bytes, tok_pos, tok_hb, tok_nb, tok_mb, d_out, &ps));
-	} else if (!c->code_v1) {
-		/* v2: parallel feature extraction (sorts / scans / count-smaller-before) + two thin serial passes (code2.hip) */
+	} else {
+		/* parallel feature extraction (sorts / scans / count-smaller-before) + two thin serial passes (code2.hip) */
 		CHK(x3_code_v2_run(c->c2, c->stream, nc, c->hchunks.data(), c->chunks.as<X3Chunk>(), c->hparse.data(), pa.result,
 		                   sa.bytes, tok_pos, pa.tok_info, tok_hb, tok_nb, tok_mb, d_out, c->cresult.as<X3CodeResult>()));
-	} else {
-		/* v1 (kept for A/B runs, X3H_CODE_V1=1): one wavefront per stream walks the tokens over growable tables (code.hip) */
-		CHK(c->mtf.reserve(toff * 4));
-		CHK(c->idxfreq.reserve(toff * 4));
-		CHK(c->ctx1.reserve(toff * sizeof(X3CtxHdr)));
-		CHK(c->ctx0.reserve(c0off * sizeof(X3CtxHdr)));
-		CHK(c->items.reserve(ioff * 8));
-		CHK(c->pkey.reserve(poff * 8));
-		CHK(c->pval.reserve(poff * 4));
-		HIPCHK(hipMemsetAsync(c->ctx1.p, 0, toff * sizeof(X3CtxHdr), c->stream));
-		HIPCHK(hipMemsetAsync(c->ctx0.p, 0, c0off * sizeof(X3CtxHdr), c->stream));
-		HIPCHK(hipMemsetAsync(c->pkey.p, 0, poff * 8, c->stream));
-		X3CodeArgs ca;
-		ca.bytes = sa.bytes; ca.chunks = sa.chunks;
-		ca.tok_pos = tok_pos; ca.tok_info = pa.tok_info; ca.parsed = pa.result;
-		ca.mtf = c->mtf.as<uint32_t>(); ca.idxfreq = c->idxfreq.as<uint32_t>();
-		ca.ctx1 = c->ctx1.as<X3CtxHdr>(); ca.ctx0 = c->ctx0.as<X3CtxHdr>();
-		ca.items = c->items.as<uint64_t>();
-		ca.pair_key = c->pkey.as<uint64_t>(); ca.pair_val = c->pval.as<uint32_t>();
-		ca.out = d_out;
-		ca.result = c->cresult.as<X3CodeResult>();
-		x3k_launch_code(&ca, (uint32_t)nc, c->stream);
-		HIPCHK(hipGetLastError());
 	}
 	HIPCHK(hipEventRecord(c->ev[5], c->stream));
 	c->hcode.resize((size_t)nc);
@@ -554,7 +534,7 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 		(void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); stats->ms_parse = ms;
 		(void)hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); stats->ms_code = ms;
 		(void)hipEventElapsedTime(&ms, c->ev[0], c->ev[5]); stats->ms_total = ms;
-		if (!pipe && !c->code_v1 && c->c2.ev[4]) {
+		if (!pipe && c->c2.ev[4]) {
 			(void)hipEventElapsedTime(&ms, c->c2.ev[0], c->c2.ev[1]); stats->ms_features = ms;
 			(void)hipEventElapsedTime(&ms, c->c2.ev[1], c->c2.ev[2]); stats->ms_modes = ms;
 			(void)hipEventElapsedTime(&ms, c->c2.ev[3], c->c2.ev[4]); stats->ms_coder = ms;
@@ -572,37 +552,55 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 	return rc;
 }
 
-/* Workspace is ~150 bytes per input byte, so very large batches are coded as consecutive sub-batches of at most `batch_bytes`
- * input bytes (X3H_BATCH_BYTES, default 1 GiB ~ 160 GB of HBM): chunks of a sub-batch still run concurrently, streams are
- * independent, so the output is identical to the unsplit run. */
+/* Workspace is ~150 bytes per input byte (+ ~32 per PADDED byte in K1), so very large batches are coded as consecutive sub-batches:
+ * at most `batch_bytes` input bytes (X3H_BATCH_BYTES, default 1 GiB ~ 160 GB of HBM) and at most `batch_pad_bytes` bytes of padded
+ * layout (every chunk occupies len + W + X3_PAD_EXTRA there, so many small chunks under a large window are bounded by THIS: K1 indexes
+ * the padded layout with 32 bits).  Chunks of a sub-batch still run concurrently, streams are independent, so the output is
+ * identical to the unsplit run.  A sub-batch that does not fit its output capacity does not stop the others: every out_lens entry is
+ * written (0 for chunks that were never coded after a hard error) and the first error is returned after the loop. */
+static void stats_add(x3h_stats &acc, const x3h_stats &part)
+{
+	for (int e = 0; e < 5; e++) acc.events[e] += part.events[e];
+	acc.dict_elems += part.dict_elems; acc.ctx0_entries += part.ctx0_entries; acc.steps += part.steps; acc.coded_symbols += part.coded_symbols;
+	acc.ms_total += part.ms_total; acc.ms_scan += part.ms_scan; acc.ms_parse += part.ms_parse; acc.ms_code += part.ms_code; acc.ms_copy += part.ms_copy;
+	acc.ms_features += part.ms_features; acc.ms_modes += part.ms_modes; acc.ms_coder += part.ms_coder; acc.ms_emit += part.ms_emit;
+	acc.mode_iters += part.mode_iters; acc.chain_symbols += part.chain_symbols; acc.pipelined |= part.pipelined;
+}
+
 static int run(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage upto, x3h_stats *stats)
 {
 	if (!c || !io.offsets || io.nchunks <= 0) return X3H_E_ARG;
-	const uint64_t limit = c->batch_bytes;
+	const uint64_t limit = c->batch_bytes, pad_limit = c->batch_pad_bytes;
+	const uint64_t window = prm_in ? prm_in->window_bytes : 8 * 1024;
+	auto padded = [&](int i) { return io.offsets[i + 1] < io.offsets[i] ? (uint64_t)0 : align_up(io.offsets[i + 1] - io.offsets[i] + window + X3_PAD_EXTRA, 256); };
+	uint64_t pad_total = 0;
+	for (int i = 0; i < io.nchunks; i++) pad_total += padded(i);
 	const uint64_t total = io.offsets[io.nchunks] - io.offsets[0];
-	if (upto != STAGE_CODE || total <= limit || io.nchunks == 1) return run_one(c, prm_in, io, upto, stats);
+	if (upto != STAGE_CODE || (total <= limit && pad_total <= pad_limit) || io.nchunks == 1) return run_one(c, prm_in, io, upto, stats);
 	x3h_stats acc, part;
 	memset(&acc, 0, sizeof acc);
-	int first = 0;
+	int first = 0, rc = X3H_OK;
 	while (first < io.nchunks) {
 		int last = first + 1;
-		while (last < io.nchunks && io.offsets[last + 1] - io.offsets[first] <= limit) last++;
+		uint64_t pad = padded(first);
+		while (last < io.nchunks && io.offsets[last + 1] - io.offsets[first] <= limit && pad + padded(last) <= pad_limit) { pad += padded(last); last++; }
 		RunIO sub = io;
 		sub.offsets = io.offsets + first;
 		sub.nchunks = last - first;
 		sub.dst = io.dst ? io.dst + (uint64_t)first * io.dst_stride : nullptr;
 		sub.out_lens = io.out_lens ? io.out_lens + first : nullptr;
-		CHK(run_one(c, prm_in, sub, upto, stats ? &part : nullptr));
-		if (stats) {
-			for (int e = 0; e < 5; e++) acc.events[e] += part.events[e];
-			acc.dict_elems += part.dict_elems; acc.ctx0_entries += part.ctx0_entries; acc.steps += part.steps; acc.coded_symbols += part.coded_symbols;
-			acc.ms_total += part.ms_total; acc.ms_scan += part.ms_scan; acc.ms_parse += part.ms_parse; acc.ms_code += part.ms_code; acc.ms_copy += part.ms_copy;
-			acc.ms_features += part.ms_features; acc.ms_modes += part.ms_modes; acc.ms_coder += part.ms_coder; acc.ms_emit += part.ms_emit; acc.mode_iters += part.mode_iters; acc.chain_symbols += part.chain_symbols; acc.pipelined |= part.pipelined;
+		memset(&part, 0, sizeof part);
+		const int r = run_one(c, prm_in, sub, upto, &part);
+		stats_add(acc, part);
+		if (r != X3H_OK && rc == X3H_OK) rc = r;
+		if (r != X3H_OK && r != X3H_E_OUTPUT_FULL) { /* hard error: the remaining chunks are not attempted */
+			if (io.out_lens) for (int i = first; i < io.nchunks; i++) io.out_lens[i] = 0;
+			break;
 		}
 		first = last;
 	}
 	if (stats) *stats = acc;
-	return X3H_OK;
+	return rc;
 }
 
 /* ------------------------------------------------------------------------------------------------------------ */
@@ -674,8 +672,8 @@ extern "C" int x3h_parse(x3h_ctx *ctx, const x3h_params *prm, const uint8_t *in,
 }
 
 /* ------------------------------------------------------------------------------------------------------------ */
-extern "C" int x3h_decompress_chunks(x3h_ctx *c, const uint8_t *in, const uint64_t *in_offsets, int nchunks,
-                                     uint8_t *out, const uint64_t *out_offsets, uint64_t *out_lens, x3h_stats *stats)
+static int decompress_batch(x3h_ctx *c, const uint8_t *in, const uint64_t *in_offsets, int nchunks,
+                            uint8_t *out, const uint64_t *out_offsets, uint64_t *out_lens, x3h_stats *stats)
 {
 	if (!c || !in_offsets || !out_offsets || !out_lens || nchunks <= 0 || (!in && in_offsets[nchunks] != in_offsets[0])) return X3H_E_ARG;
 	HIPCHK(hipSetDevice(c->device));
@@ -754,6 +752,32 @@ extern "C" int x3h_decompress_chunks(x3h_ctx *c, const uint8_t *in, const uint64
 	return rc;
 }
 
+/* The decoder's tables are sized from the output capacity (~150 B per byte), so a batch whose capacities add up to more than
+ * `dec_batch_bytes` (X3H_DEC_BATCH_BYTES, default 512 MiB) is decoded as consecutive sub-batches; streams are independent. */
+extern "C" int x3h_decompress_chunks(x3h_ctx *c, const uint8_t *in, const uint64_t *in_offsets, int nchunks,
+                                     uint8_t *out, const uint64_t *out_offsets, uint64_t *out_lens, x3h_stats *stats)
+{
+	if (!c || !in_offsets || !out_offsets || !out_lens || nchunks <= 0) return X3H_E_ARG;
+	const uint64_t limit = c->dec_batch_bytes;
+	if (out_offsets[nchunks] < out_offsets[0]) return X3H_E_ARG;
+	if (nchunks == 1 || out_offsets[nchunks] - out_offsets[0] <= limit) return decompress_batch(c, in, in_offsets, nchunks, out, out_offsets, out_lens, stats);
+	x3h_stats acc, part;
+	memset(&acc, 0, sizeof acc);
+	int first = 0, rc = X3H_OK;
+	while (first < nchunks) {
+		int last = first + 1;
+		while (last < nchunks && out_offsets[last + 1] >= out_offsets[first] && out_offsets[last + 1] - out_offsets[first] <= limit) last++;
+		memset(&part, 0, sizeof part);
+		const int r = decompress_batch(c, in, in_offsets + first, last - first, out, out_offsets + first, out_lens + first, &part);
+		stats_add(acc, part);
+		if (r != X3H_OK && rc == X3H_OK) rc = r;
+		if (r != X3H_OK && r != X3H_E_OUTPUT_FULL && r != X3H_E_CORRUPT) { for (int i = first; i < nchunks; i++) out_lens[i] = 0; break; }
+		first = last;
+	}
+	if (stats) *stats = acc;
+	return rc;
+}
+
 extern "C" int x3h_decompress(x3h_ctx *ctx, const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len, x3h_stats *stats)
 {
 	if (!ctx || !out_len || (!in && n) || (!out && cap)) return X3H_E_ARG;
@@ -761,4 +785,140 @@ extern "C" int x3h_decompress(x3h_ctx *ctx, const uint8_t *in, size_t n, uint8_t
 	int rc = x3h_decompress_chunks(ctx, in, io, 1, out, oo, &len, stats);
 	*out_len = (size_t)len;
 	return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Independent chunks over several devices (SURVEY.md 8(b) batch form / 8(e)): contiguous blocks of chunks per handle, one host
+ * thread per handle, no exchange between devices.  Then the X3C1 container on top (x3_container.c has the format).
+ * ------------------------------------------------------------------------------------------------------------ */
+#include <thread>
+
+static inline void shard(int n, int parts, int d, int *lo, int *hi) /* == dist.shard_range: config 4 puts chunk c on GPU c / (n / parts) */
+{
+	const int base = n / parts, rem = n % parts;
+	*lo = d * base + (d < rem ? d : rem);
+	*hi = *lo + base + (d < rem ? 1 : 0);
+}
+
+static void stats_merge_devices(x3h_stats *dst, const std::vector<x3h_stats> &parts)
+{
+	memset(dst, 0, sizeof *dst);
+	for (const x3h_stats &p : parts) {
+		x3h_stats t = *dst;
+		stats_add(*dst, p);
+		/* devices run side by side: times are those of the slowest one, not sums */
+		if (p.ms_total < t.ms_total) { dst->ms_total = t.ms_total; dst->ms_scan = t.ms_scan; dst->ms_parse = t.ms_parse; dst->ms_code = t.ms_code; dst->ms_copy = t.ms_copy;
+			dst->ms_features = t.ms_features; dst->ms_modes = t.ms_modes; dst->ms_coder = t.ms_coder; dst->ms_emit = t.ms_emit; }
+		else { dst->ms_total = p.ms_total; dst->ms_scan = p.ms_scan; dst->ms_parse = p.ms_parse; dst->ms_code = p.ms_code; dst->ms_copy = p.ms_copy;
+			dst->ms_features = p.ms_features; dst->ms_modes = p.ms_modes; dst->ms_coder = p.ms_coder; dst->ms_emit = p.ms_emit; }
+	}
+}
+
+template <class F> static int run_on_devices(int ndevices, int nchunks, x3h_stats *stats, F call)
+{
+	const int nd = ndevices < nchunks ? ndevices : nchunks;
+	std::vector<int> rc((size_t)nd, X3H_OK), hip((size_t)nd, 0);
+	std::vector<x3h_stats> st((size_t)nd);
+	auto work = [&](int d) {
+		int lo, hi;
+		shard(nchunks, nd, d, &lo, &hi);
+		memset(&st[(size_t)d], 0, sizeof(x3h_stats));
+		rc[(size_t)d] = call(d, lo, hi, &st[(size_t)d]);
+		hip[(size_t)d] = x3_last_hip; /* thread-local in the worker */
+	};
+	const char *ser = getenv("X3H_MULTI_SERIAL"); /* debugging aid: one device after the other on the calling thread */
+	if (nd == 1 || (ser && *ser && *ser != '0')) { for (int d = 0; d < nd; d++) work(d); }
+	else {
+		std::vector<std::thread> th;
+		for (int d = 0; d < nd; d++) th.emplace_back(work, d);
+		for (std::thread &t : th) t.join();
+	}
+	if (stats) stats_merge_devices(stats, st);
+	for (int d = 0; d < nd; d++) if (rc[(size_t)d] != X3H_OK) { x3_last_hip = hip[(size_t)d]; return rc[(size_t)d]; }
+	return X3H_OK;
+}
+
+extern "C" int x3h_compress_chunks_multi(x3h_ctx *const *ctxs, int ndevices, const x3h_params *prm, const uint8_t *in, const uint64_t *offsets,
+                                         int nchunks, uint8_t *out, uint64_t out_stride, uint64_t *out_lens, x3h_stats *stats)
+{
+	if (!ctxs || ndevices <= 0 || !offsets || nchunks <= 0 || !out || !out_lens || out_stride < 4) return X3H_E_ARG;
+	for (int d = 0; d < ndevices; d++) if (!ctxs[d]) return X3H_E_ARG;
+	return run_on_devices(ndevices, nchunks, stats, [&](int d, int lo, int hi, x3h_stats *st) {
+		return x3h_compress_chunks(ctxs[d], prm, in, offsets + lo, hi - lo, out + (uint64_t)lo * out_stride, out_stride, out_lens + lo, st);
+	});
+}
+
+extern "C" int x3h_decompress_chunks_multi(x3h_ctx *const *ctxs, int ndevices, const uint8_t *in, const uint64_t *in_offsets, int nchunks,
+                                           uint8_t *out, const uint64_t *out_offsets, uint64_t *out_lens, x3h_stats *stats)
+{
+	if (!ctxs || ndevices <= 0 || !in_offsets || !out_offsets || !out_lens || nchunks <= 0) return X3H_E_ARG;
+	for (int d = 0; d < ndevices; d++) if (!ctxs[d]) return X3H_E_ARG;
+	return run_on_devices(ndevices, nchunks, stats, [&](int d, int lo, int hi, x3h_stats *st) {
+		return x3h_decompress_chunks(ctxs[d], in, in_offsets + lo, hi - lo, out, out_offsets + lo, out_lens + lo, st);
+	});
+}
+
+extern "C" int x3h_compress_container(x3h_ctx *const *ctxs, int ndevices, const x3h_params *prm_in, const uint8_t *in, size_t n, size_t chunk_bytes,
+                                      uint8_t *out, size_t cap, size_t *out_len, x3h_stats *stats)
+{
+	if (!ctxs || ndevices <= 0 || !ctxs[0] || !out || !out_len || (!in && n) || cap < 4) return X3H_E_ARG;
+	*out_len = 0;
+	if (!chunk_bytes || chunk_bytes > X3H_MAX_CHUNK) chunk_bytes = n <= X3H_MAX_CHUNK ? (n ? n : 1) : X3H_MAX_CHUNK;
+	const uint64_t nch64 = n ? ((uint64_t)n + chunk_bytes - 1) / chunk_bytes : 1;
+	if (nch64 > 0x7FFFFFF0ull) return X3H_E_ARG;
+	const int nch = (int)nch64;
+	if (nch == 1) return x3h_compress(ctxs[0], prm_in, in, n, out, cap, out_len, stats); /* one chunk: the raw stream of x3.c:603-611, no frame */
+	x3h_params prm;
+	if (prm_in) prm = *prm_in; else x3h_default_params(&prm);
+	const size_t head = x3h_container_header_bytes(nch);
+	if (cap < head + 4 * (size_t)nch) return X3H_E_OUTPUT_FULL;
+	std::vector<uint64_t> off((size_t)nch + 1), raw((size_t)nch), lens((size_t)nch, 0);
+	for (int i = 0; i <= nch; i++) { const uint64_t o = (uint64_t)i * chunk_bytes; off[(size_t)i] = o < n ? o : n; }
+	for (int i = 0; i < nch; i++) raw[(size_t)i] = off[(size_t)i + 1] - off[(size_t)i];
+	/* streams land in a strided staging buffer first: a stride that holds any sane stream (incompressible data grows by a few percent),
+	 * then the provable bound if some chunk did not fit */
+	uint64_t stride = ((uint64_t)chunk_bytes + chunk_bytes / 4 + 4096 + 3) & ~(uint64_t)3;
+	const uint64_t bound = ((uint64_t)x3h_compress_bound(chunk_bytes) + 3) & ~(uint64_t)3;
+	if (stride > bound) stride = bound;
+	for (;;) {
+		uint8_t *stage = (uint8_t *)malloc((size_t)(stride * (uint64_t)nch));
+		if (!stage) return X3H_E_NOMEM;
+		int rc = x3h_compress_chunks_multi(ctxs, ndevices, &prm, in, off.data(), nch, stage, stride, lens.data(), stats);
+		if (rc == X3H_E_OUTPUT_FULL && stride < bound) { free(stage); stride = bound; continue; }
+		if (rc == X3H_OK) {
+			uint64_t total = head;
+			for (int i = 0; i < nch; i++) total += lens[(size_t)i];
+			if (total > cap) rc = X3H_E_OUTPUT_FULL;
+			else {
+				rc = x3h_container_write_header(out, cap, &prm, nch, raw.data(), lens.data());
+				uint64_t o = head;
+				for (int i = 0; i < nch && rc == X3H_OK; i++) { memcpy(out + o, stage + (uint64_t)i * stride, (size_t)lens[(size_t)i]); o += lens[(size_t)i]; }
+				if (rc == X3H_OK) *out_len = (size_t)total;
+			}
+		}
+		free(stage);
+		return rc;
+	}
+}
+
+extern "C" int x3h_decompress_container(x3h_ctx *const *ctxs, int ndevices, const uint8_t *in, size_t n,
+                                        uint8_t *out, size_t cap, size_t *out_len, x3h_stats *stats)
+{
+	if (!ctxs || ndevices <= 0 || !ctxs[0] || !out_len || (!in && n) || (!out && cap)) return X3H_E_ARG;
+	*out_len = 0;
+	int nch = 0;
+	uint64_t raw_total = 0;
+	const int pr = x3h_container_probe(in, n, nullptr, &nch, &raw_total);
+	if (pr == X3H_NOT_A_CONTAINER) return x3h_decompress(ctxs[0], in, n, out, cap, out_len, stats);
+	if (pr != X3H_OK) return pr;
+	if (raw_total > cap) return X3H_E_OUTPUT_FULL;
+	std::vector<uint64_t> raw((size_t)nch), coff((size_t)nch + 1), ooff((size_t)nch + 1, 0), lens((size_t)nch, 0);
+	CHK(x3h_container_table(in, n, raw.data(), coff.data()));
+	for (int i = 0; i < nch; i++) ooff[(size_t)i + 1] = ooff[(size_t)i] + raw[(size_t)i];
+	int rc = x3h_decompress_chunks_multi(ctxs, ndevices, in, coff.data(), nch, out, ooff.data(), lens.data(), stats);
+	if (rc == X3H_E_OUTPUT_FULL) rc = X3H_E_CORRUPT; /* a chunk decodes to more than its table entry says */
+	if (rc != X3H_OK) return rc;
+	for (int i = 0; i < nch; i++) if (lens[(size_t)i] != raw[(size_t)i]) return X3H_E_CORRUPT;
+	*out_len = (size_t)raw_total;
+	return X3H_OK;
 }

@@ -7,9 +7,16 @@
  * The statistics block on stderr follows x3.c:662-693 for the integer fields (the float size estimates are not
  * reproduced).  Errors print a message and exit(1) instead of abort().
  *
- * Additive option:  -g N   use GPU N (default 0).
+ * Additive options (new, none of them changes what the reference's letters do):
+ *   -g N             use GPU N (default 0)
+ *   --gpus a,b,...   use these GPUs side by side (chunks are dealt out in contiguous blocks)
+ *   --chunk-kib N    cut the input into independent chunks of N KiB, each coded as its own x3 stream, and write the X3C1
+ *                    container (include/x3hip.h); an input of one chunk is still written as the raw stream.  Inputs above
+ *                    128 MiB (X3H_MAX_CHUNK) are always chunked.
+ * -d recognises a container by its magic and decodes the chunks as one batch; anything else is a raw x3 stream.
  */
-#define _POSIX_C_SOURCE 200809L
+#define _GNU_SOURCE /* getopt_long */
+#include <getopt.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -31,6 +38,8 @@ static void print_help(const char *path) /* x3.c:465-477 */
 	fprintf(stderr, " -w NUM : window size (in kilobytes, affects compression ratio and speed)\n");
 	fprintf(stderr, " -m NUM : magic factor (affects compression ratio and speed)\n");
 	fprintf(stderr, " -g NUM : GPU to use (default 0)\n");
+	fprintf(stderr, " --gpus A,B,...  : GPUs to use side by side\n");
+	fprintf(stderr, " --chunk-kib NUM : code independent chunks of NUM KiB (X3C1 container output)\n");
 }
 
 static FILE *open_output(const char *path, int force) /* force_fopen, file.c:47-55 */
@@ -53,13 +62,17 @@ static unsigned char *read_all(FILE *f, size_t *n) /* fsize + fload, file.c:7-45
 	return p;
 }
 
+#define MAX_GPUS 64
+
 int main(int argc, char *argv[])
 {
-	int decompress = 0, force = 0, gpu = 0, o;
+	int decompress = 0, force = 0, o, ngpu = 1, gpus[MAX_GPUS] = { 0 };
+	size_t chunk_bytes = 0;
 	x3h_params prm;
 	x3h_default_params(&prm);
+	static const struct option longopts[] = { { "chunk-kib", required_argument, NULL, 1000 }, { "gpus", required_argument, NULL, 1001 }, { NULL, 0, NULL, 0 } };
 
-	while ((o = getopt(argc, argv, "zdfkht:w:m:n:xg:")) != -1) { /* x3.c:484 */
+	while ((o = getopt_long(argc, argv, "zdfkht:w:m:n:xg:", longopts, NULL)) != -1) { /* x3.c:484 */
 		switch (o) {
 			case 'z': decompress = 0; break;
 			case 'd': decompress = 1; break;
@@ -71,7 +84,22 @@ int main(int argc, char *argv[])
 			case 'm': prm.factor1 = (uint32_t)atoi(optarg); break;
 			case 'n': prm.factor2 = (uint32_t)atoi(optarg); break;
 			case 'x': prm.nl_mode = 1; break;
-			case 'g': gpu = atoi(optarg); break;
+			case 'g': ngpu = 1; gpus[0] = atoi(optarg); break;
+			case 1000: {
+				long k = atol(optarg);
+				if (k <= 0 || (size_t)k * 1024 > X3H_MAX_CHUNK) die("--chunk-kib: between 1 and 131072");
+				chunk_bytes = (size_t)k * 1024;
+				break;
+			}
+			case 1001: {
+				ngpu = 0;
+				for (char *tok = strtok(optarg, ","); tok; tok = strtok(NULL, ",")) {
+					if (ngpu == MAX_GPUS) die("--gpus: too many devices");
+					gpus[ngpu++] = atoi(tok);
+				}
+				if (!ngpu) die("--gpus: empty list");
+				break;
+			}
 			default: die("Unexpected argument");
 		}
 	}
@@ -102,8 +130,9 @@ int main(int argc, char *argv[])
 	if (!istream) die("Cannot open input file");
 	if (!ostream) die("Cannot open output file");
 
-	x3h_ctx *ctx = NULL;
-	int rc = x3h_ctx_create(&ctx, gpu);
+	x3h_ctx *ctxs[MAX_GPUS] = { NULL };
+	int rc = X3H_OK;
+	for (int i = 0; i < ngpu && rc == X3H_OK; i++) rc = x3h_ctx_create(&ctxs[i], gpus[i]);
 	if (rc != X3H_OK) { fprintf(stderr, "x3: %s (the hot path only exists as gfx950 HIP kernels; no CPU fallback)\n", x3h_strerror(rc)); return 1; }
 
 	size_t isize = 0, osize = 0;
@@ -116,29 +145,39 @@ int main(int argc, char *argv[])
 		fprintf(stderr, "forward window: %zu\n", (size_t)prm.window_bytes);
 		fprintf(stderr, "magic factor 1: %zu\n", (size_t)prm.factor1);
 		fprintf(stderr, "magic factor 2: %zu\n", (size_t)prm.factor2);
-		size_t cap = x3h_compress_bound(isize);
+		if (chunk_bytes) fprintf(stderr, "chunk size: %zu (independent x3 streams, X3C1 container)\n", chunk_bytes);
+		size_t cap = x3h_container_bound(isize, chunk_bytes);
 		optr = malloc(cap);
 		if (!optr) die("out of memory");
-		rc = x3h_compress(ctx, &prm, iptr, isize, optr, cap, &osize, &st);
+		rc = x3h_compress_container(ctxs, ngpu, &prm, iptr, isize, chunk_bytes, optr, cap, &osize, &st);
 		if (rc != X3H_OK) { fprintf(stderr, "x3: compress failed: %s\n", x3h_strerror(rc)); return 1; }
 		fprintf(stderr, "elapsed time: %f\n", st.ms_total / 1000.0);
 		fprintf(stderr, "  device ms: scan %.3f parse %.3f code %.3f copy %.3f\n", st.ms_scan, st.ms_parse, st.ms_code, st.ms_copy);
 	} else {
-#ifdef X3H_HAVE_DECOMPRESS
-		size_t cap = isize * 64 + 65536; /* the reference assumes <= 64:1 (x3.c:621); grow until it fits */
-		for (;;) {
-			optr = malloc(cap);
+		int nch = 0;
+		uint64_t raw_total = 0;
+		rc = x3h_container_probe(iptr, isize, NULL, &nch, &raw_total);
+		if (rc == X3H_OK) { /* X3C1: the table carries every chunk's size */
+			optr = malloc(raw_total ? raw_total : 1);
 			if (!optr) die("out of memory");
-			rc = x3h_decompress(ctx, iptr, isize, optr, cap, &osize, &st);
-			if (rc != X3H_E_OUTPUT_FULL) break;
-			free(optr);
-			cap *= 4;
+			rc = x3h_decompress_container(ctxs, ngpu, iptr, isize, optr, raw_total, &osize, &st);
+		} else if (rc == X3H_NOT_A_CONTAINER) {
+			/* a raw stream carries no length.  The reference assumes <= 64:1 (x3.c:621, unchecked); here the capacity is checked, so
+			 * start at 16:1 and grow until the stream fits, up to the largest stream the library codes (X3H_MAX_CHUNK) */
+			size_t cap = isize * 16 + 65536;
+			if (cap > X3H_MAX_CHUNK) cap = X3H_MAX_CHUNK;
+			for (;;) {
+				optr = malloc(cap);
+				if (!optr) die("out of memory");
+				rc = x3h_decompress(ctxs[0], iptr, isize, optr, cap, &osize, &st);
+				if (rc != X3H_E_OUTPUT_FULL) break;
+				free(optr);
+				if (cap == X3H_MAX_CHUNK) die("x3: decompress failed: the stream decodes to more than 128 MiB");
+				cap = cap > X3H_MAX_CHUNK / 4 ? X3H_MAX_CHUNK : cap * 4;
+			}
 		}
 		if (rc != X3H_OK) { fprintf(stderr, "x3: decompress failed: %s\n", x3h_strerror(rc)); return 1; }
 		fprintf(stderr, "elapsed time: %f\n", st.ms_total / 1000.0);
-#else
-		die("decompression is not built into this version");
-#endif
 	}
 	if (fwrite(optr, 1, osize, ostream) < osize) die("short write");
 
@@ -151,10 +190,10 @@ int main(int argc, char *argv[])
 	        (unsigned long long)st.events[1], (unsigned long long)st.events[2], (unsigned long long)st.events[3]);
 	fprintf(stderr, "context entries: ctx0 %llu, ctx1 %llu\n", (unsigned long long)st.ctx0_entries, (unsigned long long)st.dict_elems);
 
-	x3h_ctx_destroy(ctx);
+	for (int i = 0; i < ngpu; i++) x3h_ctx_destroy(ctxs[i]);
 	free(iptr);
 	free(optr);
 	fclose(istream);
-	fclose(ostream);
+	if (fclose(ostream)) die("short write");
 	return 0;
 }

@@ -99,23 +99,6 @@ struct X3ParseArgs {
 /* ---- K3 ------------------------------------------------------------------------------------------- */
 #define X3_CODE_THREADS 64
 
-struct X3CodeArgs {
-	const uint8_t *bytes;
-	const X3Chunk *chunks;
-	const uint32_t *tok_pos;
-	const uint32_t *tok_info;
-	const X3ParseResult *parsed;
-	uint32_t *mtf;              /* tags in recency order (dict.c:132-146 == move-to-front)         */
-	uint32_t *idxfreq;          /* model_index1 frequencies by rank (x3.c:50,187-188,419)          */
-	X3CtxHdr *ctx1;             /* by tag (x3.c:148)                                               */
-	X3CtxHdr *ctx0;             /* by pair ordinal (x3.c:147)                                      */
-	uint64_t *items;            /* (tag << 32) | freq, first-seen order (context.c:42-56)          */
-	uint64_t *pair_key;         /* ((tag0 << 32) | tag1) + 1 ; 0 = empty   (tag_pair.c)            */
-	uint32_t *pair_val;
-	uint8_t  *out;
-	X3CodeResult *result;
-};
-
 /* ---- decoder ------------------------------------------------------------------------------------------ */
 #define X3_ST_CORRUPT 3u     /* not an x3 stream (the reference abort()s, ac.c:178)                 */
 

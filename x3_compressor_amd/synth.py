@@ -160,8 +160,37 @@ def english_like(n: int = DICKENS_BYTES, seed: int = 0xD1C4E25, vocab: int = 240
     return out[:n].copy()
 
 
+MR_BYTES = 9_970_564  # size of Silesia 'mr' 
+
+
+def mr_like(n: int = MR_BYTES, seed: int = 0x4D52) -> np.ndarray:
+    """n bytes standing in for Silesia ``mr`` (a 3-D MRI volume of 16-bit little-endian samples): 256 x 256
+    slices, a near-zero noisy background around an elliptic 'head' whose tissue level is a sum of integer
+    triangle waves plus a few bits of noise.  Integer-only (splitmix64 + shifts), deterministic in (n, seed)."""
+    npix = (n + 1) // 2
+    out = np.empty(2 * npix, dtype=np.uint8)
+    step = 1 << 21
+    for s0 in range(0, npix, step):
+        k = min(step, npix - s0)
+        idx = np.arange(s0, s0 + k, dtype=np.int64)
+        x, y, z = idx & 255, (idx >> 8) & 255, idx >> 16
+        tri = lambda v, p: np.abs(v % (2 * p) - p)
+        dx, dy = x - 128, y - 120
+        inside = 3 * dx * dx + 4 * dy * dy < 30000 + 400 * tri(z, 24)
+        r = splitmix64(seed, k, s0)
+        noise = ((r >> np.uint64(40)) & np.uint64(15)).astype(np.int64)
+        bg = ((r >> np.uint64(20)) & np.uint64(3)).astype(np.int64) * (((r >> np.uint64(8)) & np.uint64(7)) == 0)
+        tissue = 300 + 3 * tri(x + 3 * z, 37) + 2 * tri(2 * y + z, 53) + 5 * tri(x + y, 29) + noise
+        val = np.where(inside, tissue, bg).astype(np.uint16)
+        out[2 * s0:2 * (s0 + k):2] = (val & 0xFF).astype(np.uint8)
+        out[2 * s0 + 1:2 * (s0 + k):2] = (val >> 8).astype(np.uint8)
+    return out[:n].copy()
+
+
 def workload(name: str, n: int | None = None) -> np.ndarray:
-    """Named workloads used by bench.py / tests: 'dickens-like', 'zipf'."""
+    """Named workloads used by bench.py / tests: 'dickens-like', 'zipf', 'mr-like'."""
+    if name == "mr-like":
+        return mr_like(MR_BYTES if n is None else n)
     if name == "dickens-like":
         return english_like(DICKENS_BYTES if n is None else n)
     if name == "zipf":
