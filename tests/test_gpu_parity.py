@@ -372,3 +372,36 @@ def test_sub_batches_are_cut_on_the_padded_layout(gpu, gpu_env):
     assert small.compress_chunks(data, off, prm) == whole
     assert small.last_stats.steps == gpu.last_stats.steps
     assert whole[7] == gpu.compress(data[7 * 3000:8 * 3000], prm)
+
+
+# ---- per-stream feature kernels (code3.hip) forced on inputs that would otherwise take the chip-wide passes ------------------------
+@pytest.mark.parametrize("name", CASES)
+def test_stream_kernels_equal_reference_golden(gpu_env, golden, name):
+    """every golden stream with the per-stream LDS kernels forced (X3H_STREAM_KERNELS=1; they are the default only for >= 48 streams)"""
+    ctx = gpu_env(X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0")
+    c = golden[name]
+    assert ctx.compress(c["data"], _lib.params_from_args(c["args"])) == c["expect"]
+
+
+def test_stream_kernels_agree_with_chipwide_passes(gpu_env):
+    """a ragged batch of 70 streams (text, Zipf, 16-bit samples, zeros, random; an empty one) coded with the per-stream kernels (default for
+    this many streams) and with the chip-wide sort / partition passes: same bytes; plus a 3 MiB stream forced through the stream kernels"""
+    rng = np.random.default_rng(17)
+    parts = []
+    for i in range(70):
+        n = int(rng.integers(1, 60_000))
+        kind = i % 5
+        if kind == 0: parts.append(synth.english_like(n, seed=300 + i).tobytes())
+        elif kind == 1: parts.append(synth.zipf_bytes(n, offset=1000 * i).tobytes())
+        elif kind == 2: parts.append(synth.mr_like(n, seed=i).tobytes())
+        elif kind == 3: parts.append(bytes(n))
+        else: parts.append(rng.integers(0, 256, n, dtype=np.uint8).tobytes())
+    parts[13] = b""
+    data = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    off = np.cumsum([0] + [len(p) for p in parts]).astype(np.uint64)
+    prm = _lib.make_params(w_kib=64, t=256)
+    new = gpu_env(X3H_STREAM_KERNELS="1").compress_chunks(data, off, prm)
+    old = gpu_env(X3H_STREAM_KERNELS="0").compress_chunks(data, off, prm)
+    assert new == old
+    big = synth.english_like(3 << 20, seed=77).tobytes()
+    assert gpu_env(X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0").compress(big, prm) == gpu_env(X3H_STREAM_KERNELS="0", X3H_PIPE_MIN="0").compress(big, prm)

@@ -811,6 +811,14 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	uint32_t **T = A + 20; /* 28 temporaries */
 	uint32_t *m_evfinal = m_ord00 + nc, *m_finallo = m_evfinal + 4 * nc; /* per chunk: 4 + 1 words */
 
+	/* A batch of many streams whose dictionaries fit the LDS tables gets the per-stream kernels of code3.hip (one wavefront per stream,
+	 * tables in LDS) instead of chip-wide sorts and partitions; X3H_STREAM_KERNELS=0/1 forces either form (both give the same bytes). */
+	uint64_t maxDict = 1;
+	for (uint32_t c = 0; c < nc; c++) if (h_parsed[c].dict_elems > maxDict) maxDict = h_parsed[c].dict_elems;
+	bool streamk = !seg && nc >= X3_STREAM_MIN_STREAMS;
+	if (const char *e = getenv("X3H_STREAM_KERNELS")) streamk = !seg && e[0] == '1';
+	streamk = streamk && x3_stream_kernels_fit(maxDict);
+
 	if (nH > 0) {
 		/* ---- F1: per step -> per hit / per event records ---- */
 		x3_foreach(nS, st, X3_LAMBDA(size_t gs) {
@@ -835,7 +843,12 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 			}
 		});
 
-		/* ---- MTF rank: touches sorted by tag give prev(e); rank = CSB(prev+1) - (prev_local+1) ---- */
+		/* ---- MTF rank ---- */
+		if (streamk) {
+			/* many streams: one wavefront per stream replays the list in LDS, 64 events per trip (code3.hip) */
+			CHK(x3_mtf_ranks_run(st, nc, maxDict, d_eo, d_dof, e_tag, e_hit, h_rank));
+		} else
+		/* touches sorted by tag give prev(e); rank = CSB(prev+1) - (prev_local+1) */
 		{
 			uint32_t *iota = T[0], *ks = T[1], *vs = T[2], *key = T[3], *keyc = T[4], *bs = T[5], *be = T[6], *cnt = T[7];
 			x3_foreach(nE, st, X3_LAMBDA(size_t i) { iota[i] = (uint32_t)i; });
@@ -860,39 +873,34 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 			});
 		}
 
-		/* ---- tag-pair ordinals (tag_pair.c) and the ctx0 group of every hit (x3.c:139-147) ---- */
-		uint32_t npairs_total = 0;
-		{
-			uint32_t *iota = T[0], *k1 = T[1], *v1 = T[2], *k2in = T[3], *k2 = T[4], *v2 = T[5], *rsf = T[6], *rs = T[7], *pf = T[8], *P = T[9], *rsflag = T[10];
-			const int tb = bits_for(nD);
+		if (streamk) {
+			/* ---- many streams: context statistics by one wavefront per stream (code3.hip); the context1 pass also finds the first use
+			 *      of every (context1, tag), which IS the tag-pair map (tag_pair.c:100-130: ordinal = rank of the first occurrence) ---- */
+			uint32_t *iota = T[0], *kA = T[1], *vA = T[2], *tA = T[3], *first = T[4], *pf = T[5], *P = T[6];
+			CHK(B.stat.reserve((nA + 4) * 16));
+			uint4 *stat = B.stat.as<uint4>();
+			uint32_t npairs_total = 0;
 			x3_foreach(nH, st, X3_LAMBDA(size_t i) { iota[i] = (uint32_t)i; });
-			CHK(x3p_sort_pairs(B.tmp, h_tag, k1, iota, v1, nH, tb, st));
-			x3_foreach(nH, st, X3_LAMBDA(size_t i) { k2in[i] = h_c1[v1[i]]; });
-			CHK(x3p_sort_pairs(B.tmp, k2in, k2, v1, v2, nH, tb, st)); /* sorted by (context1, tag), time order inside a pair */
+			CHK(x3p_sort_pairs(B.tmp, h_c1, kA, iota, vA, nH, bits_for(nD), st)); /* by context1, time order inside */
+			x3_foreach(nH, st, X3_LAMBDA(size_t i) { tA[i] = h_tag[vA[i]]; });
+			CHK(x3_ctx_stats_run(st, nc, maxDict, d_ho, d_dof, kA, vA, tA, stat));
 			x3_foreach(nH, st, X3_LAMBDA(size_t i) {
-				const bool start = i == 0 || k2[i - 1] != k2[i] || h_tag[v2[i - 1]] != h_tag[v2[i]];
-				rsflag[i] = start ? 1u : 0u;
-				rsf[i] = start ? (uint32_t)i : 0u;
+				const uint4 r = stat[i];
+				f1[i] = r.x; t1[i] = r.y; c1[i] = r.z; first[i] = r.w & 0x7FFFFFFFu; pf[i] = r.w >> 31;
 			});
-			CHK(x3p_incl_max_scan(B.tmp, rsf, rs, nH, st));
-			x3_foreach(nH, st, X3_LAMBDA(size_t i) { pf[v2[i]] = rsflag[i]; }); /* first occurrence of its pair, in time order */
 			CHK(x3p_excl_scan(B.tmp, pf, P, nH, st));
-			HIPCHK(hipMemcpyAsync(&npairs_total, P + nH, 4, hipMemcpyDeviceToHost, st)); /* read after the next synchronisation point below */
-			x3_foreach(nH, st, X3_LAMBDA(size_t i) { h_pair[v2[i]] = P[v2[rs[i]]]; });
+			HIPCHK(hipMemcpyAsync(&npairs_total, P + nH, 4, hipMemcpyDeviceToHost, st));
 			x3_foreach(nc, st, X3_LAMBDA(size_t c) {
-				const uint32_t lo = d_ho[c], hi = d_ho[c + 1];
-				m_pairbase[c] = P[lo];
-				m_npairs[c] = P[hi] - P[lo];
-				/* the pair (0,0) of this chunk (contexts after a new fragment, x3.c:424-425): lower_bound in the sorted pairs */
-				const uint32_t z = d_dof[c];
-				uint32_t a = 0, b = (uint32_t)nH;
-				while (a < b) {
-					const uint32_t mid = (a + b) >> 1;
-					const uint32_t kc = k2[mid], kt = h_tag[v2[mid]];
-					if (kc < z || (kc == z && kt < z)) a = mid + 1; else b = mid;
+				m_pairbase[c] = P[d_ho[c]];
+				m_npairs[c] = P[d_ho[c + 1]] - P[d_ho[c]];
+				m_first00[c] = NONE32; m_ord00[c] = 0;
+			});
+			x3_foreach(nH, st, X3_LAMBDA(size_t i) {
+				h_pair[i] = P[first[i]];
+				if (pf[i]) { /* the pair (0,0) of the stream: both contexts after a new fragment (x3.c:424-425) */
+					const uint32_t c = find_chunk(d_ho, nc, (uint32_t)i), z = d_dof[c];
+					if (h_tag[i] == z && h_c1[i] == z) { m_first00[c] = (uint32_t)i; m_ord00[c] = P[i]; }
 				}
-				if (hi > lo && a < nH && k2[a] == z && h_tag[v2[a]] == z) { m_first00[c] = v2[a]; m_ord00[c] = P[v2[a]]; }
-				else { m_first00[c] = NONE32; m_ord00[c] = 0; }
 			});
 			x3_foreach(nH, st, X3_LAMBDA(size_t gh) {
 				uint32_t g;
@@ -904,11 +912,61 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 				G0[gh] = g;
 			});
 			HIPCHK(hipStreamSynchronize(st)); /* npairs_total */
+			CHK(x3p_sort_pairs(B.tmp, G0, kA, iota, vA, nH, bits_for(npairs_total ? npairs_total : 1), st)); /* by ctx0 (pair ordinal) */
+			x3_foreach(nH, st, X3_LAMBDA(size_t i) { tA[i] = h_tag[vA[i]]; });
+			CHK(x3_ctx_stats_run(st, nc, maxDict, d_ho, d_dof, kA, vA, tA, stat));
+			x3_foreach(nH, st, X3_LAMBDA(size_t i) { const uint4 r = stat[i]; f0[i] = r.x; t0[i] = r.y; c0[i] = r.z; });
+		} else {
+		/* ---- tag-pair ordinals (tag_pair.c) and the ctx0 group of every hit (x3.c:139-147) ---- */
+			uint32_t npairs_total = 0;
+			{
+				uint32_t *iota = T[0], *k1 = T[1], *v1 = T[2], *k2in = T[3], *k2 = T[4], *v2 = T[5], *rsf = T[6], *rs = T[7], *pf = T[8], *P = T[9], *rsflag = T[10];
+				const int tb = bits_for(nD);
+				x3_foreach(nH, st, X3_LAMBDA(size_t i) { iota[i] = (uint32_t)i; });
+				CHK(x3p_sort_pairs(B.tmp, h_tag, k1, iota, v1, nH, tb, st));
+				x3_foreach(nH, st, X3_LAMBDA(size_t i) { k2in[i] = h_c1[v1[i]]; });
+				CHK(x3p_sort_pairs(B.tmp, k2in, k2, v1, v2, nH, tb, st)); /* sorted by (context1, tag), time order inside a pair */
+				x3_foreach(nH, st, X3_LAMBDA(size_t i) {
+					const bool start = i == 0 || k2[i - 1] != k2[i] || h_tag[v2[i - 1]] != h_tag[v2[i]];
+					rsflag[i] = start ? 1u : 0u;
+					rsf[i] = start ? (uint32_t)i : 0u;
+				});
+				CHK(x3p_incl_max_scan(B.tmp, rsf, rs, nH, st));
+				x3_foreach(nH, st, X3_LAMBDA(size_t i) { pf[v2[i]] = rsflag[i]; }); /* first occurrence of its pair, in time order */
+				CHK(x3p_excl_scan(B.tmp, pf, P, nH, st));
+				HIPCHK(hipMemcpyAsync(&npairs_total, P + nH, 4, hipMemcpyDeviceToHost, st)); /* read after the next synchronisation point below */
+				x3_foreach(nH, st, X3_LAMBDA(size_t i) { h_pair[v2[i]] = P[v2[rs[i]]]; });
+				x3_foreach(nc, st, X3_LAMBDA(size_t c) {
+					const uint32_t lo = d_ho[c], hi = d_ho[c + 1];
+					m_pairbase[c] = P[lo];
+					m_npairs[c] = P[hi] - P[lo];
+					/* the pair (0,0) of this chunk (contexts after a new fragment, x3.c:424-425): lower_bound in the sorted pairs */
+					const uint32_t z = d_dof[c];
+					uint32_t a = 0, b = (uint32_t)nH;
+					while (a < b) {
+						const uint32_t mid = (a + b) >> 1;
+						const uint32_t kc = k2[mid], kt = h_tag[v2[mid]];
+						if (kc < z || (kc == z && kt < z)) a = mid + 1; else b = mid;
+					}
+					if (hi > lo && a < nH && k2[a] == z && h_tag[v2[a]] == z) { m_first00[c] = v2[a]; m_ord00[c] = P[v2[a]]; }
+					else { m_first00[c] = NONE32; m_ord00[c] = 0; }
+				});
+				x3_foreach(nH, st, X3_LAMBDA(size_t gh) {
+					uint32_t g;
+					if (h_pv[gh]) g = h_pair[gh - 1]; /* (prev_context1, context1) is the pair the previous hit registered */
+					else {
+						const uint32_t c = find_chunk(d_ho, nc, (uint32_t)gh);
+						g = (m_first00[c] != NONE32 && m_first00[c] < gh) ? m_ord00[c] : m_pairbase[c]; /* unknown pair -> context 0 */
+					}
+					G0[gh] = g;
+				});
+				HIPCHK(hipStreamSynchronize(st)); /* npairs_total */
+			}
+	
+			/* ---- context statistics ---- */
+			CHK(ctx_stats(B, st, nH, bits_for(npairs_total ? npairs_total : 1), bits_for(nD), G0, h_tag, f0, t0, c0, T)); /* ctx0 groups are pair ordinals: sort only as many bits as there are pairs */
+			CHK(ctx_stats(B, st, nH, bits_for(nD), bits_for(nD), h_c1, h_tag, f1, t1, c1, T));
 		}
-
-		/* ---- context statistics ---- */
-		CHK(ctx_stats(B, st, nH, bits_for(npairs_total ? npairs_total : 1), bits_for(nD), G0, h_tag, f0, t0, c0, T)); /* ctx0 groups are pair ordinals: sort only as many bits as there are pairs */
-		CHK(ctx_stats(B, st, nH, bits_for(nD), bits_for(nD), h_c1, h_tag, f1, t1, c1, T));
 	}
 
 	/* ---- serial pass 1: modes ---- */

@@ -83,6 +83,7 @@ struct X3Code2Bufs {
 	DevBuf tmp, offs, chunkmeta;
 	DevBuf a[48]; /* u32 work arrays of max(hits, events)+4 entries */
 	DevBuf idxfreq, hsym, maxred, csbsmall;
+	DevBuf stat;  /* per hit {freq, total, cum, first}: what a per-stream context kernel (code3.hip) stores in one go */
 	hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
 	X3Code2Stats last = { 0, 0, 0, 0, 0, 0, 0 };
 	DevBuf y[12]; /* u32 arrays over coded symbols */
@@ -121,5 +122,14 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
                    const X3ParseResult *h_parsed, const X3ParseResult *d_parsed,
                    const uint8_t *d_bytes, const uint32_t *tok_pos, const uint32_t *tok_info, const uint32_t *tok_hb,
                    const uint32_t *tok_nb, const uint32_t *tok_mb, uint8_t *d_out, X3CodeResult *d_result, X3CodeSeg *seg = nullptr);
+
+/* ---- per-stream feature kernels for batches of many streams (code3.hip) -------------------------------------- */
+#define X3_STREAM_DMAX 8192u        /* largest per-stream dictionary the LDS tables of those kernels hold */
+#define X3_STREAM_MIN_STREAMS 48u   /* batches with fewer streams keep the chip-wide passes (one wavefront per stream would leave the chip idle) */
+bool x3_stream_kernels_fit(uint64_t max_dict);
+int x3_mtf_ranks_run(hipStream_t st, uint32_t nc, uint64_t max_dict, const uint32_t *d_eo, const uint32_t *d_dof, const uint32_t *e_tag,
+                     const uint32_t *e_hit, uint32_t *h_rank);
+int x3_ctx_stats_run(hipStream_t st, uint32_t nc, uint64_t max_dict, const uint32_t *d_ho, const uint32_t *d_dof, const uint32_t *kA,
+                     const uint32_t *vA, const uint32_t *tA, uint4 *stat /* per hit: {freq, total, cum, first hit | isfirst << 31} */);
 
 #endif /* X3_HOST_H */
