@@ -142,6 +142,7 @@ extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 	for (hipEvent_t e : pev) if (e) (void)hipEventDestroy(e);
 	for (int i = 0; i <= X3_MAX_CKPT; i++) { if (c->ev_cb[i]) (void)hipEventDestroy(c->ev_cb[i]); if (c->ev_ce[i]) (void)hipEventDestroy(c->ev_ce[i]); }
 	for (int i = 0; i < 5; i++) if (c->c2.ev[i]) (void)hipEventDestroy(c->c2.ev[i]);
+	if (c->c2.side) { (void)hipStreamDestroy(c->c2.side); (void)hipEventDestroy(c->c2.ev_fork); (void)hipEventDestroy(c->c2.ev_join); }
 	for (DevBuf &b : c->c2.a) b.release();
 	for (DevBuf &b : c->s2.a) b.release();
 	c->s2.misc.release();
@@ -445,11 +446,14 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 	uint32_t *tok_pos = c->tok_pos.as<uint32_t>(), *tok_hb = c->tok_hb.as<uint32_t>(), *tok_nb = c->tok_nb.as<uint32_t>(), *tok_mb = c->tok_mb.as<uint32_t>();
 	pa.result = c->presult.as<X3ParseResult>();
 	pa.factor1 = prm.factor1; pa.factor2 = prm.factor2; pa.nl_mode = prm.nl_mode;
+	/* batches of many streams: the coding stage walks the tokens itself (one workgroup per stream, code3.hip) */
+	const bool tokens_in_code = !pipe && upto == STAGE_CODE && (uint32_t)nc >= X3_STREAM_MIN_STREAMS;
 	if (!pipe) {
 		x3k_launch_parse(&pa, (uint32_t)nc, c->stream);
 		HIPCHK(hipGetLastError());
-		CHK(x3_token_postpass(c->c2, c->stream, nc, c->hchunks.data(), c->chunks.as<X3Chunk>(), pa.result, pa.tok_info, pa.dict_len,
-		                      tok_pos, tok_hb, tok_nb, tok_mb, 0, upto == STAGE_PARSE));
+		if (!tokens_in_code)
+			CHK(x3_token_postpass(c->c2, c->stream, nc, c->hchunks.data(), c->chunks.as<X3Chunk>(), pa.result, pa.tok_info, pa.dict_len,
+			                      tok_pos, tok_hb, tok_nb, tok_mb, 0, upto == STAGE_PARSE));
 		HIPCHK(hipEventRecord(c->ev[3], c->stream));
 		c->hparse.resize((size_t)nc);
 		HIPCHK(hipMemcpyAsync(c->hparse.data(), c->presult.p, (size_t)nc * sizeof(X3ParseResult), hipMemcpyDeviceToHost, c->stream));
@@ -498,7 +502,8 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 	} else {
 		/* parallel feature extraction (sorts / scans / count-smaller-before) + two thin serial passes (code2.hip) */
 		CHK(x3_code_v2_run(c->c2, c->stream, nc, c->hchunks.data(), c->chunks.as<X3Chunk>(), c->hparse.data(), pa.result,
-		                   sa.bytes, tok_pos, pa.tok_info, tok_hb, tok_nb, tok_mb, d_out, c->cresult.as<X3CodeResult>()));
+		                   sa.bytes, tok_pos, pa.tok_info, tok_hb, tok_nb, tok_mb, d_out, c->cresult.as<X3CodeResult>(), nullptr,
+		                   tokens_in_code ? pa.dict_len : nullptr));
 	}
 	HIPCHK(hipEventRecord(c->ev[5], c->stream));
 	c->hcode.resize((size_t)nc);

@@ -169,6 +169,28 @@ static int csb_run(X3Code2Bufs &B, hipStream_t st, size_t n, int bits, uint32_t 
 /* ============================================================================================================
  * serial pass 1: mode choice (x3.c:152-172) + model_index1 / model_events feedback (x3.c:177,188)
  * ============================================================================================================ */
+/* lanes (among `valid`) that hold the same `v` as this lane / #{ j in cand : v_j < x }: one ballot per value bit (see code3.hip) */
+__device__ static __forceinline__ uint64_t wave_same_mask_u32(uint32_t v, int bits, uint64_t valid, bool me_valid)
+{
+	uint64_t m = valid;
+	for (int b = 0; b < bits; b++) {
+		const uint64_t Bm = x3_ballot(me_valid && ((v >> b) & 1u));
+		m &= ((v >> b) & 1u) ? Bm : ~Bm;
+	}
+	return me_valid ? m : 0;
+}
+__device__ static __forceinline__ uint32_t wave_count_less_u32(uint32_t v, uint32_t x, int bits, uint64_t cand)
+{
+	uint32_t cnt = 0;
+	uint64_t A = cand;
+	for (int b = bits - 1; b >= 0; b--) {
+		const uint64_t Bm = x3_ballot((v >> b) & 1u);
+		if ((x >> b) & 1u) { cnt += (uint32_t)x3_popc64(A & ~Bm); A &= Bm; }
+		else A &= ~Bm;
+	}
+	return cnt;
+}
+
 struct X3ModesArgs {
 	const X3ParseResult *parsed;
 	const uint32_t *ho, *dof;          /* per chunk: first hit, first tag */
@@ -176,6 +198,11 @@ struct X3ModesArgs {
 	const uint32_t *rank, *dk, *step;  /* per hit: MTF rank, dictionary size at that step, step index */
 	uint32_t *idxfreq;                 /* per tag slot (by rank), pre-set to 1: spill area for ranks >= X3_IDXF_LDS */
 	uint32_t *mode;                    /* out per hit: the chosen event (E_CTX0 / E_CTX1 / E_IDX1) */
+	/* optional (pe0 != nullptr; batches of many streams): the model state every hit is coded under, straight from the chain's counters --
+	 * otherwise x3_code_v2_run recovers it from the modes with scans, sorts and a count-smaller-before over the IDX1 hits */
+	uint32_t *pe0, *pe1;               /* out per hit: model_events freq of E_CTX0 / E_CTX1 before the hit (x3.c:176-177)            */
+	uint32_t *ilist_rank, *ilist_hit;  /* out: the IDX1-coded hits of stream c in time order, at [ho[c], ho[c] + evfinal[4c+3])          */
+	uint32_t *evfinal;                 /* out per chunk: the three model_events freqs after the last hit, and the number of IDX1 hits */
 };
 
 #ifndef X3_IDXF_LDS
@@ -197,8 +224,8 @@ struct X3ModesArgs {
  *   - the remaining lanes are resolved in order with exact counters (ballot/popcount over the modes decided so far),
  *     using one vector division for the four quotients.
  * Typically only a few percent of the hits need the serial path.  ALL_LDS: every rank fits the LDS table. */
-template <bool ALL_LDS, uint32_t NIDX>
-__device__ static __forceinline__ void x3_modes_loop(const X3ModesArgs &a, uint32_t *sidx, uint32_t *scr, uint32_t *idxf, uint32_t H, uint32_t h0, uint32_t lane)
+template <bool ALL_LDS, uint32_t NIDX, bool EMIT>
+__device__ static __forceinline__ void x3_modes_loop(const X3ModesArgs &a, uint32_t *sidx, uint32_t *spre, uint32_t *scr, uint32_t *idxf, uint32_t H, uint32_t h0, uint32_t lane, uint32_t Dc)
 {
 	uint32_t E0 = 1024, E1 = 1024, E2 = 1, nidx = 0; /* model_events freqs (x3.c:239-241), IDX1 uses so far */
 	const uint64_t below = ((uint64_t)1 << lane) - 1;
@@ -282,6 +309,12 @@ __device__ static __forceinline__ void x3_modes_loop(const X3ModesArgs &a, uint3
 			if (md == X3_E_CTX0) m0 |= bit; else if (md == X3_E_CTX1) m1 |= bit; else m2 |= bit;
 		}
 		const uint32_t fin = ((m0 >> lane) & 1) ? X3_E_CTX0 : ((m1 >> lane) & 1) ? X3_E_CTX1 : X3_E_IDX1;
+		if (EMIT) {
+			/* what x3_code_v2_run would otherwise recover from the modes with scans: the model_events freqs before the hit (x3.c:176-177), and
+			 * the stream's IDX1-coded hits as a list (rank, hit) in time order for x3_idxstat_kernel */
+			if (in) { a.pe0[g] = E0 + (uint32_t)x3_popc64(m0 & below); a.pe1[g] = E1 + (uint32_t)x3_popc64(m1 & below); }
+			if (in && fin == X3_E_IDX1) { const uint32_t j = h0 + nidx + (uint32_t)x3_popc64(m2 & below); a.ilist_rank[j] = vr; a.ilist_hit[j] = g; }
+		}
 		if (in) {
 			a.mode[g] = fin;
 			if (fin == X3_E_IDX1) { if (lds_r) atomicAdd(&sidx[vr], 1u); else atomicAdd(&idxf[vr], 1u); } /* inc_model(&model_index1, index), x3.c:188 */
@@ -290,14 +323,15 @@ __device__ static __forceinline__ void x3_modes_loop(const X3ModesArgs &a, uint3
 		const uint32_t c2 = (uint32_t)x3_popc64(m2);
 		E2 += c2; nidx += c2;
 		x3_wave_sync();
-		(void)below;
 	}
+	if (a.evfinal && lane == 0) { uint32_t *ef = a.evfinal + 4 * blockIdx.x; ef[0] = E0; ef[1] = E1; ef[2] = E2; ef[3] = nidx; }
 }
 
-template <uint32_t NIDX>
+template <uint32_t NIDX, bool EMIT>
 __device__ static void x3_modes_body(const X3ModesArgs &a)
 {
 	X3_LDS uint32_t sidx[NIDX];
+	uint32_t *spre = nullptr;
 	X3_LDS uint32_t scr[256];
 	const uint32_t c = blockIdx.x, lane = x3_lane();
 	const uint32_t H = a.parsed[c].hits, h0 = a.ho[c], Dc = a.parsed[c].dict_elems;
@@ -305,8 +339,9 @@ __device__ static void x3_modes_body(const X3ModesArgs &a)
 	const uint32_t nl = Dc < NIDX ? Dc : NIDX;
 	for (uint32_t i = lane; i < nl; i += X3_WAVE) sidx[i] = 1;
 	x3_wave_sync();
-	if (Dc <= NIDX) x3_modes_loop<true, NIDX>(a, sidx, scr, idxf, H, h0, lane);
-	else x3_modes_loop<false, NIDX>(a, sidx, scr, idxf, H, h0, lane);
+	if (EMIT) x3_modes_loop<true, NIDX, true>(a, sidx, spre, scr, idxf, H, h0, lane, Dc); /* (the caller picked a table that holds every rank) */
+	else if (Dc <= NIDX) x3_modes_loop<true, NIDX, false>(a, sidx, spre, scr, idxf, H, h0, lane, Dc);
+	else x3_modes_loop<false, NIDX, false>(a, sidx, spre, scr, idxf, H, h0, lane, Dc);
 }
 
 /* ============================================================================================================
@@ -492,11 +527,18 @@ __device__ static void x3_ac2_body(const X3Ac2Args &a)
 #endif
 
 #ifndef X3_EMU
-__global__ void __launch_bounds__(X3_WAVE) x3_modes_kernel(X3ModesArgs a) { x3_modes_body<X3_IDXF_LDS>(a); }
-__global__ void __launch_bounds__(X3_WAVE) x3_modes_many_kernel(X3ModesArgs a) { x3_modes_body<X3_IDXF_LDS_SMALL>(a); }
+__global__ void __launch_bounds__(X3_WAVE) x3_modes_kernel(X3ModesArgs a) { x3_modes_body<X3_IDXF_LDS, false>(a); }
+__global__ void __launch_bounds__(X3_WAVE) x3_modes_many_kernel(X3ModesArgs a) { x3_modes_body<X3_IDXF_LDS_SMALL, false>(a); }
+__global__ void __launch_bounds__(X3_WAVE) x3_modes_stream_kernel_s(X3ModesArgs a) { x3_modes_body<2048, true>(a); }
+__global__ void __launch_bounds__(X3_WAVE) x3_modes_stream_kernel_l(X3ModesArgs a) { x3_modes_body<X3_STREAM_DMAX, true>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_ac2_kernel(X3Ac2Args a) { x3_ac2_body(a); }
-static void launch_modes(const X3ModesArgs &a, uint32_t nchunks, hipStream_t st)
+static void launch_modes(const X3ModesArgs &a, uint32_t nchunks, hipStream_t st, uint64_t max_dict)
 {
+	if (a.pe0) { /* many streams, model state handed out by the kernel: a table (and its running sums) that holds every rank */
+		if (max_dict <= 2048) hipLaunchKernelGGL(x3_modes_stream_kernel_s, dim3(nchunks), dim3(X3_WAVE), 0, st, a);
+		else hipLaunchKernelGGL(x3_modes_stream_kernel_l, dim3(nchunks), dim3(X3_WAVE), 0, st, a);
+		return;
+	}
 	/* the LDS table decides how many streams share a CU: a batch that oversubscribes the chip gets the small one */
 	if (nchunks > 256) hipLaunchKernelGGL(x3_modes_many_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, a);
 	else hipLaunchKernelGGL(x3_modes_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, a);
@@ -504,9 +546,10 @@ static void launch_modes(const X3ModesArgs &a, uint32_t nchunks, hipStream_t st)
 static void launch_ac2(const X3Ac2Args &a, uint32_t nchunks, hipStream_t st) { hipLaunchKernelGGL(x3_ac2_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, a); }
 __device__ static __forceinline__ uint32_t x3_brev32(uint32_t v) { return __brev(v); }
 #else
-static void modes_tramp(void *p) { x3_modes_body<X3_IDXF_LDS>(*(const X3ModesArgs *)p); }
+static void modes_tramp(void *p) { x3_modes_body<X3_IDXF_LDS, false>(*(const X3ModesArgs *)p); }
+static void modes_stream_tramp(void *p) { x3_modes_body<X3_STREAM_DMAX, true>(*(const X3ModesArgs *)p); }
 static void ac2_tramp(void *p) { x3_ac2_body(*(const X3Ac2Args *)p); }
-static void launch_modes(const X3ModesArgs &a, uint32_t nchunks, hipStream_t) { x3emu_launch(modes_tramp, (void *)&a, dim3(nchunks), dim3(X3_WAVE)); }
+static void launch_modes(const X3ModesArgs &a, uint32_t nchunks, hipStream_t, uint64_t) { x3emu_launch(a.pe0 ? modes_stream_tramp : modes_tramp, (void *)&a, dim3(nchunks), dim3(X3_WAVE)); }
 static void launch_ac2(const X3Ac2Args &a, uint32_t nchunks, hipStream_t) { x3emu_launch(ac2_tramp, (void *)&a, dim3(nchunks), dim3(X3_WAVE)); }
 static inline uint32_t x3_brev32(uint32_t v) { uint32_t r = 0; for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i); return r; }
 #endif
@@ -562,6 +605,162 @@ __device__ static __forceinline__ void x3_or_run(uint32_t *out32, uint32_t capw,
 		count -= c;
 	}
 }
+
+/* ============================================================================================================
+ * Bit emission for batches of many streams: ONE workgroup per stream walks the stream's symbols in tiles of 256 groups (2048 symbols)
+ * and carries the pending-bit count (mScale, ac.c:49-74) and the bit position from tile to tile -- instead of chip-wide passes
+ * (re-run groups, two scans, pending, lengths, scan, OR-writer) over arrays keyed by stream.  Per tile a thread re-runs the eight
+ * chain steps of its group from the state x3_ac2_kernel stored (x3_chain_step), keeps (n, emitted bits, k) of its symbols in registers,
+ * and three workgroup scans place its bits:
+ *   pending before a thread  = k summed since the last symbol that emitted (E1/E2 count n >= 1) -- a sum scan, a max scan of "last
+ *                              thread with an emitting symbol" and that thread's tail;
+ *   bit offset of a thread   = sum scan of the bits the threads write (n + the pending bits in front of each emitting symbol).
+ * Then ac_encode_flush (ac.c:115-126), bio_close's word padding (bio.c:105-112) and the stream's result record.
+ * ============================================================================================================ */
+#define X3_EMIT_THREADS 256u
+struct X3EmitArgs {
+	const uint32_t *yoc;        /* nc+1: symbol ranges (no-op symbols already dropped) */
+	const uint4 *sym;           /* per symbol: {cum, freq, magic, shift}               */
+	const uint32_t *state;      /* per symbol slot: {lo, R} at the first symbol of every group of X3_AC2_G */
+	const uint32_t *final_lo;   /* per stream: lo after the last symbol                */
+	const X3Chunk *chunks;      /* out_off / out_cap                                   */
+	const X3ParseResult *parsed;
+	const uint32_t *npairs, *evfinal;
+	uint8_t *out;               /* streams are assembled with ORs into pre-zeroed slots */
+	X3CodeResult *result;
+};
+
+__device__ static __forceinline__ uint32_t x3_wave_incl_maxscan_u32(uint32_t v)
+{
+#ifndef X3_EMU
+	int x = (int)v;
+#define X3_MAX_STEP(ctrl, rows) { const int y = __builtin_amdgcn_update_dpp(x, x, ctrl, rows, 0xf, false); x = (uint32_t)y > (uint32_t)x ? y : x; }
+	X3_MAX_STEP(0x111, 0xf) X3_MAX_STEP(0x112, 0xf) X3_MAX_STEP(0x114, 0xf) X3_MAX_STEP(0x118, 0xf) X3_MAX_STEP(0x142, 0xa) X3_MAX_STEP(0x143, 0xc)
+#undef X3_MAX_STEP
+	return (uint32_t)x;
+#else
+	const int l = (int)x3_lane();
+	for (int d = 1; d < X3_WAVE; d <<= 1) { const uint32_t u = x3emu_shfl(v, l >= d ? l - d : l); if (l >= d && u > v) v = u; }
+	return v;
+#endif
+}
+
+__device__ static void x3_emit_body(const X3EmitArgs &a)
+{
+	const uint32_t NW = X3_EMIT_THREADS / X3_WAVE;
+	X3_LDS uint32_t s_ksum[X3_EMIT_THREADS], s_tail[X3_EMIT_THREADS], s_lr[X3_EMIT_THREADS];
+	X3_LDS uint32_t s_w[3][X3_EMIT_THREADS / X3_WAVE];
+	const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = x3_lane(), wave = tid / X3_WAVE;
+	const uint32_t first = a.yoc[c], end = a.yoc[c + 1];
+	uint32_t *out32 = (uint32_t *)(a.out + a.chunks[c].out_off);
+	const uint32_t capw = (uint32_t)(a.chunks[c].out_cap / 4);
+	uint32_t carry_pend = 0;
+	uint64_t carry_pos = 0;
+	for (uint32_t tb = first; tb < end; tb += X3_EMIT_THREADS * X3_AC2_G) {
+		const uint32_t gi = tb + tid * X3_AC2_G;
+		const uint32_t cnt = gi >= end ? 0u : (end - gi < X3_AC2_G ? end - gi : X3_AC2_G);
+		uint32_t eb[X3_AC2_G], kq[X3_AC2_G];
+		uint32_t ktot = 0, tail = 0, has_reset = 0, nsum = 0, pinner = 0;
+		if (cnt) {
+			uint32_t lo = a.state[2 * (size_t)gi], R = a.state[2 * (size_t)gi + 1];
+#pragma unroll
+			for (uint32_t j = 0; j < X3_AC2_G; j++) {
+				eb[j] = 1; kq[j] = 0;
+				if (j < cnt) {
+					const uint2 r = x3_chain_step(lo, R, a.sym[gi + j]);
+					const uint32_t n = x3_rec_n(r.x, r.y); /* <= 30: the interval has at least two values */
+					eb[j] = (1u << n) | (x3_brev32(r.x << 1) & ((1u << n) - 1)); /* bit i = i-th emitted bit = bit 30-i of lo */
+					kq[j] = x3_rec_k(r.x, r.y);
+					if (n >= 1) {
+						nsum += n;
+						if (has_reset) pinner += tail; /* the pending bits in front of this symbol come from this thread alone (those in
+						                                * front of the thread's FIRST emitting symbol come from earlier threads too) */
+						has_reset = 1;
+						tail = 0;
+					}
+					if (has_reset) tail += kq[j];
+					else ktot += kq[j]; /* k before the first emitting symbol */
+				}
+			}
+		}
+		/* ktot: k of the symbols before the thread's first emitting symbol (all of them if none emits); tail: k from its last emitting symbol on */
+		const uint32_t kall = has_reset ? 0u : ktot; /* what the thread adds to a pending run that passes through it */
+		/* ---- scan 1: sum of kall, scan 2: last thread (+1) with an emitting symbol ---- */
+		const uint32_t ks_w = x3_wave_incl_scan_u32(kall);
+		const uint32_t lr_w = x3_wave_incl_maxscan_u32(has_reset ? tid + 1 : 0u);
+		if (lane == X3_WAVE - 1) { s_w[0][wave] = ks_w; s_w[1][wave] = lr_w; }
+		__syncthreads();
+		uint32_t kbase = 0, lrbase = 0;
+		for (uint32_t w = 0; w < wave; w++) { kbase += s_w[0][w]; lrbase = s_w[1][w] > lrbase ? s_w[1][w] : lrbase; }
+		const uint32_t ksum = ks_w + kbase;                       /* inclusive */
+		const uint32_t lr = lr_w > lrbase ? lr_w : lrbase;        /* inclusive: last emitting thread <= tid, +1; 0: none */
+		s_ksum[tid] = ksum; s_tail[tid] = tail; s_lr[tid] = lr;
+		__syncthreads();
+		/* pending count in front of this thread = after thread tid-1 */
+		uint32_t incoming = carry_pend;
+		if (tid > 0) {
+			const uint32_t plr = s_lr[tid - 1], pks = s_ksum[tid - 1];
+			incoming = plr ? s_tail[plr - 1] + (pks - s_ksum[plr - 1]) : carry_pend + pks;
+		}
+		const uint32_t bits = nsum + pinner + (has_reset ? incoming + ktot : 0u);
+		const uint32_t bs_w = x3_wave_incl_scan_u32(bits);
+		if (lane == X3_WAVE - 1) s_w[2][wave] = bs_w;
+		__syncthreads();
+		uint32_t bbase = 0, btot = 0;
+		for (uint32_t w = 0; w < NW; w++) { if (w < wave) bbase += s_w[2][w]; btot += s_w[2][w]; }
+		uint64_t bp = carry_pos + bbase + bs_w - bits;
+		/* ---- write ---- */
+		uint32_t pd = incoming;
+#pragma unroll
+		for (uint32_t j = 0; j < X3_AC2_G; j++) {
+			if (j < cnt) {
+				const uint32_t n = 31u - (uint32_t)x3_clz32(eb[j]);
+				if (n >= 1) {
+					const uint32_t rev = eb[j] ^ (1u << n);
+					if (!pd) x3_or_bits(out32, capw, bp, rev, n);
+					else {
+						x3_or_bits(out32, capw, bp, rev & 1u, 1);
+						x3_or_run(out32, capw, bp + 1, (rev & 1u) ^ 1u, pd);
+						x3_or_bits(out32, capw, bp + 1 + pd, rev >> 1, n - 1);
+					}
+					bp += n + pd;
+					pd = 0;
+				}
+				pd += kq[j];
+			}
+		}
+		/* carries: pending after the tile's last thread, bits so far */
+		const uint32_t llr = s_lr[X3_EMIT_THREADS - 1], lks = s_ksum[X3_EMIT_THREADS - 1];
+		carry_pend = llr ? s_tail[llr - 1] + (lks - s_ksum[llr - 1]) : carry_pend + lks;
+		carry_pos += btot;
+		__syncthreads();
+	}
+	if (tid == 0) { /* ac_encode_flush (ac.c:115-126) + bio_close (bio.c:105-112) + result */
+		uint64_t nbits = carry_pos;
+		if (a.final_lo[c] < 0x20000000u) {
+			x3_or_run(out32, capw, nbits + 1, 1u, carry_pend + 1); /* '0' then mScale+1 ones */
+			nbits += 2 + (uint64_t)carry_pend;
+		} else {
+			x3_or_bits(out32, capw, nbits, 1u, 1);
+			nbits += 1;
+		}
+		const uint64_t words = (nbits + 31) / 32;
+		X3CodeResult r;
+		r.out_len = (uint32_t)(words * 4); r.status = words > capw ? X3_ST_OUT_FULL : X3_ST_OK; r.pairs = a.npairs[c]; r._r = 0;
+		r.events[0] = a.evfinal[4 * c] - 1024; r.events[1] = a.evfinal[4 * c + 1] - 1024; r.events[2] = a.evfinal[4 * c + 2] - 1;
+		r.events[3] = a.parsed[c].ntok - a.parsed[c].hits;
+		r.events[4] = r.events[5] = r.events[6] = r.events[7] = 0;
+		a.result[c] = r;
+	}
+}
+
+#ifndef X3_EMU
+__global__ void __launch_bounds__(X3_EMIT_THREADS) x3_emit_kernel(X3EmitArgs a) { x3_emit_body(a); }
+static void launch_emit(const X3EmitArgs &a, uint32_t nchunks, hipStream_t st) { hipLaunchKernelGGL(x3_emit_kernel, dim3(nchunks), dim3(X3_EMIT_THREADS), 0, st, a); }
+#else
+static void emit_tramp(void *p) { x3_emit_body(*(const X3EmitArgs *)p); }
+static void launch_emit(const X3EmitArgs &a, uint32_t nchunks, hipStream_t) { x3emu_launch(emit_tramp, (void *)&a, dim3(nchunks), dim3(X3_EMIT_THREADS)); }
+#endif
 
 /* ============================================================================================================
  * context statistics of every hit for one context family (group id G per hit):
@@ -747,11 +946,11 @@ int x3_token_postpass(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk
 int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h_chunks, const X3Chunk *d_chunks,
                    const X3ParseResult *h_parsed, const X3ParseResult *d_parsed,
                    const uint8_t *d_bytes, const uint32_t *tok_pos, const uint32_t *tok_info, const uint32_t *tok_hb,
-                   const uint32_t *tok_nb, const uint32_t *tok_mb, uint8_t *d_out, X3CodeResult *d_result, X3CodeSeg *seg)
+                   const uint32_t *tok_nb, const uint32_t *tok_mb, uint8_t *d_out, X3CodeResult *d_result, X3CodeSeg *seg, const uint8_t *dict_len)
 {
 	const uint32_t nc = (uint32_t)nchunks;
 	const bool final = !seg || seg->final;
-	const uint32_t *tokb = B.pp[0].as<uint32_t>(); /* per stream: the token prefix sums {hits, elements, new-fragment bytes, position} at its first token (x3_token_postpass) */
+	const uint32_t *tokb = nullptr; /* per stream: the token prefix sums {hits, elements, new-fragment bytes, position} at its first token (x3_token_postpass) */
 	for (int i = 0; i < 5; i++) if (!B.ev[i]) HIPCHK(hipEventCreate(&B.ev[i]));
 	HIPCHK(hipEventRecord(B.ev[0], st));
 	/* ---- index spaces: steps, hits, MTF events (hits + inserted elements), tags ---- */
@@ -818,35 +1017,51 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	bool streamk = !seg && nc >= X3_STREAM_MIN_STREAMS;
 	if (const char *e = getenv("X3H_STREAM_KERNELS")) streamk = !seg && e[0] == '1';
 	streamk = streamk && x3_stream_kernels_fit(maxDict);
+	if (dict_len && (!streamk || nH == 0)) /* the caller left the token prefix sums to this call and the per-stream walk does not apply */
+		CHK(x3_token_postpass(B, st, nchunks, h_chunks, d_chunks, d_parsed, tok_info, dict_len, (uint32_t *)tok_pos, (uint32_t *)tok_hb, (uint32_t *)tok_nb, (uint32_t *)tok_mb));
+	CHK(B.pp[0].reserve((size_t)nc * 16 + 64));
+	tokb = B.pp[0].as<uint32_t>();
 
 	if (nH > 0) {
-		/* ---- F1: per step -> per hit / per event records ---- */
-		x3_foreach(nS, st, X3_LAMBDA(size_t gs) {
-			const uint32_t c = find_chunk(d_so, nc, (uint32_t)gs);
-			const uint32_t k = (uint32_t)gs - d_so[c];
-			const uint64_t base = d_chunks[c].elem_off;
-			const uint32_t info = tok_info[base + k], hb = tok_hb[base + k] - tokb[4 * c], nb = tok_nb[base + k] - tokb[4 * c + 1];
-			if (!(info & X3_TOK_MISS)) {
-				const uint32_t gh = d_ho[c] + hb, ev = d_eo[c] + hb + nb;
-				const bool pv = k > 0 && !(tok_info[base + k - 1] & X3_TOK_MISS);
-				h_tag[gh] = d_dof[c] + info;
-				h_c1[gh] = d_dof[c] + (pv ? tok_info[base + k - 1] : 0u); /* context1 (x3.c:390,425) */
-				h_pv[gh] = pv ? 1u : 0u;
-				h_dk[gh] = nb;
-				h_step[gh] = k;
-				e_tag[ev] = d_dof[c] + info;
-				e_hit[ev] = gh;
-			} else if (!(info & X3_TOK_DUP)) {
-				const uint32_t ev = d_eo[c] + hb + nb;
-				e_tag[ev] = d_dof[c] + nb; /* the new element's tag (dict.c:100) */
-				e_hit[ev] = NONE32;
-			}
-		});
+		if (streamk && dict_len) {
+			/* many streams: one workgroup per stream walks its tokens: running counts (stream-relative) + per-hit / per-touch records */
+			HIPCHK(hipMemsetAsync((void *)tokb, 0, (size_t)nc * 16, st));
+			CHK(x3_tokens_run(st, nc, d_chunks, d_parsed, tok_info, dict_len, (uint32_t *)tok_pos, (uint32_t *)tok_hb, (uint32_t *)tok_nb, (uint32_t *)tok_mb,
+			                  d_ho, d_eo, d_dof, h_tag, h_c1, h_pv, h_dk, h_step, e_tag, e_hit));
+		} else {
+			/* ---- F1: per step -> per hit / per event records ---- */
+			x3_foreach(nS, st, X3_LAMBDA(size_t gs) {
+				const uint32_t c = find_chunk(d_so, nc, (uint32_t)gs);
+				const uint32_t k = (uint32_t)gs - d_so[c];
+				const uint64_t base = d_chunks[c].elem_off;
+				const uint32_t info = tok_info[base + k], hb = tok_hb[base + k] - tokb[4 * c], nb = tok_nb[base + k] - tokb[4 * c + 1];
+				if (!(info & X3_TOK_MISS)) {
+					const uint32_t gh = d_ho[c] + hb, ev = d_eo[c] + hb + nb;
+					const bool pv = k > 0 && !(tok_info[base + k - 1] & X3_TOK_MISS);
+					h_tag[gh] = d_dof[c] + info;
+					h_c1[gh] = d_dof[c] + (pv ? tok_info[base + k - 1] : 0u); /* context1 (x3.c:390,425) */
+					h_pv[gh] = pv ? 1u : 0u;
+					h_dk[gh] = nb;
+					h_step[gh] = k;
+					e_tag[ev] = d_dof[c] + info;
+					e_hit[ev] = gh;
+				} else if (!(info & X3_TOK_DUP)) {
+					const uint32_t ev = d_eo[c] + hb + nb;
+					e_tag[ev] = d_dof[c] + nb; /* the new element's tag (dict.c:100) */
+					e_hit[ev] = NONE32;
+				}
+			});
+
+		}
 
 		/* ---- MTF rank ---- */
 		if (streamk) {
 			/* many streams: one wavefront per stream replays the list in LDS, 64 events per trip (code3.hip) */
-			CHK(x3_mtf_ranks_run(st, nc, maxDict, d_eo, d_dof, e_tag, e_hit, h_rank));
+			if (!B.side) { HIPCHK(hipStreamCreate(&B.side)); HIPCHK(hipEventCreate(&B.ev_fork)); HIPCHK(hipEventCreate(&B.ev_join)); }
+			HIPCHK(hipEventRecord(B.ev_fork, st));
+			HIPCHK(hipStreamWaitEvent(B.side, B.ev_fork, 0));
+			CHK(x3_mtf_ranks_run(B.side, nc, maxDict, d_eo, d_dof, e_tag, e_hit, h_rank)); /* beside the context statistics: both are latency-bound */
+			HIPCHK(hipEventRecord(B.ev_join, B.side));
 		} else
 		/* touches sorted by tag give prev(e); rank = CSB(prev+1) - (prev_local+1) */
 		{
@@ -969,6 +1184,8 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		}
 	}
 
+	if (streamk && nH > 0) HIPCHK(hipStreamWaitEvent(st, B.ev_join, 0)); /* the move-to-front ranks */
+
 	/* ---- serial pass 1: modes ---- */
 	uint32_t *idxf = B.idxfreq.as<uint32_t>();
 	x3_foreach(nD + 1, st, X3_LAMBDA(size_t i) { idxf[i] = 1; });
@@ -980,6 +1197,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		 * form streams ~60 B per hit of the whole batch and a dozen of them are typical: pick the cheaper (X3H_MODES=serial|fixed overrides) */
 		bool fixed = (double)maxH * 11.5e-9 > 2.0 * (double)nH * 0.45e-9 + 1e-3, done = false;
 		if (const char *e = getenv("X3H_MODES")) fixed = e[0] == 'f';
+		if (streamk) fixed = false; /* many streams: the serial kernel, which then also hands out the model state of every coded symbol */
 		B.last.mode_iters = 0;
 		if (fixed) {
 			int iters = 0;
@@ -991,60 +1209,67 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 			ma.parsed = d_parsed; ma.ho = d_ho; ma.dof = d_dof;
 			ma.f0 = f0; ma.t0 = t0; ma.f1 = f1; ma.t1 = t1; ma.rank = h_rank; ma.dk = h_dk; ma.step = h_step;
 			ma.idxfreq = idxf; ma.mode = mode;
-			launch_modes(ma, nc, st);
+			ma.pe0 = ma.pe1 = ma.ilist_rank = ma.ilist_hit = ma.evfinal = nullptr;
+			if (streamk) { ma.pe0 = T[26]; ma.pe1 = T[27]; ma.ilist_rank = T[2]; ma.ilist_hit = T[3]; ma.evfinal = m_evfinal; }
+			launch_modes(ma, nc, st, maxDict);
+			/* model_index1 as the IDX1-coded hits saw it (x3.c:187-188): one wavefront per stream, the table and its running sums in LDS */
+			if (streamk) CHK(x3_idxstat_run(st, nc, maxDict, d_ho, m_evfinal, T[2], T[3], h_dk, rfreq, rcum, itot));
 			HIPCHK(hipGetLastError());
 		}
 		HIPCHK(hipEventRecord(B.ev[2], st));
 
-		/* ---- model_events / model_index1 state at every hit, recovered from the modes by prefix sums ---- */
-		uint32_t *zi = T[0], *ci = T[1], *key = T[2], *org = T[3], *bs = T[4], *be = T[5], *cnt = T[6], *kin2 = T[7];
-		uint32_t *z0 = T[17], *c0s = T[18], *z1 = T[19], *c1s = T[20], *cid = T[21], *s1k = T[22], *s1v = T[23], *s2k = T[24], *s2v = T[25];
-		uint32_t *pe0w = T[26], *pe1w = T[27];
-		x3_foreach(nH, st, X3_LAMBDA(size_t i) {
-			const uint32_t m = mode[i];
-			z0[i] = m == X3_E_CTX0 ? 1u : 0u; z1[i] = m == X3_E_CTX1 ? 1u : 0u; zi[i] = m == X3_E_IDX1 ? 1u : 0u;
-		});
-		CHK(x3p_excl_scan(B.tmp, z0, c0s, nH, st));
-		CHK(x3p_excl_scan(B.tmp, z1, c1s, nH, st));
-		CHK(x3p_excl_scan(B.tmp, zi, ci, nH, st));
-		uint32_t nI = 0;
-		HIPCHK(hipMemcpyAsync(&nI, ci + nH, 4, hipMemcpyDeviceToHost, st));
-		x3_foreach(nH, st, X3_LAMBDA(size_t i) {
-			const uint32_t c = find_chunk(d_ho, nc, (uint32_t)i), lo = d_ho[c];
-			pe0w[i] = 1024u + c0s[i] - c0s[lo];          /* model_events freq of E_CTX0 before this hit */
-			pe1w[i] = 1024u + c1s[i] - c1s[lo];
-			itot[i] = h_dk[i] + ci[i] - ci[lo];          /* model_index1.total: one per element + one per earlier IDX1 use */
-			if (mode[i] == X3_E_IDX1) {
-				const uint32_t j = ci[i];
-				key[j] = h_rank[i]; org[j] = (uint32_t)i; bs[j] = ci[lo]; be[j] = ci[d_ho[c + 1]]; cid[j] = c;
-			}
-		});
-		x3_foreach(nc, st, X3_LAMBDA(size_t c) {
-			const uint32_t lo = d_ho[c], hi = d_ho[c + 1];
-			m_evfinal[4 * c + 0] = 1024u + c0s[hi] - c0s[lo];
-			m_evfinal[4 * c + 1] = 1024u + c1s[hi] - c1s[lo];
-			m_evfinal[4 * c + 2] = 1u + ci[hi] - ci[lo];
-			m_evfinal[4 * c + 3] = 0;
-		});
-		HIPCHK(hipStreamSynchronize(st));
-		uint64_t maxD = 1;
-		for (uint32_t c = 0; c < nc; c++) if (h_parsed[c].dict_elems > maxD) maxD = h_parsed[c].dict_elems;
-		if (nI) {
-			/* freq of the coded rank = 1 + earlier IDX1 hits of the stream with the same rank: runs of (stream, rank) */
-			CHK(x3p_sort_pairs(B.tmp, key, s1k, org, s1v, nI, bits_for(maxD), st));
-			x3_foreach(nI, st, X3_LAMBDA(size_t j) { kin2[j] = find_chunk(d_ho, nc, s1v[j]); });
-			CHK(x3p_sort_pairs(B.tmp, kin2, s2k, s1v, s2v, nI, bits_for(nc), st));
-			x3_foreach(nI, st, X3_LAMBDA(size_t j) {
-				const bool start = j == 0 || s2k[j - 1] != s2k[j] || h_rank[s2v[j - 1]] != h_rank[s2v[j]];
-				z0[j] = start ? (uint32_t)j : 0u;
+		if (!streamk) {
+			/* ---- model_events / model_index1 state at every hit, recovered from the modes by prefix sums ---- */
+			uint32_t *zi = T[0], *ci = T[1], *key = T[2], *org = T[3], *bs = T[4], *be = T[5], *cnt = T[6], *kin2 = T[7];
+			uint32_t *z0 = T[17], *c0s = T[18], *z1 = T[19], *c1s = T[20], *cid = T[21], *s1k = T[22], *s1v = T[23], *s2k = T[24], *s2v = T[25];
+			uint32_t *pe0w = T[26], *pe1w = T[27];
+			x3_foreach(nH, st, X3_LAMBDA(size_t i) {
+				const uint32_t m = mode[i];
+				z0[i] = m == X3_E_CTX0 ? 1u : 0u; z1[i] = m == X3_E_CTX1 ? 1u : 0u; zi[i] = m == X3_E_IDX1 ? 1u : 0u;
 			});
-			CHK(x3p_incl_max_scan(B.tmp, z0, z1, nI, st));
-			x3_foreach(nI, st, X3_LAMBDA(size_t j) { rfreq[s2v[j]] = 1u + (uint32_t)j - z1[j]; });
-			/* cum_freq of the coded rank = rank + earlier IDX1 hits of the stream with a smaller rank */
-			CHK(csb_run(B, st, nI, bits_for(maxD), key, bs, be, cnt, T + 8));
-			x3_foreach(nI, st, X3_LAMBDA(size_t j) { rcum[org[j]] = h_rank[org[j]] + cnt[j]; });
+			CHK(x3p_excl_scan(B.tmp, z0, c0s, nH, st));
+			CHK(x3p_excl_scan(B.tmp, z1, c1s, nH, st));
+			CHK(x3p_excl_scan(B.tmp, zi, ci, nH, st));
+			uint32_t nI = 0;
+			HIPCHK(hipMemcpyAsync(&nI, ci + nH, 4, hipMemcpyDeviceToHost, st));
+			x3_foreach(nH, st, X3_LAMBDA(size_t i) {
+				const uint32_t c = find_chunk(d_ho, nc, (uint32_t)i), lo = d_ho[c];
+				pe0w[i] = 1024u + c0s[i] - c0s[lo];          /* model_events freq of E_CTX0 before this hit */
+				pe1w[i] = 1024u + c1s[i] - c1s[lo];
+				itot[i] = h_dk[i] + ci[i] - ci[lo];          /* model_index1.total: one per element + one per earlier IDX1 use */
+				if (mode[i] == X3_E_IDX1) {
+					const uint32_t j = ci[i];
+					key[j] = h_rank[i]; org[j] = (uint32_t)i; bs[j] = ci[lo]; be[j] = ci[d_ho[c + 1]]; cid[j] = c;
+				}
+			});
+			x3_foreach(nc, st, X3_LAMBDA(size_t c) {
+				const uint32_t lo = d_ho[c], hi = d_ho[c + 1];
+				m_evfinal[4 * c + 0] = 1024u + c0s[hi] - c0s[lo];
+				m_evfinal[4 * c + 1] = 1024u + c1s[hi] - c1s[lo];
+				m_evfinal[4 * c + 2] = 1u + ci[hi] - ci[lo];
+				m_evfinal[4 * c + 3] = 0;
+			});
+			HIPCHK(hipStreamSynchronize(st));
+			uint64_t maxD = 1;
+			for (uint32_t c = 0; c < nc; c++) if (h_parsed[c].dict_elems > maxD) maxD = h_parsed[c].dict_elems;
+			if (nI) {
+				/* freq of the coded rank = 1 + earlier IDX1 hits of the stream with the same rank: runs of (stream, rank) */
+				CHK(x3p_sort_pairs(B.tmp, key, s1k, org, s1v, nI, bits_for(maxD), st));
+				x3_foreach(nI, st, X3_LAMBDA(size_t j) { kin2[j] = find_chunk(d_ho, nc, s1v[j]); });
+				CHK(x3p_sort_pairs(B.tmp, kin2, s2k, s1v, s2v, nI, bits_for(nc), st));
+				x3_foreach(nI, st, X3_LAMBDA(size_t j) {
+					const bool start = j == 0 || s2k[j - 1] != s2k[j] || h_rank[s2v[j - 1]] != h_rank[s2v[j]];
+					z0[j] = start ? (uint32_t)j : 0u;
+				});
+				CHK(x3p_incl_max_scan(B.tmp, z0, z1, nI, st));
+				x3_foreach(nI, st, X3_LAMBDA(size_t j) { rfreq[s2v[j]] = 1u + (uint32_t)j - z1[j]; });
+				/* cum_freq of the coded rank = rank + earlier IDX1 hits of the stream with a smaller rank */
+				CHK(csb_run(B, st, nI, bits_for(maxD), key, bs, be, cnt, T + 8));
+				x3_foreach(nI, st, X3_LAMBDA(size_t j) { rcum[org[j]] = h_rank[org[j]] + cnt[j]; });
+			}
+			(void)cid;
+
 		}
-		(void)cid;
 
 		/* ---- the tag / index symbol of every hit ---- */
 		uint32_t *scum = T[0], *sfreq = T[1], *stot = T[2]; /* zi/ci/key are dead now */
@@ -1079,7 +1304,8 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 			for (uint32_t j = 0; j < len; j++) bval[d_bo[c] + mb + j] = p[j];
 		}
 	});
-	for (int which = 0; which < 2; which++) {
+	if (streamk) CHK(x3_order0_run(st, nc, d_mo, lval, lsm, leq, d_bo, bval, bsm, beq)); /* one wavefront per (stream, model), counters in LDS */
+	else for (int which = 0; which < 2; which++) {
 		const size_t n = which ? nB : nM;
 		if (!n) continue;
 		const int abits = which ? 8 : 5;
@@ -1243,40 +1469,6 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		sy = syf; rec_nk = recf;
 	}
 
-	/* ---- bit emission (ac.c:49-67 put_bit + mScale, bio.c:49-72) as prefix sums over the records ----
-	 * pending after symbol i  = sum of k over (last symbol that shifted out bits (n>=1) or stream start .. i]
-	 * bits written by symbol i = n + pending before it (when n >= 1): first bit, the pending bits inverted, the other n-1 bits */
-	uint32_t *kk = Yv[5], *rv = Yv[6], *Kex = Yv[7], *LE = Yv[8], *len = Yv[9], *pos = Yv[10], *pend = Yv[11];
-	uint32_t *ebits = (uint32_t *)syr; /* the uncompacted operand array is dead now: one word per symbol goes there: 1 << n | the n bits the symbol shifts out */
-	{
-		/* x3_expand_records: the chain left its state at the first symbol of every group of X3_AC2_G; one thread re-runs each group and
-		 * derives, per symbol, n (E1/E2 shifts) with the n emitted bits, k (E3 shifts) and the "resets the pending count" marker */
-		const uint32_t *stt = rec_nk;
-		const uint4 *syc = sy;
-		x3_foreach(nYc, st, X3_LAMBDA(size_t i) {
-			const uint32_t c = find_chunk(d_yoc, nc, (uint32_t)i);
-			if (((uint32_t)i - d_yoc[c]) % X3_AC2_G) return;
-			uint32_t lo = stt[2 * i], R = stt[2 * i + 1];
-			const uint32_t first = d_yoc[c], end = d_yoc[c + 1], cnt = end - (uint32_t)i < X3_AC2_G ? end - (uint32_t)i : X3_AC2_G;
-			for (uint32_t j = 0; j < cnt; j++) {
-				const uint2 r = x3_chain_step(lo, R, syc[i + j]);
-				const uint32_t n = x3_rec_n(r.x, r.y); /* <= 30: the interval has at least two values */
-				const uint32_t rev = x3_brev32(r.x << 1) & ((1u << n) - 1); /* bit j = j-th emitted bit = bit 30-j of lo */
-				ebits[i + j] = (1u << n) | rev;
-				kk[i + j] = x3_rec_k(r.x, r.y);
-				rv[i + j] = (n >= 1 || i + j == first) ? (uint32_t)(i + j) + 1 : 0u;
-			}
-		});
-	}
-	CHK(x3p_excl_scan(B.tmp, kk, Kex, nYc, st));
-	CHK(x3p_incl_max_scan(B.tmp, rv, LE, nYc, st));
-	x3_foreach(nYc, st, X3_LAMBDA(size_t i) { pend[i] = Kex[i + 1] - Kex[LE[i] - 1]; });
-	x3_foreach(nYc, st, X3_LAMBDA(size_t i) {
-		const uint32_t n = 31u - (uint32_t)x3_clz32(ebits[i]);
-		const uint32_t c = find_chunk(d_yoc, nc, (uint32_t)i);
-		len[i] = n >= 1 ? n + (i == d_yoc[c] ? 0u : pend[i - 1]) : 0u;
-	});
-	CHK(x3p_excl_scan(B.tmp, len, pos, nYc, st));
 	{ /* the stream is assembled with ORs: zero every chunk's slot (one launch for the batch; out_off and out_cap are multiples of 4) */
 		uint64_t maxcap = 0;
 		for (uint32_t c = 0; c < nc; c++) if (h_chunks[c].out_cap > maxcap) maxcap = h_chunks[c].out_cap;
@@ -1290,42 +1482,85 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 			for (uint32_t k = 0; k < nw; k++) w[k] = 0;
 		});
 	}
-	x3_foreach(nYc, st, X3_LAMBDA(size_t i) {
-		const uint32_t ln = len[i];
-		if (!ln) return;
-		const uint32_t c = find_chunk(d_yoc, nc, (uint32_t)i);
-		uint32_t *out32 = (uint32_t *)(d_out + d_chunks[c].out_off);
-		const uint32_t capw = (uint32_t)(d_chunks[c].out_cap / 4);
-		const uint32_t eb = ebits[i], n = 31u - (uint32_t)x3_clz32(eb), pd = ln - n;
-		const uint64_t bp = pos[i] - pos[d_yoc[c]];
-		const uint32_t rev = eb ^ (1u << n);
-		if (!pd) x3_or_bits(out32, capw, bp, rev, n);
-		else {
-			x3_or_bits(out32, capw, bp, rev & 1u, 1);
-			x3_or_run(out32, capw, bp + 1, (rev & 1u) ^ 1u, pd);
-			x3_or_bits(out32, capw, bp + 1 + pd, rev >> 1, n - 1);
+	if (streamk) {
+		/* many streams: one workgroup per stream carries the pending-bit count and the bit position through its symbols */
+		X3EmitArgs ea;
+		ea.yoc = d_yoc; ea.sym = sy; ea.state = rec_nk; ea.final_lo = m_finallo; ea.chunks = d_chunks; ea.parsed = d_parsed;
+		ea.npairs = m_npairs; ea.evfinal = m_evfinal; ea.out = d_out; ea.result = d_result;
+		launch_emit(ea, nc, st);
+		HIPCHK(hipGetLastError());
+	} else {
+		/* ---- bit emission (ac.c:49-67 put_bit + mScale, bio.c:49-72) as prefix sums over the records ----
+		 * pending after symbol i  = sum of k over (last symbol that shifted out bits (n>=1) or stream start .. i]
+		 * bits written by symbol i = n + pending before it (when n >= 1): first bit, the pending bits inverted, the other n-1 bits */
+		uint32_t *kk = Yv[5], *rv = Yv[6], *Kex = Yv[7], *LE = Yv[8], *len = Yv[9], *pos = Yv[10], *pend = Yv[11];
+		uint32_t *ebits = (uint32_t *)syr; /* the uncompacted operand array is dead now: one word per symbol goes there: 1 << n | the n bits the symbol shifts out */
+		{
+			/* x3_expand_records: the chain left its state at the first symbol of every group of X3_AC2_G; one thread re-runs each group and
+			 * derives, per symbol, n (E1/E2 shifts) with the n emitted bits, k (E3 shifts) and the "resets the pending count" marker */
+			const uint32_t *stt = rec_nk;
+			const uint4 *syc = sy;
+			x3_foreach(nYc, st, X3_LAMBDA(size_t i) {
+				const uint32_t c = find_chunk(d_yoc, nc, (uint32_t)i);
+				if (((uint32_t)i - d_yoc[c]) % X3_AC2_G) return;
+				uint32_t lo = stt[2 * i], R = stt[2 * i + 1];
+				const uint32_t first = d_yoc[c], end = d_yoc[c + 1], cnt = end - (uint32_t)i < X3_AC2_G ? end - (uint32_t)i : X3_AC2_G;
+				for (uint32_t j = 0; j < cnt; j++) {
+					const uint2 r = x3_chain_step(lo, R, syc[i + j]);
+					const uint32_t n = x3_rec_n(r.x, r.y); /* <= 30: the interval has at least two values */
+					const uint32_t rev = x3_brev32(r.x << 1) & ((1u << n) - 1); /* bit j = j-th emitted bit = bit 30-j of lo */
+					ebits[i + j] = (1u << n) | rev;
+					kk[i + j] = x3_rec_k(r.x, r.y);
+					rv[i + j] = (n >= 1 || i + j == first) ? (uint32_t)(i + j) + 1 : 0u;
+				}
+			});
 		}
-	});
-	x3_foreach(nc, st, X3_LAMBDA(size_t c) { /* ac_encode_flush (ac.c:115-126) + bio_close (bio.c:105-112) + result */
-		uint32_t *out32 = (uint32_t *)(d_out + d_chunks[c].out_off);
-		const uint32_t capw = (uint32_t)(d_chunks[c].out_cap / 4);
-		const uint32_t last = d_yoc[c + 1] - 1;
-		uint64_t nbits = pos[d_yoc[c + 1]] - pos[d_yoc[c]];
-		if (m_finallo[c] < 0x20000000u) {
-			x3_or_run(out32, capw, nbits + 1, 1u, pend[last] + 1); /* '0' then mScale+1 ones */
-			nbits += 2 + (uint64_t)pend[last];
-		} else {
-			x3_or_bits(out32, capw, nbits, 1u, 1);
-			nbits += 1;
-		}
-		const uint64_t words = (nbits + 31) / 32;
-		X3CodeResult r;
-		r.out_len = (uint32_t)(words * 4); r.status = words > capw ? X3_ST_OUT_FULL : X3_ST_OK; r.pairs = m_npairs[c]; r._r = 0;
-		r.events[0] = m_evfinal[4 * c] - 1024; r.events[1] = m_evfinal[4 * c + 1] - 1024; r.events[2] = m_evfinal[4 * c + 2] - 1;
-		r.events[3] = d_parsed[c].ntok - d_parsed[c].hits;
-		r.events[4] = r.events[5] = r.events[6] = r.events[7] = 0;
-		d_result[c] = r;
-	});
+		CHK(x3p_excl_scan(B.tmp, kk, Kex, nYc, st));
+		CHK(x3p_incl_max_scan(B.tmp, rv, LE, nYc, st));
+		x3_foreach(nYc, st, X3_LAMBDA(size_t i) { pend[i] = Kex[i + 1] - Kex[LE[i] - 1]; });
+		x3_foreach(nYc, st, X3_LAMBDA(size_t i) {
+			const uint32_t n = 31u - (uint32_t)x3_clz32(ebits[i]);
+			const uint32_t c = find_chunk(d_yoc, nc, (uint32_t)i);
+			len[i] = n >= 1 ? n + (i == d_yoc[c] ? 0u : pend[i - 1]) : 0u;
+		});
+		CHK(x3p_excl_scan(B.tmp, len, pos, nYc, st));
+		x3_foreach(nYc, st, X3_LAMBDA(size_t i) {
+			const uint32_t ln = len[i];
+			if (!ln) return;
+			const uint32_t c = find_chunk(d_yoc, nc, (uint32_t)i);
+			uint32_t *out32 = (uint32_t *)(d_out + d_chunks[c].out_off);
+			const uint32_t capw = (uint32_t)(d_chunks[c].out_cap / 4);
+			const uint32_t eb = ebits[i], n = 31u - (uint32_t)x3_clz32(eb), pd = ln - n;
+			const uint64_t bp = pos[i] - pos[d_yoc[c]];
+			const uint32_t rev = eb ^ (1u << n);
+			if (!pd) x3_or_bits(out32, capw, bp, rev, n);
+			else {
+				x3_or_bits(out32, capw, bp, rev & 1u, 1);
+				x3_or_run(out32, capw, bp + 1, (rev & 1u) ^ 1u, pd);
+				x3_or_bits(out32, capw, bp + 1 + pd, rev >> 1, n - 1);
+			}
+		});
+		x3_foreach(nc, st, X3_LAMBDA(size_t c) { /* ac_encode_flush (ac.c:115-126) + bio_close (bio.c:105-112) + result */
+			uint32_t *out32 = (uint32_t *)(d_out + d_chunks[c].out_off);
+			const uint32_t capw = (uint32_t)(d_chunks[c].out_cap / 4);
+			const uint32_t last = d_yoc[c + 1] - 1;
+			uint64_t nbits = pos[d_yoc[c + 1]] - pos[d_yoc[c]];
+			if (m_finallo[c] < 0x20000000u) {
+				x3_or_run(out32, capw, nbits + 1, 1u, pend[last] + 1); /* '0' then mScale+1 ones */
+				nbits += 2 + (uint64_t)pend[last];
+			} else {
+				x3_or_bits(out32, capw, nbits, 1u, 1);
+				nbits += 1;
+			}
+			const uint64_t words = (nbits + 31) / 32;
+			X3CodeResult r;
+			r.out_len = (uint32_t)(words * 4); r.status = words > capw ? X3_ST_OUT_FULL : X3_ST_OK; r.pairs = m_npairs[c]; r._r = 0;
+			r.events[0] = m_evfinal[4 * c] - 1024; r.events[1] = m_evfinal[4 * c + 1] - 1024; r.events[2] = m_evfinal[4 * c + 2] - 1;
+			r.events[3] = d_parsed[c].ntok - d_parsed[c].hits;
+			r.events[4] = r.events[5] = r.events[6] = r.events[7] = 0;
+			d_result[c] = r;
+		});
+	}
 	(void)tok_nb;
 	B.last.symbols = nYraw; B.last.chain_symbols = nYc;
 	return X3H_OK;

@@ -278,13 +278,205 @@ __device__ static void x3_ctxseg_body(const X3CtxSegArgs &a)
 	}
 }
 
+/* ============================================================================================================
+ * The two adaptive order-0 models of a new fragment (x3.c:259-267): model_match_size over the 32 lengths, model_chars over the 256
+ * byte values; every symbol is coded and then counted (+1).  For the i-th value v of a stream:
+ *   equal   = earlier values == v  (freq = 1 + equal),   smaller = earlier values < v  (cum_freq = v + smaller).
+ * One wavefront per (stream, model): 256 counters and their running sums in LDS, 64 values per trip.
+ * ============================================================================================================ */
+struct X3Order0Args {
+	const uint32_t *off[2];    /* nc+1 ranges: fragment lengths, fragment bytes   */
+	const uint32_t *val[2];    /* the values (length-1 / byte)                    */
+	uint32_t *smaller[2], *equal[2];
+	uint32_t nc;
+};
+
+__device__ static void x3_order0_body(const X3Order0Args &a)
+{
+	X3_LDS uint32_t hist[256];
+	X3_LDS uint32_t pre[256];
+	const uint32_t which = blockIdx.x >= a.nc ? 1u : 0u, c = blockIdx.x - which * a.nc, lane = x3_lane();
+	const int bits = which ? 8 : 5;
+	const uint32_t A = which ? 256u : 32u;
+	const uint32_t i0 = a.off[which][c], i1 = a.off[which][c + 1];
+	const uint32_t *val = a.val[which];
+	uint32_t *osm = a.smaller[which], *oeq = a.equal[which];
+	const uint64_t below = ((uint64_t)1 << lane) - 1;
+	for (uint32_t i = lane; i < 256; i += X3_WAVE) { hist[i] = 0; pre[i] = 0; }
+	x3_wave_sync();
+	for (uint32_t base = i0; base < i1; base += X3_WAVE) {
+		const bool valid = base + lane < i1;
+		const uint32_t v = valid ? val[base + lane] : 0u;
+		const uint64_t V = x3_ballot(valid);
+		const uint64_t M = wave_same_mask(v, bits, V, valid);
+		const uint32_t sm = wave_count_less(v, v, bits, below & V);
+		if (valid) { oeq[base + lane] = hist[v] + (uint32_t)x3_popc64(M & below); osm[base + lane] = pre[v] + sm; }
+		x3_wave_sync();
+		if (valid) atomicAdd(&hist[v], 1u);
+		x3_wave_sync();
+		uint32_t carry = 0;
+		for (uint32_t pb = 0; pb < A; pb += X3_WAVE) {
+			const uint32_t h = hist[pb + lane];
+			const uint32_t incl = x3_wave_incl_scan_u32(h) + carry;
+			pre[pb + lane] = incl - h;
+			carry = x3_readlane_u32(incl, X3_WAVE - 1);
+		}
+		x3_wave_sync();
+	}
+}
+
+/* ============================================================================================================
+ * model_index1 as the IDX1-coded hits of a stream see it (x3.c:187-188): the symbol is the hit's move-to-front rank, its freq is
+ * 1 + earlier IDX1 hits with that rank, its cum_freq = rank + earlier IDX1 hits with a smaller rank (every rank starts at freq 1,
+ * model_enlarge ac.c:250-266), the total = dictionary elements + earlier IDX1 hits.  The mode kernel left the stream's IDX1 hits as a
+ * list (rank, hit) in time order; one wavefront per stream, counters per rank and their running sums in LDS, 64 list entries per trip.
+ * ============================================================================================================ */
+struct X3IdxStatArgs {
+	const uint32_t *ho;        /* nc+1: the list of stream c starts at ho[c]             */
+	const uint32_t *evfinal;   /* per chunk, word 3: number of list entries              */
+	const uint32_t *lrank, *lhit, *h_dk;
+	uint32_t *rfreq, *rcum, *itot; /* out per (IDX1-coded) hit                           */
+	uint32_t dbits_max;
+};
+
+template <uint32_t DMAX>
+__device__ static void x3_idxstat_body(const X3IdxStatArgs &a)
+{
+	X3_LDS uint32_t hist[DMAX];
+	X3_LDS uint32_t pre[DMAX];
+	const uint32_t c = blockIdx.x, lane = x3_lane();
+	const uint32_t i0 = a.ho[c], n = a.evfinal[4 * c + 3];
+	const uint64_t below = ((uint64_t)1 << lane) - 1;
+	const int bits = (int)a.dbits_max;
+	uint32_t rmax = 0; /* ranks seen so far are <= rmax: only that part of the tables is live */
+	for (uint32_t base = 0; base < n; base += X3_WAVE) {
+		const bool valid = base + lane < n;
+		const uint32_t r = valid ? a.lrank[i0 + base + lane] : 0u, hit = valid ? a.lhit[i0 + base + lane] : 0u;
+		const uint32_t tmax = wave_max_u32(r);
+		if (base == 0 || tmax > rmax) { /* grow the live part (zero counters, running sums continue flat) */
+			const uint32_t from = base == 0 ? 0u : rmax + 1, flat = base == 0 ? 0u : pre[rmax] + hist[rmax];
+			x3_wave_sync();
+			for (uint32_t q = from + lane; q <= tmax; q += X3_WAVE) { hist[q] = 0; pre[q] = flat; }
+			if (tmax > rmax || base == 0) rmax = tmax;
+			x3_wave_sync();
+		}
+		const uint64_t V = x3_ballot(valid);
+		const uint64_t M = wave_same_mask(r, bits, V, valid);
+		const uint32_t sm = wave_count_less(r, r, bits, below & V);
+		if (valid) {
+			a.rfreq[hit] = 1u + hist[r] + (uint32_t)x3_popc64(M & below);
+			a.rcum[hit] = r + pre[r] + sm;
+			a.itot[hit] = a.h_dk[hit] + base + lane;
+		}
+		x3_wave_sync();
+		if (valid) atomicAdd(&hist[r], 1u);
+		x3_wave_sync();
+		uint32_t carry = 0;
+		for (uint32_t pb = 0; pb <= rmax; pb += X3_WAVE) {
+			const uint32_t q = pb + lane;
+			const uint32_t h = q <= rmax ? hist[q] : 0u;
+			const uint32_t incl = x3_wave_incl_scan_u32(h) + carry;
+			if (q <= rmax) pre[q] = incl - h;
+			carry = x3_readlane_u32(incl, X3_WAVE - 1);
+		}
+		x3_wave_sync();
+	}
+}
+
+/* ============================================================================================================
+ * Token walk.  K2 leaves one word per parse step (tag of the hit element, or fragment length + "already present" flag); the coding
+ * stage indexes with running counts over that list: hits / inserted elements / new-fragment bytes / input position before each step
+ * (x3.c:394,422: p += len), and needs per-hit and per-touch records (context1 = previous tag or 0 after a new fragment, x3.c:389-390,
+ * 424-425).  One workgroup per stream walks its tokens in tiles of 256 with the four counts carried from tile to tile -- instead of
+ * four chip-wide scans plus two passes that find every step's stream by binary search.  Counts are stream-relative.
+ * ============================================================================================================ */
+#define X3_TOK_THREADS 256u
+struct X3TokArgs {
+	const X3Chunk *chunks;
+	const X3ParseResult *parsed;
+	const uint32_t *tok_info;
+	const uint8_t *dict_len;
+	uint32_t *tok_pos, *tok_hb, *tok_nb, *tok_mb;        /* out per step (layout: chunk elem_off + step)              */
+	const uint32_t *ho, *eo, *dof;                       /* per chunk: first hit / first touch event / first tag      */
+	uint32_t *h_tag, *h_c1, *h_pv, *h_dk, *h_step;       /* out per hit                                               */
+	uint32_t *e_tag, *e_hit;                             /* out per touch event (hit or insertion)                    */
+};
+
+__device__ static void x3_tokens_body(const X3TokArgs &a)
+{
+	const uint32_t NW = X3_TOK_THREADS / X3_WAVE;
+	X3_LDS uint32_t s_w[3][X3_TOK_THREADS / X3_WAVE];
+	const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = x3_lane(), wave = tid / X3_WAVE;
+	const uint64_t base = a.chunks[c].elem_off;
+	const uint32_t ntok = a.parsed[c].ntok;
+	const uint32_t ho = a.ho[c], eo = a.eo[c], dof = a.dof[c];
+	const uint64_t below = ((uint64_t)1 << lane) - 1;
+	uint32_t chb = 0, cnb = 0, cmb = 0, cpos = 0; /* counts before the tile */
+	uint32_t prev_info = X3_TOK_MISS;            /* the step before the tile's first (none: behaves like a new fragment) */
+	for (uint32_t tb = 0; tb < ntok; tb += X3_TOK_THREADS) {
+		const uint32_t k = tb + tid;
+		const bool in = k < ntok;
+		const uint32_t info = in ? a.tok_info[base + k] : X3_TOK_MISS;
+		const bool hit = in && !(info & X3_TOK_MISS), nw = in && (info & X3_TOK_MISS) && !(info & X3_TOK_DUP);
+		const uint32_t mb = in && (info & X3_TOK_MISS) ? (info & 0x3Fu) : 0u;
+		const uint32_t ln = hit ? (uint32_t)a.dict_len[base + info] : mb;
+		const uint64_t Hm = x3_ballot(hit), Nm = x3_ballot(nw);
+		const uint32_t pk_w = x3_wave_incl_scan_u32(mb | ln << 16); /* both sums stay below 2^16 inside a tile (256 x 32) */
+		if (lane == X3_WAVE - 1) { s_w[0][wave] = (uint32_t)x3_popc64(Hm); s_w[1][wave] = (uint32_t)x3_popc64(Nm); s_w[2][wave] = pk_w; }
+		__syncthreads();
+		uint32_t hbw = 0, nbw = 0, pkw = 0, hbt = 0, nbt = 0, pkt = 0;
+		for (uint32_t w = 0; w < NW; w++) {
+			if (w < wave) { hbw += s_w[0][w]; nbw += s_w[1][w]; pkw += s_w[2][w]; }
+			hbt += s_w[0][w]; nbt += s_w[1][w]; pkt += s_w[2][w];
+		}
+		const uint32_t hb = chb + hbw + (uint32_t)x3_popc64(Hm & below), nb = cnb + nbw + (uint32_t)x3_popc64(Nm & below);
+		const uint32_t pk = pkw + pk_w - (mb | ln << 16);
+		const uint32_t mbb = cmb + (pk & 0xFFFFu), pos = cpos + (pk >> 16);
+		/* the step before mine: lane - 1, the previous wave's last lane, or the previous tile's last step */
+		uint32_t pinfo = x3_shfl_up_u32(info, 1);
+		if (in) {
+			if (lane == 0) pinfo = k == 0 ? X3_TOK_MISS : a.tok_info[base + k - 1];
+			a.tok_hb[base + k] = hb; a.tok_nb[base + k] = nb; a.tok_mb[base + k] = mbb; a.tok_pos[base + k] = pos;
+			if (hit) {
+				const uint32_t gh = ho + hb, ev = eo + hb + nb;
+				const bool pv = !(pinfo & X3_TOK_MISS);
+				a.h_tag[gh] = dof + info;
+				a.h_c1[gh] = dof + (pv ? pinfo : 0u); /* context1 (x3.c:390,425) */
+				a.h_pv[gh] = pv ? 1u : 0u;
+				a.h_dk[gh] = nb;
+				a.h_step[gh] = k;
+				a.e_tag[ev] = dof + info;
+				a.e_hit[ev] = gh;
+			} else if (nw) {
+				const uint32_t ev = eo + hb + nb;
+				a.e_tag[ev] = dof + nb; /* the new element's tag (dict.c:100) */
+				a.e_hit[ev] = NONE32;
+			}
+		}
+		chb += hbt; cnb += nbt; cmb += pkt & 0xFFFFu; cpos += pkt >> 16;
+		(void)prev_info;
+		__syncthreads();
+	}
+}
+
 #ifndef X3_EMU
 __global__ void __launch_bounds__(X3_WAVE) x3_mtfrank_kernel_s(X3MtfArgs a) { x3_mtfrank_body<2048>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_mtfrank_kernel_l(X3MtfArgs a) { x3_mtfrank_body<16384>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_ctxseg_kernel_s(X3CtxSegArgs a) { x3_ctxseg_body<2048>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_ctxseg_kernel_l(X3CtxSegArgs a) { x3_ctxseg_body<8192>(a); }
+__global__ void __launch_bounds__(X3_WAVE) x3_order0_kernel(X3Order0Args a) { x3_order0_body(a); }
+__global__ void __launch_bounds__(X3_TOK_THREADS) x3_tokens_kernel(X3TokArgs a) { x3_tokens_body(a); }
+__global__ void __launch_bounds__(X3_WAVE) x3_idxstat_kernel_s(X3IdxStatArgs a) { x3_idxstat_body<2048>(a); }
+__global__ void __launch_bounds__(X3_WAVE) x3_idxstat_kernel_l(X3IdxStatArgs a) { x3_idxstat_body<X3_STREAM_DMAX>(a); }
 #define X3_LAUNCH1(kern, args, nc, st) hipLaunchKernelGGL(kern, dim3(nc), dim3(X3_WAVE), 0, st, args)
 #else
+static void order0_tramp(void *p) { x3_order0_body(*(const X3Order0Args *)p); }
+static void tokens_tramp(void *p) { x3_tokens_body(*(const X3TokArgs *)p); }
+static void idxstat_tramp_s(void *p) { x3_idxstat_body<2048>(*(const X3IdxStatArgs *)p); }
+static void idxstat_tramp_l(void *p) { x3_idxstat_body<X3_STREAM_DMAX>(*(const X3IdxStatArgs *)p); }
+#define x3_idxstat_kernel_s idxstat_tramp_s
+#define x3_idxstat_kernel_l idxstat_tramp_l
+#define x3_order0_kernel order0_tramp
 static void mtf_tramp_s(void *p) { x3_mtfrank_body<2048>(*(const X3MtfArgs *)p); }
 static void mtf_tramp_l(void *p) { x3_mtfrank_body<16384>(*(const X3MtfArgs *)p); }
 static void ctx_tramp_s(void *p) { x3_ctxseg_body<2048>(*(const X3CtxSegArgs *)p); }
@@ -319,6 +511,48 @@ int x3_ctx_stats_run(hipStream_t st, uint32_t nc, uint64_t max_dict, const uint3
 	a.dbits_max = b;
 	if (max_dict <= 2048) X3_LAUNCH1(x3_ctxseg_kernel_s, a, nc, st);
 	else X3_LAUNCH1(x3_ctxseg_kernel_l, a, nc, st);
+	HIPCHK(hipGetLastError());
+	return X3H_OK;
+}
+
+int x3_order0_run(hipStream_t st, uint32_t nc, const uint32_t *d_mo, const uint32_t *lval, uint32_t *lsm, uint32_t *leq,
+                  const uint32_t *d_bo, const uint32_t *bval, uint32_t *bsm, uint32_t *beq)
+{
+	X3Order0Args a;
+	a.off[0] = d_mo; a.val[0] = lval; a.smaller[0] = lsm; a.equal[0] = leq;
+	a.off[1] = d_bo; a.val[1] = bval; a.smaller[1] = bsm; a.equal[1] = beq;
+	a.nc = nc;
+	X3_LAUNCH1(x3_order0_kernel, a, 2 * nc, st);
+	HIPCHK(hipGetLastError());
+	return X3H_OK;
+}
+
+int x3_idxstat_run(hipStream_t st, uint32_t nc, uint64_t max_dict, const uint32_t *d_ho, const uint32_t *evfinal, const uint32_t *lrank,
+                   const uint32_t *lhit, const uint32_t *h_dk, uint32_t *rfreq, uint32_t *rcum, uint32_t *itot)
+{
+	X3IdxStatArgs a;
+	a.ho = d_ho; a.evfinal = evfinal; a.lrank = lrank; a.lhit = lhit; a.h_dk = h_dk; a.rfreq = rfreq; a.rcum = rcum; a.itot = itot;
+	uint32_t b = 1; while (b < 32 && (max_dict >> b)) b++;
+	a.dbits_max = b;
+	if (max_dict <= 2048) X3_LAUNCH1(x3_idxstat_kernel_s, a, nc, st);
+	else X3_LAUNCH1(x3_idxstat_kernel_l, a, nc, st);
+	HIPCHK(hipGetLastError());
+	return X3H_OK;
+}
+
+int x3_tokens_run(hipStream_t st, uint32_t nc, const X3Chunk *d_chunks, const X3ParseResult *d_parsed, const uint32_t *tok_info, const uint8_t *dict_len,
+                  uint32_t *tok_pos, uint32_t *tok_hb, uint32_t *tok_nb, uint32_t *tok_mb, const uint32_t *d_ho, const uint32_t *d_eo, const uint32_t *d_dof,
+                  uint32_t *h_tag, uint32_t *h_c1, uint32_t *h_pv, uint32_t *h_dk, uint32_t *h_step, uint32_t *e_tag, uint32_t *e_hit)
+{
+	X3TokArgs a;
+	a.chunks = d_chunks; a.parsed = d_parsed; a.tok_info = tok_info; a.dict_len = dict_len;
+	a.tok_pos = tok_pos; a.tok_hb = tok_hb; a.tok_nb = tok_nb; a.tok_mb = tok_mb; a.ho = d_ho; a.eo = d_eo; a.dof = d_dof;
+	a.h_tag = h_tag; a.h_c1 = h_c1; a.h_pv = h_pv; a.h_dk = h_dk; a.h_step = h_step; a.e_tag = e_tag; a.e_hit = e_hit;
+#ifndef X3_EMU
+	hipLaunchKernelGGL(x3_tokens_kernel, dim3(nc), dim3(X3_TOK_THREADS), 0, st, a);
+#else
+	x3emu_launch(tokens_tramp, (void *)&a, dim3(nc), dim3(X3_TOK_THREADS));
+#endif
 	HIPCHK(hipGetLastError());
 	return X3H_OK;
 }

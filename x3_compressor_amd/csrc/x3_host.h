@@ -85,6 +85,8 @@ struct X3Code2Bufs {
 	DevBuf idxfreq, hsym, maxred, csbsmall;
 	DevBuf stat;  /* per hit {freq, total, cum, first}: what a per-stream context kernel (code3.hip) stores in one go */
 	hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+	hipStream_t side = nullptr;                       /* batches of many streams: the move-to-front ranks run beside the context statistics */
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	X3Code2Stats last = { 0, 0, 0, 0, 0, 0, 0 };
 	DevBuf y[12]; /* u32 arrays over coded symbols */
 	DevBuf yraw;  /* symbol operands before the no-op symbols are dropped */
@@ -121,7 +123,10 @@ struct X3CodeSeg {
 int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h_chunks, const X3Chunk *d_chunks,
                    const X3ParseResult *h_parsed, const X3ParseResult *d_parsed,
                    const uint8_t *d_bytes, const uint32_t *tok_pos, const uint32_t *tok_info, const uint32_t *tok_hb,
-                   const uint32_t *tok_nb, const uint32_t *tok_mb, uint8_t *d_out, X3CodeResult *d_result, X3CodeSeg *seg = nullptr);
+                   const uint32_t *tok_nb, const uint32_t *tok_mb, uint8_t *d_out, X3CodeResult *d_result, X3CodeSeg *seg = nullptr,
+                   const uint8_t *dict_len = nullptr);
+/* dict_len != nullptr: x3_token_postpass has NOT run (api.hip leaves it out for batches of many streams): x3_code_v2_run derives the token
+ * prefix sums itself -- one workgroup per stream (code3.hip) when the per-stream kernels apply, else by calling x3_token_postpass */
 
 /* ---- per-stream feature kernels for batches of many streams (code3.hip) -------------------------------------- */
 #define X3_STREAM_DMAX 8192u        /* largest per-stream dictionary the LDS tables of those kernels hold */
@@ -131,5 +136,12 @@ int x3_mtf_ranks_run(hipStream_t st, uint32_t nc, uint64_t max_dict, const uint3
                      const uint32_t *e_hit, uint32_t *h_rank);
 int x3_ctx_stats_run(hipStream_t st, uint32_t nc, uint64_t max_dict, const uint32_t *d_ho, const uint32_t *d_dof, const uint32_t *kA,
                      const uint32_t *vA, const uint32_t *tA, uint4 *stat /* per hit: {freq, total, cum, first hit | isfirst << 31} */);
+int x3_order0_run(hipStream_t st, uint32_t nc, const uint32_t *d_mo, const uint32_t *lval, uint32_t *lsm, uint32_t *leq,
+                  const uint32_t *d_bo, const uint32_t *bval, uint32_t *bsm, uint32_t *beq);
+int x3_idxstat_run(hipStream_t st, uint32_t nc, uint64_t max_dict, const uint32_t *d_ho, const uint32_t *evfinal, const uint32_t *lrank,
+                   const uint32_t *lhit, const uint32_t *h_dk, uint32_t *rfreq, uint32_t *rcum, uint32_t *itot);
+int x3_tokens_run(hipStream_t st, uint32_t nc, const X3Chunk *d_chunks, const X3ParseResult *d_parsed, const uint32_t *tok_info, const uint8_t *dict_len,
+                  uint32_t *tok_pos, uint32_t *tok_hb, uint32_t *tok_nb, uint32_t *tok_mb, const uint32_t *d_ho, const uint32_t *d_eo, const uint32_t *d_dof,
+                  uint32_t *h_tag, uint32_t *h_c1, uint32_t *h_pv, uint32_t *h_dk, uint32_t *h_step, uint32_t *e_tag, uint32_t *e_hit);
 
 #endif /* X3_HOST_H */
