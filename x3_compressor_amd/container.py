@@ -26,19 +26,25 @@ def _lib_handle():
     return _LIB
 
 
-def pack(streams: list[bytes], raw_lens: list[int], prm) -> bytes:
-    assert len(streams) == len(raw_lens) and len(streams) >= 1
-    if len(streams) == 1:
-        return bytes(streams[0])
+def header(raw_lens: list[int], comp_lens: list[int], prm) -> bytes:
+    """The frame in front of the chunk streams (empty for a single chunk: that one stays a raw x3 stream)."""
+    assert len(raw_lens) == len(comp_lens) and len(raw_lens) >= 1
+    n = len(raw_lens)
+    if n == 1:
+        return b""
     lib = _lib_handle()
-    n = len(streams)
     head = np.empty(int(lib.x3h_container_header_bytes(n)), dtype=np.uint8)
     raw = np.asarray(raw_lens, dtype=np.uint64)
-    comp = np.asarray([len(s) for s in streams], dtype=np.uint64)
+    comp = np.asarray(comp_lens, dtype=np.uint64)
     rc = lib.x3h_container_write_header(head.ctypes.data, head.size, C.byref(prm), n, raw.ctypes.data, comp.ctypes.data)
     if rc != 0:
         raise ValueError(f"x3h_container_write_header: {lib.x3h_strerror(rc).decode()}")
-    return head.tobytes() + b"".join(streams)
+    return head.tobytes()
+
+
+def pack(streams: list[bytes], raw_lens: list[int], prm) -> bytes:
+    assert len(streams) == len(raw_lens) and len(streams) >= 1
+    return header(raw_lens, [len(s) for s in streams], prm) + b"".join(streams)
 
 
 def unpack(blob: bytes):

@@ -16,6 +16,7 @@
  * sort-based passes of code2.hip remain for anything else (and for the pipelined schedule of a few long streams).
  */
 #include "x3_host.h"
+#include <stdlib.h>
 
 #define NONE32 0xFFFFFFFFu
 #define NONE16 0xFFFFu
@@ -168,6 +169,7 @@ struct X3CtxSegArgs {
 	const uint32_t *tA;        /* ... and the hit's global tag id                         */
 	uint4 *stat;               /* out per hit: {freq, total, cum, first | isfirst << 31}  */
 	uint32_t dbits_max;        /* bits that cover every local tag of the batch            */
+	uint32_t nsub;             /* wavefronts per stream: wavefront r takes the contexts that START in the r-th part of the range (contexts are independent) */
 };
 
 /* lane i gets lane i-1's value (lane 0: its own) */
@@ -188,10 +190,31 @@ __device__ static void x3_ctxseg_body(const X3CtxSegArgs &a)
 	X3_LDS uint32_t lfirst[DMAX];    /* position -> hit that added the item                       */
 	X3_LDS uint32_t lfreq[DMAX];     /* position -> freq                                          */
 	X3_LDS uint32_t lpre[DMAX];      /* position -> cum_freq = sum of the freqs before it (count_cum_freqs, ac.c:6-18), as of the tile's start */
-	const uint32_t c = blockIdx.x, lane = x3_lane();
-	const uint32_t h0 = a.ho[c], h1 = a.ho[c + 1], dof = a.dof[c];
+	const uint32_t c = blockIdx.x / a.nsub, sub = blockIdx.x % a.nsub, lane = x3_lane();
+	const uint32_t c0 = a.ho[c], c1 = a.ho[c + 1], dof = a.dof[c];
 	const uint64_t bit = (uint64_t)1 << lane, below = bit - 1;
 	const int tbits = (int)a.dbits_max; /* covers tags and list positions alike (a list holds each tag once) */
+	/* my part of the stream's range: from the first context boundary at or after the nominal cut to the first one at or after the next cut */
+	uint32_t h0 = c0, h1 = c1;
+	if (a.nsub > 1) {
+		const uint32_t per = (c1 - c0 + a.nsub - 1) / a.nsub;
+		uint32_t cut[2];
+		for (int w = 0; w < 2; w++) {
+			uint64_t nom = (uint64_t)c0 + (uint64_t)(sub + (uint32_t)w) * per;
+			uint32_t p = nom >= c1 ? c1 : (uint32_t)nom;
+			if (p > c0 && p < c1) { /* first i >= p with kA[i] != kA[i-1] */
+				for (;;) {
+					const uint32_t i = p + lane;
+					const uint64_t bm = x3_ballot(i < c1 && a.kA[i] != a.kA[i - 1]);
+					if (bm) { p += (uint32_t)x3_ctz64(bm); break; }
+					p += X3_WAVE;
+					if (p >= c1) { p = c1; break; }
+				}
+			}
+			cut[w] = p;
+		}
+		h0 = cut[0]; h1 = cut[1];
+	}
 	for (uint32_t i = lane; i < DMAX; i += X3_WAVE) tpos[i] = NONE16;
 	bool open = false;
 	uint32_t open_g = 0, open_k = 0, open_total = 0;
@@ -462,6 +485,7 @@ __device__ static void x3_tokens_body(const X3TokArgs &a)
 #ifndef X3_EMU
 __global__ void __launch_bounds__(X3_WAVE) x3_mtfrank_kernel_s(X3MtfArgs a) { x3_mtfrank_body<2048>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_mtfrank_kernel_l(X3MtfArgs a) { x3_mtfrank_body<16384>(a); }
+__global__ void __launch_bounds__(X3_WAVE) x3_ctxseg_kernel_t(X3CtxSegArgs a) { x3_ctxseg_body<512>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_ctxseg_kernel_s(X3CtxSegArgs a) { x3_ctxseg_body<2048>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_ctxseg_kernel_l(X3CtxSegArgs a) { x3_ctxseg_body<8192>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_order0_kernel(X3Order0Args a) { x3_order0_body(a); }
@@ -479,10 +503,12 @@ static void idxstat_tramp_l(void *p) { x3_idxstat_body<X3_STREAM_DMAX>(*(const X
 #define x3_order0_kernel order0_tramp
 static void mtf_tramp_s(void *p) { x3_mtfrank_body<2048>(*(const X3MtfArgs *)p); }
 static void mtf_tramp_l(void *p) { x3_mtfrank_body<16384>(*(const X3MtfArgs *)p); }
+static void ctx_tramp_t(void *p) { x3_ctxseg_body<512>(*(const X3CtxSegArgs *)p); }
 static void ctx_tramp_s(void *p) { x3_ctxseg_body<2048>(*(const X3CtxSegArgs *)p); }
 static void ctx_tramp_l(void *p) { x3_ctxseg_body<8192>(*(const X3CtxSegArgs *)p); }
 #define x3_mtfrank_kernel_s mtf_tramp_s
 #define x3_mtfrank_kernel_l mtf_tramp_l
+#define x3_ctxseg_kernel_t ctx_tramp_t
 #define x3_ctxseg_kernel_s ctx_tramp_s
 #define x3_ctxseg_kernel_l ctx_tramp_l
 #define X3_LAUNCH1(kern, args, nc, st) x3emu_launch(kern, (void *)&(args), dim3(nc), dim3(X3_WAVE))
@@ -509,8 +535,15 @@ int x3_ctx_stats_run(hipStream_t st, uint32_t nc, uint64_t max_dict, const uint3
 	a.ho = d_ho; a.dof = d_dof; a.kA = kA; a.vA = vA; a.tA = tA; a.stat = stat;
 	uint32_t b = 1; while (b < 32 && (max_dict >> b)) b++;
 	a.dbits_max = b;
-	if (max_dict <= 2048) X3_LAUNCH1(x3_ctxseg_kernel_s, a, nc, st);
-	else X3_LAUNCH1(x3_ctxseg_kernel_l, a, nc, st);
+	/* contexts are independent, so a stream's range is cut (at context boundaries) over several wavefronts: enough of them to keep a few
+	 * per SIMD in flight -- the kernel is a chain of LDS round trips per tile, only occupancy hides them */
+	uint32_t nsub = nc >= 4096 ? 1u : 4096u / nc;
+	if (nsub > 16) nsub = 16;
+	if (const char *e = getenv("X3H_CTX_SUB")) { const int v = atoi(e); if (v >= 1 && v <= 64) nsub = (uint32_t)v; }
+	a.nsub = nsub;
+	if (max_dict <= 512) X3_LAUNCH1(x3_ctxseg_kernel_t, a, nc * nsub, st);
+	else if (max_dict <= 2048) X3_LAUNCH1(x3_ctxseg_kernel_s, a, nc * nsub, st);
+	else X3_LAUNCH1(x3_ctxseg_kernel_l, a, nc * nsub, st);
 	HIPCHK(hipGetLastError());
 	return X3H_OK;
 }

@@ -14,6 +14,7 @@ machine and numpy version (no dependence on numpy's distribution code):
 """
 from __future__ import annotations
 
+import functools
 from fractions import Fraction
 
 import numpy as np
@@ -80,6 +81,7 @@ _NUCLEI = ["a", "e", "i", "o", "u", "ea", "ou", "ee", "ai", "oo", "ie", "io"]
 _CODAS = ["", "", "n", "r", "s", "t", "d", "l", "m", "ng", "nt", "st", "ck", "ll", "ss", "rd", "nd", "ly", "ed", "er"]
 
 
+@functools.lru_cache(maxsize=4)
 def _vocabulary(size: int, seed: int) -> list[bytes]:
     words: list[str] = list(dict.fromkeys(_FUNCTION_WORDS))
     seen = set(words)
