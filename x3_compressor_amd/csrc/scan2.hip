@@ -13,7 +13,13 @@
  *      (count_0 itself is only needed when it is <= T: a binary search over at most T+1 list entries);
  *   3. only positions whose 4-gram already repeats K times in their window ("active") go deeper: one wavefront per active
  *      position sweeps the candidates of its 4-gram class that lie in the window -- ONE LANE PER CANDIDATE, coalesced reads of
- *      the class list, a 32-byte look-ahead of p broadcast from LDS -- and builds count_4..31 with ballot/popcount.
+ *      the class list, a 32-byte look-ahead of p broadcast from LDS -- and builds count_4..31 with ballot/popcount;
+ *   4. ... unless the class is DENSE around the position (more than X3_WALK_DENSE members inside its window: zero runs, sparse
+ *      16-bit samples, periodic data), where that sweep would cost O(W) per position.  Dense classes are refined one more byte at a
+ *      time instead (a stable sort of the surviving elements by (class, next byte): classes split, positions stay ascending inside
+ *      them), the level test is the same O(1) "K-th next occurrence of my class" lookup, and as soon as a position's class is no
+ *      longer dense around it, the sweep of step 3 finishes it inside that (smaller) class.  At most 28 such levels, each over a
+ *      list that only holds the classes still dense somewhere.
  * The result is exactly the reference's (verified against the brute-force kernel of scan.hip and the oracle); the cost no
  * longer depends on W.  The padding zeros of every chunk are ordinary positions of the sort, and a chunk's window never reaches
  * the next chunk's bytes (slots are W + X3_PAD_EXTRA apart), so one global sort serves a whole batch.
@@ -21,6 +27,8 @@
 #include "x3_host.h"
 
 #include <vector>
+#include <stdio.h>
+#include <stdlib.h>
 
 #define NONE32 0xFFFFFFFFu
 
@@ -36,8 +44,11 @@ __device__ static __forceinline__ uint32_t load_gram(const uint8_t *b, uint64_t 
 
 struct X3WalkArgs {
 	const uint8_t *bytes;
-	const uint32_t *S4;          /* list 4: element q stands for position q - 3 */
-	const uint32_t *active_j;    /* index of each active position in S4 */
+	const uint32_t *S4;          /* the class-sorted list: element L stands for position L - back (list 4 holds END positions: back = 3) */
+	const uint32_t *cls;         /* ... and the class of every entry (list 4: its 4-gram; refined lists: a class id) */
+	uint32_t back;
+	uint32_t kwords;             /* whole 4-byte words the members of a class are known to share (class gram length / 4) */
+	const uint32_t *active_j;    /* index of each active position in the list */
 	const uint32_t *active;      /* positions to walk */
 	const uint32_t *active_k;    /* their K */
 	const uint32_t *nactive;
@@ -47,6 +58,9 @@ struct X3WalkArgs {
 };
 
 #define X3_WALK_WAVES 4
+#ifndef X3_WALK_DENSE
+#define X3_WALK_DENSE 2048u /* a position with more members of its class than this inside its window is not swept: its class is refined */
+#endif
 
 __device__ static void x3_walk_body(const X3WalkArgs &a)
 {
@@ -59,21 +73,21 @@ __device__ static void x3_walk_body(const X3WalkArgs &a)
 	const uint8_t *b = a.bytes;
 	if (lane < 8) look[wv][lane] = load_gram(b, (uint64_t)p + 4 * lane, 4); /* the look-ahead tile of this position */
 	x3_wave_sync();
-	const uint32_t g = look[wv][0];
+	const uint32_t myj = a.active_j[idx], g = a.cls[myj];
 	const uint64_t wend = (uint64_t)p + a.ncand;
 	uint32_t cnt[28]; /* count_4 .. count_31 (wave-uniform) */
 #pragma unroll
 	for (int i = 0; i < 28; i++) cnt[i] = 0;
 	uint32_t done = 0;
-	for (uint32_t base = a.active_j[idx] + 1; base < a.total && !done; base += X3_WAVE) {
+	for (uint32_t base = myj + 1; base < a.total && !done; base += X3_WAVE) {
 		const uint32_t j = base + lane;
-		uint32_t s = j < a.total ? a.S4[j] - 3u : NONE32; /* q < 3 wraps to a huge value: fails the window test like any out-of-class entry */
+		uint32_t s = j < a.total ? a.S4[j] - a.back : NONE32; /* an end position < back wraps to a huge value: fails the window test like any out-of-class entry */
 		uint32_t lcp = 0;
 		bool inwin = false;
-		if (s != NONE32 && s <= wend && load_gram(b, s, 4) == g) { inwin = true; lcp = 4; }
+		if (s != NONE32 && s <= wend && a.cls[j] == g) { inwin = true; lcp = 4 * a.kwords; } /* same class: the class's gram in common */
 		/* extend word by word while some lane still matches everything so far (typical common prefixes are short: one or two rounds
 		 * instead of seven unconditional gram loads per candidate) */
-		for (uint32_t k = 1; k < 8; k++) {
+		for (uint32_t k = a.kwords; k < 8; k++) {
 			const bool alive = inwin && lcp == 4 * k;
 			if (!x3_ballot(alive)) break;
 			if (alive) {
@@ -137,6 +151,7 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 		return X3H_OK;
 	}
 	for (int i = 0; i < 8; i++) CHK(B.a[i].reserve((P + 8) * 4));
+	CHK(B.a[9].reserve(((size_t)P / 32 + 2) * 4 + 64)); /* padding bitmap */
 	CHK(B.misc.reserve(64));
 	uint32_t *keys = B.a[0].as<uint32_t>(), *iota = B.a[1].as<uint32_t>();
 	/* K = T+1 for almost every position (its first byte occurs more than T times in its window); the others are marked in a bitmap
@@ -148,8 +163,24 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 	HIPCHK(hipMemsetAsync(rare, 0, (P / 32 + 2) * 4, st));
 	HIPCHK(hipMemsetAsync(d_m, 0, P, st));
 	uint32_t *act = B.a[5].as<uint32_t>(), *act_k = B.a[6].as<uint32_t>(), *act_j = B.a[7].as<uint32_t>();
-	uint32_t *d_nact = B.misc.as<uint32_t>();
-	HIPCHK(hipMemsetAsync(d_nact, 0, 4, st));
+	uint32_t *d_nact = B.misc.as<uint32_t>(), *d_dense = d_nact + 1;
+	HIPCHK(hipMemsetAsync(d_nact, 0, 8, st));
+	/* positions in a chunk's padding are ordinary occurrences (the zeros take part in the window, x3.c:579,590) but never QUERIES (their m
+	 * is not read): one bit per position */
+	uint32_t *padbits = B.a[9].as<uint32_t>();
+	x3_foreach(P / 32 + 1, st, X3_LAMBDA(size_t w) {
+		const uint64_t p0 = (uint64_t)w * 32;
+		uint32_t lo = 0, hi = nc;
+		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (d_chunks[mid].byte_off <= p0) lo = mid; else hi = mid; }
+		uint32_t bits = 0;
+		for (uint32_t b = 0; b < 32; b++) {
+			const uint64_t p = p0 + b;
+			if (lo + 1 < nc && d_chunks[lo + 1].byte_off <= p) lo++;
+			if (p - d_chunks[lo].byte_off >= d_chunks[lo].len) bits |= 1u << b;
+		}
+		padbits[w] = bits;
+	});
+	const uint32_t dense_at = X3_WALK_DENSE;
 	if (window > (1u << 24)) return X3H_E_ARG; /* K is kept in 24 bits */
 	/* K = min(T+1, count_0) and count_0 <= ncand: any T >= ncand behaves like T = ncand */
 	const uint32_t Tu = (uint32_t)T > ncand ? ncand : (uint32_t)T, Pn = (uint32_t)P;
@@ -209,9 +240,10 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 				if (pass) {
 					d_m[p] = (uint8_t)(l - 1);
 					if (l == 4) { /* count_3 >= K: deeper levels need the candidates themselves -- unless p is padding (never read) */
-						uint32_t lo = 0, hi = nc;
-						while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (d_chunks[mid].byte_off <= p) lo = mid; else hi = mid; }
-						if (p - (uint32_t)d_chunks[lo].byte_off >= d_chunks[lo].len) return;
+						if ((padbits[p >> 5] >> (p & 31)) & 1u) return;
+						/* more than X3_WALK_DENSE members of the class inside the window: no sweep, the class is refined instead (below) */
+						const uint64_t ud = (uint64_t)j + dense_at;
+						if (ud < Pn && ksc[ud] == ksc[j] && (uint64_t)Sc[ud] <= (uint64_t)q + ncand) { *d_dense = 1u; return; }
 						const uint32_t slot = atomicAdd(d_nact, 1u);
 						act[slot] = p; act_k[slot] = K; act_j[slot] = (uint32_t)j;
 					}
@@ -222,16 +254,83 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 		t = kin; kin = ks; ks = t;
 		t = vin; vin = S; S = t;
 	}
-	S = vin; /* list 4 (the last pass's output) */
+	S = vin; /* list 4 (the last pass's output); kin holds its sorted keys */
+	const uint32_t *ks4 = kin;
 
-	/* active positions: one wavefront each over the in-window candidates of its 4-gram class (S still holds list 4) */
-	uint32_t nact = 0;
-	HIPCHK(hipMemcpyAsync(&nact, d_nact, 4, hipMemcpyDeviceToHost, st));
+	/* active positions: one wavefront each over the in-window candidates of its 4-gram class */
+	uint32_t hcnt[2] = { 0, 0 };
+	HIPCHK(hipMemcpyAsync(hcnt, d_nact, 8, hipMemcpyDeviceToHost, st));
 	HIPCHK(hipStreamSynchronize(st));
 	X3WalkArgs wa;
-	wa.bytes = d_bytes; wa.S4 = S; wa.active_j = act_j; wa.active = act; wa.active_k = act_k; wa.nactive = d_nact; wa.m = d_m;
+	wa.bytes = d_bytes; wa.S4 = S; wa.cls = ks4; wa.back = 3; wa.kwords = 1; wa.active_j = act_j; wa.active = act; wa.active_k = act_k; wa.nactive = d_nact; wa.m = d_m;
 	wa.total = Pn; wa.ncand = ncand;
-	launch_walk(wa, nact, st);
+	launch_walk(wa, hcnt[0], st);
 	HIPCHK(hipGetLastError());
+	if (!hcnt[1]) return X3H_OK;
+
+	/* ---- dense classes: refine them byte by byte (header, step 4).  Element = START position from here on. ---- */
+	for (int i = 10; i < 21; i++) CHK(B.a[i].reserve((P + 8) * 4));
+	uint32_t *Lp = B.a[10].as<uint32_t>(), *Lc = B.a[11].as<uint32_t>(), *Np = B.a[12].as<uint32_t>(), *Nc = B.a[13].as<uint32_t>();
+	uint32_t *keep = B.a[14].as<uint32_t>(), *flg = B.a[15].as<uint32_t>(), *scn = B.a[16].as<uint32_t>();
+	uint32_t *key = B.a[17].as<uint32_t>(), *keys_ = B.a[18].as<uint32_t>(), *idx = B.a[19].as<uint32_t>(), *perm = B.a[20].as<uint32_t>();
+	HIPCHK(hipMemsetAsync(keep, 0, (P + 8) * 4, st));
+	/* list 4 with start identity and class ids (index of the class's first entry) */
+	{
+		const uint32_t *k4 = ks4, *S4 = S;
+		x3_foreach(P, st, X3_LAMBDA(size_t j) { flg[j] = (j > 0 && k4[j] != k4[j - 1]) ? (uint32_t)j : 0u; Lp[j] = S4[j] - 3u; /* (an end position < 3 wraps: never a query, never inside a window) */ });
+		CHK(x3p_incl_max_scan(tmp, flg, Lc, P, st));
+	}
+	size_t n = P;
+	for (uint32_t len = 4; len <= X3_MAXLEN && n > 0; len++) {
+		const uint32_t nn = (uint32_t)n, stamp = len;
+		HIPCHK(hipMemsetAsync(d_nact, 0, 8, st));
+		/* the level test (gram length len): K-th next member of my class inside my window?  Then: finished by a sweep, or still dense */
+		x3_foreach(n, st, X3_LAMBDA(size_t j) {
+			const uint32_t p = Lp[j];
+			if (p >= Pn || ((padbits[p >> 5] >> (p & 31)) & 1u)) return; /* padding (or wrapped): an occurrence, not a query */
+			uint32_t K = Tu + 1;
+			if ((rare[p >> 5] >> (p & 31)) & 1u) { K = kexact[p]; if (K < 2) return; }
+			const uint32_t cj = Lc[j];
+			const uint64_t u = (uint64_t)j + K;
+			if (!(u < nn && Lc[u] == cj && (uint64_t)Lp[u] <= (uint64_t)p + ncand)) return;
+			if (len > 4) d_m[p] = (uint8_t)(len - 1); /* (level 3 was stored by the pass above) */
+			const uint64_t ud = (uint64_t)j + dense_at;
+			const bool dense = ud < nn && Lc[ud] == cj && (uint64_t)Lp[ud] <= (uint64_t)p + ncand;
+			if (dense && len < X3_MAXLEN) { keep[cj] = stamp; *d_dense = 1u; } /* (every writer stores the same value) */
+			else if (len > 4 && len < X3_MAXLEN) { /* (at length 4 the pass above queued the others already) */
+				const uint32_t slot = atomicAdd(d_nact, 1u);
+				act[slot] = p; act_k[slot] = K; act_j[slot] = (uint32_t)j;
+			}
+		});
+		HIPCHK(hipMemcpyAsync(hcnt, d_nact, 8, hipMemcpyDeviceToHost, st));
+		HIPCHK(hipStreamSynchronize(st));
+		if (len > 4 && hcnt[0]) {
+			wa.S4 = Lp; wa.cls = Lc; wa.back = 0; wa.kwords = len / 4; wa.total = nn;
+			launch_walk(wa, hcnt[0], st);
+			HIPCHK(hipGetLastError());
+		}
+		if (!hcnt[1] || len == X3_MAXLEN) break;
+		/* keep the classes that are still dense somewhere; number them 0, 1, 2, ... in list order */
+		x3_foreach(n, st, X3_LAMBDA(size_t j) { flg[j] = (keep[Lc[j]] == stamp && Lp[j] < Pn) ? 1u : 0u; });
+		CHK(x3p_excl_scan(tmp, flg, scn, n, st));
+		x3_foreach(n, st, X3_LAMBDA(size_t j) { if (flg[j]) { const uint32_t d = scn[j]; Np[d] = Lp[j]; Nc[d] = Lc[j]; } });
+		uint32_t nlive = 0;
+		HIPCHK(hipMemcpyAsync(&nlive, scn + n, 4, hipMemcpyDeviceToHost, st));
+		HIPCHK(hipStreamSynchronize(st));
+		if (getenv("X3H_DEBUG")) fprintf(stderr, "[x3h] scan: gram length %u: %zu list entries, %u swept, %u stay in dense classes\n", len, n, hcnt[0], nlive);
+		n = nlive;
+		if (!n) break;
+		x3_foreach(n, st, X3_LAMBDA(size_t i) { flg[i] = (i > 0 && Nc[i] != Nc[i - 1]) ? 1u : 0u; });
+		CHK(x3p_excl_scan(tmp, flg, scn, n, st)); /* scn[i] + flg[i] = ordinal of entry i's class */
+		uint32_t ncls = 0;
+		HIPCHK(hipMemcpyAsync(&ncls, scn + n, 4, hipMemcpyDeviceToHost, st));
+		HIPCHK(hipStreamSynchronize(st));
+		/* next level: stable sort by (class, byte behind the gram): classes split, positions stay ascending inside them */
+		const uint32_t ext = len; /* the gram at p grows by bytes[p + len] */
+		x3_foreach(n, st, X3_LAMBDA(size_t i) { key[i] = ((scn[i] + flg[i]) << 8) | (uint32_t)d_bytes[(uint64_t)Np[i] + ext]; idx[i] = (uint32_t)i; });
+		CHK(x3p_sort_pairs(tmp, key, keys_, idx, perm, n, 8 + (ncls ? 32 - __builtin_clz(ncls) : 1), st));
+		x3_foreach(n, st, X3_LAMBDA(size_t j) { Lp[j] = Np[perm[j]]; flg[j] = (j > 0 && keys_[j] != keys_[j - 1]) ? (uint32_t)j : 0u; });
+		CHK(x3p_incl_max_scan(tmp, flg, Lc, n, st));
+	}
 	return X3H_OK;
 }

@@ -72,7 +72,7 @@ int x3p_excl_scan(DevBuf &tmp, const uint32_t *in, uint32_t *out, size_t n, hipS
 int x3p_incl_max_scan(DevBuf &tmp, const uint32_t *in, uint32_t *out, size_t n, hipStream_t st);
 
 /* ---- K1 v2 (scan2.hip) ----------------------------------------------------------------------------------- */
-struct X3Scan2Bufs { DevBuf a[12]; DevBuf misc; };
+struct X3Scan2Bufs { DevBuf a[24]; DevBuf misc; };
 int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, const X3Chunk *h_chunks, const X3Chunk *d_chunks,
                    const uint8_t *d_bytes, uint8_t *d_m, uint64_t total, uint32_t window, int32_t T);
 
