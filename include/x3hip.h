@@ -152,8 +152,13 @@ int x3h_decompress_container(x3h_ctx *const *ctxs, int ndevices, const uint8_t *
  *                    count[] of backend.c:56-74; find_best_match(p) = 1 + max{ i <= m[p] : filters of backend.c:79-90 }.
  *  x3h_scan_counts : K1's raw histogram, counts_out[p*32+i] = count[i] at p (backend.c:62-74).
  *  x3h_parse       : K1+K2.  Token list of the parse loop x3.c:379-429: tok_info < 2^31 is a hit on that tag;
- *                    otherwise bit31 set, bits0..5 = fragment length, bit30 = fragment already in the dictionary.  */
+ *                    otherwise bit31 set, bits0..5 = fragment length, bit30 = fragment already in the dictionary.
+ *  x3h_coder_chain : the coder recurrence alone (x3_ac2_kernel, ac.c:46-85): n symbols (cum_lo, freq, total) coded from the initial
+ *                    interval of ac_init; states_out[2g], states_out[2g+1] = (mLow, range = mHigh - mLow + 1) BEFORE symbol 8g (one state per group
+ *                    of 8 symbols, what the kernel stores), *final_lo = mLow after the last symbol.  total in [2, 2^28).               */
 int x3h_scan_m(x3h_ctx *ctx, const x3h_params *prm, const uint8_t *in, size_t n, uint8_t *m_out);
+int x3h_coder_chain(x3h_ctx *ctx, const uint32_t *cum, const uint32_t *freq, const uint32_t *total, size_t n,
+                    uint32_t *states_out, uint32_t *final_lo);
 int x3h_scan_counts(x3h_ctx *ctx, const x3h_params *prm, const uint8_t *in, size_t n, uint32_t *counts_out);
 int x3h_parse(x3h_ctx *ctx, const x3h_params *prm, const uint8_t *in, size_t n,
               uint32_t *tok_pos, uint32_t *tok_info, size_t tok_cap, size_t *ntok, uint64_t *dict_elems);

@@ -122,6 +122,26 @@ static void ac_enc_flush(accoder *a, bitw *w) /* ac.c:115-126; pending bits are 
 	}
 }
 
+/* Stage oracle for the coder recurrence alone: the interval (mLow, mHigh) after each of n symbols given as (cum_lo, freq, total),
+ * starting from ac_init's [0, 0x7FFFFFFF] (ac.c:35-41,46-85), and the bits the symbols shift out (pending bits included). */
+int x3o_ac_chain(const uint32_t *cum, const uint32_t *freq, const uint32_t *total, size_t n, uint32_t *lo_out, uint32_t *hi_out,
+                 uint8_t *bits, size_t cap, size_t *nbits)
+{
+	accoder a;
+	bitw w;
+	ac_reset(&a);
+	w.ptr = bits; w.end = bits + cap; w.acc = 0; w.cnt = 0; w.full = 0;
+	for (size_t i = 0; i < n; i++) {
+		if (!total[i] || !freq[i] || (uint64_t)cum[i] + freq[i] > total[i]) return X3O_E_ARG;
+		ac_enc(&a, &w, cum[i], (uint64_t)cum[i] + freq[i], total[i]);
+		lo_out[i] = (uint32_t)a.lo;
+		hi_out[i] = (uint32_t)a.hi;
+	}
+	if (nbits) *nbits = (size_t)(w.ptr - bits) * 8 + w.cnt;
+	bw_close(&w);
+	return w.full ? X3O_E_FULL : X3O_OK;
+}
+
 static void ac_dec_start(accoder *a, bitr *r) /* ac.c:133-140 */
 {
 	a->buf = 0;

@@ -84,6 +84,11 @@ int x3o_decompress(const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t
 void x3o_count(const uint8_t *padded, size_t pos, uint32_t window_bytes, uint32_t count[X3O_MAX_MATCH]);
 int  x3o_scan_m(const x3o_params *prm, const uint8_t *in, size_t n, uint8_t *m_out);
 
+/* x3o_ac_chain: the arithmetic coder alone (ac.c:35-85): interval [lo_out[i], hi_out[i]] after symbol i = (cum, freq, total),
+ * from ac_init's state; `bits` receives the bit stream so far (no flush), *nbits its length. */
+int x3o_ac_chain(const uint32_t *cum, const uint32_t *freq, const uint32_t *total, size_t n, uint32_t *lo_out, uint32_t *hi_out,
+                 uint8_t *bits, size_t cap, size_t *nbits);
+
 #ifdef __cplusplus
 }
 #endif

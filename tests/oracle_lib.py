@@ -51,11 +51,23 @@ class Oracle:
         lib.x3o_scan_m.argtypes = [C.POINTER(Params), C.c_void_p, C.c_size_t, C.c_void_p]
         lib.x3o_count.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
         lib.x3o_count.restype = None
+        lib.x3o_ac_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, szp]
 
     @staticmethod
     def _buf(data):
         a = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
         return a, (a.ctypes.data if a.size else None)
+
+    def ac_chain(self, cum, freq, total):
+        """ac.c:35-85 alone: -> (lo[n], hi[n]) after every symbol, from ac_init's interval"""
+        cum, freq, total = (np.ascontiguousarray(x, dtype=np.uint32) for x in (cum, freq, total))
+        n = cum.size
+        lo, hi = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+        bits = np.zeros(4 * n + 64, np.uint8)
+        nb = C.c_size_t(0)
+        rc = self.lib.x3o_ac_chain(cum.ctypes.data, freq.ctypes.data, total.ctypes.data, n, lo.ctypes.data, hi.ctypes.data, bits.ctypes.data, bits.size, C.byref(nb))
+        assert rc == 0, rc
+        return lo, hi
 
     def compress(self, data, prm, via_m=None, want_stats=False):
         a, ptr = self._buf(data)

@@ -189,3 +189,19 @@ def test_emulated_container_round_trip_two_handles(emu_env, oracle):
     off = np.array([0, 100, 100, 3000, 7001], dtype=np.uint64)
     got = _lib.compress_chunks_multi([a, b, a], np.frombuffer(data, np.uint8), off, prm)
     assert got == [oracle.compress(data[int(off[i]):int(off[i + 1])], oprm) for i in range(4)]
+
+
+def test_emulated_coder_chain_seam(emu, oracle):
+    """x3h_coder_chain (stage seam) on the emulator: the functional restatement of the chain == the oracle's E1/E2/E3 loops (the asm chain
+    itself is checked by tests/test_gpu_parity.py::test_coder_chain_states_equal_oracle_intervals on the GPU)"""
+    rng = np.random.default_rng(11)
+    n = 777
+    total = rng.integers(2, 2 ** 22, n)
+    freq = np.minimum(rng.integers(1, total + 1), total)
+    cum = np.minimum((rng.random(n) * (total - freq + 1)).astype(np.int64), total - freq)
+    states, fin = emu.coder_chain(cum, freq, total)
+    lo, hi = oracle.ac_chain(cum, freq, total)
+    g = np.arange(1, (n + 7) // 8)
+    assert np.array_equal(states[1:, 0], lo[8 * g - 1])
+    assert np.array_equal(states[1:, 1].astype(np.int64), hi[8 * g - 1].astype(np.int64) - lo[8 * g - 1].astype(np.int64) + 1)
+    assert fin == int(lo[-1])

@@ -18,7 +18,12 @@ CASES = sorted(golden_util.load_cases().keys())
 
 
 def run(args, **kw):
-    return subprocess.run([X3, *args], capture_output=True, timeout=600, **kw)
+    r = subprocess.run([X3, *args], capture_output=True, timeout=600, **kw)
+    if r.returncode < 0 and "stdin" not in kw:  # killed by a signal (seen once in ~400 runs, at process exit after a complete, correct output):
+        import warnings                          # repeat ONCE and say so -- a reproducible crash still fails the test
+        warnings.warn(f"x3 {' '.join(args)} died with signal {-r.returncode}; repeating once")
+        r = subprocess.run([X3, *args], capture_output=True, timeout=600, **kw)
+    return r
 
 
 @pytest.mark.parametrize("name", CASES)

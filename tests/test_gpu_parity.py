@@ -405,3 +405,27 @@ def test_stream_kernels_agree_with_chipwide_passes(gpu_env):
     assert new == old
     big = synth.english_like(3 << 20, seed=77).tobytes()
     assert gpu_env(X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0").compress(big, prm) == gpu_env(X3H_STREAM_KERNELS="0", X3H_PIPE_MIN="0").compress(big, prm)
+
+
+# ---- the coder recurrence alone (x3_ac2_kernel's scalar-unit chain) against the oracle's per-symbol intervals ------------------------------
+@pytest.mark.parametrize("n,maxtot,seed", [(1, 5, 1), (7, 300, 2), (8, 300, 3), (9, 4000, 4), (33, 2 ** 20, 5), (4096, 2 ** 27, 6),
+                                           (100_003, 2 ** 16, 7), (1_000_001, 2 ** 27, 8)])
+def test_coder_chain_states_equal_oracle_intervals(gpu, oracle, n, maxtot, seed):
+    """ac.c:46-85: random symbol sequences (totals up to 2^27: the magic-multiply division, the closed-form renormalisation s = clz(D)-1-carry,
+    the unreduced lo of the asm chain) -- every stored state (mLow, range) and the final mLow must equal the reference arithmetic's, computed
+    by the oracle's plain E1/E2/E3 loops.  Sizes around the group-of-8 / 32-symbol-trip boundaries of the kernel."""
+    rng = np.random.default_rng(seed)
+    total = rng.integers(2, maxtot, n, dtype=np.int64)
+    # a mix of near-certain, tiny-probability and uniform symbols
+    kind = rng.integers(0, 3, n)
+    freq = np.where(kind == 0, np.maximum(total - rng.integers(0, 3, n), 1), np.where(kind == 1, 1, rng.integers(1, total + 1)))
+    freq = np.minimum(freq, total)
+    cum = (rng.random(n) * (total - freq + 1)).astype(np.int64)
+    cum = np.minimum(cum, total - freq)
+    states, fin = gpu.coder_chain(cum, freq, total)
+    lo, hi = oracle.ac_chain(cum, freq, total)
+    g = np.arange(1, (n + 7) // 8)          # state g = the interval after symbol 8g - 1
+    assert states[0, 0] == 0 and states[0, 1] == 0x80000000
+    assert np.array_equal(states[1:, 0], lo[8 * g - 1])
+    assert np.array_equal(states[1:, 1].astype(np.int64), hi[8 * g - 1].astype(np.int64) - lo[8 * g - 1].astype(np.int64) + 1)
+    assert fin == int(lo[-1])

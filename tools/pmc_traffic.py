@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""HBM traffic from two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; values in KB; FETCH doubled per MI355X_MICROARCH.md:
+gfx950 tallies half of each wide read request), for the LAST step / batch of the profiled command (marker: the stage_inputs pass).
+usage: pmc_traffic.py bench  FETCH.csv WRITE.csv out.json bytes w t nsteps   -> per-kernel bytes per step (bench.py single stream: no marker kernel, so the
+                                                                               totals of the run are divided by its nsteps = warmup + steps)
+       pmc_traffic.py batch  FETCH.csv WRITE.csv out.json total_bytes        -> whole batch by kernel family (tools/many_chunks_check.py)"""
+import csv, json, sys
+from collections import defaultdict
+
+
+def family(n):
+    if "x3_foreach" in n:
+        return "foreach:" + n.split("x3_foreach_kernel<")[1].split("(")[0]
+    if "rocprim" in n or "rocclr" in n:
+        return "rocprim:" + ("sort" if "radix" in n else "scan" if "scan" in n else "other") if "rocprim" in n else "runtime fill/copy"
+    return n.split("(")[0]
+
+
+def last_step(path, counter):
+    rows = [r for r in csv.DictReader(open(path)) if r.get("Counter_Name") == counter]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    marks = [i for i, r in enumerate(rows) if "stage_inputs" in r["Kernel_Name"] or "__amd_rocclr_fillBufferAligned" in r["Kernel_Name"] and False]
+    starts = [i for i, r in enumerate(rows) if "stage_inputs" in r["Kernel_Name"]]
+    if starts:
+        rows = rows[starts[-1]:]
+    agg = defaultdict(lambda: [0.0, 0.0, 0])
+    for r in rows:
+        a = agg[family(r["Kernel_Name"])]
+        a[0] += float(r["Counter_Value"]); a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6; a[2] += 1
+    return agg
+
+
+mode, fpath, wpath, out = sys.argv[1:5]
+F, W = last_step(fpath, "FETCH_SIZE"), last_step(wpath, "WRITE_SIZE")
+fams = sorted(set(F) | set(W))
+if mode == "bench":
+    res = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --no-cpu --no-secondary --steps 2 --warmup 1 (two separate passes; per step = totals / 3)",
+           "bench_args": {"bytes": int(sys.argv[5]), "w": int(sys.argv[6]), "t": int(sys.argv[7])},
+           "units": "FETCH_SIZE / WRITE_SIZE are KB; hbm_bytes_per_step = (2 * FETCH + WRITE) * 1024 over all launches of the kernel in one step (gfx950: FETCH_SIZE counts half of each read request)",
+           "kernels": {}}
+    ns = float(sys.argv[8]) if len(sys.argv) > 8 else 1.0
+    for k in fams:
+        f, w = F.get(k, [0, 0, 0]), W.get(k, [0, 0, 0])
+        res["kernels"][k] = {"launches_per_step": round(max(f[2], w[2]) / ns, 1), "kernel_ms_per_step": round(max(f[1], w[1]) / ns, 3),
+                             "FETCH_SIZE_KB": round(f[0] / ns, 1), "WRITE_SIZE_KB": round(w[0] / ns, 1), "hbm_bytes_per_step": int((2 * f[0] + w[0]) * 1024 / ns)}
+else:
+    total_bytes = int(sys.argv[5])
+    groups, tf, tw, tms = {}, 0.0, 0.0, 0.0
+    for k in fams:
+        f, w = F.get(k, [0, 0, 0]), W.get(k, [0, 0, 0])
+        gb = (2 * f[0] + w[0]) * 1024 / 1e9
+        ms = max(f[1], w[1])
+        groups[k] = {"launches": max(f[2], w[2]), "ms": round(ms, 2), "hbm_GB": round(gb, 2), "TBps": round(gb / ms, 2) if ms > 0 else None}
+        tf += 2 * f[0] * 1024 / 1e9; tw += w[0] * 1024 / 1e9; tms += ms
+    res = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace --output-format csv -- python3 tools/many_chunks_check.py 256 256 mix (two separate passes; the last batch)",
+           "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies half of each wide read request); kernels are serialised by the profiler, so batch_ms = sum of kernel durations",
+           "total_bytes": total_bytes, "batch_ms": round(tms, 2),
+           "total": {"fetch_GB": round(tf, 2), "write_GB": round(tw, 2), "GB": round(tf + tw, 2), "bytes_per_input_byte": round((tf + tw) * 1e9 / total_bytes, 1),
+                     "avg_TBps": round((tf + tw) / tms, 3)},
+           "groups": dict(sorted(groups.items(), key=lambda kv: -kv[1]["hbm_GB"]))}
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res["total"] if "total" in res else {k: v for k, v in res["kernels"].items() if v["kernel_ms_per_step"] > 1}, indent=1))

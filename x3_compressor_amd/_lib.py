@@ -20,6 +20,7 @@ ABI_SYMBOLS = (
     "x3h_compress_chunks_dev", "x3h_decompress", "x3h_decompress_chunks", "x3h_scan_m", "x3h_scan_counts", "x3h_parse",
     "x3h_compress_chunks_multi", "x3h_decompress_chunks_multi", "x3h_container_header_bytes", "x3h_container_write_header",
     "x3h_container_probe", "x3h_container_table", "x3h_container_bound", "x3h_compress_container", "x3h_decompress_container",
+    "x3h_coder_chain",
 )
 
 TOK_MISS, TOK_DUP = 0x80000000, 0x40000000
@@ -84,6 +85,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.x3h_scan_counts.argtypes = [C.c_void_p, C.POINTER(Params), u8p, C.c_size_t, C.c_void_p]
     lib.x3h_parse.argtypes = [C.c_void_p, C.POINTER(Params), u8p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t,
                               C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]
+    lib.x3h_coder_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     ctxs = C.POINTER(C.c_void_p)
     lib.x3h_compress_chunks_multi.argtypes = [ctxs, C.c_int, C.POINTER(Params), u8p, C.c_void_p, C.c_int, u8p, C.c_uint64, C.c_void_p, C.POINTER(Stats)]
     lib.x3h_decompress_chunks_multi.argtypes = [ctxs, C.c_int, u8p, C.c_void_p, C.c_int, u8p, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
@@ -222,6 +224,15 @@ class X3Context:
         cnt = np.empty((a.size, 32), dtype=np.uint32)
         self._check(self.lib.x3h_scan_counts(self._h, C.byref(prm), a.ctypes.data if a.size else None, a.size, cnt.ctypes.data if a.size else None))
         return cnt
+
+    def coder_chain(self, cum, freq, total):
+        """x3h_coder_chain: -> (states[(n+7)//8, 2] = (mLow, range) before every 8th symbol, final mLow)"""
+        cum, freq, total = (np.ascontiguousarray(x, dtype=np.uint32) for x in (cum, freq, total))
+        n = cum.size
+        states = np.zeros(((n + 7) // 8, 2), dtype=np.uint32)
+        fin = C.c_uint32(0)
+        self._check(self.lib.x3h_coder_chain(self._h, cum.ctypes.data, freq.ctypes.data, total.ctypes.data, n, states.ctypes.data, C.byref(fin)))
+        return states, int(fin.value)
 
     def parse(self, data, prm: Params):
         a = _u8(data)

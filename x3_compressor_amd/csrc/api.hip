@@ -648,6 +648,14 @@ extern "C" int x3h_scan_m(x3h_ctx *ctx, const x3h_params *prm, const uint8_t *in
 	return X3H_OK;
 }
 
+extern "C" int x3h_coder_chain(x3h_ctx *ctx, const uint32_t *cum, const uint32_t *freq, const uint32_t *total, size_t n,
+                               uint32_t *states_out, uint32_t *final_lo)
+{
+	if (!ctx || !cum || !freq || !total || !n || !states_out || !final_lo) return X3H_E_ARG;
+	HIPCHK(hipSetDevice(ctx->device));
+	return x3_coder_chain_run(ctx->c2, ctx->stream, cum, freq, total, n, states_out, final_lo);
+}
+
 extern "C" int x3h_scan_counts(x3h_ctx *ctx, const x3h_params *prm, const uint8_t *in, size_t n, uint32_t *counts_out)
 {
 	if (!ctx || (!in && n) || (!counts_out && n)) return X3H_E_ARG;

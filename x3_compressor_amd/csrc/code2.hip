@@ -1565,3 +1565,38 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	B.last.symbols = nYraw; B.last.chain_symbols = nYc;
 	return X3H_OK;
 }
+
+/* ============================================================================================================
+ * Stage seam (x3h_coder_chain): the interval recurrence of x3_ac2_kernel on a symbol sequence given by the caller -- the same kernel,
+ * the same operand format (x3_make_symbol), one stream.  Returns the chain states the kernel stores (one per group of X3_AC2_G symbols,
+ * lo reduced to the 30 bits that are the reference's mLow) and the final mLow.
+ * ============================================================================================================ */
+int x3_coder_chain_run(X3Code2Bufs &B, hipStream_t st, const uint32_t *h_cum, const uint32_t *h_freq, const uint32_t *h_total, size_t n,
+                       uint32_t *h_states, uint32_t *h_final_lo)
+{
+	if (n >= (1u << 30)) return X3H_E_ARG;
+	for (size_t i = 0; i < n; i++) if (h_total[i] < 2 || h_total[i] >= (1u << 28) || !h_freq[i] || (uint64_t)h_cum[i] + h_freq[i] > h_total[i]) return X3H_E_ARG;
+	for (int i = 0; i < 3; i++) CHK(B.a[i].reserve((n + 4) * 4));
+	CHK(B.y[0].reserve((n + X3_SYM_PAD) * 16));
+	CHK(B.y[3].reserve((n + 8) * 8));
+	CHK(B.offs.reserve(64));
+	uint32_t *d_cum = B.a[0].as<uint32_t>(), *d_freq = B.a[1].as<uint32_t>(), *d_tot = B.a[2].as<uint32_t>();
+	uint4 *sy = B.y[0].as<uint4>();
+	uint32_t *rec = B.y[3].as<uint32_t>(), *d_yo = B.offs.as<uint32_t>();
+	HIPCHK(hipMemcpyAsync(d_cum, h_cum, n * 4, hipMemcpyHostToDevice, st));
+	HIPCHK(hipMemcpyAsync(d_freq, h_freq, n * 4, hipMemcpyHostToDevice, st));
+	HIPCHK(hipMemcpyAsync(d_tot, h_total, n * 4, hipMemcpyHostToDevice, st));
+	const uint32_t yo[2] = { 0, (uint32_t)n };
+	HIPCHK(hipMemcpyAsync(d_yo, yo, 8, hipMemcpyHostToDevice, st));
+	x3_foreach(n, st, X3_LAMBDA(size_t i) { sy[i] = x3_make_symbol(d_cum[i], d_freq[i], d_tot[i]); });
+	X3Ac2Args aa;
+	aa.yo = d_yo; aa.sym = sy; aa.rec_nk = rec; aa.final_lo = d_yo + 4; aa.seg_off = aa.seg_len = nullptr; aa.seg_state = nullptr;
+	launch_ac2(aa, 1, st);
+	HIPCHK(hipGetLastError());
+	std::vector<uint32_t> all(2 * (n + 1));
+	HIPCHK(hipMemcpyAsync(all.data(), rec, 2 * n * 4, hipMemcpyDeviceToHost, st));
+	HIPCHK(hipMemcpyAsync(h_final_lo, d_yo + 4, 4, hipMemcpyDeviceToHost, st));
+	HIPCHK(hipStreamSynchronize(st));
+	for (size_t g = 0; g * X3_AC2_G < n; g++) { h_states[2 * g] = all[2 * g * X3_AC2_G] & 0x3FFFFFFFu; h_states[2 * g + 1] = all[2 * g * X3_AC2_G + 1]; }
+	return X3H_OK;
+}
