@@ -205,3 +205,17 @@ def test_emulated_coder_chain_seam(emu, oracle):
     assert np.array_equal(states[1:, 0], lo[8 * g - 1])
     assert np.array_equal(states[1:, 1].astype(np.int64), hi[8 * g - 1].astype(np.int64) - lo[8 * g - 1].astype(np.int64) + 1)
     assert fin == int(lo[-1])
+
+
+def test_emulated_pipelined_resumed_mode_chain(emu_env, oracle):
+    """growing prefixes with the serial mode kernel RESUMING behind the hits of the previous prefix (its saved chain state + the earlier
+    modes re-laid out for the new per-stream counts): streams whose dictionaries fit the kernel's LDS table (48 entries in this build)"""
+    ctx = emu_env(X3H_PIPE_MIN="1", X3H_MODES="serial")
+    kw = dict(w_kib=1, t=3)
+    parts = [b"abracadabra" * 300, bytes(3000), (b"abcabdabe" * 400)[:3500], b"xyzzy" * 500, b"ab"]
+    data = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    off = np.cumsum([0] + [len(p) for p in parts]).astype(np.uint64)
+    streams = ctx.compress_chunks(data, off, _lib.make_params(**kw))
+    assert ctx.last_stats.pipelined == 1 and ctx.last_stats.dict_elems < 48 * 5
+    for p, got in zip(parts, streams):
+        assert got == oracle.compress(p, oracle_lib.params(**kw))

@@ -133,7 +133,7 @@ extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 		               &c->c2.tmp, &c->c2.offs, &c->c2.chunkmeta, &c->c2.idxfreq, &c->c2.hsym, &c->c2.maxred, &c->c2.pp[0], &c->c2.pp[1], &c->c2.pp[2], &c->c2.pp[3],
 		               &c->cresult, &c->mtf, &c->idxfreq, &c->ctx1, &c->ctx0, &c->items, &c->pkey, &c->pval, &c->out, &c->counts, &c->din, &c->dchunks, &c->items_ord };
 	for (DevBuf *b : bufs) b->release();
-	c->coder_state.release(); c->prefix_result.release(); c->srcoff.release(); c->ckpt_pos.release(); c->seg.meta.release();
+	c->coder_state.release(); c->prefix_result.release(); c->srcoff.release(); c->ckpt_pos.release(); c->seg.meta.release(); c->seg.modes_state.release(); c->seg.mode_prev.release();
 	c->c2.yfin.release(); c->c2.yfinrec.release();
 	if (c->ckpt) (void)hipHostFree((void *)c->ckpt);
 	if (c->s_parse) (void)hipStreamDestroy(c->s_parse);
@@ -309,7 +309,7 @@ static int run_pipelined_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_byte
 
 	X3CodeSeg &seg = c->seg;
 	seg.final = false; seg.coder_stream = c->s_coder; seg.ev_ready = c->ev_ready; seg.coder_state = c->coder_state.as<uint32_t>();
-	seg.y_done.assign(nc, 0u); seg.ring_top = 0; seg.calls.clear();
+	seg.y_done.assign(nc, 0u); seg.ring_top = 0; seg.calls.clear(); seg.prev_ho.clear(); seg.prev_serial = false;
 	/* the workspace is sized ONCE, for the worst case (steps, hits + elements and new-fragment bytes are each <= input bytes): a
 	 * reallocation in mid-flight would wait for the running parse and coder (hipFree synchronises the device), and a token density
 	 * extrapolated from the first 2 % is wrong as soon as the data changes character.  run_one only pipelines batches this fits. */
@@ -319,19 +319,17 @@ static int run_pipelined_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_byte
 	int next = 0, nseg = 0;
 	bool parse_done = false;
 	for (;;) {
-		/* newest record of every stream (a long step may skip marks); a prefix call is due when EVERY stream has passed the next mark */
+		/* the next record of every stream (a long step may skip a mark); a prefix call is due when EVERY stream has passed the next mark */
 		int lowest = X3_MAX_CKPT;
 		for (uint32_t i = 0; i < nc; i++) {
 			const X3ParseCkpt *ck = c->ckpt + (size_t)i * X3_CKPT_SLOTS;
 			if (avail[i] < X3_MAX_CKPT) {
 				int best = avail[i];
-				if (ck[X3_MAX_CKPT].seq == X3_MAX_CKPT + 1) best = X3_MAX_CKPT;
-				else
-#ifndef X3_EMU
-					for (int k = (int)nmarks - 1; k > avail[i]; k--) { if (ck[k].seq == (uint32_t)k + 1) { best = k; break; } }
-#else
-					for (int k = avail[i] + 1; k < (int)nmarks; k++) { if (ck[k].seq == (uint32_t)k + 1) { best = k; if (k >= next) break; } } /* the emulator's parse has finished by now: walk through every mark */
-#endif
+				/* the marks are taken ONE BY ONE even when the parse is already further: a prefix call costs time in proportion to its
+				 * prefix, and the coder must not run dry while a long call is under way (16 x 8 MiB: the parse is done after 100 ms, the
+				 * coder needs 420 ms -- skipping from the 26 % mark straight to the end left it idle for 150 ms) */
+				for (int k = avail[i] + 1; k < (int)nmarks; k++) { if (ck[k].seq == (uint32_t)k + 1) { best = k; if (k >= next) break; } }
+				if ((best < next || best == avail[i]) && ck[X3_MAX_CKPT].seq == X3_MAX_CKPT + 1) best = X3_MAX_CKPT; /* no mark left to take: the stream is done */
 				if (best != avail[i]) {
 					avail[i] = best;
 					pr[i] = X3ParseResult();
@@ -342,18 +340,6 @@ static int run_pipelined_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_byte
 			if (avail[i] < lowest) lowest = avail[i];
 		}
 		bool final = false;
-#ifdef X3_EMU
-		if (lowest == X3_MAX_CKPT && next < (int)nmarks) { /* test build: every stream is done already -- still take the marks one by one */
-			lowest = next;
-			for (uint32_t i = 0; i < nc; i++) {
-				const X3ParseCkpt *ck = c->ckpt + (size_t)i * X3_CKPT_SLOTS;
-				int k = next; while (k < (int)nmarks && ck[k].seq != (uint32_t)k + 1) k++;
-				const int use = k < (int)nmarks ? k : X3_MAX_CKPT;
-				pr[i] = X3ParseResult();
-				pr[i].ntok = ck[use].ntok; pr[i].hits = ck[use].hits; pr[i].dict_elems = ck[use].dict_elems; pr[i].miss_bytes = ck[use].miss_bytes; pr[i]._r0 = ck[use].p;
-			}
-		}
-#endif
 		if (lowest == X3_MAX_CKPT) {
 			/* every stream is parsed: final call with the kernel's own results */
 			HIPCHK(hipStreamSynchronize(c->s_parse));

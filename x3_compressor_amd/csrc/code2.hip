@@ -203,7 +203,13 @@ struct X3ModesArgs {
 	uint32_t *pe0, *pe1;               /* out per hit: model_events freq of E_CTX0 / E_CTX1 before the hit (x3.c:176-177)            */
 	uint32_t *ilist_rank, *ilist_hit;  /* out: the IDX1-coded hits of stream c in time order, at [ho[c], ho[c] + evfinal[4c+3])          */
 	uint32_t *evfinal;                 /* out per chunk: the three model_events freqs after the last hit, and the number of IDX1 hits */
+	/* optional (state != nullptr; growing prefixes of a few long streams): the chain's state after the last hit is saved per stream
+	 * {E0, E1, E2, nidx, hits done, table entries, 0, 0, table...} (stride X3_MODES_STATE_STRIDE words), and a later call on a longer prefix
+	 * resumes behind the hits already decided instead of starting over (their modes are in `mode` already) */
+	uint32_t *state;
+	uint32_t resume;                   /* 1: continue from the saved state where it is valid (hits done <= this prefix's hits) */
 };
+#define X3_MODES_STATE_STRIDE (X3_IDXF_LDS + 8u)
 
 #ifndef X3_IDXF_LDS
 #define X3_IDXF_LDS 32768u /* ranks whose model_index1 frequency lives in LDS (128 KiB); beyond that: global memory */
@@ -225,19 +231,21 @@ struct X3ModesArgs {
  *     using one vector division for the four quotients.
  * Typically only a few percent of the hits need the serial path.  ALL_LDS: every rank fits the LDS table. */
 template <bool ALL_LDS, uint32_t NIDX, bool EMIT>
-__device__ static __forceinline__ void x3_modes_loop(const X3ModesArgs &a, uint32_t *sidx, uint32_t *spre, uint32_t *scr, uint32_t *idxf, uint32_t H, uint32_t h0, uint32_t lane, uint32_t Dc)
+__device__ static __forceinline__ void x3_modes_loop(const X3ModesArgs &a, uint32_t *sidx, uint32_t *spre, uint32_t *scr, uint32_t *idxf, uint32_t H, uint32_t h0, uint32_t lane, uint32_t Dc,
+                                                     uint32_t first = 0, const uint32_t *st0 = nullptr, uint32_t *st1 = nullptr)
 {
 	uint32_t E0 = 1024, E1 = 1024, E2 = 1, nidx = 0; /* model_events freqs (x3.c:239-241), IDX1 uses so far */
+	if (st0) { E0 = st0[0]; E1 = st0[1]; E2 = st0[2]; nidx = st0[3]; } /* resumed behind `first` hits */
 	const uint64_t below = ((uint64_t)1 << lane) - 1;
 	/* features of the next block are fetched while this block is decided (a lone wave cannot hide the load latency otherwise) */
 	uint32_t nf0, nt0, nf1, nt1, nr, nd, ns;
 	{
-		const bool in0 = lane < H;
-		const uint32_t g0 = h0 + lane;
+		const bool in0 = first + lane < H;
+		const uint32_t g0 = h0 + first + lane;
 		nf0 = in0 ? a.f0[g0] : 0; nt0 = in0 ? a.t0[g0] : 1; nf1 = in0 ? a.f1[g0] : 0; nt1 = in0 ? a.t1[g0] : 1;
 		nr = in0 ? a.rank[g0] : 0; nd = in0 ? a.dk[g0] : 1; ns = in0 ? a.step[g0] : 0;
 	}
-	for (uint32_t base = 0; base < H; base += X3_WAVE) {
+	for (uint32_t base = first; base < H; base += X3_WAVE) {
 		const uint32_t g = h0 + base + lane;
 		const bool in = base + lane < H;
 		const uint32_t vf0 = nf0, vt0 = nt0, vf1 = nf1, vt1 = nt1, vr = nr, vd = nd, vs = ns;
@@ -325,6 +333,7 @@ __device__ static __forceinline__ void x3_modes_loop(const X3ModesArgs &a, uint3
 		x3_wave_sync();
 	}
 	if (a.evfinal && lane == 0) { uint32_t *ef = a.evfinal + 4 * blockIdx.x; ef[0] = E0; ef[1] = E1; ef[2] = E2; ef[3] = nidx; }
+	if (st1 && lane == 0) { st1[0] = E0; st1[1] = E1; st1[2] = E2; st1[3] = nidx; st1[4] = H; st1[5] = Dc; }
 }
 
 template <uint32_t NIDX, bool EMIT>
@@ -337,11 +346,17 @@ __device__ static void x3_modes_body(const X3ModesArgs &a)
 	const uint32_t H = a.parsed[c].hits, h0 = a.ho[c], Dc = a.parsed[c].dict_elems;
 	uint32_t *idxf = a.idxfreq + a.dof[c];
 	const uint32_t nl = Dc < NIDX ? Dc : NIDX;
-	for (uint32_t i = lane; i < nl; i += X3_WAVE) sidx[i] = 1;
+	/* saved state of an earlier, shorter prefix of this stream (X3ModesArgs::state): only with the whole table in LDS */
+	uint32_t *st = (!EMIT && NIDX == X3_IDXF_LDS && a.state && Dc <= NIDX) ? a.state + (size_t)c * X3_MODES_STATE_STRIDE : nullptr;
+	const bool resumed = st && a.resume && st[4] <= H && st[5] <= Dc && st[4] > 0;
+	const uint32_t dsaved = resumed ? st[5] : 0u;
+	for (uint32_t i = lane; i < nl; i += X3_WAVE) sidx[i] = i < dsaved ? st[8 + i] : 1u;
 	x3_wave_sync();
 	if (EMIT) x3_modes_loop<true, NIDX, true>(a, sidx, spre, scr, idxf, H, h0, lane, Dc); /* (the caller picked a table that holds every rank) */
-	else if (Dc <= NIDX) x3_modes_loop<true, NIDX, false>(a, sidx, spre, scr, idxf, H, h0, lane, Dc);
+	else if (Dc <= NIDX) x3_modes_loop<true, NIDX, false>(a, sidx, spre, scr, idxf, H, h0, lane, Dc, resumed ? st[4] : 0u, resumed ? st : nullptr, st);
 	else x3_modes_loop<false, NIDX, false>(a, sidx, spre, scr, idxf, H, h0, lane, Dc);
+	if (st) { x3_wave_sync(); for (uint32_t i = lane; i < nl; i += X3_WAVE) st[8 + i] = sidx[i]; }
+	else if (a.state && lane == 0) a.state[(size_t)c * X3_MODES_STATE_STRIDE + 4] = 0; /* nothing to resume from */
 }
 
 /* ============================================================================================================
@@ -1199,6 +1214,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		if (const char *e = getenv("X3H_MODES")) fixed = e[0] == 'f';
 		if (streamk) fixed = false; /* many streams: the serial kernel, which then also hands out the model state of every coded symbol */
 		B.last.mode_iters = 0;
+		if (seg && (fixed || streamk)) seg->prev_serial = false; /* (the saved chain state, if any, is stale after a call that did not use the serial kernel) */
 		if (fixed) {
 			int iters = 0;
 			CHK(modes_fixed_point(B, st, nH, nc, d_ho, bits_for(maxDk), f0, t0, f1, t1, h_rank, h_dk, h_step, mode, T, 256, &iters, &done));
@@ -1210,6 +1226,27 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 			ma.f0 = f0; ma.t0 = t0; ma.f1 = f1; ma.t1 = t1; ma.rank = h_rank; ma.dk = h_dk; ma.step = h_step;
 			ma.idxfreq = idxf; ma.mode = mode;
 			ma.pe0 = ma.pe1 = ma.ilist_rank = ma.ilist_hit = ma.evfinal = nullptr;
+			ma.state = nullptr; ma.resume = 0;
+			if (seg) {
+				/* growing prefixes: the serial chain continues where the previous call stopped.  The hit arrays are laid out by the CURRENT
+				 * per-stream counts, so the modes decided earlier are moved to their new places first. */
+				CHK(seg->modes_state.reserve((size_t)nc * X3_MODES_STATE_STRIDE * 4));
+				ma.state = seg->modes_state.as<uint32_t>();
+				if (seg->prev_ho.size() == nc + 1 && seg->prev_serial) {
+					const size_t nprev = seg->prev_ho[nc];
+					if (nprev) {
+						CHK(seg->mode_prev.reserve((nprev + 4) * 4 + (size_t)(nc + 1) * 4));
+						uint32_t *old = seg->mode_prev.as<uint32_t>(), *d_pho = old + nprev + 2;
+						HIPCHK(hipMemcpyAsync(old, mode, nprev * 4, hipMemcpyDeviceToDevice, st));
+						HIPCHK(hipMemcpyAsync(d_pho, seg->prev_ho.data(), (nc + 1) * 4, hipMemcpyHostToDevice, st));
+						x3_foreach(nprev, st, X3_LAMBDA(size_t i) { const uint32_t c = find_chunk(d_pho, nc, (uint32_t)i); mode[d_ho[c] + ((uint32_t)i - d_pho[c])] = old[i]; });
+					}
+					ma.resume = 1;
+				} else {
+					HIPCHK(hipMemsetAsync(ma.state, 0, (size_t)nc * X3_MODES_STATE_STRIDE * 4, st));
+				}
+				seg->prev_ho = ho; seg->prev_serial = true;
+			}
 			if (streamk) { ma.pe0 = T[26]; ma.pe1 = T[27]; ma.ilist_rank = T[2]; ma.ilist_hit = T[3]; ma.evfinal = m_evfinal; }
 			launch_modes(ma, nc, st, maxDict);
 			/* model_index1 as the IDX1-coded hits saw it (x3.c:187-188): one wavefront per stream, the table and its running sums in LDS */

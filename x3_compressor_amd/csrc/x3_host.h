@@ -117,6 +117,9 @@ struct X3CodeSeg {
 	uint64_t ring_top = 0;            /* bump pointer of the operand / state rings, in symbols                                     */
 	std::vector<X3CodeSegCall> calls; /* what every call put where                                                                 */
 	DevBuf meta;                      /* device copy of (off, len, before) of every call                                           */
+	DevBuf modes_state, mode_prev;    /* serial mode kernel: saved chain state per stream; the previous call's modes while they are re-laid out */
+	std::vector<uint32_t> prev_ho;    /* hit offsets of the previous call (its layout of the per-hit arrays)                      */
+	bool prev_serial = false;         /* the previous call ran the serial mode kernel (its saved state is valid)                  */
 	size_t res_steps = 0, res_hits = 0, res_elems = 0, res_mbytes = 0, res_bytes = 0; /* sizing estimates for the whole batch: nothing is reallocated while other streams run */
 };
 
