@@ -297,20 +297,20 @@ def main():
                                       "best": max(sweep, key=lambda e: e["value"])["value"]}
 
         if args.many_chunks_mib > 0:
-            # aggregate figure: many independent streams in ONE batch, 256 KiB chunks of FRESH content (half text, a quarter Zipf bytes, a
-            # quarter 16-bit image-like samples -- nothing repeated)
+            # aggregate figure: many independent streams in ONE batch, 256 KiB chunks of FRESH content (half English-like text, half Zipf(s=1)
+            # bytes -- nothing repeated)
             mtot, mcb = args.many_chunks_mib << 20, 256 << 10
-            q = mtot // 4
-            mdata = np.concatenate([synth.english_like(2 * q, seed=0xBA7C4), synth.zipf_bytes(q, offset=1 << 33), synth.mr_like(q, seed=0xBA7)])
+            q = mtot // 2
+            mdata = np.concatenate([synth.english_like(q, seed=0xBA7C4), synth.zipf_bytes(mtot - q, offset=1 << 33)])
             d_min = torch.from_numpy(mdata).to(dev)
             mdt, mlens, mst, moff, d_mout, mstride = chunk_batch(ctx, d_min, mtot, mcb, prm, dev)
             line["many_chunks_batch"] = {
-                "chunks": len(moff) - 1, "chunk_bytes": mcb, "total_bytes": mtot, "content": "fresh: 1/2 English-like text, 1/4 Zipf(s=1) bytes, 1/4 mr-like 16-bit samples",
+                "chunks": len(moff) - 1, "chunk_bytes": mcb, "total_bytes": mtot, "content": "fresh: 1/2 English-like text, 1/2 Zipf(s=1) bytes",
                 "value": round(mtot / mdt / 1e6, 2), "unit": "MB/s", "ms": round(mdt * 1e3, 2), "ratio": round(mtot / float(mlens.sum()), 4),
                 "stage_ms": {"scan": round(mst.ms_scan, 2), "parse": round(mst.ms_parse, 2), "features": round(mst.ms_features, 2),
                              "modes": round(mst.ms_modes, 2), "coder": round(mst.ms_coder, 2), "emit": round(mst.ms_emit, 2)}}
-            tdt, tlens, tst, _, d_tout, _ = chunk_batch(ctx, d_min[:2 * q], 2 * q, mcb, prm, dev)  # the text half alone (round 1 measured tiled text)
-            line["many_chunks_batch"]["text_only"] = {"total_bytes": 2 * q, "value": round(2 * q / tdt / 1e6, 2), "unit": "MB/s", "ratio": round(2 * q / float(tlens.sum()), 4)}
+            tdt, tlens, tst, _, d_tout, _ = chunk_batch(ctx, d_min[:q], q, mcb, prm, dev)  # the text half alone (round 1 measured tiled text)
+            line["many_chunks_batch"]["text_only"] = {"total_bytes": q, "value": round(q / tdt / 1e6, 2), "unit": "MB/s", "ratio": round(q / float(tlens.sum()), 4)}
             tpath = os.path.join(ROOT, "profiles", "r02_many_chunks_pmc_traffic.json")
             if os.path.exists(tpath):
                 t = json.load(open(tpath))
@@ -319,6 +319,15 @@ def main():
                                                                 "avg_TBps_over_kernel_time": t["total"]["avg_TBps"], "frac_of_hbm_peak": round(t["total"]["avg_TBps"] * 1e12 / HBM_PEAK, 3),
                                                                 "source": "profiles/r02_many_chunks_pmc_traffic.json (separate rocprofv3 --pmc passes of tools/many_chunks_check.py on the same batch)"}
             del d_min, d_mout, d_tout
+            # data with DENSE classes (sparse 16-bit samples: thousands of repeats of a gram inside every window): K1 refines such classes byte
+            # by byte instead of sweeping them (scan2.hip) -- bounded, but the scan dominates
+            ddata = synth.mr_like(64 << 20, seed=0xBA7)
+            d_din = torch.from_numpy(ddata).to(dev)
+            ddt, dlens, dst_, _, d_dout, _ = chunk_batch(ctx, d_din, ddata.size, mcb, prm, dev, reps=1)
+            line["many_chunks_dense_classes"] = {"content": "mr-like 16-bit samples (zero background, sparse noise)", "total_bytes": int(ddata.size), "chunks": ddata.size // mcb,
+                                                 "value": round(ddata.size / ddt / 1e6, 2), "unit": "MB/s", "ratio": round(ddata.size / float(dlens.sum()), 4),
+                                                 "stage_ms": {"scan": round(dst_.ms_scan, 2), "parse": round(dst_.ms_parse, 2), "code": round(dst_.ms_code, 2)}}
+            del d_din, d_dout
 
         # one GPU's share of config 4 (16 chunks x 8 MiB of the Zipf stream): what every rank does at N > 1, without the gather
         zdata = synth.zipf_bytes(16 * CHUNK4)

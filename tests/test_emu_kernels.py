@@ -219,3 +219,27 @@ def test_emulated_pipelined_resumed_mode_chain(emu_env, oracle):
     assert ctx.last_stats.pipelined == 1 and ctx.last_stats.dict_elems < 48 * 5
     for p, got in zip(parts, streams):
         assert got == oracle.compress(p, oracle_lib.params(**kw))
+
+
+def _dense_cases():
+    rng = np.random.default_rng(3)
+    sparse = np.zeros(3000, np.uint8)
+    sparse[rng.integers(0, 3000, 250)] = rng.integers(1, 4, 250)
+    return [
+        ("zipf_endzeros", synth.zipf_bytes(1500).tobytes() + bytes(40), dict(w_kib=1, t=3)),
+        ("zeros_t2", bytes(700), dict(w_kib=1, t=2)),
+        ("sparse", sparse.tobytes(), dict(w_kib=1, t=4)),
+        ("mr", synth.mr_like(4000).tobytes(), dict(w_kib=2, t=6)),
+        ("text_then_zeros", synth.english_like(1200).tobytes() + bytes(300), dict(w_kib=1, t=3)),
+        ("zero_then_text", bytes(200) + synth.english_like(1200).tobytes() + b"\0", dict(w_kib=1, t=3)),
+        ("periodic", b"\0\0\0\1" * 600, dict(w_kib=1, t=5)),
+    ]
+
+
+@pytest.mark.parametrize("name,data,kw", _dense_cases(), ids=[c[0] for c in _dense_cases()])
+def test_emulated_scan_dense_classes_and_padding(emu, oracle, name, data, kw):
+    """K1 with DENSE classes (this build: more than 6 members of a class inside a window): byte-by-byte refinement instead of the sweep,
+    padding positions counted analytically once they are dropped from the lists -- m[] and the stream against the oracle"""
+    prm, oprm = _lib.make_params(**kw), oracle_lib.params(**kw)
+    assert np.array_equal(emu.scan_m(data, prm), oracle.scan_m(data, oprm))
+    assert emu.compress(data, prm) == oracle.compress(data, oprm)

@@ -429,3 +429,40 @@ def test_coder_chain_states_equal_oracle_intervals(gpu, oracle, n, maxtot, seed)
     assert np.array_equal(states[1:, 0], lo[8 * g - 1])
     assert np.array_equal(states[1:, 1].astype(np.int64), hi[8 * g - 1].astype(np.int64) - lo[8 * g - 1].astype(np.int64) + 1)
     assert fin == int(lo[-1])
+
+
+# ---- K1 on data with dense classes (more than 2048 members of a class inside a window) and zero runs at the chunk end ----------------------------
+def test_scan_dense_classes_equal_brute_force_kernel(gpu, monkeypatch):
+    """zero runs, sparse 16-bit samples, periodic data, Zipf bytes ending in zeros: the refinement path of scan2.hip (instead of the
+    per-position sweep) and the analytic count of padding members, against the brute-force window sweep of scan.hip; batch of chunks too"""
+    monkeypatch.setenv("X3H_SCAN_V1", "1")
+    brute = _lib.X3Context(0)
+    monkeypatch.delenv("X3H_SCAN_V1")
+    rng = np.random.default_rng(33)
+    sparse = np.zeros(200_000, np.uint8)
+    sparse[rng.integers(0, 200_000, 9000)] = rng.integers(1, 4, 9000)
+    cases = [
+        (synth.mr_like(300_000).tobytes(), dict(w_kib=64, t=256)),
+        (sparse.tobytes(), dict(w_kib=64, t=256)),
+        (bytes(150_000), dict(w_kib=64, t=256)),
+        (synth.zipf_bytes(200_000).tobytes() + bytes(5000), dict(w_kib=64, t=256)),
+        (synth.english_like(100_000).tobytes() + bytes(70_000) + b"tail", dict(w_kib=32, t=100)),
+        ((b"\0\0\0\1" * 60_000), dict(w_kib=16, t=40)),
+        (synth.mr_like(400_000, seed=3).tobytes(), dict(w_kib=256, t=1024)),
+    ]
+    try:
+        for data, kw in cases:
+            prm = _lib.make_params(**kw)
+            a, b = gpu.scan_m(data, prm), brute.scan_m(data, prm)
+            assert np.array_equal(a, b), f"{kw}: first diff at {first_diff(a, b)}"
+    finally:
+        brute.close()
+    # as chunks of one batch (every chunk has its own padding), against chunk-by-chunk coding
+    parts = [c[0][:60_000] for c in cases[:5]]
+    data = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    off = np.cumsum([0] + [len(p) for p in parts]).astype(np.uint64)
+    prm = _lib.make_params(w_kib=64, t=256)
+    streams = gpu.compress_chunks(data, off, prm)
+    for i, p in enumerate(parts):
+        assert streams[i] == gpu.compress(p, prm), f"chunk {i}"
+        assert gpu.decompress(streams[i], len(p)) == p

@@ -1,5 +1,5 @@
 """Aggregate throughput of one batch of many independent chunks (device-resident in/out).
-usage: many_chunks_check.py [total_MiB] [chunk_KiB] [text|mix]   (mix = bench.py's fresh batch: 1/2 text, 1/4 Zipf bytes, 1/4 mr-like samples)"""
+usage: many_chunks_check.py [total_MiB] [chunk_KiB] [text|mix|mr]   (mix = bench.py's fresh batch: 1/2 text, 1/2 Zipf bytes; mr = mr-like samples)"""
 import sys, time
 sys.path.insert(0, '.')
 import numpy as np, torch
@@ -7,8 +7,10 @@ from x3_compressor_amd import _lib, synth
 total = (int(sys.argv[1]) if len(sys.argv) > 1 else 256) << 20
 cb = (int(sys.argv[2]) if len(sys.argv) > 2 else 256) << 10
 if len(sys.argv) > 3 and sys.argv[3] == "mix":
-    q = total // 4
-    data = np.concatenate([synth.english_like(2 * q, seed=0xBA7C4), synth.zipf_bytes(q, offset=1 << 33), synth.mr_like(q, seed=0xBA7)])
+    q = total // 2
+    data = np.concatenate([synth.english_like(q, seed=0xBA7C4), synth.zipf_bytes(total - q, offset=1 << 33)])
+elif len(sys.argv) > 3 and sys.argv[3] == "mr":
+    data = synth.mr_like(total, seed=0xBA7)
 else:
     base = synth.english_like(8 << 20)
     data = np.tile(base, total // base.size)        # chunks are independent streams, so repeated content costs the same as fresh content

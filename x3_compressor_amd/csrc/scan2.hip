@@ -48,6 +48,10 @@ struct X3WalkArgs {
 	const uint32_t *cls;         /* ... and the class of every entry (list 4: its 4-gram; refined lists: a class id) */
 	uint32_t back;
 	uint32_t kwords;             /* whole 4-byte words the members of a class are known to share (class gram length / 4) */
+	const uint32_t *padbits;     /* one bit per position: inside a chunk's zero padding */
+	uint32_t pad_dropped;        /* the list holds no padding positions: those inside the window are counted, not met */
+	const uint32_t *dataend;     /* per 256-byte block of the layout: first padding position of the chunk it lies in */
+	uint32_t npos;
 	const uint32_t *active_j;    /* index of each active position in the list */
 	const uint32_t *active;      /* positions to walk */
 	const uint32_t *active_k;    /* their K */
@@ -78,13 +82,22 @@ __device__ static void x3_walk_body(const X3WalkArgs &a)
 	uint32_t cnt[28]; /* count_4 .. count_31 (wave-uniform) */
 #pragma unroll
 	for (int i = 0; i < 28; i++) cnt[i] = 0;
-	uint32_t done = 0;
+	uint32_t done = 0, npad = 0;
 	for (uint32_t base = myj + 1; base < a.total && !done; base += X3_WAVE) {
 		const uint32_t j = base + lane;
 		uint32_t s = j < a.total ? a.S4[j] - a.back : NONE32; /* an end position < back wraps to a huge value: fails the window test like any out-of-class entry */
 		uint32_t lcp = 0;
 		bool inwin = false;
 		if (s != NONE32 && s <= wend && a.cls[j] == g) { inwin = true; lcp = 4 * a.kwords; } /* same class: the class's gram in common */
+		/* A candidate inside the chunk's zero padding: every later in-window member of the class is padding too (positions ascend, the padding
+		 * is the slot's tail), and each of them shares exactly p's leading zero run with p.  They are not swept but counted (below). */
+		const bool padc = inwin && ((a.padbits[s >> 5] >> (s & 31)) & 1u);
+		const uint64_t padm = x3_ballot(padc);
+		if (padm) {
+			const uint32_t fp = x3_readlane_u32(s, (uint32_t)x3_ctz64(padm)); /* the first padding position of the class inside the window */
+			npad = (uint32_t)(wend - fp + 1);
+			if (padc) inwin = false; /* ends the walk like any out-of-window entry */
+		}
 		/* extend word by word while some lane still matches everything so far (typical common prefixes are short: one or two rounds
 		 * instead of seven unconditional gram loads per candidate) */
 		for (uint32_t k = a.kwords; k < 8; k++) {
@@ -109,6 +122,15 @@ __device__ static void x3_walk_body(const X3WalkArgs &a)
 			cnt[i] += (uint32_t)x3_popc64(mk);
 		}
 		if (cnt[27] >= K) done = 1; /* count_31 >= K: nothing can be longer */
+	}
+	if (a.pad_dropped && wend < a.npos && ((a.padbits[wend >> 5] >> (wend & 31)) & 1u)) { /* the window reaches the padding */
+		npad = (uint32_t)(wend - a.dataend[p >> 8] + 1);
+	}
+	if (npad) { /* the padding members: common prefix with p = p's run of zero bytes (<= 32) */
+		uint32_t zr = 32;
+		for (int k = 7; k >= 0; k--) { const uint32_t wd = look[wv][k]; if (wd) zr = 4u * (uint32_t)k + ((uint32_t)x3_ctz32(wd) >> 3); }
+#pragma unroll
+		for (int i = 0; i < 28; i++) if ((uint32_t)i + 4 < zr) cnt[i] += npad;
 	}
 	uint32_t m = 3; /* count_3 >= K is what made the position active */
 #pragma unroll
@@ -180,7 +202,18 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 		}
 		padbits[w] = bits;
 	});
-	const uint32_t dense_at = X3_WALK_DENSE;
+	/* ... and, per 256-byte block of the layout (a block lies inside ONE chunk's slot: slots are 256-byte aligned), where that chunk's
+	 * data ends = its first padding position */
+	CHK(B.a[21].reserve(((size_t)P / 256 + 2) * 4));
+	uint32_t *dataend = B.a[21].as<uint32_t>();
+	x3_foreach(P / 256 + 1, st, X3_LAMBDA(size_t b) {
+		const uint64_t p0 = (uint64_t)b * 256;
+		uint32_t lo = 0, hi = nc;
+		while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (d_chunks[mid].byte_off <= p0) lo = mid; else hi = mid; }
+		dataend[b] = (uint32_t)(d_chunks[lo].byte_off + d_chunks[lo].len);
+	});
+	uint32_t dense_at = X3_WALK_DENSE;
+	if (const char *e = getenv("X3H_WALK_DENSE")) { const int v = atoi(e); if (v >= 2) dense_at = (uint32_t)v; } /* tuning / tests */
 	if (window > (1u << 24)) return X3H_E_ARG; /* K is kept in 24 bits */
 	/* K = min(T+1, count_0) and count_0 <= ncand: any T >= ncand behaves like T = ncand */
 	const uint32_t Tu = (uint32_t)T > ncand ? ncand : (uint32_t)T, Pn = (uint32_t)P;
@@ -243,7 +276,7 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 						if ((padbits[p >> 5] >> (p & 31)) & 1u) return;
 						/* more than X3_WALK_DENSE members of the class inside the window: no sweep, the class is refined instead (below) */
 						const uint64_t ud = (uint64_t)j + dense_at;
-						if (ud < Pn && ksc[ud] == ksc[j] && (uint64_t)Sc[ud] <= (uint64_t)q + ncand) { *d_dense = 1u; return; }
+						if (ud < Pn && ksc[ud] == ksc[j] && (uint64_t)Sc[ud] <= (uint64_t)q + ncand && !((padbits[(Sc[ud] - 3u) >> 5] >> ((Sc[ud] - 3u) & 31)) & 1u)) { *d_dense = 1u; return; }
 						const uint32_t slot = atomicAdd(d_nact, 1u);
 						act[slot] = p; act_k[slot] = K; act_j[slot] = (uint32_t)j;
 					}
@@ -263,7 +296,7 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 	HIPCHK(hipStreamSynchronize(st));
 	X3WalkArgs wa;
 	wa.bytes = d_bytes; wa.S4 = S; wa.cls = ks4; wa.back = 3; wa.kwords = 1; wa.active_j = act_j; wa.active = act; wa.active_k = act_k; wa.nactive = d_nact; wa.m = d_m;
-	wa.total = Pn; wa.ncand = ncand;
+	wa.total = Pn; wa.ncand = ncand; wa.padbits = padbits; wa.pad_dropped = 0; wa.dataend = dataend; wa.npos = Pn;
 	launch_walk(wa, hcnt[0], st);
 	HIPCHK(hipGetLastError());
 	if (!hcnt[1]) return X3H_OK;
@@ -283,6 +316,7 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 	size_t n = P;
 	for (uint32_t len = 4; len <= X3_MAXLEN && n > 0; len++) {
 		const uint32_t nn = (uint32_t)n, stamp = len;
+		const bool pad_dropped = len > 4; /* list 4 still holds the padding positions; the first compaction drops them and they are counted analytically from then on */
 		HIPCHK(hipMemsetAsync(d_nact, 0, 8, st));
 		/* the level test (gram length len): K-th next member of my class inside my window?  Then: finished by a sweep, or still dense */
 		x3_foreach(n, st, X3_LAMBDA(size_t j) {
@@ -291,11 +325,24 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 			uint32_t K = Tu + 1;
 			if ((rare[p >> 5] >> (p & 31)) & 1u) { K = kexact[p]; if (K < 2) return; }
 			const uint32_t cj = Lc[j];
-			const uint64_t u = (uint64_t)j + K;
-			if (!(u < nn && Lc[u] == cj && (uint64_t)Lp[u] <= (uint64_t)p + ncand)) return;
+			/* padding members of the class are not in these lists: if p's window reaches its chunk's padding and p's gram is all zeros, every
+			 * padding position inside the window is an occurrence */
+			const uint64_t wend = (uint64_t)p + ncand;
+			uint32_t cpad = 0;
+			if (pad_dropped && wend < Pn && ((padbits[wend >> 5] >> (wend & 31)) & 1u)) {
+				uint32_t nz = 0;
+				for (uint32_t k = 0; k < len; k += 4) nz |= load_gram(d_bytes, (uint64_t)p + k, len - k >= 4 ? 4 : len - k);
+				if (!nz) cpad = (uint32_t)(wend - dataend[p >> 8] + 1);
+			}
+			if (cpad < K) {
+				const uint64_t u = (uint64_t)j + (K - cpad);
+				if (!(u < nn && Lc[u] == cj && (uint64_t)Lp[u] <= wend)) return;
+			}
 			if (len > 4) d_m[p] = (uint8_t)(len - 1); /* (level 3 was stored by the pass above) */
+			/* a class that was dense at length 4 is refined to the end: sweeping its members later (deep common prefixes, hundreds of
+			 * candidates each) measured several times slower than carrying them through the remaining levels */
 			const uint64_t ud = (uint64_t)j + dense_at;
-			const bool dense = ud < nn && Lc[ud] == cj && (uint64_t)Lp[ud] <= (uint64_t)p + ncand;
+			const bool dense = len > 4 || (ud < nn && Lc[ud] == cj && (uint64_t)Lp[ud] <= wend && !((padbits[Lp[ud] >> 5] >> (Lp[ud] & 31)) & 1u));
 			if (dense && len < X3_MAXLEN) { keep[cj] = stamp; *d_dense = 1u; } /* (every writer stores the same value) */
 			else if (len > 4 && len < X3_MAXLEN) { /* (at length 4 the pass above queued the others already) */
 				const uint32_t slot = atomicAdd(d_nact, 1u);
@@ -305,13 +352,13 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 		HIPCHK(hipMemcpyAsync(hcnt, d_nact, 8, hipMemcpyDeviceToHost, st));
 		HIPCHK(hipStreamSynchronize(st));
 		if (len > 4 && hcnt[0]) {
-			wa.S4 = Lp; wa.cls = Lc; wa.back = 0; wa.kwords = len / 4; wa.total = nn;
+			wa.S4 = Lp; wa.cls = Lc; wa.back = 0; wa.kwords = len / 4; wa.total = nn; wa.pad_dropped = pad_dropped ? 1u : 0u;
 			launch_walk(wa, hcnt[0], st);
 			HIPCHK(hipGetLastError());
 		}
 		if (!hcnt[1] || len == X3_MAXLEN) break;
 		/* keep the classes that are still dense somewhere; number them 0, 1, 2, ... in list order */
-		x3_foreach(n, st, X3_LAMBDA(size_t j) { flg[j] = (keep[Lc[j]] == stamp && Lp[j] < Pn) ? 1u : 0u; });
+		x3_foreach(n, st, X3_LAMBDA(size_t j) { const uint32_t p = Lp[j]; flg[j] = (keep[Lc[j]] == stamp && p < Pn && !((padbits[p >> 5] >> (p & 31)) & 1u)) ? 1u : 0u; });
 		CHK(x3p_excl_scan(tmp, flg, scn, n, st));
 		x3_foreach(n, st, X3_LAMBDA(size_t j) { if (flg[j]) { const uint32_t d = scn[j]; Np[d] = Lp[j]; Nc[d] = Lc[j]; } });
 		uint32_t nlive = 0;
