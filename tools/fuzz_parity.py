@@ -15,7 +15,7 @@ ZIPF = synth.zipf_bytes(1 << 20, offset=seed & 0xFFFF).tobytes()
 
 
 def gen(n):
-    kind = int(rng.integers(0, 6))
+    kind = int(rng.integers(0, 8))
     if n == 0: return b""
     o = int(rng.integers(0, (1 << 20) - n)) if n < (1 << 20) else 0
     if kind == 0: return TEXT[o:o + n]
@@ -23,7 +23,9 @@ def gen(n):
     if kind == 2: return bytes(rng.integers(0, 256, n, dtype=np.uint8))
     if kind == 3: return bytes(rng.integers(0, int(rng.integers(1, 5)), n, dtype=np.uint8))          # tiny alphabet, zero bytes included
     if kind == 4: p = bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8)); return (p * (n // len(p) + 1))[:n]   # periodic
-    return TEXT[o:o + n // 2] + bytes(n - n // 2)                                                      # text then a run of zeros
+    if kind == 5: return TEXT[o:o + n // 2] + bytes(n - n // 2)                                         # text then a run of zeros
+    if kind == 6: return synth.mr_like(n, seed=int(rng.integers(0, 1 << 30))).tobytes()                  # sparse 16-bit samples: dense classes
+    a = np.zeros(n, np.uint8); k = max(1, n // 12); a[rng.integers(0, n, k)] = rng.integers(1, 4, k); return a.tobytes()   # zeros with sparse noise
 
 
 ctxs = {}
@@ -39,11 +41,13 @@ def ctx_for(env):
     return ctxs[key]
 
 
-ENVS = [dict(), dict(X3H_PIPE_MIN="1"), dict(X3H_PIPE_MIN="1", X3H_MODES="fixed"), dict(X3H_PIPE_MIN="0", X3H_MODES="serial"), dict(X3H_PIPE_MIN="0", X3H_MODES="fixed")]
+ENVS = [dict(), dict(X3H_PIPE_MIN="1"), dict(X3H_PIPE_MIN="1", X3H_MODES="fixed"), dict(X3H_PIPE_MIN="0", X3H_MODES="serial"), dict(X3H_PIPE_MIN="0", X3H_MODES="fixed"),
+        dict(X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0"), dict(X3H_STREAM_KERNELS="0"), dict(X3H_WALK_DENSE="16"), dict(X3H_WALK_DENSE="40", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0"),
+        dict(X3H_PIPE_MIN="1", X3H_MODES="serial"), dict(X3H_CTX_SUB="3")]
 t0, cases = time.time(), 0
 while time.time() - t0 < budget:
-    nch = int(rng.choice([1, 1, 1, 2, 3, 7, 40, 300]))   # 300: above the switch to the small-LDS kernel variants
-    sizes = [int(rng.integers(0, 3000)) for _ in range(nch)] if nch > 100 else [int(rng.choice([0, 1, 2, 31, 32, 33, 200, 2047, 2048, 2049, 5000, 20000, 70000])) if rng.random() < 0.5 else int(rng.integers(0, 30000)) for _ in range(nch)]
+    nch = int(rng.choice([1, 1, 1, 2, 3, 7, 40, 60, 130, 300]))   # >= 48: the per-stream kernels of code3.hip; 300: above the switch to the small-LDS kernel variants
+    sizes = [int(rng.integers(0, 3000)) for _ in range(nch)] if nch > 100 else [int(rng.integers(0, 9000)) for _ in range(nch)] if nch > 45 else [int(rng.choice([0, 1, 2, 31, 32, 33, 200, 2047, 2048, 2049, 5000, 20000, 70000])) if rng.random() < 0.5 else int(rng.integers(0, 30000)) for _ in range(nch)]
     w = int(rng.choice([0, 1, 1, 2, 4, 8, 8, 16, 64]))
     kw = dict(w_kib=w, t=int(rng.choice([0, 1, 2, 3, 8, 15, 16, 64, 256, 5000])), m=int(rng.choice([0, 1, 4, 4, 4, 9])),
               n=int(rng.choice([0, 0, 0, 1, 2, 5])), x=int(rng.random() < 0.15))

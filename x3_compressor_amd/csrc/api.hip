@@ -45,7 +45,7 @@ struct x3h_ctx {
 	uint32_t ckpt_cap = 0;
 	X3CodeSeg seg;
 	DevBuf coder_state, prefix_result, srcoff, ckpt_pos;
-	uint64_t batch_bytes = (uint64_t)1 << 30;
+	uint64_t batch_bytes = (uint64_t)512 << 20; /* X3H_BATCH_BYTES: input bytes of one sub-batch (the workspace is ~350 B per input byte) */
 	uint64_t dec_batch_bytes = (uint64_t)512 << 20; /* X3H_DEC_BATCH_BYTES */
 	uint64_t batch_pad_bytes = (uint64_t)2 << 30; /* X3H_BATCH_PAD_BYTES: padded layout of one sub-batch (K1 needs < 2^32 - 256) */
 	uint64_t pad_total = 0;
@@ -544,7 +544,7 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 }
 
 /* Workspace is ~150 bytes per input byte (+ ~32 per PADDED byte in K1), so very large batches are coded as consecutive sub-batches:
- * at most `batch_bytes` input bytes (X3H_BATCH_BYTES, default 1 GiB ~ 160 GB of HBM) and at most `batch_pad_bytes` bytes of padded
+ * at most `batch_bytes` input bytes (X3H_BATCH_BYTES, default 512 MiB ~ 190 GB of HBM) and at most `batch_pad_bytes` bytes of padded
  * layout (every chunk occupies len + W + X3_PAD_EXTRA there, so many small chunks under a large window are bounded by THIS: K1 indexes
  * the padded layout with 32 bits).  Chunks of a sub-batch still run concurrently, streams are independent, so the output is
  * identical to the unsplit run.  A sub-batch that does not fit its output capacity does not stop the others: every out_lens entry is
