@@ -436,8 +436,11 @@ typedef uint32_t x3_u32x4 __attribute__((ext_vector_type(4)));
 		const uint32_t cz = (uint32_t)__builtin_clz(D), x = NLO ^ NHI, t = 31u - cz;                                            \
 		uint32_t sh;                                                                                                            \
 		asm("s_bitcmp0_b32 %1, %2\n\ts_subb_u32 %0, %3, 1" : "=s"(sh) : "s"(x), "s"(t), "s"(cz) : "scc");                      \
-		lo = NLO << sh;                                                                                                         \
-		R = sf << sh;                                                                                                           \
+		/* both shifts in ONE s_lshl_b64 of the pair {sf (low word), NLO (high word)}: sf << sh stays below 2^32 (it is the renormalised   \
+		 * range), so nothing crosses into the high word, whose own top bits fall off as in a 32-bit shift */                         \
+		const uint64_t pr_ = (((uint64_t)NLO << 32) | sf) << sh;                                                                \
+		lo = (uint32_t)(pr_ >> 32);                                                                                             \
+		R = (uint32_t)pr_;                                                                                                      \
 	}
 #define X3_AC2_STATE(OFF)                                                                                                       \
 	{                                                                                                                           \
