@@ -466,3 +466,22 @@ def test_scan_dense_classes_equal_brute_force_kernel(gpu, monkeypatch):
     for i, p in enumerate(parts):
         assert streams[i] == gpu.compress(p, prm), f"chunk {i}"
         assert gpu.decompress(streams[i], len(p)) == p
+
+
+def test_many_streams_with_one_oversized_dictionary(gpu, oracle):
+    """50 streams, one of which has more dictionary elements (> 8192) than the LDS tables of the per-stream kernels hold: the whole batch
+    takes the chip-wide passes instead (x3_code_v2_run derives the token prefix sums itself in that case) -- same bytes as stream by stream"""
+    rng = np.random.default_rng(91)
+    words = rng.integers(0, 256, (9000, 5), dtype=np.uint8)
+    big = np.repeat(words, 4, axis=0).reshape(-1).tobytes()          # every 5-byte word four times in a row: ~9000 elements at -w 1 -t 1
+    parts = [synth.english_like(2000 + 37 * i, seed=500 + i).tobytes() for i in range(49)] + [big]
+    data = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    off = np.cumsum([0] + [len(p) for p in parts]).astype(np.uint64)
+    kw = dict(w_kib=1, t=1)
+    prm = _lib.make_params(**kw)
+    streams = gpu.compress_chunks(data, off, prm)
+    assert gpu.last_stats.dict_elems > 8192
+    for i in (0, 17, 48, 49):
+        assert streams[i] == gpu.compress(parts[i], prm), f"stream {i}"
+    assert streams[3] == oracle.compress(parts[3], oracle_lib.params(**kw))
+    assert gpu.decompress(streams[49], len(big)) == big
