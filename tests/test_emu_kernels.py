@@ -243,3 +243,33 @@ def test_emulated_scan_dense_classes_and_padding(emu, oracle, name, data, kw):
     prm, oprm = _lib.make_params(**kw), oracle_lib.params(**kw)
     assert np.array_equal(emu.scan_m(data, prm), oracle.scan_m(data, oprm))
     assert emu.compress(data, prm) == oracle.compress(data, oprm)
+
+
+# ---- per-stream kernels of code3.hip (tokens, move-to-front ranks, context statistics, mode state, order-0 models, bit emission) -----------
+@pytest.mark.parametrize("name,data,kw", CASES + PIPE_CASES[2:4], ids=[c[0] for c in CASES] + ["english9k", "zipf4k"])
+def test_emulated_stream_kernels_forced(emu_env, oracle, name, data, kw):
+    """X3H_STREAM_KERNELS=1: the per-stream LDS kernels on single streams (they are the default only for batches of >= 48 streams)"""
+    ctx = emu_env(X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0")
+    assert ctx.compress(data, _lib.make_params(**kw)) == oracle.compress(data, oracle_lib.params(**kw))
+
+
+def test_emulated_stream_kernels_batch_of_52(emu_env, oracle):
+    """a ragged batch of 52 streams takes the many-stream schedule by default: token walk kernel, side-stream move-to-front ranks, context
+    kernel with several wavefronts per stream (cut at context boundaries), emit kernel with carried pending bits"""
+    rng = np.random.default_rng(5)
+    parts = []
+    for i in range(52):
+        n, kind = int(rng.integers(0, 500)), i % 5
+        if kind == 0: parts.append(synth.english_like(n + 200, seed=i).tobytes())
+        elif kind == 1: parts.append(synth.zipf_bytes(n, offset=100 * i).tobytes())
+        elif kind == 2: parts.append(bytes(n))
+        elif kind == 3: parts.append(rng.integers(0, 256, n, dtype=np.uint8).tobytes())
+        else: parts.append((b"abcab" * 200)[:n])
+    parts[7], parts[20] = b"", b"x"
+    kw = dict(w_kib=1, t=3)
+    data = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    off = np.cumsum([0] + [len(p) for p in parts]).astype(np.uint64)
+    for env in (dict(), dict(X3H_CTX_SUB="3"), dict(X3H_STREAM_KERNELS="0")):
+        streams = emu_env(**env).compress_chunks(data, off, _lib.make_params(**kw))
+        for i, (p, got) in enumerate(zip(parts, streams)):
+            assert got == oracle.compress(p, oracle_lib.params(**kw)), f"{env}: stream {i}"
