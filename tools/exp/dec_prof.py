@@ -6,7 +6,10 @@ from x3_compressor_amd import _lib, synth
 ctx = _lib.X3Context(0, library=sys.argv[1] if len(sys.argv) > 1 else None)
 for name, data, kw in (("text 1 MB -w64 -t256", synth.english_like(1_000_000).tobytes(), dict(w_kib=64, t=256)),
                        ("mr 1 MB -w512 -t4096", synth.mr_like(1_000_000).tobytes(), dict(w_kib=512, t=4096)),
-                       ("zipf 1 MB -w64 -t256", synth.zipf_bytes(1_000_000).tobytes(), dict(w_kib=64, t=256))):
+                       ("zipf 1 MB -w64 -t256", synth.zipf_bytes(1_000_000).tobytes(), dict(w_kib=64, t=256)),
+                       ("text 4 MB -w512 -t4096", synth.english_like(4_000_000).tobytes(), dict(w_kib=512, t=4096)),
+                       ("mr 4 MB -w512 -t4096", synth.mr_like(4_000_000).tobytes(), dict(w_kib=512, t=4096)),
+                       ("text 256 KiB -w64 -t256", synth.english_like(262144).tobytes(), dict(w_kib=64, t=256))):
     os.environ.pop("X3H_DEBUG", None)
     stream = ctx.compress(data, _lib.make_params(**kw))
     steps = ctx.last_stats.steps

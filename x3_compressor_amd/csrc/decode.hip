@@ -85,7 +85,7 @@ __device__ static __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t l
 __device__ static __forceinline__ bool dec_below(uint32_t off, uint32_t step, uint32_t incl) { return (uint64_t)off < (uint64_t)incl * step; }
 
 /* find the symbol of a frequency array (global memory, `count` entries) that holds `value`; returns 0xFFFFFFFF if none */
-__device__ static uint32_t find_in_array(const uint32_t *freq, uint32_t count, uint32_t off, uint32_t step, uint32_t lane, uint32_t &cum_out, uint32_t &fq_out)
+__device__ static __forceinline__ uint32_t find_in_array(const uint32_t *freq, uint32_t count, uint32_t off, uint32_t step, uint32_t lane, uint32_t &cum_out, uint32_t &fq_out)
 {
 	uint32_t carry = 0;
 	for (uint32_t base = 0; base < count; base += X3_WAVE) {
@@ -108,6 +108,17 @@ __device__ static uint32_t find_in_array(const uint32_t *freq, uint32_t count, u
 __device__ static uint32_t find_in_ctx(const X3CtxHdr h, const uint64_t *pool, uint32_t off, uint32_t step, uint32_t lane, uint64_t first, uint32_t &cum_out, uint32_t &fq_out, uint32_t &tag_out)
 {
 	uint32_t carry = 0;
+	if (h.items <= X3_WAVE) { /* the usual case as straight-line code: no load, so nothing here makes the wave wait for loads that are in flight */
+		const uint32_t fq = (uint32_t)first; /* lanes beyond the list hold 0 */
+		const uint32_t incl = wave_incl_scan(fq, lane);
+		const uint64_t mask = x3_ballot(lane < h.items && dec_below(off, step, incl));
+		if (!mask) return 0xFFFFFFFFu;
+		const uint32_t l = (uint32_t)x3_ctz64(mask);
+		fq_out = x3_readlane_u32(fq, l);
+		cum_out = x3_readlane_u32(incl, l) - fq_out;
+		tag_out = x3_readlane_u32((uint32_t)(first >> 32), l);
+		return l;
+	}
 	for (uint32_t base = 0; base < h.items; base += X3_WAVE) {
 		const uint32_t i = base + lane;
 		const uint64_t it = base == 0 ? first : (i < h.items ? pool[(uint64_t)h.off + i] : 0); /* items [0, 64) were prefetched with the header */
@@ -131,6 +142,11 @@ __device__ static CtxQ ctx_find_tag(const X3CtxHdr h, const uint64_t *pool, uint
 {
 	CtxQ q;
 	q.found = 0; q.pos = 0; q.freq = 0; q.cum = 0;
+	if (h.items <= X3_WAVE) { /* straight-line, no load (see find_in_ctx) */
+		const uint64_t mask = x3_ballot(lane < h.items && (uint32_t)(first >> 32) == tag);
+		if (mask) { q.found = 1; q.pos = (uint32_t)x3_ctz64(mask); }
+		return q;
+	}
 	for (uint32_t base = 0; base < h.items; base += X3_WAVE) {
 		const uint32_t i = base + lane;
 		const uint64_t it = base == 0 ? first : (i < h.items ? pool[(uint64_t)h.off + i] : 0);
@@ -143,7 +159,7 @@ __device__ static CtxQ ctx_find_tag(const X3CtxHdr h, const uint64_t *pool, uint
 /* ctx_touch (x3_tables.h) for the decoder: the lanes already hold items [0, 64) of the list (`first`), so bumping a frequency is a
  * plain store from the lane that holds the item -- no read-modify-write round trip on the chain.  pord != nullptr: a context1 list,
  * whose new item also records the ordinal of the pair (context1, tag) it stands for. */
-__device__ static void dec_ctx_touch(X3CtxHdr *hp, X3CtxHdr h, const CtxQ q, uint32_t tag, uint64_t first, uint32_t ord, uint64_t *pool, uint32_t *pord,
+__device__ static void dec_ctx_touch(X3CtxHdr *hp, X3CtxHdr &h, const CtxQ q, uint32_t tag, uint64_t first, uint32_t ord, uint64_t *pool, uint32_t *pord,
                                      uint64_t &pool_top, uint64_t pool_cap, uint32_t &status, uint32_t lane)
 {
 	if (q.found) {
@@ -170,11 +186,44 @@ __device__ static void dec_ctx_touch(X3CtxHdr *hp, X3CtxHdr h, const CtxQ q, uin
 }
 
 #ifndef X3_DEC_LDS
-#define X3_DEC_LDS 16384u /* dictionary elements whose recency list + index-model frequencies live in LDS (2 x 64 KiB) */
+#define X3_DEC_LDS 8192u /* dictionary elements whose recency list, index-model frequencies and (position, length) live in LDS: 10 bytes each */
 #endif
 #ifndef X3_DEC_LDS_SMALL
-#define X3_DEC_LDS_SMALL 2048u /* ... in batches of many streams: 16 KiB of LDS per stream, so ten streams share a CU instead of one */
+#define X3_DEC_LDS_SMALL 1024u /* ... in batches of many streams: 10 KiB of LDS per stream, so sixteen streams share a CU (the batch rate is streams in flight x the per-stream rate) */
 #endif
+
+/* The move-to-front list (dict.c:132-146), typed by where it lives: uint16_t in LDS, uint32_t in global memory.  Separate instantiations
+ * on purpose: through one generic pointer every access is a FLAT instruction, and each of those waits for all outstanding global stores. */
+template <typename T>
+__device__ static __forceinline__ void dec_mtf_to_front(T *mtf, uint32_t r, uint32_t tag, uint32_t lane)
+{
+	if (r < X3_WAVE) { /* recent elements are the usual ones: one read and one write, straight-line */
+		const bool act = lane >= 1 && lane <= r;
+		const T v = act ? mtf[lane - 1] : (T)tag;
+		x3_wave_order(); /* every lane has read before any lane overwrites its neighbour's source */
+		if (lane <= r) mtf[lane] = v;
+		return;
+	}
+	for (int base = (int)(r & ~(uint32_t)(X3_WAVE - 1)); base >= 0; base -= X3_WAVE) {
+		const uint32_t j = (uint32_t)base + lane;
+		const bool act = j >= 1 && j <= r;
+		const T v = act ? mtf[j - 1] : (T)0;
+		x3_wave_order();
+		if (act) mtf[j] = v;
+	}
+	if (lane == 0) mtf[0] = (T)tag;
+}
+/* dict_get_index_by_tag (dict.c:174-183): rank of `tag`, 0xFFFFFFFF if it is not in the list */
+template <typename T>
+__device__ static __forceinline__ uint32_t dec_mtf_rank(const T *mtf, uint32_t D, uint32_t tag, uint32_t lane)
+{
+	for (uint32_t base = 0; base < D; base += X3_WAVE) {
+		const uint32_t i = base + lane;
+		const uint64_t mask = x3_ballot(i < D && (uint32_t)mtf[i] == tag);
+		if (mask) return base + (uint32_t)x3_ctz64(mask);
+	}
+	return 0xFFFFFFFFu;
+}
 
 #define DFNV_OFF 2166136261u
 #define DFNV_MUL 16777619u
@@ -192,8 +241,10 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 {
 	/* the two tables every step sweeps (move-to-front list, model_index1 frequencies) start in LDS and migrate to their global
 	 * arrays only if the stream's dictionary outgrows NLDS elements */
-	X3_LDS uint32_t s_mtf[NLDS];
+	X3_LDS uint16_t s_mtf[NLDS];
 	X3_LDS uint32_t s_idx[NLDS];
+	X3_LDS uint32_t s_el[NLDS]; /* element: position in the output << 5 | length - 1  (positions < 2^27 = X3H_MAX_CHUNK) */
+	static_assert(NLDS <= 65536, "tags in the LDS list are 16 bits wide");
 	const X3DecChunk ck = a.chunks[blockIdx.x];
 	const uint32_t lane = x3_lane();
 	uint8_t *out = a.out + ck.out_off;
@@ -202,7 +253,7 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 	uint32_t *ht = a.ht + ck.ht_off;
 	const uint32_t hlog = ck.ht_log2, hmask = (1u << hlog) - 1;
 	uint32_t *gmtf = a.mtf + ck.tag_off, *gidx = a.idxfreq + ck.tag_off;
-	uint32_t *mtf = s_mtf, *idxfreq = s_idx;
+	bool lds = true; /* wave-uniform */
 	X3CtxHdr *ctx1 = a.ctx1 + ck.tag_off, *ctx0 = a.ctx0 + ck.ctx0_off;
 	uint64_t *pool = a.items + ck.item_off;
 	uint32_t *pord = a.item_ord + ck.item_off;
@@ -214,8 +265,7 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 	d.lo = 0; d.hi = 0x7FFFFFFFu; d.buf = 0; /* ac_init */
 	d.buf = br_take(br, 31); /* ac_decode_init, ac.c:133-140 */
 
-	uint32_t ev[5] = { 1024, 1024, 1, 1, 1 }, evtotal = 2051; /* create(), x3.c:236-244 */
-	uint32_t nev[4] = { 0, 0, 0, 0 };
+	uint32_t evf = lane < 2 ? 1024u : lane < 5 ? 1u : 0u, evtotal = 2051; /* create(), x3.c:236-244: the frequency of event `lane` lives in that lane (an array indexed by the decision would live in scratch memory: a memory round trip per read on the chain) */
 	uint32_t lf = 1, lftotal = 32;
 	uint32_t cf0 = 1, cf1 = 1, cf2 = 1, cf3 = 1, cftotal = 256;
 	uint32_t D = 0, idxtotal = 0, npairs = 0, status = X3_ST_OK;
@@ -235,20 +285,24 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 		/* ---- the event (x3.c:293-295) ---- */
 		/* ac_decode_target + index_of_value (ac.c:128-131,167-179) without the second division:  (buf-lo)/step < c  <=>  buf-lo < c*step */
 		uint32_t step = (d.hi - d.lo + 1) / evtotal;
-		const uint32_t off_e = d.buf - d.lo;
-		uint32_t cum = 0, decision = 5;
-		for (uint32_t s = 0; s < 5; s++) {
-			if ((uint64_t)off_e < (uint64_t)(cum + ev[s]) * step) { decision = s; break; }
-			cum += ev[s];
+		uint32_t decision;
+		{
+			const uint32_t incl = x3_row8_incl_scan_u32(evf);
+			const uint64_t mask = x3_ballot(lane < 5 && dec_below(d.buf - d.lo, step, incl));
+			if (!mask) { status = X3_ST_CORRUPT; break; } /* the reference abort()s, ac.c:178 */
+			decision = (uint32_t)x3_ctz64(mask);
+			const uint32_t fq = x3_readlane_u32(evf, decision), cum = x3_readlane_u32(incl, decision) - fq;
+			if (!dec_narrow(d, br, step, cum, cum + fq)) { status = X3_ST_CORRUPT; break; }
+			if (lane == decision) evf++;
+			evtotal++;
 		}
-		if (decision == 5) { status = X3_ST_CORRUPT; break; } /* the reference abort()s, ac.c:178 */
-		if (!dec_narrow(d, br, step, cum, cum + ev[decision])) { status = X3_ST_CORRUPT; break; }
-		ev[decision]++; evtotal++;
 		if (decision == X3_E_EOF) break;
+#ifdef X3_DEC_TRACE
+		if (lane == 0) fprintf(stderr, "T %u %u D %u\n", p, decision, D);
+#endif
 
 		if (decision == X3_E_NEW) {
 			/* ---- decode_match, x3.c:272-283 ---- */
-			nev[3]++;
 			uint32_t len;
 			{
 				step = (d.hi - d.lo + 1) / lftotal;
@@ -287,7 +341,7 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 				h = (h ^ ch) * DFNV_MUL;
 			}
 			if (bad) { status = X3_ST_CORRUPT; break; }
-			x3_wave_sync(); /* the fragment is in memory for every lane */
+			x3_wave_order(); /* the fragment is in memory for every lane */
 			/* dict_query_elem (x3.c:309): exact lookup of (len, bytes) */
 			int dup = 0;
 			uint32_t slot = dht_slot(h, len, hlog);
@@ -299,22 +353,27 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 				while (k < len && ds[k] == out[p + k]) k++;
 				if (k == len) { dup = 1; break; }
 			}
-			x3_wave_sync();
+			x3_wave_order();
 			if (!dup) { /* x3.c:310-317 */
-				if (D == NLDS && mtf == s_mtf) { /* outgrew LDS: continue in global memory */
+				if (D == NLDS && lds) { /* outgrew LDS: continue in global memory (dpos/dlen are written there from the start) */
 					for (uint32_t i = lane; i < D; i += X3_WAVE) { gmtf[i] = s_mtf[i]; gidx[i] = s_idx[i]; }
-					x3_wave_sync();
-					mtf = gmtf; idxfreq = gidx;
+					x3_wave_order();
+					lds = false;
 				}
 				if (lane == 0) { dpos[D] = p; dlen[D] = (uint8_t)len; ht[slot] = D + 1; }
-				mtf_to_front(mtf, D, D, lane);
-				if (lane == 0) idxfreq[D] = 1;
+				if (lds) {
+					dec_mtf_to_front(s_mtf, D, D, lane);
+					if (lane == 0) { s_idx[D] = 1; s_el[D] = (p << 5) | (len - 1); }
+				} else {
+					dec_mtf_to_front(gmtf, D, D, lane);
+					if (lane == 0) gidx[D] = 1;
+				}
 				D++;
 				idxtotal++;
 			}
 			p += len;
 			ctx1tag = 0; /* x3.c:321-322: both contexts reset */
-			x3_wave_sync();
+			x3_wave_order();
 			/* the next hit step's contexts: pair (0, 0) if it is known, else context 0 (x3.c:142-145) */
 			n_c0id = have00 ? ord00 : 0u;
 			n_h0 = ctx0[n_c0id]; n_h1 = ctx1[0];
@@ -328,7 +387,6 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 		DPROF_T(t_b)
 		DPROF_ADD(pc_ev, t_a, t_b)
 		if (D == 0) { status = X3_ST_CORRUPT; break; }
-		nev[decision]++;
 		const uint32_t c0id = n_c0id;
 		X3CtxHdr *h0p = ctx0 + c0id, *h1p = ctx1 + ctx1tag;
 		const X3CtxHdr h0 = uni_hdr(n_h0), h1 = uni_hdr(n_h1); /* pinned here, not where the loads were issued: they stay in flight until now */
@@ -338,12 +396,11 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 		if (decision == X3_E_IDX1) {
 			step = (d.hi - d.lo + 1) / idxtotal;
 			uint32_t cl = 0, fq = 0;
-			rank = find_in_array(idxfreq, D, d.buf - d.lo, step, lane, cl, fq);
+			rank = lds ? find_in_array(s_idx, D, d.buf - d.lo, step, lane, cl, fq) : find_in_array(gidx, D, d.buf - d.lo, step, lane, cl, fq);
 			if (rank == 0xFFFFFFFFu) { status = X3_ST_CORRUPT; break; }
 			if (!dec_narrow(d, br, step, cl, cl + fq)) { status = X3_ST_CORRUPT; break; }
-			tag = x3_uniform(mtf[rank]);
-			x3_wave_sync();
-			if (lane == 0) idxfreq[rank] = fq + 1; /* inc_model(&model_index1, index), x3.c:89 */
+			if (lds) { tag = x3_uniform(s_mtf[rank]); x3_wave_order(); if (lane == 0) s_idx[rank] = fq + 1; } /* inc_model(&model_index1, index), x3.c:89 */
+			else { tag = x3_uniform(gmtf[rank]); x3_wave_order(); if (lane == 0) gidx[rank] = fq + 1; }
 			idxtotal++;
 		} else {
 			const X3CtxHdr hc = decision == X3_E_CTX0 ? h0 : h1;
@@ -355,21 +412,26 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 			cpos = pos;
 			if (!dec_narrow(d, br, step, cl, cl + fq)) { status = X3_ST_CORRUPT; break; }
 			/* dict_get_index_by_tag (x3.c:79,84) */
-			uint32_t found = 0;
-			for (uint32_t base = 0; base < D; base += X3_WAVE) {
-				const uint32_t i = base + lane;
-				const uint64_t mask = x3_ballot(i < D && mtf[i] == tag);
-				if (mask) { rank = base + (uint32_t)x3_ctz64(mask); found = 1; break; }
-			}
-			if (!found) { status = X3_ST_CORRUPT; break; }
+			rank = lds ? dec_mtf_rank(s_mtf, D, tag, lane) : dec_mtf_rank(gmtf, D, tag, lane);
+			if (rank == 0xFFFFFFFFu) { status = X3_ST_CORRUPT; break; }
 		}
 		DPROF_T(t_c)
 		DPROF_ADD(pc_sym, t_b, t_c)
+		/* the tag is known: everything the rest of the step and the next step will wait for is requested NOW, in the order it will be needed --
+		 * the element's bytes, then the header of the next context1 list (the tag just decoded; its list is only touched by this step when the
+		 * tag follows itself, and then the updated header below is the one to use) */
+		uint32_t len, src;
+		if (lds) { const uint32_t e = x3_uniform(s_el[tag]); len = (e & 31u) + 1; src = e >> 5; }
+		else { len = x3_uniform(dlen[tag]); src = x3_uniform(dpos[tag]); }
+		if ((uint64_t)p + len > cap) { status = X3_ST_OUT_FULL; break; }
+		const uint8_t piece = lane < len ? out[src + lane] : (uint8_t)0; /* len <= 32; src + len <= p */
+		const bool self1 = tag == ctx1tag;
+		const X3CtxHdr e_h1 = ctx1[tag]; /* unconditional, into its own registers: nothing below needs it before the updates are done, so the load stays in flight */
 		/* x3.c:99-126: both contexts learn the tag, (context1, tag) becomes a known pair */
 		CtxQ q0, q1; /* the context the tag was decoded from already told its list position */
 		if (decision == X3_E_CTX0) { q0.found = 1; q0.pos = cpos; q0.freq = q0.cum = 0; } else q0 = ctx_find_tag(h0, pool, tag, lane, it0);
 		if (decision == X3_E_CTX1) { q1.found = 1; q1.pos = cpos; q1.freq = q1.cum = 0; } else q1 = ctx_find_tag(h1, pool, tag, lane, it1);
-		x3_wave_sync();
+		x3_wave_order();
 		/* the pair (context1, tag) is this step's item in the context1 list -- and the (prev, context1) pair of the NEXT step */
 		uint32_t ord;
 		if (q1.found) ord = q1.pos < X3_WAVE ? x3_readlane_u32(po1, q1.pos) : x3_uniform(pord[(uint64_t)h1.off + q1.pos]);
@@ -379,24 +441,29 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 			npairs++;
 		}
 		n_c0id = ord;
-		dec_ctx_touch(h0p, h0, q0, tag, it0, 0, pool, nullptr, pool_top, ck.item_cap, status, lane);
-		dec_ctx_touch(h1p, h1, q1, tag, it1, ord, pool, pord, pool_top, ck.item_cap, status, lane);
+		/* the next context0 list: a new pair's header is still all zero (the workspace is cleared per batch), and when the pair repeats itself
+		 * the list is this step's own, updated below */
+		const bool self0 = ord == c0id;
+		const X3CtxHdr e_h0 = ctx0[ord]; /* ord <= pairs so far <= output capacity: inside the table; all zero for a new pair */
+		X3CtxHdr u0 = h0, u1 = h1;
+		dec_ctx_touch(h0p, u0, q0, tag, it0, 0, pool, nullptr, pool_top, ck.item_cap, status, lane);
+		dec_ctx_touch(h1p, u1, q1, tag, it1, ord, pool, pord, pool_top, ck.item_cap, status, lane);
 		if (status != X3_ST_OK) break;
+		/* x3.c:332-348: the element moves to the front (LDS work, while the header loads above are in flight) */
+		if (lds) dec_mtf_to_front(s_mtf, rank, tag, lane); else dec_mtf_to_front(gmtf, rank, tag, lane);
+		x3_wave_order(); /* lane 0's new item / the bumped frequency is stored before the lane that holds that list position loads it below */
+		n_h1 = self1 ? u1 : e_h1;
+		n_h0 = self0 ? u0 : e_h0;
 		DPROF_T(t_d)
 		DPROF_ADD(pc_ctx, t_c, t_d)
-		/* x3.c:332-348: copy the element, move it to the front */
-		const uint32_t len = x3_uniform(dlen[tag]), src = x3_uniform(dpos[tag]);
-		if ((uint64_t)p + len > cap) { status = X3_ST_OUT_FULL; break; }
-		if (lane < len) out[p + lane] = out[src + lane]; /* len <= 32; src + len <= p */
-		mtf_to_front(mtf, rank, tag, lane);
-		ctx1tag = tag; /* x3.c:346-347 */
-		p += len;
-		x3_wave_sync();
-		/* the next step's contexts, in flight while its event symbol is decoded (this step's updates are already stored) */
-		n_h0 = ctx0[n_c0id]; n_h1 = ctx1[ctx1tag];
-		n_it0 = lane < n_h0.items ? pool[(uint64_t)n_h0.off + lane] : 0;
+		/* items [0, 64) of both lists: in flight while the element is copied and the next event symbol is decoded (this step's updates are already stored) */
 		n_it1 = lane < n_h1.items ? pool[(uint64_t)n_h1.off + lane] : 0;
 		n_po1 = lane < n_h1.items ? pord[(uint64_t)n_h1.off + lane] : 0;
+		n_it0 = lane < n_h0.items ? pool[(uint64_t)n_h0.off + lane] : 0;
+		if (lane < len) out[p + lane] = piece; /* x3.c:332-340: the element's bytes */
+		ctx1tag = tag; /* x3.c:346-347 */
+		p += len;
+		x3_wave_order();
 		DPROF_T(t_e)
 		DPROF_ADD(pc_tail, t_d, t_e)
 	}
@@ -404,13 +471,13 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 	if (lane == 0) {
 		X3CodeResult r;
 		r.out_len = p; r.status = status; r.pairs = npairs; r._r = D;
-		for (int i = 0; i < 4; i++) r.events[i] = nev[i];
-		r.events[4] = r.events[5] = r.events[6] = r.events[7] = 0;
+		for (int i = 0; i < 8; i++) r.events[i] = 0;
 #ifdef X3_DEC_PROFILE
 		r.events[4] = (uint32_t)(pc_ev >> 10); r.events[5] = (uint32_t)(pc_sym >> 10); r.events[6] = (uint32_t)(pc_ctx >> 10); r.events[7] = (uint32_t)(pc_tail >> 10);
 #endif
 		a.result[blockIdx.x] = r;
 	}
+	if (lane < 4) a.result[blockIdx.x].events[lane] = evf - (lane < 2 ? 1024u : 1u); /* events decoded = what the model counted */
 }
 
 #ifndef X3_EMU

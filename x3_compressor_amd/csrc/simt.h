@@ -50,9 +50,22 @@ __device__ __forceinline__ uint32_t x3_wave_incl_scan_u32(uint32_t v)
 	return (uint32_t)x;
 }
 __device__ __forceinline__ uint32_t x3_wave_sum_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)x3_wave_incl_scan_u32(v), 63); }
+/* inclusive prefix sum that is only valid in lanes 0..7 (three row shifts): models with a handful of symbols */
+__device__ __forceinline__ uint32_t x3_row8_incl_scan_u32(uint32_t v)
+{
+	int x = (int)v;
+	x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false); /* row_shr:1 */
+	x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false); /* row_shr:2 */
+	x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false); /* row_shr:4 */
+	return (uint32_t)x;
+}
 /* Orders this wave's earlier LDS/global accesses before its later ones when different lanes touch the same
  * address (the compiler only tracks per-lane dependencies). */
 __device__ __forceinline__ void x3_wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+/* The same ordering for a kernel whose work-group is ONE wave, as a compiler barrier only: the memory instructions of a wave are issued in
+ * program order and performed in that order per address, so no s_waitcnt is needed -- while the fence above makes the compiler wait for
+ * every outstanding load AND store (vmcnt(0)), i.e. a full memory round trip, wherever it stands. */
+__device__ __forceinline__ void x3_wave_order() { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
 __device__ __forceinline__ uint64_t x3_clock() { return (uint64_t)clock64(); } /* s_memtime: shader cycles */
 __device__ __forceinline__ int x3_popc64(uint64_t v) { return __popcll(v); }
 __device__ __forceinline__ int x3_ctz64(uint64_t v) { return __ffsll((long long)v) - 1; }           /* v != 0 */
@@ -101,8 +114,10 @@ static inline uint32_t x3_wave_incl_scan_u32(uint32_t v)
 	for (int d = 1; d < X3_WAVE; d <<= 1) { const uint32_t u = x3emu_shfl(v, l >= d ? l - d : l); if (l >= d) v += u; }
 	return v;
 }
+static inline uint32_t x3_row8_incl_scan_u32(uint32_t v) { return x3_wave_incl_scan_u32(v); }
 static inline uint32_t x3_wave_sum_u32(uint32_t v) { return x3emu_shfl(x3_wave_incl_scan_u32(v), X3_WAVE - 1); }
 static inline void x3_wave_sync() { (void)x3emu_ballot(0); }
+static inline void x3_wave_order() { (void)x3emu_ballot(0); }
 static inline uint64_t x3_clock() { return 0; }
 static inline int x3_popc64(uint64_t v) { return __builtin_popcountll(v); }
 static inline int x3_ctz64(uint64_t v) { return __builtin_ctzll(v); }
