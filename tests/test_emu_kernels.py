@@ -57,6 +57,36 @@ def test_emulated_decoder_reproduces_golden_inputs(emu, golden, name):
     assert emu.decompress(c["expect"], len(c["data"]) + 8) == c["data"]
 
 
+def test_emulated_decoder_random_streams(emu, oracle):
+    """decode.hip on the ORACLE's streams of random inputs / parameters, singly and as ragged batches: dictionaries beyond the (emulator-sized)
+    LDS tables, tags that follow themselves, pairs that repeat themselves, lists of more than 64 items, every capacity from exact to +8"""
+    rng = np.random.default_rng(20260)
+    text, zipf = synth.english_like(1 << 15, seed=3).tobytes(), synth.zipf_bytes(1 << 15, offset=77).tobytes()
+
+    def gen(n):
+        kind = int(rng.integers(0, 8))
+        if n == 0: return b""
+        o = int(rng.integers(0, (1 << 15) - n))
+        if kind == 0: return text[o:o + n]
+        if kind == 1: return zipf[o:o + n]
+        if kind == 2: return bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        if kind == 3: return bytes(rng.integers(0, int(rng.integers(1, 5)), n, dtype=np.uint8))
+        if kind == 4: q = bytes(rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8)); return (q * (n // len(q) + 1))[:n]
+        if kind == 5: return text[o:o + n // 2] + bytes(n - n // 2)
+        if kind == 6: return synth.mr_like(n, seed=int(rng.integers(0, 1 << 30))).tobytes()
+        a = np.zeros(n, np.uint8); k = max(1, n // 12); a[rng.integers(0, n, k)] = rng.integers(1, 4, k); return a.tobytes()
+
+    for case in range(36):
+        nch = int(rng.choice([1, 1, 2, 5]))
+        sizes = [int(rng.choice([0, 1, 2, 33, 200, 700, 1500, 3000, 5000])) for _ in range(nch)]
+        kw = dict(w_kib=int(rng.choice([1, 1, 2, 4])), t=int(rng.choice([0, 1, 2, 3, 8, 16, 64])), m=int(rng.choice([0, 1, 4, 4, 9])),
+                  n=int(rng.choice([0, 0, 1, 2])), x=int(rng.random() < 0.15))
+        parts = [gen(n) for n in sizes]
+        streams = [oracle.compress(q, oracle_lib.params(**kw)) for q in parts]
+        back = emu.decompress_chunks(streams, [n + int(rng.integers(0, 9)) for n in sizes]) if nch > 1 else [emu.decompress(streams[0], sizes[0] + 3)]
+        assert back == parts, f"case {case}: sizes {sizes} params {kw}"
+
+
 def test_emulated_decoder_errors(emu, golden):
     with pytest.raises(_lib.X3Error) as e:
         emu.decompress(golden["zeros5000"]["expect"], 100)   # ratio > 64:1 -- the reference overruns its buffer here (x3.c:621)

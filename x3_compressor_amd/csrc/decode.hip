@@ -20,12 +20,21 @@
  */
 #include "x3_tables.h"
 
-#ifdef X3_DEC_PROFILE /* experiment builds: cycles per section of the hit path, reported in the unused event slots */
+#ifdef X3_DEC_PROFILE /* experiment builds: cycles per section of the hit path, reported in the unused event slots (2: the context section in four parts instead) */
 #define DPROF_T(var) const uint64_t var = x3_clock();
 #define DPROF_ADD(acc, a, b) acc += (b) - (a);
 #else
 #define DPROF_T(var)
 #define DPROF_ADD(acc, a, b)
+#endif
+#if defined(X3_DEC_PROFILE) && X3_DEC_PROFILE == 2
+#define DPROF2_T(var) const uint64_t var = x3_clock();
+#define DPROF2_ADD(acc, a, b) acc += (b) - (a);
+#define DPROF1_ADD(acc, a, b)
+#else
+#define DPROF2_T(var)
+#define DPROF2_ADD(acc, a, b)
+#define DPROF1_ADD(acc, a, b) DPROF_ADD(acc, a, b)
 #endif
 
 /* The chain's state is wave-uniform, but every value that comes out of a (vector) load looks divergent to the compiler: pinning the
@@ -40,17 +49,32 @@ static inline uint32_t dec_brev32(uint32_t v) { uint32_t r = 0; for (int i = 0; 
 #endif
 
 struct BitReader { /* bio.c:5-42: bit k of the stream = bit k mod 32 (LSB first) of the little-endian word k / 32 */
-	const uint8_t *p, *end;
-	uint64_t w;   /* unread bits, next one at bit 0 */
-	uint32_t nb;  /* how many */
+	const uint32_t *base; /* the stream's words; whole words only, like the reference's reader (bio.c:35-39) */
+	uint32_t nwords, wi;  /* ... how many, and the index of the next one to take */
+	uint32_t cur, nxt;    /* lane l: word (block * 64 + l) of the block being consumed and of the one after it -- the stream is read 256 bytes at a
+	                       * time, one block ahead, so taking the next word is a v_readlane and no load ever sits on the chain */
+	uint64_t w;           /* unread bits, next one at bit 0 */
+	uint32_t nb;          /* how many */
 };
+
+__device__ static __forceinline__ uint32_t br_block(const BitReader &r, uint32_t blk)
+{
+	const uint32_t i = blk * X3_WAVE + x3_lane();
+	return i < r.nwords ? r.base[i] : 0x80000000u; /* bio.c:10,35-39: past the last whole word the reader feeds 0x80000000 */
+}
+__device__ static __forceinline__ void br_open(BitReader &r, const uint8_t *in, uint32_t len)
+{
+	r.base = (const uint32_t *)in; r.nwords = len >> 2; r.wi = 0; r.w = 0; r.nb = 0; /* bio_open(READ), bio.c:14-15 */
+	r.cur = br_block(r, 0); r.nxt = br_block(r, 1);
+}
 
 /* the next n (0..31) bits of the stream, first one most significant -- what n calls of get_bit shifted into mBuffer would leave */
 __device__ static __forceinline__ uint32_t br_take(BitReader &r, uint32_t n)
 {
-	if (r.nb < n) { /* one more word (bio.c:10,35-39: past the last whole word the reader feeds 0x80000000) */
-		uint32_t nx = 0x80000000u;
-		if (r.end - r.p >= 4) { nx = x3_uniform((uint32_t)r.p[0] | (uint32_t)r.p[1] << 8 | (uint32_t)r.p[2] << 16 | (uint32_t)r.p[3] << 24); r.p += 4; }
+	if (r.nb < n) { /* one more word */
+		const uint32_t nx = x3_readlane_u32(r.cur, r.wi & (X3_WAVE - 1));
+		r.wi++;
+		if ((r.wi & (X3_WAVE - 1)) == 0) { r.cur = r.nxt; r.nxt = br_block(r, (r.wi >> 6) + 1); }
 		r.w |= (uint64_t)nx << r.nb;
 		r.nb += 32;
 	}
@@ -62,6 +86,23 @@ __device__ static __forceinline__ uint32_t br_take(BitReader &r, uint32_t n)
 }
 
 struct Dec { uint32_t lo, hi, buf; };
+
+/* range / total (ac.c:128-131) on the chain: a double-precision reciprocal and one fix-up step instead of the ~28-instruction integer
+ * expansion of a 32-bit division (n <= 2^31, 0 < t < 2^28: the quotient estimate is off by at most one, and q * t cannot overflow) */
+__device__ static __forceinline__ uint32_t dec_div(uint32_t n, uint32_t t)
+{
+#ifndef X3_EMU
+	const double td = (double)t;
+	double r = __builtin_amdgcn_rcp(td);       /* v_rcp_f64: an approximation ... */
+	r = __builtin_fma(r, __builtin_fma(-td, r, 1.0), r); /* ... one Newton step makes it good to ~2^-50 whatever its accuracy class */
+	uint32_t q = (uint32_t)((double)n * r);
+	const int32_t rem = (int32_t)(n - q * t);
+	q += rem < 0 ? 0xFFFFFFFFu : (uint32_t)rem >= t ? 1u : 0u;
+	return x3_uniform(q);
+#else
+	return n / t;
+#endif
+}
 
 /* ac_decode_symbol's interval update + ac_decode_scale (ac.c:192-195,142-165) in closed form, like the encoder's chain (code2.hip):
  * all E1/E2/E3 shifts together are  s = clz(D) - 1 - carry  with D = hi - lo after narrowing; lo and the range scale by 2^s, and since
@@ -157,13 +198,14 @@ __device__ static CtxQ ctx_find_tag(const X3CtxHdr h, const uint64_t *pool, uint
 }
 
 /* ctx_touch (x3_tables.h) for the decoder: the lanes already hold items [0, 64) of the list (`first`), so bumping a frequency is a
- * plain store from the lane that holds the item -- no read-modify-write round trip on the chain.  pord != nullptr: a context1 list,
- * whose new item also records the ordinal of the pair (context1, tag) it stands for. */
-__device__ static void dec_ctx_touch(X3CtxHdr *hp, X3CtxHdr &h, const CtxQ q, uint32_t tag, uint64_t first, uint32_t ord, uint64_t *pool, uint32_t *pord,
-                                     uint64_t &pool_top, uint64_t pool_cap, uint32_t &status, uint32_t lane)
+ * plain store from the lane that holds the item -- no read-modify-write round trip on the chain.  `first` (and `po`, the pair ordinals
+ * of a context1 list: with_ord) come back as the list reads AFTER the update, so a list that is also the next step's context needs no
+ * reload; the caller stores the updated header `h` wherever headers of that kind live. */
+__device__ static __forceinline__ void dec_ctx_touch(X3CtxHdr &h, const CtxQ q, uint32_t tag, uint64_t &first, uint32_t &po, bool with_ord, uint32_t ord,
+                                                     uint64_t *pool, uint32_t *pord, uint64_t &pool_top, uint64_t pool_cap, uint32_t &status, uint32_t lane)
 {
 	if (q.found) {
-		if (q.pos < X3_WAVE) { if (lane == q.pos) pool[(uint64_t)h.off + q.pos] = first + 1; }
+		if (q.pos < X3_WAVE) { if (lane == q.pos) { first += 1; pool[(uint64_t)h.off + q.pos] = first; } }
 		else if (lane == 0) pool[(uint64_t)h.off + q.pos] += 1;
 	} else {
 		if (h.items == h.cap) {
@@ -173,23 +215,26 @@ __device__ static void dec_ctx_touch(X3CtxHdr *hp, X3CtxHdr &h, const CtxQ q, ui
 			pool_top += ncap;
 			for (uint32_t i = lane; i < h.items; i += X3_WAVE) {
 				pool[(uint64_t)noff + i] = pool[(uint64_t)h.off + i];
-				if (pord) pord[(uint64_t)noff + i] = pord[(uint64_t)h.off + i];
+				if (with_ord) pord[(uint64_t)noff + i] = pord[(uint64_t)h.off + i];
 			}
 			h.off = noff;
 			h.cap = ncap;
 		}
-		if (lane == 0) { pool[(uint64_t)h.off + h.items] = ((uint64_t)tag << 32) | 1u; if (pord) pord[(uint64_t)h.off + h.items] = ord; }
+		const uint64_t it = ((uint64_t)tag << 32) | 1u;
+		if (lane == 0) { pool[(uint64_t)h.off + h.items] = it; if (with_ord) pord[(uint64_t)h.off + h.items] = ord; }
+		if (lane == h.items) { first = it; po = ord; } /* items < 64: the lane of the new list position */
 		h.items++;
 	}
 	h.total++;
-	if (lane == 0) *hp = h;
 }
+/* list capacities only ever double from 2 (above), so the LDS copy of a header does not store one */
+__device__ static __forceinline__ uint32_t dec_cap_of(uint32_t n) { return n == 0 ? 0u : n <= 2 ? 2u : 1u << (32 - x3_clz32(n - 1)); }
 
 #ifndef X3_DEC_LDS
-#define X3_DEC_LDS 8192u /* dictionary elements whose recency list, index-model frequencies and (position, length) live in LDS: 10 bytes each */
+#define X3_DEC_LDS 4096u /* dictionary elements whose tables live in LDS, 20 bytes each: recency list, index-model frequency, (position, length), header of the element's context1 list */
 #endif
 #ifndef X3_DEC_LDS_SMALL
-#define X3_DEC_LDS_SMALL 1024u /* ... in batches of many streams: 10 KiB of LDS per stream, so sixteen streams share a CU (the batch rate is streams in flight x the per-stream rate) */
+#define X3_DEC_LDS_SMALL 512u /* ... in batches of many streams: 10 KiB of LDS per stream, so sixteen streams share a CU (the batch rate is streams in flight x the per-stream rate) */
 #endif
 
 /* The move-to-front list (dict.c:132-146), typed by where it lives: uint16_t in LDS, uint32_t in global memory.  Separate instantiations
@@ -236,248 +281,315 @@ __device__ static __forceinline__ uint32_t dht_slot(uint32_t h, uint32_t len, ui
 	return x >> (32 - hlog);
 }
 
-template <uint32_t NLDS>
-__device__ static void x3_decode_body(const X3DecArgs &a)
+/* per-stream tables in global memory + constants (wave-uniform) */
+struct DecT {
+	uint8_t *out;
+	uint32_t *dpos; uint8_t *dlen; uint32_t *ht; uint32_t hlog, hmask;
+	uint32_t *gmtf, *gidx;
+	X3CtxHdr *ctx1, *ctx0;
+	uint64_t *pool; uint32_t *pord; uint64_t pool_cap;
+	uint32_t cap;
+};
+/* the chain's state, carried from the LDS-resident loop into the spilled one */
+struct DecS {
+	BitReader br; Dec d;
+	uint32_t evf, evtotal;            /* event model: the frequency of event `lane` lives in that lane (an array indexed by the decision would sit in scratch memory: a round trip per read on the chain) */
+	uint32_t lf, lftotal;             /* length model, one symbol per lane */
+	uint32_t cf0, cf1, cf2, cf3, cftotal; /* byte model, four symbols per lane */
+	uint32_t D, idxtotal, npairs, status;
+	uint64_t pool_top;
+	uint32_t ctx1tag, p;
+	/* the context state of the NEXT hit step, loaded ahead: ctx0 ordinal (0 when the pair is unknown, x3.c:142-145), both headers, items [0,64) of both lists, pair ordinals of the context1 items */
+	uint32_t n_c0id; X3CtxHdr n_h0, n_h1; uint64_t n_it0, n_it1; uint32_t n_po1;
+	uint32_t ord00, have00;           /* the pair (0, 0): what both contexts are after a new fragment (x3.c:321-322) */
+	uint64_t pc_ev, pc_sym, pc_ctx, pc_tail;
+};
+
+/* One instantiation per residence of the per-element tables: LDS = true while the dictionary has fewer than NLDS elements (recency
+ * list, index-model frequencies, element (position, length) and the headers of the context1 lists are LDS arrays: the only global
+ * round trip between decoding a tag and having the next step's context1 items is the item load itself), LDS = false after they
+ * migrated to global memory.  Returns true when the LDS tables are full (the caller migrates them and continues with the other loop). */
+template <uint32_t NLDS, bool LDS>
+__device__ static __forceinline__ bool dec_loop(const DecT &t, DecS &s, uint16_t *s_mtf, uint32_t *s_idx, uint32_t *s_el, uint32_t *s_c1off, uint32_t *s_c1tot, uint16_t *s_c1n, const uint32_t lane)
 {
-	/* the two tables every step sweeps (move-to-front list, model_index1 frequencies) start in LDS and migrate to their global
-	 * arrays only if the stream's dictionary outgrows NLDS elements */
-	X3_LDS uint16_t s_mtf[NLDS];
-	X3_LDS uint32_t s_idx[NLDS];
-	X3_LDS uint32_t s_el[NLDS]; /* element: position in the output << 5 | length - 1  (positions < 2^27 = X3H_MAX_CHUNK) */
-	static_assert(NLDS <= 65536, "tags in the LDS list are 16 bits wide");
-	const X3DecChunk ck = a.chunks[blockIdx.x];
-	const uint32_t lane = x3_lane();
-	uint8_t *out = a.out + ck.out_off;
-	uint32_t *dpos = a.dict_pos + ck.tag_off;
-	uint8_t *dlen = a.dict_len + ck.tag_off;
-	uint32_t *ht = a.ht + ck.ht_off;
-	const uint32_t hlog = ck.ht_log2, hmask = (1u << hlog) - 1;
-	uint32_t *gmtf = a.mtf + ck.tag_off, *gidx = a.idxfreq + ck.tag_off;
-	bool lds = true; /* wave-uniform */
-	X3CtxHdr *ctx1 = a.ctx1 + ck.tag_off, *ctx0 = a.ctx0 + ck.ctx0_off;
-	uint64_t *pool = a.items + ck.item_off;
-	uint32_t *pord = a.item_ord + ck.item_off;
-	const uint32_t cap = ck.out_cap;
-
-	BitReader br;
-	br.p = a.in + ck.in_off; br.end = br.p + ck.in_len; br.w = 0; br.nb = 0; /* bio_open(READ), bio.c:14-15 */
-	Dec d;
-	d.lo = 0; d.hi = 0x7FFFFFFFu; d.buf = 0; /* ac_init */
-	d.buf = br_take(br, 31); /* ac_decode_init, ac.c:133-140 */
-
-	uint32_t evf = lane < 2 ? 1024u : lane < 5 ? 1u : 0u, evtotal = 2051; /* create(), x3.c:236-244: the frequency of event `lane` lives in that lane (an array indexed by the decision would live in scratch memory: a memory round trip per read on the chain) */
-	uint32_t lf = 1, lftotal = 32;
-	uint32_t cf0 = 1, cf1 = 1, cf2 = 1, cf3 = 1, cftotal = 256;
-	uint32_t D = 0, idxtotal = 0, npairs = 0, status = X3_ST_OK;
-	uint64_t pool_top = 0;
-	uint64_t pc_ev = 0, pc_sym = 0, pc_rank = 0, pc_ctx = 0, pc_tail = 0; (void)pc_ev; (void)pc_sym; (void)pc_rank; (void)pc_ctx; (void)pc_tail;
-	uint32_t ctx1tag = 0; /* context1; the (prev, context1) pair of x3.c:139 is tracked as its ordinal n_c0id */
-	uint32_t p = 0;
-	/* the context state of the NEXT hit step, loaded ahead: ctx0 ordinal (0 when the pair is unknown, x3.c:142-145), both headers, items [0,64) of both lists */
-	uint32_t n_c0id = 0;
-	X3CtxHdr n_h0 = ctx0[0], n_h1 = ctx1[0]; /* both empty at the start (zeroed workspace) */
-	uint64_t n_it0 = 0, n_it1 = 0;
-	uint32_t n_po1 = 0;               /* ... and the pair ordinals of the context1 items */
-	uint32_t ord00 = 0, have00 = 0;   /* the pair (0, 0): what both contexts are after a new fragment (x3.c:321-322) */
-
+	uint8_t *const out = t.out;
+	uint64_t *const pool = t.pool;
+	uint32_t *const pord = t.pord;
+	BitReader &br = s.br;
+	Dec &d = s.d;
 	for (;;) {
+		if (LDS && s.D == NLDS) return true;
 		DPROF_T(t_a)
 		/* ---- the event (x3.c:293-295) ---- */
 		/* ac_decode_target + index_of_value (ac.c:128-131,167-179) without the second division:  (buf-lo)/step < c  <=>  buf-lo < c*step */
-		uint32_t step = (d.hi - d.lo + 1) / evtotal;
+		uint32_t step = dec_div(d.hi - d.lo + 1, s.evtotal);
 		uint32_t decision;
 		{
-			const uint32_t incl = x3_row8_incl_scan_u32(evf);
+			const uint32_t incl = x3_row8_incl_scan_u32(s.evf);
 			const uint64_t mask = x3_ballot(lane < 5 && dec_below(d.buf - d.lo, step, incl));
-			if (!mask) { status = X3_ST_CORRUPT; break; } /* the reference abort()s, ac.c:178 */
+			if (!mask) { s.status = X3_ST_CORRUPT; break; } /* the reference abort()s, ac.c:178 */
 			decision = (uint32_t)x3_ctz64(mask);
-			const uint32_t fq = x3_readlane_u32(evf, decision), cum = x3_readlane_u32(incl, decision) - fq;
-			if (!dec_narrow(d, br, step, cum, cum + fq)) { status = X3_ST_CORRUPT; break; }
-			if (lane == decision) evf++;
-			evtotal++;
+			const uint32_t fq = x3_readlane_u32(s.evf, decision), cum = x3_readlane_u32(incl, decision) - fq;
+			if (!dec_narrow(d, br, step, cum, cum + fq)) { s.status = X3_ST_CORRUPT; break; }
+			if (lane == decision) s.evf++;
+			s.evtotal++;
 		}
 		if (decision == X3_E_EOF) break;
-#ifdef X3_DEC_TRACE
-		if (lane == 0) fprintf(stderr, "T %u %u D %u\n", p, decision, D);
-#endif
 
 		if (decision == X3_E_NEW) {
 			/* ---- decode_match, x3.c:272-283 ---- */
 			uint32_t len;
 			{
-				step = (d.hi - d.lo + 1) / lftotal;
-				const uint32_t incl = wave_incl_scan(lane < 32 ? lf : 0u, lane);
+				step = dec_div(d.hi - d.lo + 1, s.lftotal);
+				const uint32_t incl = wave_incl_scan(lane < 32 ? s.lf : 0u, lane);
 				const uint64_t mask = x3_ballot(lane < 32 && dec_below(d.buf - d.lo, step, incl));
-				if (!mask) { status = X3_ST_CORRUPT; break; }
+				if (!mask) { s.status = X3_ST_CORRUPT; break; }
 				const uint32_t l = (uint32_t)x3_ctz64(mask);
-				const uint32_t fq = x3_readlane_u32(lf, l), cl = x3_readlane_u32(incl, l) - fq;
-				if (!dec_narrow(d, br, step, cl, cl + fq)) { status = X3_ST_CORRUPT; break; }
-				if (lane == l) lf++;
-				lftotal++;
+				const uint32_t fq = x3_readlane_u32(s.lf, l), cl = x3_readlane_u32(incl, l) - fq;
+				if (!dec_narrow(d, br, step, cl, cl + fq)) { s.status = X3_ST_CORRUPT; break; }
+				if (lane == l) s.lf++;
+				s.lftotal++;
 				len = l + 1;
 			}
-			if ((uint64_t)p + len > cap) { status = X3_ST_OUT_FULL; break; }
+			const uint32_t p = s.p;
+			if ((uint64_t)p + len > t.cap) { s.status = X3_ST_OUT_FULL; break; }
 			uint32_t h = DFNV_OFF;
 			int bad = 0;
 			for (uint32_t j = 0; j < len; j++) {
-				step = (d.hi - d.lo + 1) / cftotal;
+				step = dec_div(d.hi - d.lo + 1, s.cftotal);
 				const uint32_t offb = d.buf - d.lo;
-				const uint32_t s4 = cf0 + cf1 + cf2 + cf3;
+				const uint32_t s4 = s.cf0 + s.cf1 + s.cf2 + s.cf3;
 				const uint32_t incl = wave_incl_scan(s4, lane);
 				const uint64_t mask = x3_ballot(dec_below(offb, step, incl));
 				if (!mask) { bad = 1; break; }
 				const uint32_t l = (uint32_t)x3_ctz64(mask);
-				const uint32_t b0 = x3_readlane_u32(cf0, l), b1 = x3_readlane_u32(cf1, l), b2 = x3_readlane_u32(cf2, l), b3 = x3_readlane_u32(cf3, l);
+				const uint32_t b0 = x3_readlane_u32(s.cf0, l), b1 = x3_readlane_u32(s.cf1, l), b2 = x3_readlane_u32(s.cf2, l), b3 = x3_readlane_u32(s.cf3, l);
 				uint32_t cl = x3_readlane_u32(incl, l) - (b0 + b1 + b2 + b3), sub, fq;
 				if (dec_below(offb, step, cl + b0)) { sub = 0; fq = b0; }
 				else if (dec_below(offb, step, cl + b0 + b1)) { sub = 1; fq = b1; cl += b0; }
 				else if (dec_below(offb, step, cl + b0 + b1 + b2)) { sub = 2; fq = b2; cl += b0 + b1; }
 				else { sub = 3; fq = b3; cl += b0 + b1 + b2; }
 				if (!dec_narrow(d, br, step, cl, cl + fq)) { bad = 1; break; }
-				if (lane == l) { if (sub == 0) cf0++; else if (sub == 1) cf1++; else if (sub == 2) cf2++; else cf3++; }
-				cftotal++;
+				if (lane == l) { if (sub == 0) s.cf0++; else if (sub == 1) s.cf1++; else if (sub == 2) s.cf2++; else s.cf3++; }
+				s.cftotal++;
 				const uint32_t ch = 4 * l + sub;
 				if (lane == 0) out[p + j] = (uint8_t)ch;
 				h = (h ^ ch) * DFNV_MUL;
 			}
-			if (bad) { status = X3_ST_CORRUPT; break; }
+			if (bad) { s.status = X3_ST_CORRUPT; break; }
 			x3_wave_order(); /* the fragment is in memory for every lane */
 			/* dict_query_elem (x3.c:309): exact lookup of (len, bytes) */
 			int dup = 0;
-			uint32_t slot = dht_slot(h, len, hlog);
-			for (uint32_t e = ht[slot]; e != 0; slot = (slot + 1) & hmask, e = ht[slot]) {
+			uint32_t slot = dht_slot(h, len, t.hlog);
+			for (uint32_t e = t.ht[slot]; e != 0; slot = (slot + 1) & t.hmask, e = t.ht[slot]) {
 				const uint32_t tg = e - 1;
-				if (dlen[tg] != len) continue;
-				const uint8_t *ds = out + dpos[tg];
+				if (t.dlen[tg] != len) continue;
+				const uint8_t *ds = out + t.dpos[tg];
 				uint32_t k = 0;
 				while (k < len && ds[k] == out[p + k]) k++;
 				if (k == len) { dup = 1; break; }
 			}
 			x3_wave_order();
 			if (!dup) { /* x3.c:310-317 */
-				if (D == NLDS && lds) { /* outgrew LDS: continue in global memory (dpos/dlen are written there from the start) */
-					for (uint32_t i = lane; i < D; i += X3_WAVE) { gmtf[i] = s_mtf[i]; gidx[i] = s_idx[i]; }
-					x3_wave_order();
-					lds = false;
-				}
-				if (lane == 0) { dpos[D] = p; dlen[D] = (uint8_t)len; ht[slot] = D + 1; }
-				if (lds) {
+				const uint32_t D = s.D;
+				if (lane == 0) { t.dpos[D] = p; t.dlen[D] = (uint8_t)len; t.ht[slot] = D + 1; } /* the hash table reads these two, wherever the other tables live */
+				if (LDS) {
 					dec_mtf_to_front(s_mtf, D, D, lane);
-					if (lane == 0) { s_idx[D] = 1; s_el[D] = (p << 5) | (len - 1); }
+					if (lane == 0) { s_idx[D] = 1; s_el[D] = (p << 5) | (len - 1); s_c1off[D] = 0; s_c1tot[D] = 0; s_c1n[D] = 0; }
 				} else {
-					dec_mtf_to_front(gmtf, D, D, lane);
-					if (lane == 0) gidx[D] = 1;
+					dec_mtf_to_front(t.gmtf, D, D, lane);
+					if (lane == 0) t.gidx[D] = 1;
 				}
-				D++;
-				idxtotal++;
+				s.D++;
+				s.idxtotal++;
 			}
-			p += len;
-			ctx1tag = 0; /* x3.c:321-322: both contexts reset */
+			s.p = p + len;
+			s.ctx1tag = 0; /* x3.c:321-322: both contexts reset */
 			x3_wave_order();
 			/* the next hit step's contexts: pair (0, 0) if it is known, else context 0 (x3.c:142-145) */
-			n_c0id = have00 ? ord00 : 0u;
-			n_h0 = ctx0[n_c0id]; n_h1 = ctx1[0];
-			n_it0 = lane < n_h0.items ? pool[(uint64_t)n_h0.off + lane] : 0;
-			n_it1 = lane < n_h1.items ? pool[(uint64_t)n_h1.off + lane] : 0;
-			n_po1 = lane < n_h1.items ? pord[(uint64_t)n_h1.off + lane] : 0;
+			s.n_c0id = s.have00 ? s.ord00 : 0u;
+			s.n_h0 = t.ctx0[s.n_c0id];
+			if (LDS) { s.n_h1.off = x3_uniform(s_c1off[0]); s.n_h1.items = x3_uniform((uint32_t)s_c1n[0]); s.n_h1.total = x3_uniform(s_c1tot[0]); s.n_h1.cap = dec_cap_of(s.n_h1.items); }
+			else s.n_h1 = t.ctx1[0];
+			s.n_it0 = lane < s.n_h0.items ? pool[(uint64_t)s.n_h0.off + lane] : 0;
+			s.n_it1 = lane < s.n_h1.items ? pool[(uint64_t)s.n_h1.off + lane] : 0;
+			s.n_po1 = lane < s.n_h1.items ? pord[(uint64_t)s.n_h1.off + lane] : 0;
 			continue;
 		}
 
 		/* ---- decode_tag, x3.c:58-129 ---- */
 		DPROF_T(t_b)
-		DPROF_ADD(pc_ev, t_a, t_b)
-		if (D == 0) { status = X3_ST_CORRUPT; break; }
-		const uint32_t c0id = n_c0id;
-		X3CtxHdr *h0p = ctx0 + c0id, *h1p = ctx1 + ctx1tag;
-		const X3CtxHdr h0 = uni_hdr(n_h0), h1 = uni_hdr(n_h1); /* pinned here, not where the loads were issued: they stay in flight until now */
-		const uint64_t it0 = n_it0, it1 = n_it1;
-		const uint32_t po1 = n_po1;
+		DPROF1_ADD(s.pc_ev, t_a, t_b)
+		const uint32_t D = s.D;
+		if (D == 0) { s.status = X3_ST_CORRUPT; break; }
+		const uint32_t c0id = s.n_c0id, ctx1tag = s.ctx1tag;
+		const X3CtxHdr h0 = uni_hdr(s.n_h0), h1 = uni_hdr(s.n_h1); /* pinned here, not where the loads were issued: they stay in flight until now */
+		const uint64_t it0 = s.n_it0, it1 = s.n_it1;
+		const uint32_t po1 = s.n_po1;
 		uint32_t tag = 0, rank = 0, cpos = 0;
 		if (decision == X3_E_IDX1) {
-			step = (d.hi - d.lo + 1) / idxtotal;
+			step = dec_div(d.hi - d.lo + 1, s.idxtotal);
 			uint32_t cl = 0, fq = 0;
-			rank = lds ? find_in_array(s_idx, D, d.buf - d.lo, step, lane, cl, fq) : find_in_array(gidx, D, d.buf - d.lo, step, lane, cl, fq);
-			if (rank == 0xFFFFFFFFu) { status = X3_ST_CORRUPT; break; }
-			if (!dec_narrow(d, br, step, cl, cl + fq)) { status = X3_ST_CORRUPT; break; }
-			if (lds) { tag = x3_uniform(s_mtf[rank]); x3_wave_order(); if (lane == 0) s_idx[rank] = fq + 1; } /* inc_model(&model_index1, index), x3.c:89 */
-			else { tag = x3_uniform(gmtf[rank]); x3_wave_order(); if (lane == 0) gidx[rank] = fq + 1; }
-			idxtotal++;
+			rank = LDS ? find_in_array(s_idx, D, d.buf - d.lo, step, lane, cl, fq) : find_in_array(t.gidx, D, d.buf - d.lo, step, lane, cl, fq);
+			if (rank == 0xFFFFFFFFu) { s.status = X3_ST_CORRUPT; break; }
+			if (!dec_narrow(d, br, step, cl, cl + fq)) { s.status = X3_ST_CORRUPT; break; }
+			if (LDS) { tag = x3_uniform((uint32_t)s_mtf[rank]); x3_wave_order(); if (lane == 0) s_idx[rank] = fq + 1; } /* inc_model(&model_index1, index), x3.c:89 */
+			else { tag = x3_uniform(t.gmtf[rank]); x3_wave_order(); if (lane == 0) t.gidx[rank] = fq + 1; }
+			s.idxtotal++;
 		} else {
 			const X3CtxHdr hc = decision == X3_E_CTX0 ? h0 : h1;
-			if (hc.items == 0 || hc.total == 0) { status = X3_ST_CORRUPT; break; }
-			step = (d.hi - d.lo + 1) / hc.total;
+			if (hc.items == 0 || hc.total == 0) { s.status = X3_ST_CORRUPT; break; }
+			step = dec_div(d.hi - d.lo + 1, hc.total);
 			uint32_t cl = 0, fq = 0;
 			const uint32_t pos = find_in_ctx(hc, pool, d.buf - d.lo, step, lane, decision == X3_E_CTX0 ? it0 : it1, cl, fq, tag);
-			if (pos == 0xFFFFFFFFu) { status = X3_ST_CORRUPT; break; }
+			if (pos == 0xFFFFFFFFu) { s.status = X3_ST_CORRUPT; break; }
 			cpos = pos;
-			if (!dec_narrow(d, br, step, cl, cl + fq)) { status = X3_ST_CORRUPT; break; }
+			if (!dec_narrow(d, br, step, cl, cl + fq)) { s.status = X3_ST_CORRUPT; break; }
 			/* dict_get_index_by_tag (x3.c:79,84) */
-			rank = lds ? dec_mtf_rank(s_mtf, D, tag, lane) : dec_mtf_rank(gmtf, D, tag, lane);
-			if (rank == 0xFFFFFFFFu) { status = X3_ST_CORRUPT; break; }
+			rank = LDS ? dec_mtf_rank(s_mtf, D, tag, lane) : dec_mtf_rank(t.gmtf, D, tag, lane);
+			if (rank == 0xFFFFFFFFu) { s.status = X3_ST_CORRUPT; break; }
 		}
 		DPROF_T(t_c)
-		DPROF_ADD(pc_sym, t_b, t_c)
-		/* the tag is known: everything the rest of the step and the next step will wait for is requested NOW, in the order it will be needed --
-		 * the element's bytes, then the header of the next context1 list (the tag just decoded; its list is only touched by this step when the
-		 * tag follows itself, and then the updated header below is the one to use) */
+		DPROF1_ADD(s.pc_sym, t_b, t_c)
+		/* the tag is known: everything the rest of the step and the next step will wait for is requested NOW -- the element's bytes, and the
+		 * next context1 list (the one of the tag just decoded; this step only touches it when the tag follows itself, and then the registers
+		 * updated below are used instead of what is loaded here) */
 		uint32_t len, src;
-		if (lds) { const uint32_t e = x3_uniform(s_el[tag]); len = (e & 31u) + 1; src = e >> 5; }
-		else { len = x3_uniform(dlen[tag]); src = x3_uniform(dpos[tag]); }
-		if ((uint64_t)p + len > cap) { status = X3_ST_OUT_FULL; break; }
+		if (LDS) { const uint32_t e = x3_uniform(s_el[tag]); len = (e & 31u) + 1; src = e >> 5; }
+		else { len = x3_uniform(t.dlen[tag]); src = x3_uniform(t.dpos[tag]); }
+		const uint32_t p = s.p;
+		if ((uint64_t)p + len > t.cap) { s.status = X3_ST_OUT_FULL; break; }
 		const uint8_t piece = lane < len ? out[src + lane] : (uint8_t)0; /* len <= 32; src + len <= p */
 		const bool self1 = tag == ctx1tag;
-		const X3CtxHdr e_h1 = ctx1[tag]; /* unconditional, into its own registers: nothing below needs it before the updates are done, so the load stays in flight */
+		X3CtxHdr e_h1;
+		uint64_t e_it1 = 0;
+		uint32_t e_po1 = 0;
+		if (LDS) {
+			e_h1.off = x3_uniform(s_c1off[tag]); e_h1.items = x3_uniform((uint32_t)s_c1n[tag]); e_h1.total = x3_uniform(s_c1tot[tag]); e_h1.cap = dec_cap_of(e_h1.items);
+			e_it1 = lane < e_h1.items ? pool[(uint64_t)e_h1.off + lane] : 0;
+			e_po1 = lane < e_h1.items ? pord[(uint64_t)e_h1.off + lane] : 0;
+		} else e_h1 = t.ctx1[tag]; /* into its own registers: nothing below needs it before the updates are done, so the load stays in flight */
+		DPROF2_T(u_a)
+		DPROF2_ADD(s.pc_ev, t_c, u_a)
 		/* x3.c:99-126: both contexts learn the tag, (context1, tag) becomes a known pair */
 		CtxQ q0, q1; /* the context the tag was decoded from already told its list position */
 		if (decision == X3_E_CTX0) { q0.found = 1; q0.pos = cpos; q0.freq = q0.cum = 0; } else q0 = ctx_find_tag(h0, pool, tag, lane, it0);
 		if (decision == X3_E_CTX1) { q1.found = 1; q1.pos = cpos; q1.freq = q1.cum = 0; } else q1 = ctx_find_tag(h1, pool, tag, lane, it1);
-		x3_wave_order();
 		/* the pair (context1, tag) is this step's item in the context1 list -- and the (prev, context1) pair of the NEXT step */
 		uint32_t ord;
 		if (q1.found) ord = q1.pos < X3_WAVE ? x3_readlane_u32(po1, q1.pos) : x3_uniform(pord[(uint64_t)h1.off + q1.pos]);
 		else {
-			ord = npairs;
-			if (ctx1tag == 0 && tag == 0) { ord00 = npairs; have00 = 1; }
-			npairs++;
+			ord = s.npairs;
+			if (ctx1tag == 0 && tag == 0) { s.ord00 = s.npairs; s.have00 = 1; }
+			s.npairs++;
 		}
-		n_c0id = ord;
 		/* the next context0 list: a new pair's header is still all zero (the workspace is cleared per batch), and when the pair repeats itself
 		 * the list is this step's own, updated below */
 		const bool self0 = ord == c0id;
-		const X3CtxHdr e_h0 = ctx0[ord]; /* ord <= pairs so far <= output capacity: inside the table; all zero for a new pair */
+		const X3CtxHdr e_h0 = t.ctx0[ord]; /* ord <= pairs so far <= output capacity: inside the table */
+		DPROF2_T(u_b)
+		DPROF2_ADD(s.pc_sym, u_a, u_b)
 		X3CtxHdr u0 = h0, u1 = h1;
-		dec_ctx_touch(h0p, u0, q0, tag, it0, 0, pool, nullptr, pool_top, ck.item_cap, status, lane);
-		dec_ctx_touch(h1p, u1, q1, tag, it1, ord, pool, pord, pool_top, ck.item_cap, status, lane);
-		if (status != X3_ST_OK) break;
-		/* x3.c:332-348: the element moves to the front (LDS work, while the header loads above are in flight) */
-		if (lds) dec_mtf_to_front(s_mtf, rank, tag, lane); else dec_mtf_to_front(gmtf, rank, tag, lane);
-		x3_wave_order(); /* lane 0's new item / the bumped frequency is stored before the lane that holds that list position loads it below */
-		n_h1 = self1 ? u1 : e_h1;
-		n_h0 = self0 ? u0 : e_h0;
+		uint64_t p_it0 = it0, p_it1 = it1;
+		uint32_t p_po1 = po1, nopo = 0;
+		dec_ctx_touch(u0, q0, tag, p_it0, nopo, false, 0, pool, pord, s.pool_top, t.pool_cap, s.status, lane);
+		dec_ctx_touch(u1, q1, tag, p_it1, p_po1, true, ord, pool, pord, s.pool_top, t.pool_cap, s.status, lane);
+		if (s.status != X3_ST_OK) break;
+		if (lane == 0) {
+			t.ctx0[c0id] = u0;
+			if (LDS) { s_c1off[ctx1tag] = u1.off; s_c1n[ctx1tag] = (uint16_t)u1.items; s_c1tot[ctx1tag] = u1.total; }
+			else t.ctx1[ctx1tag] = u1;
+		}
+		DPROF2_T(u_c)
+		DPROF2_ADD(s.pc_ctx, u_b, u_c)
+		/* x3.c:332-348: the element moves to the front (LDS work, while the loads above are in flight) */
+		if (LDS) dec_mtf_to_front(s_mtf, rank, tag, lane); else dec_mtf_to_front(t.gmtf, rank, tag, lane);
+		x3_wave_order(); /* this step's stores come before the loads below in program order, also for the lanes that did not store */
 		DPROF_T(t_d)
-		DPROF_ADD(pc_ctx, t_c, t_d)
-		/* items [0, 64) of both lists: in flight while the element is copied and the next event symbol is decoded (this step's updates are already stored) */
-		n_it1 = lane < n_h1.items ? pool[(uint64_t)n_h1.off + lane] : 0;
-		n_po1 = lane < n_h1.items ? pord[(uint64_t)n_h1.off + lane] : 0;
-		n_it0 = lane < n_h0.items ? pool[(uint64_t)n_h0.off + lane] : 0;
+		DPROF2_ADD(s.pc_tail, u_c, t_d)
+		DPROF1_ADD(s.pc_ctx, t_c, t_d)
+		if (!LDS) { /* spilled: the header came from global memory, its items are requested only now */
+			e_it1 = lane < e_h1.items ? pool[(uint64_t)e_h1.off + lane] : 0;
+			e_po1 = lane < e_h1.items ? pord[(uint64_t)e_h1.off + lane] : 0;
+		}
+		s.n_c0id = ord;
+		s.n_h1 = self1 ? u1 : e_h1; s.n_it1 = self1 ? p_it1 : e_it1; s.n_po1 = self1 ? p_po1 : e_po1;
+		const uint64_t e_it0 = lane < e_h0.items ? pool[(uint64_t)e_h0.off + lane] : 0; /* in flight while the next event symbol is decoded */
+		s.n_h0 = self0 ? u0 : e_h0; s.n_it0 = self0 ? p_it0 : e_it0;
 		if (lane < len) out[p + lane] = piece; /* x3.c:332-340: the element's bytes */
-		ctx1tag = tag; /* x3.c:346-347 */
-		p += len;
+		s.ctx1tag = tag; /* x3.c:346-347 */
+		s.p = p + len;
 		x3_wave_order();
 		DPROF_T(t_e)
-		DPROF_ADD(pc_tail, t_d, t_e)
+		DPROF1_ADD(s.pc_tail, t_d, t_e)
+	}
+	return false;
+}
+
+template <uint32_t NLDS>
+__device__ static void x3_decode_body(const X3DecArgs &a)
+{
+	/* per dictionary element while there are fewer than NLDS of them: rank -> tag of the move-to-front list, model_index1 frequency by rank,
+	 * (position << 5 | length - 1) of the element (positions < 2^27 = X3H_MAX_CHUNK), offset / total / item count of its context1 list */
+	X3_LDS uint16_t s_mtf[NLDS];
+	X3_LDS uint32_t s_idx[NLDS];
+	X3_LDS uint32_t s_el[NLDS];
+	X3_LDS uint32_t s_c1off[NLDS];
+	X3_LDS uint32_t s_c1tot[NLDS];
+	X3_LDS uint16_t s_c1n[NLDS];
+	static_assert(NLDS <= 65536, "tags and list lengths in the LDS tables are 16 bits wide");
+	const X3DecChunk ck = a.chunks[blockIdx.x];
+	const uint32_t lane = x3_lane();
+	DecT t;
+	t.out = a.out + ck.out_off;
+	t.dpos = a.dict_pos + ck.tag_off; t.dlen = a.dict_len + ck.tag_off;
+	t.ht = a.ht + ck.ht_off; t.hlog = ck.ht_log2; t.hmask = (1u << ck.ht_log2) - 1;
+	t.gmtf = a.mtf + ck.tag_off; t.gidx = a.idxfreq + ck.tag_off;
+	t.ctx1 = a.ctx1 + ck.tag_off; t.ctx0 = a.ctx0 + ck.ctx0_off;
+	t.pool = a.items + ck.item_off; t.pord = a.item_ord + ck.item_off; t.pool_cap = ck.item_cap;
+	t.cap = ck.out_cap;
+
+	DecS s;
+	br_open(s.br, a.in + ck.in_off, ck.in_len);
+	s.d.lo = 0; s.d.hi = 0x7FFFFFFFu; s.d.buf = 0; /* ac_init */
+	s.d.buf = br_take(s.br, 31); /* ac_decode_init, ac.c:133-140 */
+	s.evf = lane < 2 ? 1024u : lane < 5 ? 1u : 0u; s.evtotal = 2051; /* create(), x3.c:236-244 */
+	s.lf = 1; s.lftotal = 32;
+	s.cf0 = s.cf1 = s.cf2 = s.cf3 = 1; s.cftotal = 256;
+	s.D = 0; s.idxtotal = 0; s.npairs = 0; s.status = X3_ST_OK;
+	s.pool_top = 0;
+	s.ctx1tag = 0; s.p = 0;
+	s.n_c0id = 0;
+	s.n_h0.off = s.n_h0.items = s.n_h0.cap = s.n_h0.total = 0; /* both contexts are empty at the start */
+	s.n_h1 = s.n_h0;
+	s.n_it0 = s.n_it1 = 0; s.n_po1 = 0;
+	s.ord00 = 0; s.have00 = 0;
+	s.pc_ev = s.pc_sym = s.pc_ctx = s.pc_tail = 0;
+	if (lane == 0) { s_c1off[0] = 0; s_c1tot[0] = 0; s_c1n[0] = 0; } /* the list of context 0 is looked at before element 0 exists */
+	x3_wave_order();
+
+	if (dec_loop<NLDS, true>(t, s, s_mtf, s_idx, s_el, s_c1off, s_c1tot, s_c1n, lane)) {
+		/* NLDS elements: the tables continue in global memory (dpos/dlen were written there from the start) */
+		for (uint32_t i = lane; i < NLDS; i += X3_WAVE) {
+			t.gmtf[i] = s_mtf[i]; t.gidx[i] = s_idx[i];
+			X3CtxHdr h; h.off = s_c1off[i]; h.items = s_c1n[i]; h.cap = dec_cap_of(h.items); h.total = s_c1tot[i];
+			t.ctx1[i] = h;
+		}
+		x3_wave_order();
+		(void)dec_loop<NLDS, false>(t, s, s_mtf, s_idx, s_el, s_c1off, s_c1tot, s_c1n, lane);
 	}
 
 	if (lane == 0) {
 		X3CodeResult r;
-		r.out_len = p; r.status = status; r.pairs = npairs; r._r = D;
+		r.out_len = s.p; r.status = s.status; r.pairs = s.npairs; r._r = s.D;
 		for (int i = 0; i < 8; i++) r.events[i] = 0;
 #ifdef X3_DEC_PROFILE
-		r.events[4] = (uint32_t)(pc_ev >> 10); r.events[5] = (uint32_t)(pc_sym >> 10); r.events[6] = (uint32_t)(pc_ctx >> 10); r.events[7] = (uint32_t)(pc_tail >> 10);
+		r.events[4] = (uint32_t)(s.pc_ev >> 10); r.events[5] = (uint32_t)(s.pc_sym >> 10); r.events[6] = (uint32_t)(s.pc_ctx >> 10); r.events[7] = (uint32_t)(s.pc_tail >> 10);
 #endif
 		a.result[blockIdx.x] = r;
 	}
-	if (lane < 4) a.result[blockIdx.x].events[lane] = evf - (lane < 2 ? 1024u : 1u); /* events decoded = what the model counted */
+	x3_wave_order();
+	if (lane < 4) a.result[blockIdx.x].events[lane] = s.evf - (lane < 2 ? 1024u : 1u); /* events decoded = what the model counted */
 }
 
 #ifndef X3_EMU
