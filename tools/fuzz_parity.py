@@ -65,6 +65,12 @@ while time.time() - t0 < budget:
         if got[i] != want[i]:
             print("MISMATCH: seed", seed, "case", cases, "chunk", i, "sizes", sizes, "params", kw, "env", env, flush=True)
             sys.exit(1)
+    if rng.random() < 0.5:   # decoder: the whole batch back (more than 256 streams: the small-LDS kernel variant, whose tables spill at 512 elements)
+        back = ctx.decompress_chunks(got, [n + int(rng.integers(0, 9)) for n in sizes])
+        for i in range(nch):
+            if back[i] != parts[i]:
+                print("BATCH DECODE MISMATCH: seed", seed, "case", cases, "chunk", i, "sizes", sizes, "params", kw, "env", env, flush=True)
+                sys.exit(1)
     if rng.random() < 0.3:   # decoder round trip of one stream
         i = int(rng.integers(0, nch))
         back = ctx.decompress(got[i], sizes[i] + 8)

@@ -20,22 +20,35 @@
  */
 #include "x3_tables.h"
 
-#ifdef X3_DEC_PROFILE /* experiment builds: cycles per section of the hit path, reported in the unused event slots (2: the context section in four parts instead) */
+/* experiment builds (tools/exp/dec_prof.py): -DX3_DEC_PROFILE=1 cycles per section of a hit step, =2 the context section in four parts,
+ * =3 cycles spent in s_waitcnt vmcnt(0) at three points of the step; reported in the unused event slots of the result */
+#if defined(X3_DEC_PROFILE)
 #define DPROF_T(var) const uint64_t var = x3_clock();
-#define DPROF_ADD(acc, a, b) acc += (b) - (a);
 #else
 #define DPROF_T(var)
-#define DPROF_ADD(acc, a, b)
+#endif
+#if defined(X3_DEC_PROFILE) && X3_DEC_PROFILE == 1
+#define DPROF1_ADD(acc, a, b) acc += (b) - (a);
+#else
+#define DPROF1_ADD(acc, a, b)
 #endif
 #if defined(X3_DEC_PROFILE) && X3_DEC_PROFILE == 2
 #define DPROF2_T(var) const uint64_t var = x3_clock();
 #define DPROF2_ADD(acc, a, b) acc += (b) - (a);
-#define DPROF1_ADD(acc, a, b)
 #else
 #define DPROF2_T(var)
 #define DPROF2_ADD(acc, a, b)
-#define DPROF1_ADD(acc, a, b) DPROF_ADD(acc, a, b)
 #endif
+#if defined(X3_DEC_PROFILE) && X3_DEC_PROFILE == 3
+#define DPROF3_WAIT(acc) { const uint64_t w0_ = x3_clock(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); acc += x3_clock() - w0_; }
+#else
+#define DPROF3_WAIT(acc)
+#endif
+
+/* A lone wave pays for every taken branch with an instruction-fetch bubble, and this loop is ~80 branches per step: the likely side of each
+ * is marked so that the hot path is laid out as fall-through code. */
+#define X3_LIKELY(x)   __builtin_expect(!!(x), 1)
+#define X3_UNLIKELY(x) __builtin_expect(!!(x), 0)
 
 /* The chain's state is wave-uniform, but every value that comes out of a (vector) load looks divergent to the compiler: pinning the
  * loaded words with readfirstlane keeps the interval arithmetic, the bit reader and the control flow on the scalar unit. */
@@ -71,14 +84,14 @@ __device__ static __forceinline__ void br_open(BitReader &r, const uint8_t *in, 
 /* the next n (0..31) bits of the stream, first one most significant -- what n calls of get_bit shifted into mBuffer would leave */
 __device__ static __forceinline__ uint32_t br_take(BitReader &r, uint32_t n)
 {
-	if (r.nb < n) { /* one more word */
+	if (X3_UNLIKELY(r.nb < n)) { /* one more word */
 		const uint32_t nx = x3_readlane_u32(r.cur, r.wi & (X3_WAVE - 1));
 		r.wi++;
-		if ((r.wi & (X3_WAVE - 1)) == 0) { r.cur = r.nxt; r.nxt = br_block(r, (r.wi >> 6) + 1); }
+		if (X3_UNLIKELY((r.wi & (X3_WAVE - 1)) == 0)) { r.cur = r.nxt; r.nxt = br_block(r, (r.wi >> 6) + 1); }
 		r.w |= (uint64_t)nx << r.nb;
 		r.nb += 32;
 	}
-	if (!n) return 0;
+	if (X3_UNLIKELY(!n)) return 0;
 	const uint32_t field = (uint32_t)r.w & (0xFFFFFFFFu >> (32 - n));
 	r.w >>= n;
 	r.nb -= n;
@@ -111,7 +124,7 @@ __device__ static __forceinline__ uint32_t dec_div(uint32_t n, uint32_t t)
 __device__ static __forceinline__ bool dec_narrow(Dec &d, BitReader &r, uint32_t step, uint32_t cum_lo, uint32_t cum_hi)
 {
 	const uint32_t nlo = d.lo + step * cum_lo, nhi = d.lo + step * cum_hi - 1, D = nhi - nlo;
-	if (D == 0 || ((nlo | nhi) >> 31) || nhi < nlo || d.buf < nlo || d.buf > nhi) return false;
+	if (X3_UNLIKELY(D == 0 || ((nlo | nhi) >> 31) || nhi < nlo || d.buf < nlo || d.buf > nhi)) return false;
 	const uint32_t cz = (uint32_t)x3_clz32(D), t = 31u - cz;
 	const uint32_t sh = cz - 1 - ((((nlo ^ nhi) >> t) & 1u) ^ 1u);
 	const uint32_t lo = (nlo << sh) & 0x3FFFFFFFu;
@@ -145,15 +158,47 @@ __device__ static __forceinline__ uint32_t find_in_array(const uint32_t *freq, u
 	return 0xFFFFFFFFu;
 }
 
+/* ... with entries [0, 64) already in registers (`first`: lane l holds freq[l]) */
+__device__ static __forceinline__ uint32_t find_in_array_pre(const uint32_t *freq, uint32_t first, uint32_t count, uint32_t off, uint32_t step, uint32_t lane, uint32_t &cum_out, uint32_t &fq_out)
+{
+	uint32_t carry;
+	{
+		const uint32_t fq = lane < count ? first : 0;
+		const uint32_t incl = wave_incl_scan(fq, lane);
+		const uint64_t mask = x3_ballot(lane < count && dec_below(off, step, incl));
+		if (X3_LIKELY(mask != 0)) {
+			const uint32_t l = (uint32_t)x3_ctz64(mask);
+			fq_out = x3_readlane_u32(fq, l);
+			cum_out = x3_readlane_u32(incl, l) - fq_out;
+			return l;
+		}
+		carry = x3_readlane_u32(incl, X3_WAVE - 1);
+	}
+	for (uint32_t base = X3_WAVE; base < count; base += X3_WAVE) {
+		const uint32_t i = base + lane;
+		const uint32_t fq = i < count ? freq[i] : 0;
+		const uint32_t incl = wave_incl_scan(fq, lane) + carry;
+		const uint64_t mask = x3_ballot(i < count && dec_below(off, step, incl));
+		if (mask) {
+			const uint32_t l = (uint32_t)x3_ctz64(mask);
+			fq_out = x3_readlane_u32(fq, l);
+			cum_out = x3_readlane_u32(incl, l) - fq_out;
+			return base + l;
+		}
+		carry = x3_readlane_u32(incl, X3_WAVE - 1);
+	}
+	return 0xFFFFFFFFu;
+}
+
 /* same over a context's item list; returns the list position */
 __device__ static uint32_t find_in_ctx(const X3CtxHdr h, const uint64_t *pool, uint32_t off, uint32_t step, uint32_t lane, uint64_t first, uint32_t &cum_out, uint32_t &fq_out, uint32_t &tag_out)
 {
 	uint32_t carry = 0;
-	if (h.items <= X3_WAVE) { /* the usual case as straight-line code: no load, so nothing here makes the wave wait for loads that are in flight */
+	if (X3_LIKELY(h.items <= X3_WAVE)) { /* the usual case as straight-line code: no load, so nothing here makes the wave wait for loads that are in flight */
 		const uint32_t fq = (uint32_t)first; /* lanes beyond the list hold 0 */
 		const uint32_t incl = wave_incl_scan(fq, lane);
 		const uint64_t mask = x3_ballot(lane < h.items && dec_below(off, step, incl));
-		if (!mask) return 0xFFFFFFFFu;
+		if (X3_UNLIKELY(!mask)) return 0xFFFFFFFFu;
 		const uint32_t l = (uint32_t)x3_ctz64(mask);
 		fq_out = x3_readlane_u32(fq, l);
 		cum_out = x3_readlane_u32(incl, l) - fq_out;
@@ -183,7 +228,7 @@ __device__ static CtxQ ctx_find_tag(const X3CtxHdr h, const uint64_t *pool, uint
 {
 	CtxQ q;
 	q.found = 0; q.pos = 0; q.freq = 0; q.cum = 0;
-	if (h.items <= X3_WAVE) { /* straight-line, no load (see find_in_ctx) */
+	if (X3_LIKELY(h.items <= X3_WAVE)) { /* straight-line, no load (see find_in_ctx) */
 		const uint64_t mask = x3_ballot(lane < h.items && (uint32_t)(first >> 32) == tag);
 		if (mask) { q.found = 1; q.pos = (uint32_t)x3_ctz64(mask); }
 		return q;
@@ -205,10 +250,10 @@ __device__ static __forceinline__ void dec_ctx_touch(X3CtxHdr &h, const CtxQ q, 
                                                      uint64_t *pool, uint32_t *pord, uint64_t &pool_top, uint64_t pool_cap, uint32_t &status, uint32_t lane)
 {
 	if (q.found) {
-		if (q.pos < X3_WAVE) { if (lane == q.pos) { first += 1; pool[(uint64_t)h.off + q.pos] = first; } }
+		if (X3_LIKELY(q.pos < X3_WAVE)) { if (lane == q.pos) { first += 1; pool[(uint64_t)h.off + q.pos] = first; } }
 		else if (lane == 0) pool[(uint64_t)h.off + q.pos] += 1;
 	} else {
-		if (h.items == h.cap) {
+		if (X3_UNLIKELY(h.items == h.cap)) {
 			const uint32_t ncap = h.cap ? 2 * h.cap : 2;
 			if (pool_top + ncap > pool_cap) { status = X3_ST_POOL_FULL; return; }
 			const uint32_t noff = (uint32_t)pool_top;
@@ -242,7 +287,7 @@ __device__ static __forceinline__ uint32_t dec_cap_of(uint32_t n) { return n == 
 template <typename T>
 __device__ static __forceinline__ void dec_mtf_to_front(T *mtf, uint32_t r, uint32_t tag, uint32_t lane)
 {
-	if (r < X3_WAVE) { /* recent elements are the usual ones: one read and one write, straight-line */
+	if (X3_LIKELY(r < X3_WAVE)) { /* recent elements are the usual ones: one read and one write, straight-line */
 		const bool act = lane >= 1 && lane <= r;
 		const T v = act ? mtf[lane - 1] : (T)tag;
 		x3_wave_order(); /* every lane has read before any lane overwrites its neighbour's source */
@@ -260,9 +305,9 @@ __device__ static __forceinline__ void dec_mtf_to_front(T *mtf, uint32_t r, uint
 }
 /* dict_get_index_by_tag (dict.c:174-183): rank of `tag`, 0xFFFFFFFF if it is not in the list */
 template <typename T>
-__device__ static __forceinline__ uint32_t dec_mtf_rank(const T *mtf, uint32_t D, uint32_t tag, uint32_t lane)
+__device__ static __forceinline__ uint32_t dec_mtf_rank(const T *mtf, uint32_t D, uint32_t tag, uint32_t lane, uint32_t from = 0)
 {
-	for (uint32_t base = 0; base < D; base += X3_WAVE) {
+	for (uint32_t base = from; base < D; base += X3_WAVE) {
 		const uint32_t i = base + lane;
 		const uint64_t mask = x3_ballot(i < D && (uint32_t)mtf[i] == tag);
 		if (mask) return base + (uint32_t)x3_ctz64(mask);
@@ -318,7 +363,12 @@ __device__ static __forceinline__ bool dec_loop(const DecT &t, DecS &s, uint16_t
 	BitReader &br = s.br;
 	Dec &d = s.d;
 	for (;;) {
-		if (LDS && s.D == NLDS) return true;
+		if (LDS && X3_UNLIKELY(s.D == NLDS)) return true;
+		/* ranks [0, 64) of the recency list and of the index model, read ahead of the event symbol: recent elements are the usual ones, and then
+		 * neither the rank search nor the move-to-front waits for an LDS read (lanes >= D hold nothing meaningful; the new-fragment path below
+		 * changes both tables and comes back here) */
+		uint32_t m0 = 0, i0 = 0;
+		if (LDS) { m0 = s_mtf[lane]; i0 = s_idx[lane]; }
 		DPROF_T(t_a)
 		/* ---- the event (x3.c:293-295) ---- */
 		/* ac_decode_target + index_of_value (ac.c:128-131,167-179) without the second division:  (buf-lo)/step < c  <=>  buf-lo < c*step */
@@ -327,32 +377,32 @@ __device__ static __forceinline__ bool dec_loop(const DecT &t, DecS &s, uint16_t
 		{
 			const uint32_t incl = x3_row8_incl_scan_u32(s.evf);
 			const uint64_t mask = x3_ballot(lane < 5 && dec_below(d.buf - d.lo, step, incl));
-			if (!mask) { s.status = X3_ST_CORRUPT; break; } /* the reference abort()s, ac.c:178 */
+			if (X3_UNLIKELY(!mask)) { s.status = X3_ST_CORRUPT; break; } /* the reference abort()s, ac.c:178 */
 			decision = (uint32_t)x3_ctz64(mask);
 			const uint32_t fq = x3_readlane_u32(s.evf, decision), cum = x3_readlane_u32(incl, decision) - fq;
-			if (!dec_narrow(d, br, step, cum, cum + fq)) { s.status = X3_ST_CORRUPT; break; }
+			if (X3_UNLIKELY(!dec_narrow(d, br, step, cum, cum + fq))) { s.status = X3_ST_CORRUPT; break; }
 			if (lane == decision) s.evf++;
 			s.evtotal++;
 		}
-		if (decision == X3_E_EOF) break;
+		if (X3_UNLIKELY(decision == X3_E_EOF)) break;
 
-		if (decision == X3_E_NEW) {
+		if (X3_UNLIKELY(decision == X3_E_NEW)) {
 			/* ---- decode_match, x3.c:272-283 ---- */
 			uint32_t len;
 			{
 				step = dec_div(d.hi - d.lo + 1, s.lftotal);
 				const uint32_t incl = wave_incl_scan(lane < 32 ? s.lf : 0u, lane);
 				const uint64_t mask = x3_ballot(lane < 32 && dec_below(d.buf - d.lo, step, incl));
-				if (!mask) { s.status = X3_ST_CORRUPT; break; }
+				if (X3_UNLIKELY(!mask)) { s.status = X3_ST_CORRUPT; break; }
 				const uint32_t l = (uint32_t)x3_ctz64(mask);
 				const uint32_t fq = x3_readlane_u32(s.lf, l), cl = x3_readlane_u32(incl, l) - fq;
-				if (!dec_narrow(d, br, step, cl, cl + fq)) { s.status = X3_ST_CORRUPT; break; }
+				if (X3_UNLIKELY(!dec_narrow(d, br, step, cl, cl + fq))) { s.status = X3_ST_CORRUPT; break; }
 				if (lane == l) s.lf++;
 				s.lftotal++;
 				len = l + 1;
 			}
 			const uint32_t p = s.p;
-			if ((uint64_t)p + len > t.cap) { s.status = X3_ST_OUT_FULL; break; }
+			if (X3_UNLIKELY((uint64_t)p + len > t.cap)) { s.status = X3_ST_OUT_FULL; break; }
 			uint32_t h = DFNV_OFF;
 			int bad = 0;
 			for (uint32_t j = 0; j < len; j++) {
@@ -361,7 +411,7 @@ __device__ static __forceinline__ bool dec_loop(const DecT &t, DecS &s, uint16_t
 				const uint32_t s4 = s.cf0 + s.cf1 + s.cf2 + s.cf3;
 				const uint32_t incl = wave_incl_scan(s4, lane);
 				const uint64_t mask = x3_ballot(dec_below(offb, step, incl));
-				if (!mask) { bad = 1; break; }
+				if (X3_UNLIKELY(!mask)) { bad = 1; break; }
 				const uint32_t l = (uint32_t)x3_ctz64(mask);
 				const uint32_t b0 = x3_readlane_u32(s.cf0, l), b1 = x3_readlane_u32(s.cf1, l), b2 = x3_readlane_u32(s.cf2, l), b3 = x3_readlane_u32(s.cf3, l);
 				uint32_t cl = x3_readlane_u32(incl, l) - (b0 + b1 + b2 + b3), sub, fq;
@@ -369,14 +419,14 @@ __device__ static __forceinline__ bool dec_loop(const DecT &t, DecS &s, uint16_t
 				else if (dec_below(offb, step, cl + b0 + b1)) { sub = 1; fq = b1; cl += b0; }
 				else if (dec_below(offb, step, cl + b0 + b1 + b2)) { sub = 2; fq = b2; cl += b0 + b1; }
 				else { sub = 3; fq = b3; cl += b0 + b1 + b2; }
-				if (!dec_narrow(d, br, step, cl, cl + fq)) { bad = 1; break; }
+				if (X3_UNLIKELY(!dec_narrow(d, br, step, cl, cl + fq))) { bad = 1; break; }
 				if (lane == l) { if (sub == 0) s.cf0++; else if (sub == 1) s.cf1++; else if (sub == 2) s.cf2++; else s.cf3++; }
 				s.cftotal++;
 				const uint32_t ch = 4 * l + sub;
 				if (lane == 0) out[p + j] = (uint8_t)ch;
 				h = (h ^ ch) * DFNV_MUL;
 			}
-			if (bad) { s.status = X3_ST_CORRUPT; break; }
+			if (X3_UNLIKELY(bad)) { s.status = X3_ST_CORRUPT; break; }
 			x3_wave_order(); /* the fragment is in memory for every lane */
 			/* dict_query_elem (x3.c:309): exact lookup of (len, bytes) */
 			int dup = 0;
@@ -421,7 +471,8 @@ __device__ static __forceinline__ bool dec_loop(const DecT &t, DecS &s, uint16_t
 		DPROF_T(t_b)
 		DPROF1_ADD(s.pc_ev, t_a, t_b)
 		const uint32_t D = s.D;
-		if (D == 0) { s.status = X3_ST_CORRUPT; break; }
+		if (X3_UNLIKELY(D == 0)) { s.status = X3_ST_CORRUPT; break; }
+		DPROF3_WAIT(s.pc_ev)
 		const uint32_t c0id = s.n_c0id, ctx1tag = s.ctx1tag;
 		const X3CtxHdr h0 = uni_hdr(s.n_h0), h1 = uni_hdr(s.n_h1); /* pinned here, not where the loads were issued: they stay in flight until now */
 		const uint64_t it0 = s.n_it0, it1 = s.n_it1;
@@ -430,24 +481,27 @@ __device__ static __forceinline__ bool dec_loop(const DecT &t, DecS &s, uint16_t
 		if (decision == X3_E_IDX1) {
 			step = dec_div(d.hi - d.lo + 1, s.idxtotal);
 			uint32_t cl = 0, fq = 0;
-			rank = LDS ? find_in_array(s_idx, D, d.buf - d.lo, step, lane, cl, fq) : find_in_array(t.gidx, D, d.buf - d.lo, step, lane, cl, fq);
-			if (rank == 0xFFFFFFFFu) { s.status = X3_ST_CORRUPT; break; }
-			if (!dec_narrow(d, br, step, cl, cl + fq)) { s.status = X3_ST_CORRUPT; break; }
-			if (LDS) { tag = x3_uniform((uint32_t)s_mtf[rank]); x3_wave_order(); if (lane == 0) s_idx[rank] = fq + 1; } /* inc_model(&model_index1, index), x3.c:89 */
+			rank = LDS ? find_in_array_pre(s_idx, i0, D, d.buf - d.lo, step, lane, cl, fq) : find_in_array(t.gidx, D, d.buf - d.lo, step, lane, cl, fq);
+			if (X3_UNLIKELY(rank == 0xFFFFFFFFu)) { s.status = X3_ST_CORRUPT; break; }
+			if (X3_UNLIKELY(!dec_narrow(d, br, step, cl, cl + fq))) { s.status = X3_ST_CORRUPT; break; }
+			if (LDS) { tag = X3_LIKELY(rank < X3_WAVE) ? x3_readlane_u32(m0, rank) : x3_uniform((uint32_t)s_mtf[rank]); x3_wave_order(); if (lane == 0) s_idx[rank] = fq + 1; } /* inc_model(&model_index1, index), x3.c:89 */
 			else { tag = x3_uniform(t.gmtf[rank]); x3_wave_order(); if (lane == 0) t.gidx[rank] = fq + 1; }
 			s.idxtotal++;
 		} else {
 			const X3CtxHdr hc = decision == X3_E_CTX0 ? h0 : h1;
-			if (hc.items == 0 || hc.total == 0) { s.status = X3_ST_CORRUPT; break; }
+			if (X3_UNLIKELY(hc.items == 0 || hc.total == 0)) { s.status = X3_ST_CORRUPT; break; }
 			step = dec_div(d.hi - d.lo + 1, hc.total);
 			uint32_t cl = 0, fq = 0;
 			const uint32_t pos = find_in_ctx(hc, pool, d.buf - d.lo, step, lane, decision == X3_E_CTX0 ? it0 : it1, cl, fq, tag);
-			if (pos == 0xFFFFFFFFu) { s.status = X3_ST_CORRUPT; break; }
+			if (X3_UNLIKELY(pos == 0xFFFFFFFFu)) { s.status = X3_ST_CORRUPT; break; }
 			cpos = pos;
-			if (!dec_narrow(d, br, step, cl, cl + fq)) { s.status = X3_ST_CORRUPT; break; }
+			if (X3_UNLIKELY(!dec_narrow(d, br, step, cl, cl + fq))) { s.status = X3_ST_CORRUPT; break; }
 			/* dict_get_index_by_tag (x3.c:79,84) */
-			rank = LDS ? dec_mtf_rank(s_mtf, D, tag, lane) : dec_mtf_rank(t.gmtf, D, tag, lane);
-			if (rank == 0xFFFFFFFFu) { s.status = X3_ST_CORRUPT; break; }
+			if (LDS) {
+				const uint64_t mask = x3_ballot(lane < D && m0 == tag);
+				rank = X3_LIKELY(mask != 0) ? (uint32_t)x3_ctz64(mask) : dec_mtf_rank(s_mtf, D, tag, lane, X3_WAVE);
+			} else rank = dec_mtf_rank(t.gmtf, D, tag, lane);
+			if (X3_UNLIKELY(rank == 0xFFFFFFFFu)) { s.status = X3_ST_CORRUPT; break; }
 		}
 		DPROF_T(t_c)
 		DPROF1_ADD(s.pc_sym, t_b, t_c)
@@ -455,17 +509,19 @@ __device__ static __forceinline__ bool dec_loop(const DecT &t, DecS &s, uint16_t
 		 * next context1 list (the one of the tag just decoded; this step only touches it when the tag follows itself, and then the registers
 		 * updated below are used instead of what is loaded here) */
 		uint32_t len, src;
-		if (LDS) { const uint32_t e = x3_uniform(s_el[tag]); len = (e & 31u) + 1; src = e >> 5; }
-		else { len = x3_uniform(t.dlen[tag]); src = x3_uniform(t.dpos[tag]); }
+		X3CtxHdr e_h1;
+		if (LDS) { /* four LDS reads in flight together */
+			const uint32_t e = s_el[tag], ho = s_c1off[tag], hn = s_c1n[tag], ht = s_c1tot[tag];
+			len = (x3_uniform(e) & 31u) + 1; src = x3_uniform(e) >> 5;
+			e_h1.off = x3_uniform(ho); e_h1.items = x3_uniform(hn); e_h1.total = x3_uniform(ht); e_h1.cap = dec_cap_of(e_h1.items);
+		} else { len = x3_uniform(t.dlen[tag]); src = x3_uniform(t.dpos[tag]); }
 		const uint32_t p = s.p;
-		if ((uint64_t)p + len > t.cap) { s.status = X3_ST_OUT_FULL; break; }
+		if (X3_UNLIKELY((uint64_t)p + len > t.cap)) { s.status = X3_ST_OUT_FULL; break; }
 		const uint8_t piece = lane < len ? out[src + lane] : (uint8_t)0; /* len <= 32; src + len <= p */
 		const bool self1 = tag == ctx1tag;
-		X3CtxHdr e_h1;
 		uint64_t e_it1 = 0;
 		uint32_t e_po1 = 0;
 		if (LDS) {
-			e_h1.off = x3_uniform(s_c1off[tag]); e_h1.items = x3_uniform((uint32_t)s_c1n[tag]); e_h1.total = x3_uniform(s_c1tot[tag]); e_h1.cap = dec_cap_of(e_h1.items);
 			e_it1 = lane < e_h1.items ? pool[(uint64_t)e_h1.off + lane] : 0;
 			e_po1 = lane < e_h1.items ? pord[(uint64_t)e_h1.off + lane] : 0;
 		} else e_h1 = t.ctx1[tag]; /* into its own registers: nothing below needs it before the updates are done, so the load stays in flight */
@@ -477,7 +533,7 @@ __device__ static __forceinline__ bool dec_loop(const DecT &t, DecS &s, uint16_t
 		if (decision == X3_E_CTX1) { q1.found = 1; q1.pos = cpos; q1.freq = q1.cum = 0; } else q1 = ctx_find_tag(h1, pool, tag, lane, it1);
 		/* the pair (context1, tag) is this step's item in the context1 list -- and the (prev, context1) pair of the NEXT step */
 		uint32_t ord;
-		if (q1.found) ord = q1.pos < X3_WAVE ? x3_readlane_u32(po1, q1.pos) : x3_uniform(pord[(uint64_t)h1.off + q1.pos]);
+		if (X3_LIKELY(q1.found)) ord = X3_LIKELY(q1.pos < X3_WAVE) ? x3_readlane_u32(po1, q1.pos) : x3_uniform(pord[(uint64_t)h1.off + q1.pos]);
 		else {
 			ord = s.npairs;
 			if (ctx1tag == 0 && tag == 0) { s.ord00 = s.npairs; s.have00 = 1; }
@@ -494,7 +550,7 @@ __device__ static __forceinline__ bool dec_loop(const DecT &t, DecS &s, uint16_t
 		uint32_t p_po1 = po1, nopo = 0;
 		dec_ctx_touch(u0, q0, tag, p_it0, nopo, false, 0, pool, pord, s.pool_top, t.pool_cap, s.status, lane);
 		dec_ctx_touch(u1, q1, tag, p_it1, p_po1, true, ord, pool, pord, s.pool_top, t.pool_cap, s.status, lane);
-		if (s.status != X3_ST_OK) break;
+		if (X3_UNLIKELY(s.status != X3_ST_OK)) break;
 		if (lane == 0) {
 			t.ctx0[c0id] = u0;
 			if (LDS) { s_c1off[ctx1tag] = u1.off; s_c1n[ctx1tag] = (uint16_t)u1.items; s_c1tot[ctx1tag] = u1.total; }
@@ -503,8 +559,12 @@ __device__ static __forceinline__ bool dec_loop(const DecT &t, DecS &s, uint16_t
 		DPROF2_T(u_c)
 		DPROF2_ADD(s.pc_ctx, u_b, u_c)
 		/* x3.c:332-348: the element moves to the front (LDS work, while the loads above are in flight) */
-		if (LDS) dec_mtf_to_front(s_mtf, rank, tag, lane); else dec_mtf_to_front(t.gmtf, rank, tag, lane);
+		if (LDS) {
+			if (X3_LIKELY(rank < X3_WAVE)) { const uint32_t below = x3_wave_shr1_u32(m0); if (lane <= rank) s_mtf[lane] = (uint16_t)(lane ? below : tag); } /* no read: ranks [0, 64) are in registers */
+			else dec_mtf_to_front(s_mtf, rank, tag, lane);
+		} else dec_mtf_to_front(t.gmtf, rank, tag, lane);
 		x3_wave_order(); /* this step's stores come before the loads below in program order, also for the lanes that did not store */
+		DPROF3_WAIT(s.pc_sym)
 		DPROF_T(t_d)
 		DPROF2_ADD(s.pc_tail, u_c, t_d)
 		DPROF1_ADD(s.pc_ctx, t_c, t_d)
@@ -516,6 +576,7 @@ __device__ static __forceinline__ bool dec_loop(const DecT &t, DecS &s, uint16_t
 		s.n_h1 = self1 ? u1 : e_h1; s.n_it1 = self1 ? p_it1 : e_it1; s.n_po1 = self1 ? p_po1 : e_po1;
 		const uint64_t e_it0 = lane < e_h0.items ? pool[(uint64_t)e_h0.off + lane] : 0; /* in flight while the next event symbol is decoded */
 		s.n_h0 = self0 ? u0 : e_h0; s.n_it0 = self0 ? p_it0 : e_it0;
+		DPROF3_WAIT(s.pc_ctx)
 		if (lane < len) out[p + lane] = piece; /* x3.c:332-340: the element's bytes */
 		s.ctx1tag = tag; /* x3.c:346-347 */
 		s.p = p + len;
@@ -537,7 +598,7 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 	X3_LDS uint32_t s_c1off[NLDS];
 	X3_LDS uint32_t s_c1tot[NLDS];
 	X3_LDS uint16_t s_c1n[NLDS];
-	static_assert(NLDS <= 65536, "tags and list lengths in the LDS tables are 16 bits wide");
+	static_assert(NLDS >= X3_WAVE && NLDS <= 65536, "tags and list lengths in the LDS tables are 16 bits wide; ranks [0, 64) are read without a bounds check");
 	const X3DecChunk ck = a.chunks[blockIdx.x];
 	const uint32_t lane = x3_lane();
 	DecT t;

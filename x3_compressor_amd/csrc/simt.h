@@ -50,6 +50,8 @@ __device__ __forceinline__ uint32_t x3_wave_incl_scan_u32(uint32_t v)
 	return (uint32_t)x;
 }
 __device__ __forceinline__ uint32_t x3_wave_sum_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)x3_wave_incl_scan_u32(v), 63); }
+/* v of the lane below (lane 0: 0) as one DPP move across the whole wave (wave_shr:1, a GFX9 control) */
+__device__ __forceinline__ uint32_t x3_wave_shr1_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true); }
 /* inclusive prefix sum that is only valid in lanes 0..7 (three row shifts): models with a handful of symbols */
 __device__ __forceinline__ uint32_t x3_row8_incl_scan_u32(uint32_t v)
 {
@@ -115,6 +117,7 @@ static inline uint32_t x3_wave_incl_scan_u32(uint32_t v)
 	return v;
 }
 static inline uint32_t x3_row8_incl_scan_u32(uint32_t v) { return x3_wave_incl_scan_u32(v); }
+static inline uint32_t x3_wave_shr1_u32(uint32_t v) { const int l = (int)x3_lane(); const uint32_t u = x3emu_shfl(v, l ? l - 1 : 0); return l ? u : 0u; }
 static inline uint32_t x3_wave_sum_u32(uint32_t v) { return x3emu_shfl(x3_wave_incl_scan_u32(v), X3_WAVE - 1); }
 static inline void x3_wave_sync() { (void)x3emu_ballot(0); }
 static inline void x3_wave_order() { (void)x3emu_ballot(0); }
