@@ -452,21 +452,10 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 		c->hparse.assign((size_t)nc, X3ParseResult());
 	}
 
-	/* ---- K3 workspace from the exact D / hits of every chunk ---- */
-	uint64_t toff = 0, c0off = 0, ioff = 0, poff = 0, ooff = 0;
+	/* ---- where every chunk's stream goes ---- */
+	uint64_t ooff = 0;
 	for (int i = 0; i < nc; i++) {
 		X3Chunk &k = c->hchunks[(size_t)i];
-		const X3ParseResult &r = c->hparse[(size_t)i];
-		k.tag_off = toff;
-		k.ctx0_off = c0off;
-		k.item_off = ioff;
-		k.item_cap = 8 * (uint64_t)r.hits + 64;
-		k.pair_log2 = ceil_log2(2 * ((uint64_t)r.hits + 2));
-		k.pair_off = poff;
-		toff += (uint64_t)r.dict_elems + 8;
-		c0off += (uint64_t)r.hits + 8;
-		ioff += k.item_cap;
-		poff += (uint64_t)1 << k.pair_log2;
 		if (io.dst_dev) {
 			k.out_off = (uint64_t)i * io.dst_stride;
 			k.out_cap = io.dst_stride & ~(uint64_t)3;
@@ -678,7 +667,7 @@ static int decompress_batch(x3h_ctx *c, const uint8_t *in, const uint64_t *in_of
 	HIPCHK(hipSetDevice(c->device));
 	const int nc = nchunks;
 	std::vector<X3DecChunk> dk((size_t)nc);
-	uint64_t ioff = 0, ooff = 0, toff = 0, c0off = 0, itoff = 0, poff = 0, hoff = 0;
+	uint64_t ioff = 0, ooff = 0, toff = 0, c0off = 0, itoff = 0, hoff = 0;
 	for (int i = 0; i < nc; i++) {
 		if (in_offsets[i + 1] < in_offsets[i] || out_offsets[i + 1] < out_offsets[i]) return X3H_E_ARG;
 		const uint64_t ilen = in_offsets[i + 1] - in_offsets[i], cap = out_offsets[i + 1] - out_offsets[i];
@@ -686,10 +675,9 @@ static int decompress_batch(x3h_ctx *c, const uint8_t *in, const uint64_t *in_of
 		X3DecChunk &k = dk[(size_t)i];
 		k.in_off = ioff; k.in_len = (uint32_t)ilen; k.out_cap = (uint32_t)cap; k.out_off = ooff;
 		k.tag_off = toff; k.ctx0_off = c0off; k.item_off = itoff; k.item_cap = 8 * cap + 64;
-		k.pair_log2 = ceil_log2(2 * (cap + 2)); k.pair_off = poff;
 		k.ht_log2 = ceil_log2(2 * (cap + 1)); if (k.ht_log2 < 4) k.ht_log2 = 4; k.ht_off = hoff;
 		ioff += align_up(ilen, 16) + 16; ooff += align_up(cap, 256) + 256;
-		toff += cap + 8; c0off += cap + 8; itoff += k.item_cap; poff += (uint64_t)1 << k.pair_log2; hoff += (uint64_t)1 << k.ht_log2;
+		toff += cap + 8; c0off += cap + 8; itoff += k.item_cap; hoff += (uint64_t)1 << k.ht_log2;
 	}
 	CHK(c->din.reserve(ioff + 64));
 	CHK(c->out.reserve(ooff + 256));
@@ -712,7 +700,7 @@ static int decompress_batch(x3h_ctx *c, const uint8_t *in, const uint64_t *in_of
 	da.dict_pos = c->dict_pos.as<uint32_t>(); da.dict_len = c->dict_len.as<uint8_t>(); da.ht = c->ht.as<uint32_t>();
 	da.mtf = c->mtf.as<uint32_t>(); da.idxfreq = c->idxfreq.as<uint32_t>();
 	da.ctx1 = c->ctx1.as<X3CtxHdr>(); da.ctx0 = c->ctx0.as<X3CtxHdr>(); da.items = c->items.as<uint64_t>();
-	da.item_ord = c->items_ord.as<uint32_t>(); da.pair_key = nullptr; da.pair_val = nullptr; da.result = c->cresult.as<X3CodeResult>();
+	da.item_ord = c->items_ord.as<uint32_t>(); da.result = c->cresult.as<X3CodeResult>();
 	HIPCHK(hipEventRecord(c->ev[4], c->stream));
 	x3k_launch_decode(&da, (uint32_t)nc, c->stream);
 	HIPCHK(hipGetLastError());

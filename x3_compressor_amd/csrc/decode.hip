@@ -8,7 +8,7 @@
  *   index_of_value (ac.c:167-179)        -> inclusive wave scan of 64 frequencies + ballot for the first cum > value
  *   dict_get_index_by_tag (dict.c:174-183) -> ballot search of the move-to-front list
  *   dict_query_elem (dict.c:148-157)     -> exact hash lookup; an element is a (pos,len) reference into the OUTPUT
- *   dict_update_costs + qsort            -> move-to-front (x3_tables.h)
+ *   dict_update_costs + qsort            -> move-to-front (dec_mtf_to_front)
  * The chain is latency-bound (a dozen dependent global loads per step in the naive order), so the loop PREFETCHES the next step's
  * context state as soon as it is known: the pair looked up / inserted at the end of a hit step (x3.c:213-222) IS the (prev, context1)
  * pair the next step would look up, so its ordinal is carried over instead of looked up again -- and it needs no hash map at all: a
@@ -18,7 +18,9 @@
  * Streams of a batch decode concurrently (grid = streams).  The reference's unchecked 64x output buffer (x3.c:621) is
  * replaced by a capacity check (X3_ST_OUT_FULL), malformed input ends in X3_ST_CORRUPT instead of abort() (ac.c:178).
  */
-#include "x3_tables.h"
+#include "x3_kernels.h"
+
+struct CtxQ { uint32_t found, pos, freq, cum; }; /* where a tag sits in a context's item list */
 
 /* experiment builds (tools/exp/dec_prof.py): -DX3_DEC_PROFILE=1 cycles per section of a hit step, =2 the context section in four parts,
  * =3 cycles spent in s_waitcnt vmcnt(0) at three points of the step; reported in the unused event slots of the result */
@@ -242,7 +244,7 @@ __device__ static CtxQ ctx_find_tag(const X3CtxHdr h, const uint64_t *pool, uint
 	return q;
 }
 
-/* ctx_touch (x3_tables.h) for the decoder: the lanes already hold items [0, 64) of the list (`first`), so bumping a frequency is a
+/* x3.c:197-209 (add the tag with frequency 1 or bump its frequency) for the decoder: the lanes already hold items [0, 64) of the list (`first`), so bumping a frequency is a
  * plain store from the lane that holds the item -- no read-modify-write round trip on the chain.  `first` (and `po`, the pair ordinals
  * of a context1 list: with_ord) come back as the list reads AFTER the update, so a list that is also the next step's context needs no
  * reload; the caller stores the updated header `h` wherever headers of that kind live. */

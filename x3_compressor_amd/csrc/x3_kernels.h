@@ -37,14 +37,6 @@ struct X3Chunk {           /* one independent x3 stream */
 	uint32_t ht_log2_max;  /* K2: log2 of the hash-table slots reserved for this chunk                   */
 	uint64_t elem_off;     /* K2: offset (elements) into dict_pos/dict_len/tok_pos/tok_info              */
 	uint64_t ht_off;       /* K2: offset (slots) into ht                                                 */
-	/* K3 workspace, filled by the host after K2 reported D and hits */
-	uint64_t tag_off;      /* offset (elements) into mtf / idxfreq / ctx1                                */
-	uint64_t ctx0_off;     /* offset (headers) into ctx0                                                 */
-	uint64_t item_off;     /* offset (items) into the context item pool                                  */
-	uint64_t item_cap;     /* items reserved                                                             */
-	uint64_t pair_off;     /* offset (slots) into pair_key/pair_val                                      */
-	uint32_t pair_log2;    /* log2 slots of the pair map                                                 */
-	uint32_t _pad;
 	uint64_t out_off;      /* byte offset of the chunk's stream in the output buffer                     */
 	uint64_t out_cap;      /* bytes reserved (multiple of 4)                                             */
 };
@@ -106,8 +98,8 @@ struct X3DecChunk {          /* one stream to decode; workspace sized from the o
 	uint64_t in_off;
 	uint32_t in_len, out_cap;
 	uint64_t out_off;
-	uint64_t tag_off, ctx0_off, item_off, item_cap, pair_off, ht_off;
-	uint32_t pair_log2, ht_log2;
+	uint64_t tag_off, ctx0_off, item_off, item_cap, ht_off;
+	uint32_t ht_log2, _pad;
 };
 
 struct X3DecArgs {
@@ -120,9 +112,7 @@ struct X3DecArgs {
 	uint32_t *mtf, *idxfreq;
 	X3CtxHdr *ctx1, *ctx0;
 	uint64_t *items;
-	uint32_t *item_ord;         /* per item slot of a context1 list: the ordinal of the pair (context1, tag) -- replaces the pair map */
-	uint64_t *pair_key;
-	uint32_t *pair_val;
+	uint32_t *item_ord;         /* per item slot of a context1 list: the ordinal of the pair (context1, tag) -- no pair map needed */
 	X3CodeResult *result;       /* out_len = decoded bytes, _r = dictionary elements                */
 };
 
