@@ -249,7 +249,7 @@ __device__ static CtxQ ctx_find_tag(const X3CtxHdr h, const uint64_t *pool, uint
  * of a context1 list: with_ord) come back as the list reads AFTER the update, so a list that is also the next step's context needs no
  * reload; the caller stores the updated header `h` wherever headers of that kind live. */
 __device__ static __forceinline__ void dec_ctx_touch(X3CtxHdr &h, const CtxQ q, uint32_t tag, uint64_t &first, uint32_t &po, bool with_ord, uint32_t ord,
-                                                     uint64_t *pool, uint32_t *pord, uint64_t &pool_top, uint64_t pool_cap, uint32_t &status, uint32_t lane)
+                                                     uint64_t *pool, uint32_t *pord, uint32_t &pool_top, uint32_t pool_cap, uint32_t &status, uint32_t lane)
 {
 	if (q.found) {
 		if (X3_LIKELY(q.pos < X3_WAVE)) { if (lane == q.pos) { first += 1; pool[(uint64_t)h.off + q.pos] = first; } }
@@ -257,8 +257,8 @@ __device__ static __forceinline__ void dec_ctx_touch(X3CtxHdr &h, const CtxQ q, 
 	} else {
 		if (X3_UNLIKELY(h.items == h.cap)) {
 			const uint32_t ncap = h.cap ? 2 * h.cap : 2;
-			if (pool_top + ncap > pool_cap) { status = X3_ST_POOL_FULL; return; }
-			const uint32_t noff = (uint32_t)pool_top;
+			if ((uint64_t)pool_top + ncap > pool_cap) { status = X3_ST_POOL_FULL; return; }
+			const uint32_t noff = pool_top;
 			pool_top += ncap;
 			for (uint32_t i = lane; i < h.items; i += X3_WAVE) {
 				pool[(uint64_t)noff + i] = pool[(uint64_t)h.off + i];
@@ -334,21 +334,21 @@ struct DecT {
 	uint32_t *dpos; uint8_t *dlen; uint32_t *ht; uint32_t hlog, hmask;
 	uint32_t *gmtf, *gidx;
 	X3CtxHdr *ctx1, *ctx0;
-	uint64_t *pool; uint32_t *pord; uint64_t pool_cap;
+	uint64_t *pool; uint32_t *pord; uint32_t pool_cap;
 	uint32_t cap;
 };
 /* the chain's state, carried from the LDS-resident loop into the spilled one */
 struct DecS {
 	BitReader br; Dec d;
 	uint32_t evf, evtotal;            /* event model: the frequency of event `lane` lives in that lane (an array indexed by the decision would sit in scratch memory: a round trip per read on the chain) */
-	uint32_t lf, lftotal;             /* length model, one symbol per lane */
-	uint32_t cf0, cf1, cf2, cf3, cftotal; /* byte model, four symbols per lane */
-	uint32_t D, idxtotal, npairs, status;
-	uint64_t pool_top;
+	uint32_t lf;                      /* length model, one symbol per lane (its total is 32 + the fragments so far: the event model counts those) */
+	uint32_t cf0, cf1, cf2, cf3;      /* byte model, four symbols per lane (total = their sum, taken when a fragment starts) */
+	uint32_t D, npairs, status;       /* (the index model's total is D + the index events so far) */
+	uint32_t pool_top;
 	uint32_t ctx1tag, p;
 	/* the context state of the NEXT hit step, loaded ahead: ctx0 ordinal (0 when the pair is unknown, x3.c:142-145), both headers, items [0,64) of both lists, pair ordinals of the context1 items */
 	uint32_t n_c0id; X3CtxHdr n_h0, n_h1; uint64_t n_it0, n_it1; uint32_t n_po1;
-	uint32_t ord00, have00;           /* the pair (0, 0): what both contexts are after a new fragment (x3.c:321-322) */
+	uint32_t ord00;                   /* ordinal of the pair (0, 0), what both contexts are after a new fragment (x3.c:321-322); 0xFFFFFFFF while unknown */
 	uint64_t pc_ev, pc_sym, pc_ctx, pc_tail;
 };
 
@@ -392,7 +392,8 @@ __device__ static __forceinline__ bool dec_loop(const DecT &t, DecS &s, uint16_t
 			/* ---- decode_match, x3.c:272-283 ---- */
 			uint32_t len;
 			{
-				step = dec_div(d.hi - d.lo + 1, s.lftotal);
+				const uint32_t lftotal = 30u + x3_readlane_u32(s.evf, X3_E_NEW); /* 32 + the fragments before this one: the event model started at 1 and has counted this one already */
+				step = dec_div(d.hi - d.lo + 1, lftotal);
 				const uint32_t incl = wave_incl_scan(lane < 32 ? s.lf : 0u, lane);
 				const uint64_t mask = x3_ballot(lane < 32 && dec_below(d.buf - d.lo, step, incl));
 				if (X3_UNLIKELY(!mask)) { s.status = X3_ST_CORRUPT; break; }
@@ -400,15 +401,14 @@ __device__ static __forceinline__ bool dec_loop(const DecT &t, DecS &s, uint16_t
 				const uint32_t fq = x3_readlane_u32(s.lf, l), cl = x3_readlane_u32(incl, l) - fq;
 				if (X3_UNLIKELY(!dec_narrow(d, br, step, cl, cl + fq))) { s.status = X3_ST_CORRUPT; break; }
 				if (lane == l) s.lf++;
-				s.lftotal++;
 				len = l + 1;
 			}
 			const uint32_t p = s.p;
 			if (X3_UNLIKELY((uint64_t)p + len > t.cap)) { s.status = X3_ST_OUT_FULL; break; }
-			uint32_t h = DFNV_OFF;
+			uint32_t h = DFNV_OFF, cftotal = x3_wave_sum_u32(s.cf0 + s.cf1 + s.cf2 + s.cf3);
 			int bad = 0;
 			for (uint32_t j = 0; j < len; j++) {
-				step = dec_div(d.hi - d.lo + 1, s.cftotal);
+				step = dec_div(d.hi - d.lo + 1, cftotal);
 				const uint32_t offb = d.buf - d.lo;
 				const uint32_t s4 = s.cf0 + s.cf1 + s.cf2 + s.cf3;
 				const uint32_t incl = wave_incl_scan(s4, lane);
@@ -423,7 +423,7 @@ __device__ static __forceinline__ bool dec_loop(const DecT &t, DecS &s, uint16_t
 				else { sub = 3; fq = b3; cl += b0 + b1 + b2; }
 				if (X3_UNLIKELY(!dec_narrow(d, br, step, cl, cl + fq))) { bad = 1; break; }
 				if (lane == l) { if (sub == 0) s.cf0++; else if (sub == 1) s.cf1++; else if (sub == 2) s.cf2++; else s.cf3++; }
-				s.cftotal++;
+				cftotal++;
 				const uint32_t ch = 4 * l + sub;
 				if (lane == 0) out[p + j] = (uint8_t)ch;
 				h = (h ^ ch) * DFNV_MUL;
@@ -453,13 +453,12 @@ __device__ static __forceinline__ bool dec_loop(const DecT &t, DecS &s, uint16_t
 					if (lane == 0) t.gidx[D] = 1;
 				}
 				s.D++;
-				s.idxtotal++;
 			}
 			s.p = p + len;
 			s.ctx1tag = 0; /* x3.c:321-322: both contexts reset */
 			x3_wave_order();
 			/* the next hit step's contexts: pair (0, 0) if it is known, else context 0 (x3.c:142-145) */
-			s.n_c0id = s.have00 ? s.ord00 : 0u;
+			s.n_c0id = s.ord00 != 0xFFFFFFFFu ? s.ord00 : 0u;
 			s.n_h0 = t.ctx0[s.n_c0id];
 			if (LDS) { s.n_h1.off = x3_uniform(s_c1off[0]); s.n_h1.items = x3_uniform((uint32_t)s_c1n[0]); s.n_h1.total = x3_uniform(s_c1tot[0]); s.n_h1.cap = dec_cap_of(s.n_h1.items); }
 			else s.n_h1 = t.ctx1[0];
@@ -481,14 +480,14 @@ __device__ static __forceinline__ bool dec_loop(const DecT &t, DecS &s, uint16_t
 		const uint32_t po1 = s.n_po1;
 		uint32_t tag = 0, rank = 0, cpos = 0;
 		if (decision == X3_E_IDX1) {
-			step = dec_div(d.hi - d.lo + 1, s.idxtotal);
+			const uint32_t idxtotal = D + x3_readlane_u32(s.evf, X3_E_IDX1) - 2u; /* one per element + one per index event before this one */
+			step = dec_div(d.hi - d.lo + 1, idxtotal);
 			uint32_t cl = 0, fq = 0;
 			rank = LDS ? find_in_array_pre(s_idx, i0, D, d.buf - d.lo, step, lane, cl, fq) : find_in_array(t.gidx, D, d.buf - d.lo, step, lane, cl, fq);
 			if (X3_UNLIKELY(rank == 0xFFFFFFFFu)) { s.status = X3_ST_CORRUPT; break; }
 			if (X3_UNLIKELY(!dec_narrow(d, br, step, cl, cl + fq))) { s.status = X3_ST_CORRUPT; break; }
 			if (LDS) { tag = X3_LIKELY(rank < X3_WAVE) ? x3_readlane_u32(m0, rank) : x3_uniform((uint32_t)s_mtf[rank]); x3_wave_order(); if (lane == 0) s_idx[rank] = fq + 1; } /* inc_model(&model_index1, index), x3.c:89 */
 			else { tag = x3_uniform(t.gmtf[rank]); x3_wave_order(); if (lane == 0) t.gidx[rank] = fq + 1; }
-			s.idxtotal++;
 		} else {
 			const X3CtxHdr hc = decision == X3_E_CTX0 ? h0 : h1;
 			if (X3_UNLIKELY(hc.items == 0 || hc.total == 0)) { s.status = X3_ST_CORRUPT; break; }
@@ -538,7 +537,7 @@ __device__ static __forceinline__ bool dec_loop(const DecT &t, DecS &s, uint16_t
 		if (X3_LIKELY(q1.found)) ord = X3_LIKELY(q1.pos < X3_WAVE) ? x3_readlane_u32(po1, q1.pos) : x3_uniform(pord[(uint64_t)h1.off + q1.pos]);
 		else {
 			ord = s.npairs;
-			if (ctx1tag == 0 && tag == 0) { s.ord00 = s.npairs; s.have00 = 1; }
+			if (ctx1tag == 0 && tag == 0) s.ord00 = s.npairs;
 			s.npairs++;
 		}
 		/* the next context0 list: a new pair's header is still all zero (the workspace is cleared per batch), and when the pair repeats itself
@@ -609,7 +608,7 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 	t.ht = a.ht + ck.ht_off; t.hlog = ck.ht_log2; t.hmask = (1u << ck.ht_log2) - 1;
 	t.gmtf = a.mtf + ck.tag_off; t.gidx = a.idxfreq + ck.tag_off;
 	t.ctx1 = a.ctx1 + ck.tag_off; t.ctx0 = a.ctx0 + ck.ctx0_off;
-	t.pool = a.items + ck.item_off; t.pord = a.item_ord + ck.item_off; t.pool_cap = ck.item_cap;
+	t.pool = a.items + ck.item_off; t.pord = a.item_ord + ck.item_off; t.pool_cap = (uint32_t)ck.item_cap; /* 8 * capacity + 64 <= 2^30 + 64 */
 	t.cap = ck.out_cap;
 
 	DecS s;
@@ -617,16 +616,16 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 	s.d.lo = 0; s.d.hi = 0x7FFFFFFFu; s.d.buf = 0; /* ac_init */
 	s.d.buf = br_take(s.br, 31); /* ac_decode_init, ac.c:133-140 */
 	s.evf = lane < 2 ? 1024u : lane < 5 ? 1u : 0u; s.evtotal = 2051; /* create(), x3.c:236-244 */
-	s.lf = 1; s.lftotal = 32;
-	s.cf0 = s.cf1 = s.cf2 = s.cf3 = 1; s.cftotal = 256;
-	s.D = 0; s.idxtotal = 0; s.npairs = 0; s.status = X3_ST_OK;
+	s.lf = 1;
+	s.cf0 = s.cf1 = s.cf2 = s.cf3 = 1;
+	s.D = 0; s.npairs = 0; s.status = X3_ST_OK;
 	s.pool_top = 0;
 	s.ctx1tag = 0; s.p = 0;
 	s.n_c0id = 0;
 	s.n_h0.off = s.n_h0.items = s.n_h0.cap = s.n_h0.total = 0; /* both contexts are empty at the start */
 	s.n_h1 = s.n_h0;
 	s.n_it0 = s.n_it1 = 0; s.n_po1 = 0;
-	s.ord00 = 0; s.have00 = 0;
+	s.ord00 = 0xFFFFFFFFu;
 	s.pc_ev = s.pc_sym = s.pc_ctx = s.pc_tail = 0;
 	if (lane == 0) { s_c1off[0] = 0; s_c1tot[0] = 0; s_c1n[0] = 0; } /* the list of context 0 is looked at before element 0 exists */
 	x3_wave_order();
