@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define X3H_ABI_VERSION 3 /* 2: x3h_stats grew (mode_iters, chain_symbols, pipelined); 3: X3C1 container + multi-device batch entries */
+#define X3H_ABI_VERSION 4 /* 2: x3h_stats grew (mode_iters, chain_symbols, pipelined); 3: X3C1 container + multi-device batch entries; 4: x3h_decompress_chunks_dev */
 
 /* status codes (the reference abort()s on every error: file.c:9-18, x3.c:515,547,554,583) */
 enum {
@@ -111,6 +111,12 @@ int x3h_decompress(x3h_ctx *ctx, const uint8_t *in, size_t n, uint8_t *out, size
  * into out[out_offsets[c] .. out_offsets[c+1]) (that span is its capacity); out_lens[c] receives the decoded size. Host pointers. */
 int x3h_decompress_chunks(x3h_ctx *ctx, const uint8_t *in, const uint64_t *in_offsets, int nchunks,
                           uint8_t *out, const uint64_t *out_offsets, uint64_t *out_lens, x3h_stats *stats);
+
+/* Same, but `d_in` and `d_out` are DEVICE pointers on ctx's GPU: the streams are read and the bytes written where they are (no copy).
+ * d_in is 4-byte aligned and every in_offsets[c] a multiple of 4 (x3 streams are whole 32-bit words, so streams stored back to back
+ * qualify); in_offsets / out_offsets / out_lens stay host arrays. */
+int x3h_decompress_chunks_dev(x3h_ctx *ctx, const void *d_in, const uint64_t *in_offsets, int nchunks,
+                              void *d_out, const uint64_t *out_offsets, uint64_t *out_lens, x3h_stats *stats);
 
 /* ---- independent chunks across several GPUs + the X3C1 chunk container (SURVEY.md 8(b) batch form, 8(e), 8(f).2) --------------
  * The reference has one stream per file (x3.c:599-611) and no container.  Independent chunks are the only way the path shards

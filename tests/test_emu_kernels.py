@@ -87,6 +87,23 @@ def test_emulated_decoder_random_streams(emu, oracle):
         assert back == parts, f"case {case}: sizes {sizes} params {kw}"
 
 
+def test_emulated_device_resident_decode(emu, oracle):
+    """x3h_decompress_chunks_dev: streams read and bytes written in place (the emulator's device memory is host memory)"""
+    parts = [synth.english_like(900, seed=2).tobytes(), b"", synth.zipf_bytes(700, offset=5).tobytes(), b"z" * 300]
+    kw = dict(w_kib=1, t=3)
+    streams = [oracle.compress(q, oracle_lib.params(**kw)) for q in parts]
+    blob = np.frombuffer(b"".join(streams), dtype=np.uint8).copy()
+    ioff = np.cumsum([0] + [len(x) for x in streams]).astype(np.uint64)
+    caps = [len(q) + 3 for q in parts]
+    ooff = np.cumsum([0] + caps).astype(np.uint64)
+    out = np.full(int(ooff[-1]), 0xEE, dtype=np.uint8)
+    lens, _ = emu.decompress_chunks_dev(blob.ctypes.data, ioff, out.ctypes.data, ooff)
+    assert [int(x) for x in lens] == [len(q) for q in parts]
+    for i, q in enumerate(parts):
+        assert out[int(ooff[i]):int(ooff[i]) + len(q)].tobytes() == q
+        assert (out[int(ooff[i]) + len(q):int(ooff[i + 1])] == 0xEE).all()       # the slack of every capacity is untouched
+
+
 def test_emulated_decoder_errors(emu, golden):
     with pytest.raises(_lib.X3Error) as e:
         emu.decompress(golden["zeros5000"]["expect"], 100)   # ratio > 64:1 -- the reference overruns its buffer here (x3.c:621)

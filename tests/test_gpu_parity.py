@@ -2,6 +2,7 @@
 against the oracle on seeded inputs.  Bit-exact is the bar everywhere (byte / integer / index work)."""
 import numpy as np
 import pytest
+import torch  # before libx3hip.so is loaded: torch brings its own HIP runtime, and the process must end up with one (the first one loaded)
 
 import golden_util
 import oracle_lib
@@ -485,3 +486,36 @@ def test_many_streams_with_one_oversized_dictionary(gpu, oracle):
         assert streams[i] == gpu.compress(parts[i], prm), f"stream {i}"
     assert streams[3] == oracle.compress(parts[3], oracle_lib.params(**kw))
     assert gpu.decompress(streams[49], len(big)) == big
+
+
+def test_device_resident_batch_round_trip(gpu, oracle):
+    """x3h_compress_chunks_dev -> streams compacted back to back in HBM -> x3h_decompress_chunks_dev: nothing crosses PCIe but lengths;
+    streams equal the oracle's, decoded bytes equal the input, capacities exact and generous"""
+    rng = np.random.default_rng(11)
+    parts = [synth.english_like(5000, seed=1).tobytes(), b"", synth.zipf_bytes(3000, offset=9).tobytes(), bytes(2500), b"q",
+             rng.integers(0, 256, 1800, dtype=np.uint8).tobytes(), synth.mr_like(4000, seed=3).tobytes()]
+    kw = dict(w_kib=2, t=4)
+    sizes = [len(q) for q in parts]
+    off = np.cumsum([0] + sizes).astype(np.uint64)
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(np.frombuffer(b"".join(parts), dtype=np.uint8).copy()).to(dev)
+    stride = 8192
+    d_out = torch.zeros(stride * len(parts), dtype=torch.uint8, device=dev)
+    lens, _ = gpu.compress_chunks_dev(d_in.data_ptr(), off, _lib.make_params(**kw), d_out.data_ptr(), stride)
+    want = [oracle.compress(q, oracle_lib.params(**kw)) for q in parts]
+    for i, w in enumerate(want):
+        assert d_out[i * stride:i * stride + int(lens[i])].cpu().numpy().tobytes() == w, f"stream {i}"
+    d_cmp = torch.cat([d_out[i * stride:i * stride + int(lens[i])] for i in range(len(parts))])   # back to back: every offset a multiple of 4
+    ioff = np.cumsum([0] + [int(x) for x in lens]).astype(np.uint64)
+    caps = [n + (0 if i % 2 else 5) for i, n in enumerate(sizes)]
+    ooff = np.cumsum([0] + caps).astype(np.uint64)
+    d_back = torch.full((int(ooff[-1]) + 1,), 0xEE, dtype=torch.uint8, device=dev)
+    dlens, _ = gpu.decompress_chunks_dev(d_cmp.data_ptr(), ioff, d_back.data_ptr(), ooff)
+    assert [int(x) for x in dlens] == sizes
+    hb = d_back.cpu().numpy()
+    for i, q in enumerate(parts):
+        assert hb[int(ooff[i]):int(ooff[i]) + sizes[i]].tobytes() == q, f"decoded stream {i}"
+    assert hb[-1] == 0xEE                                                          # nothing written past the last capacity
+    with pytest.raises(_lib.X3Error) as e:                                         # an offset that is not a multiple of 4
+        gpu.decompress_chunks_dev(d_cmp.data_ptr(), np.array([2, int(ioff[1])], dtype=np.uint64), d_back.data_ptr(), ooff[:2])
+    assert e.value.status == -1

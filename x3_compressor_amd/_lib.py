@@ -17,7 +17,7 @@ DEFAULT_SO = os.path.join(HERE, "csrc", "libx3hip.so")
 ABI_SYMBOLS = (
     "x3h_abi_version", "x3h_strerror", "x3h_last_hip_error", "x3h_device_count", "x3h_default_params",
     "x3h_compress_bound", "x3h_ctx_create", "x3h_ctx_destroy", "x3h_compress", "x3h_compress_chunks",
-    "x3h_compress_chunks_dev", "x3h_decompress", "x3h_decompress_chunks", "x3h_scan_m", "x3h_scan_counts", "x3h_parse",
+    "x3h_compress_chunks_dev", "x3h_decompress", "x3h_decompress_chunks", "x3h_decompress_chunks_dev", "x3h_scan_m", "x3h_scan_counts", "x3h_parse",
     "x3h_compress_chunks_multi", "x3h_decompress_chunks_multi", "x3h_container_header_bytes", "x3h_container_write_header",
     "x3h_container_probe", "x3h_container_table", "x3h_container_bound", "x3h_compress_container", "x3h_decompress_container",
     "x3h_coder_chain",
@@ -26,7 +26,7 @@ ABI_SYMBOLS = (
 TOK_MISS, TOK_DUP = 0x80000000, 0x40000000
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 NOT_A_CONTAINER = 1  # x3h_container_probe: the bytes are one raw x3 stream
 
 
@@ -88,6 +88,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.x3h_coder_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     ctxs = C.POINTER(C.c_void_p)
     lib.x3h_compress_chunks_multi.argtypes = [ctxs, C.c_int, C.POINTER(Params), u8p, C.c_void_p, C.c_int, u8p, C.c_uint64, C.c_void_p, C.POINTER(Stats)]
+    lib.x3h_decompress_chunks_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
     lib.x3h_decompress_chunks_multi.argtypes = [ctxs, C.c_int, u8p, C.c_void_p, C.c_int, u8p, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
     lib.x3h_container_header_bytes.restype = C.c_size_t
     lib.x3h_container_header_bytes.argtypes = [C.c_int]
@@ -188,6 +189,18 @@ class X3Context:
         st = Stats()
         self._check(self.lib.x3h_compress_chunks_dev(self._h, C.byref(prm), C.c_void_p(d_in), off.ctypes.data, nch,
                                                      C.c_void_p(d_out), stride, lens.ctypes.data, C.byref(st)))
+        self.last_stats = st
+        return lens, st
+
+    def decompress_chunks_dev(self, d_in: int, in_offsets, d_out: int, out_offsets):
+        """Device-resident decode: streams back to back at d_in (offsets multiples of 4), stream c decodes into d_out[out_offsets[c]:out_offsets[c+1]). -> (lens, Stats)"""
+        ioff = np.ascontiguousarray(in_offsets, dtype=np.uint64)
+        ooff = np.ascontiguousarray(out_offsets, dtype=np.uint64)
+        nch = ioff.size - 1
+        lens = np.zeros(nch, dtype=np.uint64)
+        st = Stats()
+        self._check(self.lib.x3h_decompress_chunks_dev(self._h, C.c_void_p(d_in), ioff.ctypes.data, nch, C.c_void_p(d_out), ooff.ctypes.data,
+                                                       lens.ctypes.data, C.byref(st)))
         self.last_stats = st
         return lens, st
 

@@ -660,8 +660,10 @@ extern "C" int x3h_parse(x3h_ctx *ctx, const x3h_params *prm, const uint8_t *in,
 }
 
 /* ------------------------------------------------------------------------------------------------------------ */
+/* dev: `in` / `out` are device pointers on c's GPU -- the kernel reads the streams and writes the bytes where they are, no copy at all
+ * (stream c at in + in_offsets[c], a multiple of 4 from a 4-byte aligned base; its bytes at out + out_offsets[c]) */
 static int decompress_batch(x3h_ctx *c, const uint8_t *in, const uint64_t *in_offsets, int nchunks,
-                            uint8_t *out, const uint64_t *out_offsets, uint64_t *out_lens, x3h_stats *stats)
+                            uint8_t *out, const uint64_t *out_offsets, uint64_t *out_lens, x3h_stats *stats, bool dev = false)
 {
 	if (!c || !in_offsets || !out_offsets || !out_lens || nchunks <= 0 || (!in && in_offsets[nchunks] != in_offsets[0])) return X3H_E_ARG;
 	HIPCHK(hipSetDevice(c->device));
@@ -673,14 +675,15 @@ static int decompress_batch(x3h_ctx *c, const uint8_t *in, const uint64_t *in_of
 		const uint64_t ilen = in_offsets[i + 1] - in_offsets[i], cap = out_offsets[i + 1] - out_offsets[i];
 		if (ilen > 0xFFFFFFF0ull || cap > X3H_MAX_CHUNK) return X3H_E_ARG;
 		X3DecChunk &k = dk[(size_t)i];
-		k.in_off = ioff; k.in_len = (uint32_t)ilen; k.out_cap = (uint32_t)cap; k.out_off = ooff;
+		k.in_off = dev ? in_offsets[i] : ioff; k.in_len = (uint32_t)ilen; k.out_cap = (uint32_t)cap; k.out_off = dev ? out_offsets[i] : ooff;
+		if (dev && (in_offsets[i] & 3)) return X3H_E_ARG;
 		k.tag_off = toff; k.ctx0_off = c0off; k.item_off = itoff; k.item_cap = 8 * cap + 64;
 		k.ht_log2 = ceil_log2(2 * (cap + 1)); if (k.ht_log2 < 4) k.ht_log2 = 4; k.ht_off = hoff;
 		ioff += align_up(ilen, 16) + 16; ooff += align_up(cap, 256) + 256;
 		toff += cap + 8; c0off += cap + 8; itoff += k.item_cap; hoff += (uint64_t)1 << k.ht_log2;
 	}
-	CHK(c->din.reserve(ioff + 64));
-	CHK(c->out.reserve(ooff + 256));
+	if (dev && (((uintptr_t)in & 3) || (!out && out_offsets[nc] != out_offsets[0]))) return X3H_E_ARG;
+	if (!dev) { CHK(c->din.reserve(ioff + 64)); CHK(c->out.reserve(ooff + 256)); }
 	CHK(c->dchunks.reserve((size_t)nc * sizeof(X3DecChunk)));
 	CHK(c->cresult.reserve((size_t)nc * sizeof(X3CodeResult)));
 	CHK(c->dict_pos.reserve(toff * 4)); CHK(c->dict_len.reserve(toff));
@@ -688,7 +691,7 @@ static int decompress_batch(x3h_ctx *c, const uint8_t *in, const uint64_t *in_of
 	CHK(c->ctx1.reserve(toff * sizeof(X3CtxHdr))); CHK(c->ctx0.reserve(c0off * sizeof(X3CtxHdr)));
 	CHK(c->items.reserve(itoff * 8)); CHK(c->items_ord.reserve(itoff * 4)); CHK(c->ht.reserve(hoff * 4));
 	HIPCHK(hipEventRecord(c->ev[0], c->stream));
-	for (int i = 0; i < nc; i++)
+	for (int i = 0; i < nc && !dev; i++)
 		if (dk[(size_t)i].in_len)
 			HIPCHK(hipMemcpyAsync(c->din.as<uint8_t>() + dk[(size_t)i].in_off, in + in_offsets[i], dk[(size_t)i].in_len, hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipMemcpyAsync(c->dchunks.p, dk.data(), (size_t)nc * sizeof(X3DecChunk), hipMemcpyHostToDevice, c->stream));
@@ -696,7 +699,7 @@ static int decompress_batch(x3h_ctx *c, const uint8_t *in, const uint64_t *in_of
 	HIPCHK(hipMemsetAsync(c->ctx0.p, 0, c0off * sizeof(X3CtxHdr), c->stream));
 	HIPCHK(hipMemsetAsync(c->ht.p, 0, hoff * 4, c->stream));
 	X3DecArgs da;
-	da.in = c->din.as<uint8_t>(); da.chunks = c->dchunks.as<X3DecChunk>(); da.out = c->out.as<uint8_t>();
+	da.in = dev ? in : c->din.as<uint8_t>(); da.chunks = c->dchunks.as<X3DecChunk>(); da.out = dev ? out : c->out.as<uint8_t>();
 	da.dict_pos = c->dict_pos.as<uint32_t>(); da.dict_len = c->dict_len.as<uint8_t>(); da.ht = c->ht.as<uint32_t>();
 	da.mtf = c->mtf.as<uint32_t>(); da.idxfreq = c->idxfreq.as<uint32_t>();
 	da.ctx1 = c->ctx1.as<X3CtxHdr>(); da.ctx0 = c->ctx0.as<X3CtxHdr>(); da.items = c->items.as<uint64_t>();
@@ -719,7 +722,7 @@ static int decompress_batch(x3h_ctx *c, const uint8_t *in, const uint64_t *in_of
 		else if (r.status == X3_ST_OUT_FULL && rc == X3H_OK) rc = X3H_E_OUTPUT_FULL;
 		else if (r.status != X3_ST_OK && rc == X3H_OK) rc = X3H_E_INTERNAL;
 	}
-	if (rc == X3H_OK) {
+	if (rc == X3H_OK && !dev) {
 		for (int i = 0; i < nc; i++)
 			if (c->hcode[(size_t)i].out_len)
 				HIPCHK(hipMemcpyAsync(out + out_offsets[i], c->out.as<uint8_t>() + dk[(size_t)i].out_off, c->hcode[(size_t)i].out_len, hipMemcpyDeviceToHost, c->stream));
@@ -741,13 +744,13 @@ static int decompress_batch(x3h_ctx *c, const uint8_t *in, const uint64_t *in_of
 
 /* The decoder's tables are sized from the output capacity (~150 B per byte), so a batch whose capacities add up to more than
  * `dec_batch_bytes` (X3H_DEC_BATCH_BYTES, default 512 MiB) is decoded as consecutive sub-batches; streams are independent. */
-extern "C" int x3h_decompress_chunks(x3h_ctx *c, const uint8_t *in, const uint64_t *in_offsets, int nchunks,
-                                     uint8_t *out, const uint64_t *out_offsets, uint64_t *out_lens, x3h_stats *stats)
+static int decompress_chunks(x3h_ctx *c, const uint8_t *in, const uint64_t *in_offsets, int nchunks,
+                             uint8_t *out, const uint64_t *out_offsets, uint64_t *out_lens, x3h_stats *stats, bool dev)
 {
 	if (!c || !in_offsets || !out_offsets || !out_lens || nchunks <= 0) return X3H_E_ARG;
 	const uint64_t limit = c->dec_batch_bytes;
 	if (out_offsets[nchunks] < out_offsets[0]) return X3H_E_ARG;
-	if (nchunks == 1 || out_offsets[nchunks] - out_offsets[0] <= limit) return decompress_batch(c, in, in_offsets, nchunks, out, out_offsets, out_lens, stats);
+	if (nchunks == 1 || out_offsets[nchunks] - out_offsets[0] <= limit) return decompress_batch(c, in, in_offsets, nchunks, out, out_offsets, out_lens, stats, dev);
 	x3h_stats acc, part;
 	memset(&acc, 0, sizeof acc);
 	int first = 0, rc = X3H_OK;
@@ -755,7 +758,7 @@ extern "C" int x3h_decompress_chunks(x3h_ctx *c, const uint8_t *in, const uint64
 		int last = first + 1;
 		while (last < nchunks && out_offsets[last + 1] >= out_offsets[first] && out_offsets[last + 1] - out_offsets[first] <= limit) last++;
 		memset(&part, 0, sizeof part);
-		const int r = decompress_batch(c, in, in_offsets + first, last - first, out, out_offsets + first, out_lens + first, &part);
+		const int r = decompress_batch(c, in, in_offsets + first, last - first, out, out_offsets + first, out_lens + first, &part, dev);
 		stats_add(acc, part);
 		if (r != X3H_OK && rc == X3H_OK) rc = r;
 		if (r != X3H_OK && r != X3H_E_OUTPUT_FULL && r != X3H_E_CORRUPT) { for (int i = first; i < nchunks; i++) out_lens[i] = 0; break; }
@@ -763,6 +766,17 @@ extern "C" int x3h_decompress_chunks(x3h_ctx *c, const uint8_t *in, const uint64
 	}
 	if (stats) *stats = acc;
 	return rc;
+}
+
+extern "C" int x3h_decompress_chunks(x3h_ctx *c, const uint8_t *in, const uint64_t *in_offsets, int nchunks,
+                                     uint8_t *out, const uint64_t *out_offsets, uint64_t *out_lens, x3h_stats *stats)
+{
+	return decompress_chunks(c, in, in_offsets, nchunks, out, out_offsets, out_lens, stats, false);
+}
+extern "C" int x3h_decompress_chunks_dev(x3h_ctx *c, const void *d_in, const uint64_t *in_offsets, int nchunks,
+                                         void *d_out, const uint64_t *out_offsets, uint64_t *out_lens, x3h_stats *stats)
+{
+	return decompress_chunks(c, (const uint8_t *)d_in, in_offsets, nchunks, (uint8_t *)d_out, out_offsets, out_lens, stats, true);
 }
 
 extern "C" int x3h_decompress(x3h_ctx *ctx, const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len, x3h_stats *stats)
