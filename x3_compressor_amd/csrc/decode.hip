@@ -280,6 +280,9 @@ __device__ static __forceinline__ uint32_t dec_cap_of(uint32_t n) { return n == 
 #ifndef X3_DEC_LDS
 #define X3_DEC_LDS 4096u /* dictionary elements whose tables live in LDS, 20 bytes each: recency list, index-model frequency, (position, length), header of the element's context1 list */
 #endif
+#ifndef X3_DEC_LDS_MID
+#define X3_DEC_LDS_MID 2048u /* ... in batches of up to 1024 streams: 40 KiB per stream, four streams (one per SIMD) share a CU */
+#endif
 #ifndef X3_DEC_LDS_SMALL
 #define X3_DEC_LDS_SMALL 512u /* ... in batches of many streams: 10 KiB of LDS per stream, so sixteen streams share a CU (the batch rate is streams in flight x the per-stream rate) */
 #endif
@@ -656,12 +659,14 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 
 #ifndef X3_EMU
 __global__ void __launch_bounds__(X3_WAVE) x3_decode_kernel(X3DecArgs a) { x3_decode_body<X3_DEC_LDS>(a); }
+__global__ void __launch_bounds__(X3_WAVE) x3_decode_mid_kernel(X3DecArgs a) { x3_decode_body<X3_DEC_LDS_MID>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_decode_many_kernel(X3DecArgs a) { x3_decode_body<X3_DEC_LDS_SMALL>(a); }
 extern "C" void x3k_launch_decode(const X3DecArgs *a, uint32_t nchunks, hipStream_t st)
 {
-	/* one wavefront per stream; the LDS tables decide how many streams share a CU: a few streams get the big tables (no spill to
-	 * global memory up to 16384 elements), a batch that oversubscribes the chip gets small ones (ten streams per CU) */
-	if (nchunks > 256) hipLaunchKernelGGL(x3_decode_many_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, *a);
+	/* one wavefront per stream; the LDS tables decide how many streams share a CU: up to one stream per CU gets the big tables (4096
+	 * elements before they migrate to global memory), up to one per SIMD the middle ones, a batch beyond that the small ones (16 per CU) */
+	if (nchunks > 1024) hipLaunchKernelGGL(x3_decode_many_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, *a);
+	else if (nchunks > 256) hipLaunchKernelGGL(x3_decode_mid_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, *a);
 	else hipLaunchKernelGGL(x3_decode_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, *a);
 }
 #else
