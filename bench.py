@@ -259,7 +259,7 @@ def main():
                      "frac": round(kernels[dom]["alg_bytes"] / (kernels[dom]["ms"] * 1e-3) / HBM_PEAK, 7), "traffic": traffic,
                      "traffic_source": traffic_src, "algorithmic_bytes": kernels[dom]["alg_bytes"], "kernel_ms": kernels[dom]["ms"],
                      "launches_per_step": 5 if int(st.pipelined) else 1,
-                     "note": "dominant kernel by time: ONE wavefront's dependent chain per stream, 14.2 scalar instructions per symbol at the 4-cycle single-wave issue rate, operands and chain states through the scalar cache; HBM is the stated bound, not the limiter (255 of 256 CUs idle: the x3 format fixes one adaptive coder chain per stream)"},
+                     "note": "dominant kernel by time: ONE wavefront's dependent chain per stream, 13 scalar instructions per symbol at the 4-cycle single-wave issue rate, operands and chain states through the scalar cache; HBM is the stated bound, not the limiter (255 of 256 CUs idle: the x3 format fixes one adaptive coder chain per stream)"},
         "kernels": kernels,
         "path_roofline": {"algorithmic_bytes": path_bytes, "achieved_GBps": round(path_bytes / (ms_per_step * 1e-3) / 1e9, 2),
                           "frac_of_hbm_peak": round(path_bytes / (ms_per_step * 1e-3) / HBM_PEAK, 5),
