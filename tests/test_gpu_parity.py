@@ -519,3 +519,21 @@ def test_device_resident_batch_round_trip(gpu, oracle):
     with pytest.raises(_lib.X3Error) as e:                                         # an offset that is not a multiple of 4
         gpu.decompress_chunks_dev(d_cmp.data_ptr(), np.array([2, int(ioff[1])], dtype=np.uint64), d_back.data_ptr(), ooff[:2])
     assert e.value.status == -1
+
+
+@pytest.mark.parametrize("nstreams,nbytes,vocab,floor", [(1, 1_500_000, 12_000, 4096), (300, 150_000, 3_500, 2048), (1100, 40_000, 1_000, 512)],
+                         ids=["big_tables_4096", "middle_tables_2048", "small_tables_512"])
+def test_decoder_tables_migrate_out_of_lds(gpu, nstreams, nbytes, vocab, floor):
+    """dictionaries that outgrow the decoder's LDS tables in each of its three kernel variants (random words of a large vocabulary, window =
+    the whole stream, -t 1: every word becomes an element -- ranks beyond 64, context lists beyond 64 items): the tables continue in
+    global memory mid-stream and the round trip is exact"""
+    rng = np.random.default_rng(77 + nstreams)
+    words = np.concatenate([rng.integers(97, 123, (vocab, 6), dtype=np.uint8), np.full((vocab, 1), 32, np.uint8)], axis=1)
+    data = np.ascontiguousarray(words[rng.integers(0, vocab, nstreams * nbytes // 7 + 1)].reshape(-1)[:nstreams * nbytes])
+    parts = [data[i * nbytes:(i + 1) * nbytes].tobytes() for i in range(nstreams)]
+    off = np.arange(0, (nstreams + 1) * nbytes, nbytes, dtype=np.uint64)
+    streams = gpu.compress_chunks(data, off, _lib.make_params(w_kib=2048, t=1))
+    back = gpu.decompress_chunks(streams, [nbytes + (i % 3) for i in range(nstreams)])
+    st = gpu.last_stats
+    assert st.dict_elems / nstreams > floor, f"only {st.dict_elems / nstreams:.0f} elements per stream, the spill path was not taken"
+    assert back == parts
