@@ -38,6 +38,8 @@ struct x3h_ctx {
 	/* single-stream pipelining (run_pipelined): the parse on its own stream publishes checkpoints, the coding stage of every prefix
 	 * runs while the parse continues, the coder recurrence of a segment on a third stream */
 	int pipe_max_streams = 32; /* X3H_PIPE_STREAMS */
+	double pipe_marks[X3_MAX_CKPT] = { 0.02, 0.08, 0.26, 0.62 }; /* where the parse publishes checkpoints (X3H_PIPE_MARKS: up to 8 ascending fractions) */
+	uint32_t pipe_nmarks = 4;
 	uint64_t pipe_min = (uint64_t)256 << 10; /* streams at least this long are pipelined (X3H_PIPE_MIN; 0: never): measured faster from 256 KiB up */
 	hipStream_t s_parse = nullptr, s_coder = nullptr;
 	hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr, ev_ready = nullptr, ev_cb[X3_MAX_CKPT + 1] = {}, ev_ce[X3_MAX_CKPT + 1] = {};
@@ -116,6 +118,12 @@ extern "C" int x3h_ctx_create(x3h_ctx **out, int device)
 	{ const char *e = getenv("X3H_BATCH_PAD_BYTES"); if (e && atoll(e) > 0) c->batch_pad_bytes = (uint64_t)atoll(e); }
 	if (c->batch_pad_bytes > 0xF0000000ull) c->batch_pad_bytes = 0xF0000000ull;
 	{ const char *e = getenv("X3H_PIPE_MIN"); if (e && *e) c->pipe_min = (uint64_t)atoll(e); }
+	{ const char *e = getenv("X3H_PIPE_MARKS");
+	  if (e && *e) { /* e.g. "0.02,0.08,0.26,0.62,0.85": anything malformed keeps the default */
+		double m[X3_MAX_CKPT]; uint32_t k = 0; const char *q = e; bool ok = true;
+		while (*q && k < X3_MAX_CKPT) { char *end = nullptr; const double v = strtod(q, &end); if (end == q || v <= (k ? m[k - 1] : 0.0) || v >= 1.0) { ok = false; break; } m[k++] = v; q = end; if (*q == ',') q++; }
+		if (ok && k && !*q) { for (uint32_t i = 0; i < k; i++) c->pipe_marks[i] = m[i]; c->pipe_nmarks = k; }
+	  } }
 	{ const char *e = getenv("X3H_PIPE_STREAMS"); if (e && *e) c->pipe_max_streams = atoi(e); }
 	if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return X3H_E_HIP; }
 	for (int i = 0; i < 6; i++)
@@ -272,8 +280,8 @@ static int run_pipelined_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_byte
                               uint8_t *d_out, PipeStats *ps)
 {
 	const uint32_t nc = (uint32_t)c->hchunks.size();
-	static const double marks[] = { 0.02, 0.08, 0.26, 0.62 };
-	const uint32_t nmarks = (uint32_t)(sizeof(marks) / sizeof(marks[0]));
+	const double *marks = c->pipe_marks;
+	const uint32_t nmarks = c->pipe_nmarks;
 	/* checkpoint memory (host-mapped) and the marks of every stream */
 	if (c->ckpt_cap < nc) {
 		if (c->ckpt) (void)hipHostFree((void *)c->ckpt);
