@@ -147,6 +147,14 @@ def test_emulated_pipelined_single_stream(emu_env, oracle, name, data, kw):
     assert ctx.compress(data, _lib.make_params(**kw)) == oracle.compress(data, oracle_lib.params(**kw))
 
 
+@pytest.mark.parametrize("marks", ["0.5", "0.1,0.2,0.3,0.4,0.5,0.6,0.7,0.8", "0.9,0.95", "garbage"])
+def test_emulated_pipelined_other_checkpoints(emu_env, oracle, marks):
+    """X3H_PIPE_MARKS: one checkpoint, the maximum of eight, late ones, and a malformed list (keeps the default): same bytes"""
+    ctx = emu_env(X3H_PIPE_MIN="1", X3H_PIPE_MARKS=marks)
+    data, kw = synth.english_like(7000, seed=9).tobytes(), dict(w_kib=2, t=4)
+    assert ctx.compress(data, _lib.make_params(**kw)) == oracle.compress(data, oracle_lib.params(**kw))
+
+
 @pytest.mark.parametrize("pipe", ["0", "1"])
 def test_emulated_fixed_point_modes(emu_env, oracle, pipe):
     """code2.hip modes_fixed_point (forced): the mode sequence as the fixed point of a chip-wide iteration."""

@@ -43,7 +43,8 @@ def ctx_for(env):
 
 ENVS = [dict(), dict(X3H_PIPE_MIN="1"), dict(X3H_PIPE_MIN="1", X3H_MODES="fixed"), dict(X3H_PIPE_MIN="0", X3H_MODES="serial"), dict(X3H_PIPE_MIN="0", X3H_MODES="fixed"),
         dict(X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0"), dict(X3H_STREAM_KERNELS="0"), dict(X3H_WALK_DENSE="16"), dict(X3H_WALK_DENSE="40", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0"),
-        dict(X3H_PIPE_MIN="1", X3H_MODES="serial"), dict(X3H_CTX_SUB="3")]
+        dict(X3H_PIPE_MIN="1", X3H_MODES="serial"), dict(X3H_CTX_SUB="3"), dict(X3H_PIPE_MIN="1", X3H_PIPE_MARKS="0.1,0.2,0.3,0.4,0.5,0.6,0.7,0.8"),
+        dict(X3H_PIPE_MIN="1", X3H_PIPE_MARKS="0.6")]
 t0, cases = time.time(), 0
 while time.time() - t0 < budget:
     nch = int(rng.choice([1, 1, 1, 2, 3, 7, 40, 60, 130, 300]))   # >= 48: the per-stream kernels of code3.hip; 300: above the switch to the small-LDS kernel variants
