@@ -104,6 +104,34 @@ def test_emulated_device_resident_decode(emu, oracle):
         assert (out[int(ooff[i]) + len(q):int(ooff[i + 1])] == 0xEE).all()       # the slack of every capacity is untouched
 
 
+def test_emulated_decoder_survives_damaged_streams(emu, oracle):
+    """bit flips, overwritten bytes, truncation and plain noise: the decoder ends with a status (corrupt / output full) or some output --
+    never a fault or a hang (the reference abort()s or overruns its buffer, ac.c:178, x3.c:621)"""
+    rng = np.random.default_rng(99)
+    base = [oracle.compress(synth.english_like(2500, seed=s).tobytes(), oracle_lib.params(w_kib=1, t=2)) for s in range(2)]
+    base.append(oracle.compress(synth.zipf_bytes(2000, offset=7).tobytes(), oracle_lib.params(w_kib=1, t=1)))
+    seen = set()
+    for case in range(60):
+        kind = case % 4
+        if kind == 0:
+            s = bytes(rng.integers(0, 256, int(rng.integers(0, 300)) * 4, dtype=np.uint8))
+        else:
+            b = bytearray(base[int(rng.integers(0, len(base)))])
+            for _ in range(int(rng.integers(1, 5))):
+                i = int(rng.integers(0, len(b)))
+                if kind == 1: b[i] ^= 1 << int(rng.integers(0, 8))
+                elif kind == 2: b[i] = int(rng.integers(0, 256))
+                else: b = b[:max(4, (i // 4) * 4)]
+            s = bytes(b)
+        try:
+            emu.decompress(s, int(rng.choice([0, 10, 3000, 50000])))
+            seen.add(0)
+        except _lib.X3Error as e:
+            assert e.status in (-3, -4), e.status
+            seen.add(e.status)
+    assert -4 in seen and -3 in seen
+
+
 def test_emulated_decoder_errors(emu, golden):
     with pytest.raises(_lib.X3Error) as e:
         emu.decompress(golden["zeros5000"]["expect"], 100)   # ratio > 64:1 -- the reference overruns its buffer here (x3.c:621)
