@@ -172,7 +172,10 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 		HIPCHK(hipMemsetAsync(d_m, 0, P, st));
 		return X3H_OK;
 	}
-	for (int i = 0; i < 8; i++) CHK(B.a[i].reserve((P + 8) * 4));
+	uint64_t max_len = 0;
+	for (uint32_t c = 0; c < nc; c++) if (h_chunks[c].len > max_len) max_len = h_chunks[c].len;
+	const bool seg = x3_scan_seg_applies(nc, max_len); /* many chunks: one workgroup per chunk sorts and tests its own positions (scan3.hip) */
+	for (int i = 0; i < 8; i++) CHK(B.a[i].reserve((P + 8) * (seg && i < 2 ? 8 : 4)));
 	CHK(B.a[9].reserve(((size_t)P / 32 + 2) * 4 + 64)); /* padding bitmap */
 	CHK(B.misc.reserve(64));
 	uint32_t *keys = B.a[0].as<uint32_t>(), *iota = B.a[1].as<uint32_t>();
@@ -183,7 +186,7 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 	CHK(B.a[8].reserve((P / 32 + 2) * 4));
 	uint32_t *rare = B.a[8].as<uint32_t>();
 	HIPCHK(hipMemsetAsync(rare, 0, (P / 32 + 2) * 4, st));
-	HIPCHK(hipMemsetAsync(d_m, 0, P, st));
+	if (!seg) HIPCHK(hipMemsetAsync(d_m, 0, P, st));
 	uint32_t *act = B.a[5].as<uint32_t>(), *act_k = B.a[6].as<uint32_t>(), *act_j = B.a[7].as<uint32_t>();
 	uint32_t *d_nact = B.misc.as<uint32_t>(), *d_dense = d_nact + 1;
 	HIPCHK(hipMemsetAsync(d_nact, 0, 8, st));
@@ -218,12 +221,36 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 	/* K = min(T+1, count_0) and count_0 <= ncand: any T >= ncand behaves like T = ncand */
 	const uint32_t Tu = (uint32_t)T > ncand ? ncand : (uint32_t)T, Pn = (uint32_t)P;
 
+	uint32_t *S = nullptr;
+	const uint32_t *ks4 = nullptr;
+	if (seg) {
+		X3SegArgs ga;
+		ga.bytes = d_bytes; ga.chunks = d_chunks; ga.la = B.a[0].as<uint2>(); ga.lb = B.a[1].as<uint2>();
+		ga.S4 = B.a[2].as<uint32_t>(); ga.K4 = B.a[3].as<uint32_t>(); ga.m = d_m; ga.rare = rare; ga.kexact = kexact;
+		ga.act = act; ga.act_k = act_k; ga.act_j = act_j; ga.nact = d_nact;
+		ga.window = window; ga.ncand = ncand; ga.Tu = Tu; ga.dense_at = dense_at;
+		if (getenv("X3H_DEBUG")) fprintf(stderr, "[x3h] scan: one workgroup per chunk (%u chunks, longest %llu)\n", nc, (unsigned long long)max_len);
+		ga.prof = nullptr;
+		const bool prof = getenv("X3H_SEG_PROF") != nullptr;
+		if (prof) { CHK(B.a[22].reserve(128)); HIPCHK(hipMemsetAsync(B.a[22].p, 0, 128, st)); ga.prof = B.a[22].as<uint64_t>(); }
+		CHK(x3_scan_seg_launch(ga, nc, st));
+		if (prof) {
+			uint64_t h[16];
+			HIPCHK(hipMemcpyAsync(h, B.a[22].p, 128, hipMemcpyDeviceToHost, st));
+			HIPCHK(hipStreamSynchronize(st));
+			fprintf(stderr, "[x3h] scan3 kcycles per chunk: keys %llu | passes %llu %llu %llu %llu | levels %llu %llu %llu %llu\n", (unsigned long long)(h[0] / nc / 1000),
+			        (unsigned long long)(h[1] / nc / 1000), (unsigned long long)(h[2] / nc / 1000), (unsigned long long)(h[3] / nc / 1000), (unsigned long long)(h[4] / nc / 1000),
+			        (unsigned long long)(h[5] / nc / 1000), (unsigned long long)(h[6] / nc / 1000), (unsigned long long)(h[7] / nc / 1000), (unsigned long long)(h[8] / nc / 1000));
+		}
+		S = ga.S4; ks4 = ga.K4;
+	} else {
 	/* element q: key = the four bytes ENDING at q (bytes before the buffer read as 0), value = q */
 	x3_foreach(P, st, X3_LAMBDA(size_t q) {
 		iota[q] = (uint32_t)q;
 		keys[q] = q >= 3 ? __builtin_bswap32(load_gram(d_bytes, q - 3, 4)) : __builtin_bswap32(load_gram(d_bytes, 0, 4) << (8 * (3 - (uint32_t)q)));
 	});
-	uint32_t *kin = keys, *vin = iota, *ks = B.a[2].as<uint32_t>(), *S = B.a[3].as<uint32_t>();
+	uint32_t *kin = keys, *vin = iota, *ks = B.a[2].as<uint32_t>();
+	S = B.a[3].as<uint32_t>();
 	for (uint32_t l = 1; l <= 4; l++) {
 		/* pass l of the LSD sort: the list is now ordered by the l-gram starting at p = q-(l-1) (stable: ascending positions inside a class) */
 		/* (rocPRIM 4.2's small-input merge path builds its digit mask with 1 << end_bit, which is wrong for end_bit == 32: below its
@@ -288,7 +315,8 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 		t = vin; vin = S; S = t;
 	}
 	S = vin; /* list 4 (the last pass's output); kin holds its sorted keys */
-	const uint32_t *ks4 = kin;
+	ks4 = kin;
+	}
 
 	/* active positions: one wavefront each over the in-window candidates of its 4-gram class */
 	uint32_t hcnt[2] = { 0, 0 };

@@ -76,6 +76,28 @@ struct X3Scan2Bufs { DevBuf a[24]; DevBuf misc; };
 int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, const X3Chunk *h_chunks, const X3Chunk *d_chunks,
                    const uint8_t *d_bytes, uint8_t *d_m, uint64_t total, uint32_t window, int32_t T);
 
+/* ---- K1 for many chunks: one workgroup per chunk (scan3.hip) ------------------------------------------------- */
+#define X3_SEG_THREADS 1024u
+#ifndef X3_SEG_MAXLEN
+#define X3_SEG_MAXLEN (384u << 10)   /* longest chunk whose 2-bit level counters fit the workgroup's LDS (96 KiB) */
+#endif
+#ifndef X3_SEG_MIN_STREAMS
+#define X3_SEG_MIN_STREAMS 48u       /* fewer chunks: the chip-wide sort of scan2.hip */
+#endif
+struct X3SegArgs {
+	const uint8_t *bytes;        /* padded chunks */
+	const X3Chunk *chunks;
+	uint2 *la, *lb;              /* ping-pong lists of (key, END position), one entry per position of the padded layout; chunk c's list starts at entry byte_off */
+	uint32_t *S4, *K4;           /* out: list 4 (END positions ordered by 4-gram) and its keys, same layout; slot tails hold fillers */
+	uint8_t *m;                  /* out: m[p] for levels 0..3 (the walk kernel raises it where the 4-gram repeats often enough) */
+	uint32_t *rare, *kexact;     /* out: positions with K < T+1 (bitmap, zeroed by the caller) and their K */
+	uint32_t *act, *act_k, *act_j, *nact; /* out: positions for the walk kernel; nact[0] = their number, nact[1] = a dense class was met */
+	uint32_t window, ncand, Tu, dense_at;
+	uint64_t *prof;              /* nullptr, or 16 cycle counters: phase 0, passes 1-4, levels 1-4 (X3H_SEG_PROF, debugging) */
+};
+bool x3_scan_seg_applies(uint32_t nchunks, uint64_t max_len);
+int x3_scan_seg_launch(const X3SegArgs &a, uint32_t nchunks, hipStream_t st);
+
 /* ---- v2 coding stage (code2.hip) ------------------------------------------------------------------------- */
 struct X3Code2Stats { double ms_features, ms_modes, ms_coder, ms_emit; uint64_t symbols, chain_symbols; int mode_iters; /* fixed-point iterations of the mode choice (0: serial kernel, < 0: not converged, serial kernel ran) */ };
 

@@ -189,6 +189,22 @@ def mr_like(n: int = MR_BYTES, seed: int = 0x4D52) -> np.ndarray:
     return out[:n].copy()
 
 
+# sizes of the 12 Silesia files, in the corpus' alphabetical order
+SILESIA = dict(dickens=10192446, mozilla=51220480, mr=9970564, nci=33553445, ooffice=6152192, osdb=10085684, reymont=6627202,
+               samba=21606400, sao=7251944, webster=41458703, xray=8474240, xml=5345280)
+
+
+def config3_part_spec(i: int) -> tuple[str, dict]:
+    """(generator name, kwargs) of stream i of the config-3 stand-in: every third stream Zipf bytes, the others text"""
+    n = list(SILESIA.values())[i]
+    return ("english_like", dict(n=n, seed=1000 + i)) if i % 3 else ("zipf_bytes", dict(n=n, offset=i << 26))
+
+
+def config3_part(i: int) -> np.ndarray:
+    g, kw = config3_part_spec(i)
+    return globals()[g](**kw)
+
+
 def workload(name: str, n: int | None = None) -> np.ndarray:
     """Named workloads used by bench.py / tests: 'dickens-like', 'zipf', 'mr-like'."""
     if name == "mr-like":
