@@ -42,9 +42,49 @@ __device__ static __forceinline__ uint64_t seg_match8(uint32_t d, bool valid)
 	return mask;
 }
 
+/* the test of level lv (gram length lv) for entry j = `it` of list lv; `la` = entry j + T + 1 of the same list (position 0xFFFFFFFF when
+ * there is none); list = list lv as (key, position) pairs.  Level 1 fixes K = min(T+1, count_0) (positions with a smaller K are marked in
+ * `rbits`, their K goes to kexact); levels 2, 3 add one to the position's 2-bit counter when count_{lv-1} >= K. */
+__device__ static __forceinline__ void seg_level(uint32_t lv, const uint2 it, const uint2 la, uint32_t j, const uint2 *list, uint32_t L, uint32_t n,
+                                                 uint32_t base, uint32_t ncand, uint32_t Tu, uint32_t *mfield, uint32_t *rbits, uint32_t *kexact)
+{
+	if (lv == 1u) {
+		const uint32_t prel = it.y - base;
+		if (prel >= n) return; /* padding: an occurrence, never a query */
+		const uint32_t kj = it.x & 0xFFu, wend = prel + ncand;
+		if ((la.x & 0xFFu) == kj && la.y - base <= wend) return; /* the (T+1)-th next occurrence of the byte is inside the window: K = T+1 */
+		uint32_t lo = 0, bnd = Tu; /* count them: binary search, predicate true at lo */
+		if (j + bnd >= L) bnd = L - 1u - j;
+		while (lo < bnd) {
+			const uint32_t mid = (lo + bnd + 1u) >> 1;
+			const uint2 em = list[j + mid];
+			if ((em.x & 0xFFu) == kj && em.y - base <= wend) lo = mid; else bnd = mid - 1u;
+		}
+		kexact[it.y] = lo; /* == count_0 */
+		atomicOr(&rbits[prel >> 5], 1u << (prel & 31u));
+		return;
+	}
+	const uint32_t back = lv - 1u, msk = (1u << (8u * lv)) - 1u; /* lv = 2, 3 */
+	const uint32_t qrel = it.y - base;
+	if (qrel < back || qrel - back >= n) return; /* the gram starts before the chunk or in its padding */
+	const uint32_t prel = qrel - back, wend = qrel + ncand; /* both sides of the window test carry the same +back */
+	/* first with K = T+1, from the list alone (K <= T+1: if even the (T+1)-th next occurrence is inside the window the level passes);
+	 * only if that fails can a smaller K matter, and only marked positions have one */
+	bool pass = ((la.x ^ it.x) & msk) == 0u && la.y - base <= wend;
+	if (!pass && ((rbits[prel >> 5] >> (prel & 31u)) & 1u)) {
+		const uint32_t K = kexact[base + prel];
+		if (K >= 2u && j + K < L) { /* K < 2: count_0 < 2, nothing repeats */
+			const uint2 eu = list[j + K];
+			pass = ((eu.x ^ it.x) & msk) == 0u && eu.y - base <= wend;
+		}
+	}
+	if (pass) atomicAdd(&mfield[prel >> 4], 1u << (2u * (prel & 15u)));
+}
+
 __device__ static void x3_segscan_body(const X3SegArgs &a)
 {
 	X3_LDS uint32_t mfield[X3_SEG_MAXLEN / 16];        /* 2 bits per position: levels 1..3 passed so far */
+	X3_LDS uint32_t rbits[X3_SEG_MAXLEN / 32];         /* positions whose K is below T+1 */
 	X3_LDS uint32_t cnt[256 * X3_SEG_WAVES];           /* [digit][wave]: counts, then exclusive prefix in tile-sorted order */
 	X3_LDS uint2 stage[X3_SEG_TILE];                   /* the tile in sorted order (phase 0: eight copies of the byte histogram) */
 	X3_LDS uint32_t bbase[256], bcur[256], wtot[X3_SEG_WAVES];
@@ -67,6 +107,7 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 #define SEG_MARK(k) do { if (a.prof && tid == 0) { const uint64_t now_ = x3_clock(); atomicAdd((unsigned long long *)&a.prof[k], (unsigned long long)(now_ - tclk)); tclk = now_; } } while (0)
 	uint32_t *hist = (uint32_t *)stage;
 	for (uint32_t i = tid; i < (n + 15u) / 16u; i += X3_SEG_THREADS) mfield[i] = 0u;
+	for (uint32_t i = tid; i < (n + 31u) / 32u; i += X3_SEG_THREADS) rbits[i] = 0u;
 	for (uint32_t i = tid; i < 8u * 256u; i += X3_SEG_THREADS) hist[i] = 0u;
 	__syncthreads();
 
@@ -113,21 +154,33 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 	__syncthreads();
 	SEG_MARK(0);
 
+	const uint2 none = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
 	for (uint32_t l = 1; l <= 4; l++) {
+		/* ---- pass l: stable counting sort on key byte l-1 of list l-1 -> list l; the entries read are tested for level l-1 on the way ---- */
 		const uint2 *in = (l & 1u) ? A : Bq;
 		uint2 *out = (l & 1u) ? Bq : A;
-		const uint32_t sh = 8u * (l - 1u);
+		const uint32_t sh = 8u * (l - 1u), lv = l - 1u;
 		if (tid < 256u) bcur[tid] = bbase[tid];
-		/* ---- pass l: stable counting sort on key byte l-1 ---- */
+		uint2 nx[X3_SEG_E];
+		{
+			const uint32_t i0 = wv * (X3_SEG_E * X3_WAVE) + lane;
+#pragma unroll
+			for (uint32_t e = 0; e < X3_SEG_E; e++) nx[e] = i0 + e * X3_WAVE < L ? in[i0 + e * X3_WAVE] : none;
+		}
 		for (uint32_t t0 = 0; t0 < L; t0 += X3_SEG_TILE) {
 			*(uint4 *)&cnt[tid * 4u] = make_uint4(0u, 0u, 0u, 0u);
-			uint2 it[X3_SEG_E];
+			uint2 it[X3_SEG_E], la[X3_SEG_E];
 			uint32_t rk[X3_SEG_E];
 			const uint32_t i0 = t0 + wv * (X3_SEG_E * X3_WAVE) + lane;
 #pragma unroll
-			for (uint32_t e = 0; e < X3_SEG_E; e++) {
-				const uint32_t idx = i0 + e * X3_WAVE;
-				if (idx < L) it[e] = in[idx]; else { it[e].x = 0u; it[e].y = 0u; }
+			for (uint32_t e = 0; e < X3_SEG_E; e++) it[e] = nx[e];
+			if (t0 + X3_SEG_TILE < L) { /* the next tile's entries are on their way while this one is ranked */
+#pragma unroll
+				for (uint32_t e = 0; e < X3_SEG_E; e++) { const uint32_t idx = i0 + X3_SEG_TILE + e * X3_WAVE; nx[e] = idx < L ? in[idx] : none; }
+			}
+			if (lv) {
+#pragma unroll
+				for (uint32_t e = 0; e < X3_SEG_E; e++) { const uint32_t u = i0 + e * X3_WAVE + Tu + 1u; la[e] = u < L ? in[u] : none; }
 			}
 			__syncthreads();
 #pragma unroll
@@ -142,6 +195,11 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 				x3_wave_order();
 				rk[e] = prev + lower;
 			}
+			if (lv) {
+#pragma unroll
+				for (uint32_t e = 0; e < X3_SEG_E; e++)
+					if (i0 + e * X3_WAVE < L) seg_level(lv, it[e], la[e], i0 + e * X3_WAVE, in, L, n, base, ncand, Tu, mfield, rbits, a.kexact);
+			}
 			__syncthreads();
 			/* exclusive scan of the counter table in (digit, wave) order = the tile-sorted order */
 			const uint4 c = *(const uint4 *)&cnt[tid * 4u];
@@ -153,12 +211,14 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 			for (uint32_t w = 0; w < wv; w++) ex += wtot[w];
 			*(uint4 *)&cnt[tid * 4u] = make_uint4(ex, ex + c.x, ex + c.x + c.y, ex + c.x + c.y + c.z);
 			__syncthreads();
+			const uint32_t tile_n = L - t0 < X3_SEG_TILE ? L - t0 : X3_SEG_TILE;
+			uint32_t delta = 0; /* entries of digit `tid` in this tile */
+			if (tid < 256u) delta = (tid < 255u ? cnt[(tid + 1u) * X3_SEG_WAVES] : tile_n) - cnt[tid * X3_SEG_WAVES];
 #pragma unroll
 			for (uint32_t e = 0; e < X3_SEG_E; e++) {
 				if (i0 + e * X3_WAVE < L) stage[cnt[((it[e].x >> sh) & 0xFFu) * X3_SEG_WAVES + wv] + rk[e]] = it[e];
 			}
 			__syncthreads();
-			const uint32_t tile_n = L - t0 < X3_SEG_TILE ? L - t0 : X3_SEG_TILE;
 #pragma unroll
 			for (uint32_t e = 0; e < X3_SEG_E; e++) {
 				const uint32_t i = e * X3_SEG_THREADS + tid;
@@ -171,99 +231,59 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 				}
 			}
 			__syncthreads();
-			if (tid < 256u) {
-				const uint32_t nxt = tid < 255u ? cnt[(tid + 1u) * X3_SEG_WAVES] : tile_n;
-				bcur[tid] += nxt - cnt[tid * X3_SEG_WAVES];
-			}
-			__syncthreads();
-		}
-
-		SEG_MARK(l);
-		/* ---- level l on the list just written ---- */
-		if (l == 1u) {
-			/* K = min(T+1, count_0): is the (T+1)-th next occurrence of the byte inside the window?  else count them (binary search) */
-			for (uint32_t j = tid; j < L; j += X3_SEG_THREADS) {
-				const uint2 e = out[j];
-				const uint32_t prel = e.y - base;
-				if (prel >= n) continue; /* padding: an occurrence, never a query */
-				const uint32_t kj = e.x & 0xFFu, wend = prel + ncand;
-				const uint32_t u = j + Tu + 1u;
-				bool full = false;
-				if (u < L) { const uint2 eu = out[u]; full = (eu.x & 0xFFu) == kj && eu.y - base <= wend; }
-				if (!full) {
-					uint32_t lo = 0, bnd = Tu; /* predicate true at lo */
-					if (j + bnd >= L) bnd = L - 1u - j;
-					while (lo < bnd) {
-						const uint32_t mid = (lo + bnd + 1u) >> 1;
-						const uint2 em = out[j + mid];
-						if ((em.x & 0xFFu) == kj && em.y - base <= wend) lo = mid; else bnd = mid - 1u;
-					}
-					a.kexact[e.y] = lo; /* == count_0 */
-					atomicOr(&a.rare[e.y >> 5], 1u << (e.y & 31u));
-				}
-			}
-		} else {
-			const uint32_t back = l - 1u, msk = l >= 4u ? 0xFFFFFFFFu : ((1u << (8u * l)) - 1u);
-			for (uint32_t j0 = 0; j0 < L; j0 += X3_SEG_THREADS) { /* uniform trip count: the queue push below is a wave operation */
-				const uint32_t j = j0 + tid;
-				bool push = false;
-				uint32_t K = Tu + 1u, gp = 0;
-				if (j < L) {
-					uint2 e;
-					if (l < 4u) e = out[j]; else { e.x = K4[j]; e.y = S4[j]; }
-					const uint32_t qrel = e.y - base;
-					if (qrel >= back && qrel - back < n) { /* the l-gram starts inside the chunk's data */
-						const uint32_t prel = qrel - back, wend = qrel + ncand; /* both sides of the window test carry the same +back */
-						gp = base + prel;
-						/* first with K = T+1, from the list alone (K <= T+1: if even the (T+1)-th next occurrence is inside the window the level passes);
-						 * only if that fails can a smaller K matter, and only marked positions have one */
-						uint32_t u = j + K;
-						bool pass = false;
-						if (u < L) {
-							uint2 eu;
-							if (l < 4u) eu = out[u]; else { eu.x = K4[u]; eu.y = S4[u]; }
-							pass = ((eu.x ^ e.x) & msk) == 0u && eu.y - base <= wend;
-						}
-						if (!pass && ((a.rare[gp >> 5] >> (gp & 31u)) & 1u)) {
-							K = a.kexact[gp];
-							u = j + K;
-							if (K >= 2u && u < L) { /* K < 2: count_0 < 2, nothing repeats */
-								uint2 eu;
-								if (l < 4u) eu = out[u]; else { eu.x = K4[u]; eu.y = S4[u]; }
-								pass = ((eu.x ^ e.x) & msk) == 0u && eu.y - base <= wend;
-							}
-						}
-						if (pass) {
-							atomicAdd(&mfield[prel >> 4], 1u << (2u * (prel & 15u)));
-							if (l == 4u) {
-								/* count_3 >= K: deeper levels need the candidates themselves (walk kernel) -- unless the class has more than dense_at
-								 * members inside the window: then it is refined instead (scan2.hip) */
-								const uint32_t ud = j + a.dense_at;
-								if (ud < L && K4[ud] == e.x && S4[ud] - base <= wend && S4[ud] - base - 3u < n) a.nact[1] = 1u;
-								else push = true;
-							}
-						}
-					}
-				}
-				if (l == 4u) {
-					const uint64_t mk = x3_ballot(push);
-					if (mk) {
-						uint32_t s0 = 0;
-						if (lane == (uint32_t)x3_ctz64(mk)) s0 = atomicAdd(&a.nact[0], (uint32_t)x3_popc64(mk));
-						s0 = x3_readlane_u32(s0, (uint32_t)x3_ctz64(mk));
-						if (push) {
-							const uint32_t s = s0 + (uint32_t)x3_popc64(mk & (((uint64_t)1 << lane) - 1u));
-							a.act[s] = gp; a.act_k[s] = K; a.act_j[s] = base + j;
-						}
-					}
-				}
-			}
+			if (tid < 256u) bcur[tid] += delta; /* (read again only behind the next tile's barriers) */
 		}
 		__syncthreads();
-		SEG_MARK(4u + l);
+		SEG_MARK(l);
 	}
 
-	/* ---- m[] of the chunk: the 2-bit level counters as bytes, 16 positions (one counter word) per thread ---- */
+	/* ---- level 4 on list 4: count_3 >= K -> m >= 3, and deeper levels need the candidates themselves (walk kernel) -- unless the class has
+	 * more than dense_at members inside the window: then it is refined instead (scan2.hip) ---- */
+	for (uint32_t j0 = 0; j0 < L; j0 += X3_SEG_TILE) { /* uniform trip count: the queue push below is a wave operation */
+		uint32_t kk[X3_SEG_E], ss[X3_SEG_E], ku[X3_SEG_E], su[X3_SEG_E];
+#pragma unroll
+		for (uint32_t e = 0; e < X3_SEG_E; e++) {
+			const uint32_t j = j0 + e * X3_SEG_THREADS + tid, u = j + Tu + 1u;
+			kk[e] = j < L ? K4[j] : 0u; ss[e] = j < L ? S4[j] : 0xFFFFFFFFu;
+			ku[e] = u < L ? K4[u] : 0u; su[e] = u < L ? S4[u] : 0xFFFFFFFFu;
+		}
+#pragma unroll
+		for (uint32_t e = 0; e < X3_SEG_E; e++) {
+			const uint32_t j = j0 + e * X3_SEG_THREADS + tid;
+			bool push = false;
+			uint32_t K = Tu + 1u, gp = 0;
+			const uint32_t qrel = ss[e] - base;
+			if (j < L && qrel >= 3u && qrel - 3u < n) {
+				const uint32_t prel = qrel - 3u, wend = qrel + ncand;
+				gp = base + prel;
+				bool pass = ku[e] == kk[e] && su[e] - base <= wend;
+				if (!pass && ((rbits[prel >> 5] >> (prel & 31u)) & 1u)) {
+					K = a.kexact[gp];
+					if (K >= 2u && j + K < L) pass = K4[j + K] == kk[e] && S4[j + K] - base <= wend;
+				}
+				if (pass) {
+					atomicAdd(&mfield[prel >> 4], 1u << (2u * (prel & 15u)));
+					const uint32_t ud = j + a.dense_at;
+					if (ud < L && K4[ud] == kk[e] && S4[ud] - base <= wend && S4[ud] - base - 3u < n) a.nact[1] = 1u;
+					else push = true;
+				}
+			}
+			const uint64_t mk = x3_ballot(push);
+			if (mk) {
+				uint32_t s0 = 0;
+				if (lane == (uint32_t)x3_ctz64(mk)) s0 = atomicAdd(&a.nact[0], (uint32_t)x3_popc64(mk));
+				s0 = x3_readlane_u32(s0, (uint32_t)x3_ctz64(mk));
+				if (push) {
+					const uint32_t sl = s0 + (uint32_t)x3_popc64(mk & (((uint64_t)1 << lane) - 1u));
+					a.act[sl] = gp; a.act_k[sl] = K; a.act_j[sl] = base + j;
+				}
+			}
+		}
+	}
+	__syncthreads();
+	SEG_MARK(5);
+
+	/* ---- m[] of the chunk: the 2-bit level counters as bytes, 16 positions (one counter word) per thread; the marks of the positions with a small K ---- */
 	for (uint32_t w = tid; w < (n + 15u) / 16u; w += X3_SEG_THREADS) {
 		const uint32_t f = mfield[w];
 		uint32_t o[4];
@@ -274,6 +294,7 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 		}
 		*(uint4 *)(a.m + base + 16u * w) = make_uint4(o[0], o[1], o[2], o[3]); /* (the last word may spill <= 15 bytes into the slot's padding) */
 	}
+	for (uint32_t w = tid; w < (n + 31u) / 32u; w += X3_SEG_THREADS) a.rare[(base >> 5) + w] = rbits[w];
 }
 
 #ifndef X3_EMU

@@ -79,7 +79,7 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 /* ---- K1 for many chunks: one workgroup per chunk (scan3.hip) ------------------------------------------------- */
 #define X3_SEG_THREADS 1024u
 #ifndef X3_SEG_MAXLEN
-#define X3_SEG_MAXLEN (384u << 10)   /* longest chunk whose 2-bit level counters fit the workgroup's LDS (96 KiB) */
+#define X3_SEG_MAXLEN (256u << 10)   /* longest chunk whose level counters (2 bits per position) and small-K marks (1 bit) fit the workgroup's LDS: 96 KiB */
 #endif
 #ifndef X3_SEG_MIN_STREAMS
 #define X3_SEG_MIN_STREAMS 48u       /* fewer chunks: the chip-wide sort of scan2.hip */
