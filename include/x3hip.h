@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define X3H_ABI_VERSION 4 /* 2: x3h_stats grew (mode_iters, chain_symbols, pipelined); 3: X3C1 container + multi-device batch entries; 4: x3h_decompress_chunks_dev */
+#define X3H_ABI_VERSION 5 /* 2: x3h_stats grew (mode_iters, chain_symbols, pipelined); 3: X3C1 container + multi-device batch entries; 4: x3h_decompress_chunks_dev; 5: x3h_compress_container_rccl */
 
 /* status codes (the reference abort()s on every error: file.c:9-18, x3.c:515,547,554,583) */
 enum {
@@ -30,7 +30,8 @@ enum {
 	X3H_E_CORRUPT     = -4, /* decoder: not an x3 stream                                          */
 	X3H_E_NO_DEVICE   = -5, /* no usable HIP device                                               */
 	X3H_E_HIP         = -6, /* a HIP runtime call failed (x3h_last_hip_error() has the code)      */
-	X3H_E_INTERNAL    = -7  /* a device-side workspace bound was violated (bug)                   */
+	X3H_E_INTERNAL    = -7, /* a device-side workspace bound was violated (bug)                   */
+	X3H_E_RCCL        = -8  /* librccl could not be loaded, or a send / receive of the gather failed */
 };
 
 #define X3H_MAX_CHUNK ((size_t)1 << 27) /* one stream <= 128 MiB: keeps every model total < 2^28, which the coder kernel relies on */
@@ -83,6 +84,10 @@ size_t       x3h_compress_bound(size_t n);                  /* replaces the unch
 /* create()/destroy() of the reference (x3.c:225-249, 436-458) become handle life time. */
 int  x3h_ctx_create(x3h_ctx **ctx, int device);
 void x3h_ctx_destroy(x3h_ctx *ctx);
+/* A batch of chunks is coded in consecutive sub-batches of at most `input_bytes` (default 512 MiB, >= 1 MiB): the workspace is ~350 bytes of
+ * HBM per input byte of a sub-batch.  A short-lived process (the CLI) wants it small: the driver hands out memory that an earlier process
+ * freed at ~40 GB/s only, so a 90 GB workspace costs two seconds right behind another process.  Output does not depend on it.        */
+int  x3h_ctx_set_batch_bytes(x3h_ctx *ctx, uint64_t input_bytes);
 
 /* Whole path, host buffers.  Replaces   create(); bio_open(); ac_init(); compress(ptr,size,&bio);
  * ac_encode_flush(); bio_close();   (x3.c:562,593-604).  `in` needs no padding (the W zero bytes of
@@ -152,6 +157,17 @@ int x3h_compress_container(x3h_ctx *const *ctxs, int ndevices, const x3h_params 
                            uint8_t *out, size_t cap, size_t *out_len, x3h_stats *stats);
 int x3h_decompress_container(x3h_ctx *const *ctxs, int ndevices, const uint8_t *in, size_t n,
                              uint8_t *out, size_t cap, size_t *out_len, x3h_stats *stats);
+
+/* The same container, with the final concat as ONE RCCL exchange over xGMI (BASELINE north star; the reference has no counterpart: one
+ * stream per file, x3.c:599-611): every device keeps its block of the input and its streams in its own HBM, packs the streams back to
+ * back, one ncclGroupStart .. ncclSend / ncclRecv .. ncclGroupEnd moves every block to ctxs[0]'s GPU behind the header laid down there,
+ * and the finished container crosses PCIe once.  The handles must sit on DISTINCT GPUs (one rank per GPU; X3H_E_ARG otherwise); with one
+ * handle the block is sent to itself through RCCL (so the leg can be exercised on a one-GPU machine).  librccl is loaded on first use;
+ * X3H_E_RCCL if that fails.  Output is byte-identical to x3h_compress_container's.  x3h_rccl_release() destroys the cached
+ * communicators (call it before the handles' GPUs go away; harmless otherwise).                                                        */
+int  x3h_compress_container_rccl(x3h_ctx *const *ctxs, int ndevices, const x3h_params *prm, const uint8_t *in, size_t n, size_t chunk_bytes,
+                                 uint8_t *out, size_t cap, size_t *out_len, x3h_stats *stats);
+void x3h_rccl_release(void);
 
 /* Stage-level entry points (kernel parity tests; the seams named in SURVEY.md 8(b)).
  *  x3h_scan_m      : K1 alone.  m_out[p] = max{ i : count[i] > min(T, count[0]-1) } (0 if T<=0 or count[0]<2) with

@@ -362,6 +362,26 @@ def test_container_from_hip_streams(gpu, oracle):
     assert e.value.status == -3
 
 
+def test_container_through_rccl_equals_host_staged_container(gpu):
+    """x3h_compress_container_rccl: streams stay in HBM, one ncclSend/ncclRecv group concatenates them behind the header on the root GPU.
+    On a one-GPU machine the block is sent to itself through RCCL; the bytes must equal x3h_compress_container's; two handles on ONE GPU are
+    refused (one rank per GPU); a one-chunk input stays the raw stream."""
+    data = synth.english_like(300_000, seed=9).tobytes() + synth.zipf_bytes(100_000, offset=5 << 20).tobytes()
+    prm = _lib.make_params(w_kib=8, t=16)
+    want = _lib.compress_container([gpu], data, prm, 32_768)
+    for _ in range(2):  # the second call reuses the cached communicator
+        assert _lib.compress_container([gpu], data, prm, 32_768, rccl=True) == want
+    assert _lib.compress_container([gpu], data[:30_000], prm, 32_768, rccl=True) == gpu.compress(data[:30_000], prm)
+    assert _lib.decompress_container([gpu], want, len(data)) == data
+    with _lib.X3Context(0) as second:
+        with pytest.raises(_lib.X3Error) as e:
+            _lib.compress_container([gpu, second], data, prm, 32_768, rccl=True)
+        assert e.value.status == -1
+    gpu.lib.x3h_rccl_release()
+    assert _lib.compress_container([gpu], data, prm, 65_536, rccl=True) == _lib.compress_container([gpu], data, prm, 65_536)
+    gpu.lib.x3h_rccl_release()
+
+
 def test_sub_batches_are_cut_on_the_padded_layout(gpu, gpu_env):
     """many small chunks under a 512 KiB window: every chunk occupies len + W + slack in the padded layout that K1 indexes with 32 bits,
     so the sub-batch cut must look at that, not at the input bytes (here the limit is lowered to three padded chunks)"""

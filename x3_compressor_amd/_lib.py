@@ -20,13 +20,13 @@ ABI_SYMBOLS = (
     "x3h_compress_chunks_dev", "x3h_decompress", "x3h_decompress_chunks", "x3h_decompress_chunks_dev", "x3h_scan_m", "x3h_scan_counts", "x3h_parse",
     "x3h_compress_chunks_multi", "x3h_decompress_chunks_multi", "x3h_container_header_bytes", "x3h_container_write_header",
     "x3h_container_probe", "x3h_container_table", "x3h_container_bound", "x3h_compress_container", "x3h_decompress_container",
-    "x3h_coder_chain",
+    "x3h_coder_chain", "x3h_compress_container_rccl", "x3h_rccl_release", "x3h_ctx_set_batch_bytes",
 )
 
 TOK_MISS, TOK_DUP = 0x80000000, 0x40000000
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 NOT_A_CONTAINER = 1  # x3h_container_probe: the bytes are one raw x3 stream
 
 
@@ -100,6 +100,9 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.x3h_compress_container.argtypes = [ctxs, C.c_int, C.POINTER(Params), u8p, C.c_size_t, C.c_size_t, u8p, C.c_size_t,
                                            C.POINTER(C.c_size_t), C.POINTER(Stats)]
     lib.x3h_decompress_container.argtypes = [ctxs, C.c_int, u8p, C.c_size_t, u8p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(Stats)]
+    lib.x3h_compress_container_rccl.argtypes = lib.x3h_compress_container.argtypes
+    lib.x3h_rccl_release.restype = None
+    lib.x3h_ctx_set_batch_bytes.argtypes = [C.c_void_p, C.c_uint64]
     return lib
 
 
@@ -282,16 +285,17 @@ def compress_chunks_multi(ctxs: list[X3Context], data, offsets, prm: Params, str
     return [out[i * stride:i * stride + int(lens[i])].tobytes() for i in range(nch)]
 
 
-def compress_container(ctxs: list[X3Context], data, prm: Params, chunk_bytes: int) -> bytes:
-    """x3h_compress_container: what `x3 -z --chunk-kib N` writes (raw stream if the input is one chunk)."""
+def compress_container(ctxs: list[X3Context], data, prm: Params, chunk_bytes: int, rccl: bool = False) -> bytes:
+    """x3h_compress_container: what `x3 -z --chunk-kib N` writes (raw stream if the input is one chunk).
+    rccl=True: x3h_compress_container_rccl -- the streams stay in HBM and ONE RCCL send/receive group concatenates them on the first GPU."""
     lib = ctxs[0].lib
     a = _u8(data)
     cap = int(lib.x3h_container_bound(a.size, chunk_bytes))
     out = np.empty(cap, dtype=np.uint8)
     n_out, st = C.c_size_t(0), Stats()
     arr, n = _handles(ctxs)
-    ctxs[0]._check(lib.x3h_compress_container(arr, n, C.byref(prm), a.ctypes.data if a.size else None, a.size, chunk_bytes,
-                                              out.ctypes.data, cap, C.byref(n_out), C.byref(st)))
+    fn = lib.x3h_compress_container_rccl if rccl else lib.x3h_compress_container
+    ctxs[0]._check(fn(arr, n, C.byref(prm), a.ctypes.data if a.size else None, a.size, chunk_bytes, out.ctypes.data, cap, C.byref(n_out), C.byref(st)))
     ctxs[0].last_stats = st
     return out[:n_out.value].tobytes()
 

@@ -25,6 +25,10 @@ extern "C" void x3k_launch_parse(const X3ParseArgs *a, uint32_t nchunks, hipStre
 extern "C" void x3k_launch_decode(const X3DecArgs *a, uint32_t nchunks, hipStream_t st);
 
 thread_local int x3_last_hip = 0;
+thread_local double x3_alloc_ms = 0;
+thread_local unsigned long long x3_alloc_bytes = 0, x3_alloc_calls = 0;
+#include <time.h>
+double x3_now_ms() { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
 #define g_last_hip x3_last_hip
 
 struct x3h_ctx {
@@ -53,6 +57,7 @@ struct x3h_ctx {
 	uint64_t pad_total = 0;
 	DevBuf mtf, idxfreq, ctx1, ctx0, items, pkey, pval, out, counts;
 	DevBuf din, dchunks, items_ord; /* decoder: input streams, stream table, pair ordinal per context item */
+	DevBuf g_in, g_out, g_pack, g_final; /* x3h_compress_container_rccl: this device's input block, its strided streams, the packed block, the finished container (root) */
 	std::vector<X3Chunk> hchunks;
 	std::vector<X3ParseResult> hparse;
 	std::vector<X3CodeResult> hcode;
@@ -75,6 +80,7 @@ extern "C" const char *x3h_strerror(int s)
 		case X3H_E_NO_DEVICE: return "no HIP device";
 		case X3H_E_HIP: return "HIP runtime error";
 		case X3H_E_INTERNAL: return "internal workspace bound violated";
+		case X3H_E_RCCL: return "RCCL unavailable or a send/receive failed";
 		default: return "unknown status";
 	}
 }
@@ -132,6 +138,14 @@ extern "C" int x3h_ctx_create(x3h_ctx **out, int device)
 	return X3H_OK;
 }
 
+extern "C" int x3h_ctx_set_batch_bytes(x3h_ctx *c, uint64_t input_bytes)
+{
+	if (!c || input_bytes < ((uint64_t)1 << 20)) return X3H_E_ARG;
+	c->batch_bytes = input_bytes;
+	c->dec_batch_bytes = 2 * input_bytes; /* the decoder cuts on output capacity, at ~150 B of workspace per byte; its rate is streams in flight x the per-stream rate */
+	return X3H_OK;
+}
+
 extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 {
 	if (!c) return;
@@ -139,7 +153,8 @@ extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	DevBuf *bufs[] = { &c->pad, &c->m, &c->dict_pos, &c->dict_len, &c->ht, &c->tok_pos, &c->tok_info, &c->tok_hb, &c->tok_nb, &c->tok_mb, &c->chunks, &c->presult,
 		               &c->c2.tmp, &c->c2.offs, &c->c2.chunkmeta, &c->c2.idxfreq, &c->c2.hsym, &c->c2.maxred, &c->c2.pp[0], &c->c2.pp[1], &c->c2.pp[2], &c->c2.pp[3],
-		               &c->cresult, &c->mtf, &c->idxfreq, &c->ctx1, &c->ctx0, &c->items, &c->pkey, &c->pval, &c->out, &c->counts, &c->din, &c->dchunks, &c->items_ord };
+		               &c->cresult, &c->mtf, &c->idxfreq, &c->ctx1, &c->ctx0, &c->items, &c->pkey, &c->pval, &c->out, &c->counts, &c->din, &c->dchunks, &c->items_ord,
+		               &c->g_in, &c->g_out, &c->g_pack, &c->g_final };
 	for (DevBuf *b : bufs) b->release();
 	c->coder_state.release(); c->prefix_result.release(); c->srcoff.release(); c->ckpt_pos.release(); c->seg.meta.release(); c->seg.modes_state.release(); c->seg.mode_prev.release();
 	c->c2.yfin.release(); c->c2.yfinrec.release();
@@ -399,6 +414,10 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 	HIPCHK(hipSetDevice(c->device));
 	const int nc = io.nchunks;
 	uint64_t max_len = 0;
+	const double dbg_t0 = x3_now_ms(), dbg_a0 = x3_alloc_ms;
+	const unsigned long long dbg_b0 = x3_alloc_bytes, dbg_c0 = x3_alloc_calls;
+	struct DbgAlloc { double t0, a0; unsigned long long b0, c0; ~DbgAlloc() { if (getenv("X3H_DEBUG")) fprintf(stderr, "[x3h] call: %.1f ms wall, of which %.1f ms in %llu hipMalloc/hipFree calls for %.2f GB of workspace\n",
+		x3_now_ms() - t0, x3_alloc_ms - a0, x3_alloc_calls - c0, (double)(x3_alloc_bytes - b0) / 1e9); } } dbg_alloc = { dbg_t0, dbg_a0, dbg_b0, dbg_c0 };
 
 	HIPCHK(hipEventRecord(c->ev[0], c->stream));
 	CHK(stage_inputs(c, &prm, io, &max_len));
@@ -931,3 +950,197 @@ extern "C" int x3h_decompress_container(x3h_ctx *const *ctxs, int ndevices, cons
 	*out_len = (size_t)raw_total;
 	return X3H_OK;
 }
+
+/* ------------------------------------------------------------------------------------------------------------
+ * The final bitstream concat of a multi-GPU batch as ONE RCCL exchange, behind the C boundary (BASELINE north star: "independent input
+ * chunks partition across the GPUs of one node with a single RCCL gather over xGMI for the final bitstream concat").  Every device
+ * codes its contiguous block of chunks with inputs and streams resident in ITS HBM, packs its streams back to back, and one
+ * ncclGroupStart .. ncclSend / ncclRecv .. ncclGroupEnd brings every block to ctxs[0]'s GPU, directly behind the X3C1 header that
+ * is laid down there; the finished container crosses PCIe once.  No host staging of the streams (x3h_compress_container goes through a
+ * host buffer per device).  librccl is loaded on first use (dlopen): a process that never calls this never pays for it.
+ * ------------------------------------------------------------------------------------------------------------ */
+#ifndef X3_EMU
+#include <dlfcn.h>
+#include <mutex>
+#include <rccl/rccl.h>
+
+namespace {
+struct RcclApi {
+	void *lib = nullptr;
+	ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*GroupStart)() = nullptr;
+	ncclResult_t (*GroupEnd)() = nullptr;
+	std::vector<int> devs;          /* the communicators in hand were made for these devices, in this order */
+	std::vector<ncclComm_t> comms;
+	std::mutex mu;
+};
+RcclApi g_rccl;
+
+bool rccl_load()
+{
+	if (g_rccl.lib) return true;
+	void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+	if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+	if (!h) return false;
+#define X3_SYM(field, name) *(void **)&g_rccl.field = dlsym(h, name); if (!g_rccl.field) { dlclose(h); return false; }
+	X3_SYM(CommInitAll, "ncclCommInitAll") X3_SYM(CommDestroy, "ncclCommDestroy") X3_SYM(Send, "ncclSend") X3_SYM(Recv, "ncclRecv")
+	X3_SYM(GroupStart, "ncclGroupStart") X3_SYM(GroupEnd, "ncclGroupEnd")
+#undef X3_SYM
+	g_rccl.lib = h;
+	return true;
+}
+
+void rccl_drop_comms()
+{
+	for (ncclComm_t c : g_rccl.comms) if (c) (void)g_rccl.CommDestroy(c);
+	g_rccl.comms.clear(); g_rccl.devs.clear();
+}
+} // namespace
+
+extern "C" void x3h_rccl_release(void)
+{
+	std::lock_guard<std::mutex> lk(g_rccl.mu);
+	if (g_rccl.lib) rccl_drop_comms();
+}
+
+struct GatherDev { /* what one device contributes */
+	int lo = 0, hi = 0;
+	uint64_t payload = 0;           /* bytes of its packed streams */
+	uint8_t *packed = nullptr;      /* where they are (device memory of that GPU) */
+};
+
+extern "C" int x3h_compress_container_rccl(x3h_ctx *const *ctxs, int ndevices, const x3h_params *prm_in, const uint8_t *in, size_t n, size_t chunk_bytes,
+                                           uint8_t *out, size_t cap, size_t *out_len, x3h_stats *stats)
+{
+	if (!ctxs || ndevices <= 0 || !out || !out_len || (!in && n) || cap < 4) return X3H_E_ARG;
+	for (int d = 0; d < ndevices; d++) {
+		if (!ctxs[d]) return X3H_E_ARG;
+		for (int e = 0; e < d; e++) if (ctxs[e]->device == ctxs[d]->device) return X3H_E_ARG; /* one rank per GPU */
+	}
+	*out_len = 0;
+	if (!chunk_bytes || chunk_bytes > X3H_MAX_CHUNK) chunk_bytes = n <= X3H_MAX_CHUNK ? (n ? n : 1) : X3H_MAX_CHUNK;
+	const uint64_t nch64 = n ? ((uint64_t)n + chunk_bytes - 1) / chunk_bytes : 1;
+	if (nch64 > 0x7FFFFFF0ull) return X3H_E_ARG;
+	const int nch = (int)nch64;
+	if (nch == 1) return x3h_compress(ctxs[0], prm_in, in, n, out, cap, out_len, stats); /* one chunk: the raw stream, nothing to gather */
+	x3h_params prm;
+	if (prm_in) prm = *prm_in; else x3h_default_params(&prm);
+	const int nd = ndevices < nch ? ndevices : nch;
+	const size_t head = x3h_container_header_bytes(nch);
+	if (cap < head + 4 * (size_t)nch) return X3H_E_OUTPUT_FULL;
+
+	std::lock_guard<std::mutex> lk(g_rccl.mu);
+	if (!rccl_load()) return X3H_E_RCCL;
+	std::vector<int> devs((size_t)nd);
+	for (int d = 0; d < nd; d++) devs[(size_t)d] = ctxs[d]->device;
+	if (g_rccl.devs != devs) {
+		rccl_drop_comms();
+		g_rccl.comms.assign((size_t)nd, nullptr);
+		if (g_rccl.CommInitAll(g_rccl.comms.data(), nd, devs.data()) != ncclSuccess) { g_rccl.comms.clear(); return X3H_E_RCCL; }
+		g_rccl.devs = devs;
+	}
+
+	std::vector<uint64_t> off((size_t)nch + 1), raw((size_t)nch), lens((size_t)nch, 0);
+	for (int i = 0; i <= nch; i++) { const uint64_t o = (uint64_t)i * chunk_bytes; off[(size_t)i] = o < n ? o : n; }
+	for (int i = 0; i < nch; i++) raw[(size_t)i] = off[(size_t)i + 1] - off[(size_t)i];
+	uint64_t stride = ((uint64_t)chunk_bytes + chunk_bytes / 4 + 4096 + 3) & ~(uint64_t)3;
+	const uint64_t bound = ((uint64_t)x3h_compress_bound(chunk_bytes) + 3) & ~(uint64_t)3;
+	if (stride > bound) stride = bound;
+	std::vector<GatherDev> gd((size_t)nd);
+	for (;;) {
+		/* every device: H2D of its block of the input, the three stages with streams left in its HBM, streams packed back to back */
+		int rc = run_on_devices(nd, nch, stats, [&](int d, int lo, int hi, x3h_stats *st) -> int {
+			x3h_ctx *c = ctxs[d];
+			GatherDev &g = gd[(size_t)d];
+			g.lo = lo; g.hi = hi; g.payload = 0; g.packed = nullptr;
+			HIPCHK(hipSetDevice(c->device));
+			const int k = hi - lo;
+			const uint64_t bytes = off[(size_t)hi] - off[(size_t)lo];
+			CHK(c->g_in.reserve(bytes + 16));
+			CHK(c->g_out.reserve(stride * (uint64_t)k + 16));
+			HIPCHK(hipMemcpyAsync(c->g_in.p, in + off[(size_t)lo], bytes, hipMemcpyHostToDevice, c->stream));
+			std::vector<uint64_t> rel((size_t)k + 1);
+			for (int i = 0; i <= k; i++) rel[(size_t)i] = off[(size_t)(lo + i)] - off[(size_t)lo];
+			RunIO io = { c->g_in.as<uint8_t>(), true, rel.data(), k, c->g_out.as<uint8_t>(), true, stride, lens.data() + lo, false };
+			CHK(run(c, &prm, io, STAGE_CODE, st));
+			std::vector<uint64_t> po((size_t)k + 1, 0); /* packed offsets (x3 streams are whole 32-bit words) */
+			for (int i = 0; i < k; i++) po[(size_t)i + 1] = po[(size_t)i] + lens[(size_t)(lo + i)];
+			g.payload = po[(size_t)k];
+			/* device 0's block is the first of the container: it is packed straight behind the header */
+			const uint64_t lead = d == 0 ? head : 0;
+			CHK(c->g_pack.reserve(lead + g.payload + 16));
+			CHK(c->srcoff.reserve((size_t)(k + 1) * 8));
+			HIPCHK(hipMemcpyAsync(c->srcoff.p, po.data(), (size_t)(k + 1) * 8, hipMemcpyHostToDevice, c->stream));
+			const uint64_t *dpo = c->srcoff.as<uint64_t>();
+			const uint32_t *src = c->g_out.as<uint32_t>();
+			uint32_t *dst = (uint32_t *)(c->g_pack.as<uint8_t>() + lead);
+			const uint64_t wstride = stride / 4;
+			uint64_t maxw = 0;
+			for (int i = 0; i < k; i++) if (lens[(size_t)(lo + i)] / 4 > maxw) maxw = lens[(size_t)(lo + i)] / 4;
+			x3_foreach((size_t)(maxw * (uint64_t)k), c->stream, X3_LAMBDA(size_t t) {
+				const uint32_t ci = (uint32_t)(t / maxw);
+				const uint64_t w = t % maxw, b0 = dpo[ci] / 4, nw = dpo[ci + 1] / 4 - b0;
+				if (w < nw) dst[b0 + w] = src[(uint64_t)ci * wstride + w];
+			});
+			HIPCHK(hipGetLastError());
+			HIPCHK(hipStreamSynchronize(c->stream));
+			g.packed = c->g_pack.as<uint8_t>() + lead;
+			return X3H_OK;
+		});
+		if (rc == X3H_E_OUTPUT_FULL && stride < bound) { stride = bound; continue; }
+		if (rc != X3H_OK) return rc;
+		break;
+	}
+	uint64_t total = head;
+	for (int i = 0; i < nch; i++) total += lens[(size_t)i];
+	if (total > cap) return X3H_E_OUTPUT_FULL;
+
+	/* root: header + its own block are in place; the other blocks arrive behind them.  ndevices == 1: the block makes the round trip
+	 * through RCCL all the same (send to self), so that this leg is exercised on a one-GPU machine. */
+	x3h_ctx *root = ctxs[0];
+	HIPCHK(hipSetDevice(root->device));
+	std::vector<uint8_t> hdr(head);
+	CHK(x3h_container_write_header(hdr.data(), head, &prm, nch, raw.data(), lens.data()));
+	uint8_t *final_buf = root->g_pack.as<uint8_t>();
+	if (nd == 1) { /* self-send: the packed block moves to a second buffer behind a copy of the header */
+		CHK(root->g_final.reserve(total + 16));
+		final_buf = root->g_final.as<uint8_t>();
+	} else {
+		uint64_t need = total + 16; /* g_pack of the root was sized for its own block only */
+		if (root->g_pack.cap < need) {
+			CHK(root->g_final.reserve(need));
+			HIPCHK(hipMemcpyAsync(root->g_final.p, root->g_pack.p, head + gd[0].payload, hipMemcpyDeviceToDevice, root->stream));
+			final_buf = root->g_final.as<uint8_t>();
+		}
+	}
+	HIPCHK(hipMemcpyAsync(final_buf, hdr.data(), head, hipMemcpyHostToDevice, root->stream));
+	bool ok = g_rccl.GroupStart() == ncclSuccess;
+	uint64_t at = head + (nd == 1 ? 0 : gd[0].payload);
+	for (int d = (nd == 1 ? 0 : 1); d < nd && ok; d++) {
+		const GatherDev &g = gd[(size_t)d];
+		if (g.payload) {
+			ok = ok && g_rccl.Send(g.packed, (size_t)g.payload, ncclUint8, 0, g_rccl.comms[(size_t)d], ctxs[d]->stream) == ncclSuccess;
+			ok = ok && g_rccl.Recv(final_buf + at, (size_t)g.payload, ncclUint8, d, g_rccl.comms[0], root->stream) == ncclSuccess;
+		}
+		at += g.payload;
+	}
+	ok = (g_rccl.GroupEnd() == ncclSuccess) && ok;
+	if (!ok) { rccl_drop_comms(); return X3H_E_RCCL; }
+	for (int d = 1; d < nd; d++) { HIPCHK(hipSetDevice(ctxs[d]->device)); HIPCHK(hipStreamSynchronize(ctxs[d]->stream)); }
+	HIPCHK(hipSetDevice(root->device));
+	HIPCHK(hipMemcpyAsync(out, final_buf, (size_t)total, hipMemcpyDeviceToHost, root->stream)); /* the ONE transfer of the container over PCIe */
+	HIPCHK(hipStreamSynchronize(root->stream));
+	*out_len = (size_t)total;
+	return X3H_OK;
+}
+#else
+extern "C" void x3h_rccl_release(void) {}
+extern "C" int x3h_compress_container_rccl(x3h_ctx *const *, int, const x3h_params *, const uint8_t *, size_t, size_t, uint8_t *, size_t, size_t *out_len, x3h_stats *)
+{
+	if (out_len) *out_len = 0;
+	return X3H_E_RCCL; /* the SIMT emulator build (tests) has no RCCL */
+}
+#endif

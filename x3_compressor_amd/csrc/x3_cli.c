@@ -9,21 +9,42 @@
  *
  * Additive options (new, none of them changes what the reference's letters do):
  *   -g N             use GPU N (default 0)
- *   --gpus a,b,...   use these GPUs side by side (chunks are dealt out in contiguous blocks)
+ *   --gpus a,b,...   use these GPUs side by side (chunks are dealt out in contiguous blocks); the finished streams are
+ *                    concatenated by ONE RCCL send/receive group on the first GPU (x3h_compress_container_rccl)
  *   --chunk-kib N    cut the input into independent chunks of N KiB, each coded as its own x3 stream, and write the X3C1
  *                    container (include/x3hip.h); an input of one chunk is still written as the raw stream.  Inputs above
  *                    128 MiB (X3H_MAX_CHUNK) are always chunked.
+ *   --batch-mib N    chunks are coded in sub-batches of at most N MiB of input (default 64): bounds the workspace in HBM (~350 B per byte)
  * -d recognises a container by its magic and decodes the chunks as one batch; anything else is a raw x3 stream.
  */
 #define _GNU_SOURCE /* getopt_long */
+#include <execinfo.h>
 #include <getopt.h>
+#include <signal.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <unistd.h>
 #include "../../include/x3hip.h"
 
 static void die(const char *msg) { fprintf(stderr, "%s\n", msg); exit(1); }
+
+/* A fatal signal says where it struck (phase of main() + the faulting thread's stack) and is then delivered again with its default
+ * action, so the exit status still names it.  The reference abort()s on every error (file.c:9-18); a drop-in must at least say where. */
+static volatile sig_atomic_t g_phase; /* 1 options, 2 handles, 3 input read, 4 library call, 5 output written, 6 handles released, 7 leaving */
+static void on_fatal(int sig)
+{
+	char msg[64];
+	int k = snprintf(msg, sizeof msg, "x3: fatal signal %d in phase %d\n", sig, (int)g_phase);
+	if (k > 0 && write(2, msg, (size_t)k) < 0) { /* nothing left to do about it */ }
+	void *bt[48];
+	backtrace_symbols_fd(bt, backtrace(bt, 48), 2);
+	signal(sig, SIG_DFL);
+	raise(sig);
+}
+
+static double now_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
 
 static void print_help(const char *path) /* x3.c:465-477 */
 {
@@ -40,6 +61,7 @@ static void print_help(const char *path) /* x3.c:465-477 */
 	fprintf(stderr, " -g NUM : GPU to use (default 0)\n");
 	fprintf(stderr, " --gpus A,B,...  : GPUs to use side by side\n");
 	fprintf(stderr, " --chunk-kib NUM : code independent chunks of NUM KiB (X3C1 container output)\n");
+	fprintf(stderr, " --batch-mib NUM : code at most NUM MiB of chunks at a time (default 64; bounds the GPU workspace)\n");
 }
 
 static FILE *open_output(const char *path, int force) /* force_fopen, file.c:47-55 */
@@ -68,9 +90,13 @@ int main(int argc, char *argv[])
 {
 	int decompress = 0, force = 0, o, ngpu = 1, gpus[MAX_GPUS] = { 0 };
 	size_t chunk_bytes = 0;
+	uint64_t batch_mib = 64;
 	x3h_params prm;
+	const int fatal[] = { SIGSEGV, SIGBUS, SIGILL, SIGFPE, SIGABRT };
+	for (size_t i = 0; i < sizeof fatal / sizeof fatal[0]; i++) signal(fatal[i], on_fatal);
+	g_phase = 1;
 	x3h_default_params(&prm);
-	static const struct option longopts[] = { { "chunk-kib", required_argument, NULL, 1000 }, { "gpus", required_argument, NULL, 1001 }, { NULL, 0, NULL, 0 } };
+	static const struct option longopts[] = { { "chunk-kib", required_argument, NULL, 1000 }, { "gpus", required_argument, NULL, 1001 }, { "batch-mib", required_argument, NULL, 1002 }, { NULL, 0, NULL, 0 } };
 
 	while ((o = getopt_long(argc, argv, "zdfkht:w:m:n:xg:", longopts, NULL)) != -1) { /* x3.c:484 */
 		switch (o) {
@@ -98,6 +124,12 @@ int main(int argc, char *argv[])
 					gpus[ngpu++] = atoi(tok);
 				}
 				if (!ngpu) die("--gpus: empty list");
+				break;
+			}
+			case 1002: {
+				long k = atol(optarg);
+				if (k < 1 || k > 4096) die("--batch-mib: between 1 and 4096");
+				batch_mib = (uint64_t)k;
 				break;
 			}
 			default: die("Unexpected argument");
@@ -132,11 +164,19 @@ int main(int argc, char *argv[])
 
 	x3h_ctx *ctxs[MAX_GPUS] = { NULL };
 	int rc = X3H_OK;
+	g_phase = 2;
+	const double t_start = now_ms();
 	for (int i = 0; i < ngpu && rc == X3H_OK; i++) rc = x3h_ctx_create(&ctxs[i], gpus[i]);
+	/* a command-line process lives for one call: keep its workspace small (the sub-batches of a big input follow each other, x3hip.h) */
+	if (!getenv("X3H_BATCH_BYTES")) for (int i = 0; i < ngpu && rc == X3H_OK; i++) rc = x3h_ctx_set_batch_bytes(ctxs[i], batch_mib << 20);
+	const double t_ctx = now_ms();
 	if (rc != X3H_OK) { fprintf(stderr, "x3: %s (the hot path only exists as gfx950 HIP kernels; no CPU fallback)\n", x3h_strerror(rc)); return 1; }
 
 	size_t isize = 0, osize = 0;
+	g_phase = 3;
 	unsigned char *iptr = read_all(istream, &isize), *optr = NULL;
+	g_phase = 4;
+	const double t_read = now_ms();
 	x3h_stats st;
 	memset(&st, 0, sizeof st);
 
@@ -149,7 +189,15 @@ int main(int argc, char *argv[])
 		size_t cap = x3h_container_bound(isize, chunk_bytes);
 		optr = malloc(cap);
 		if (!optr) die("out of memory");
-		rc = x3h_compress_container(ctxs, ngpu, &prm, iptr, isize, chunk_bytes, optr, cap, &osize, &st);
+		/* several GPUs: the chunk streams stay in HBM and ONE RCCL exchange concatenates them on the first GPU (x3h_compress_container_rccl);
+		 * X3_NO_RCCL=1, the same GPU named twice, or a machine without librccl: host-staged concat, same bytes */
+		rc = X3H_E_RCCL;
+		if (ngpu > 1 && !getenv("X3_NO_RCCL")) {
+			rc = x3h_compress_container_rccl(ctxs, ngpu, &prm, iptr, isize, chunk_bytes, optr, cap, &osize, &st);
+			x3h_rccl_release();
+			if (rc == X3H_OK) fprintf(stderr, "final concat: one RCCL gather over %d GPUs\n", ngpu);
+		}
+		if (rc == X3H_E_RCCL || rc == X3H_E_ARG) rc = x3h_compress_container(ctxs, ngpu, &prm, iptr, isize, chunk_bytes, optr, cap, &osize, &st);
 		if (rc != X3H_OK) { fprintf(stderr, "x3: compress failed: %s\n", x3h_strerror(rc)); return 1; }
 		fprintf(stderr, "elapsed time: %f\n", st.ms_total / 1000.0);
 		fprintf(stderr, "  device ms: scan %.3f parse %.3f code %.3f copy %.3f\n", st.ms_scan, st.ms_parse, st.ms_code, st.ms_copy);
@@ -179,7 +227,10 @@ int main(int argc, char *argv[])
 		if (rc != X3H_OK) { fprintf(stderr, "x3: decompress failed: %s\n", x3h_strerror(rc)); return 1; }
 		fprintf(stderr, "elapsed time: %f\n", st.ms_total / 1000.0);
 	}
+	const double t_call = now_ms();
 	if (fwrite(optr, 1, osize, ostream) < osize) die("short write");
+	g_phase = 5;
+	const double t_write = now_ms();
 
 	size_t size = decompress ? osize : isize, asize = decompress ? isize : osize;
 	fprintf(stderr, "input stream size: %zu\n", size);
@@ -191,6 +242,7 @@ int main(int argc, char *argv[])
 	fprintf(stderr, "context entries: ctx0 %llu, ctx1 %llu\n", (unsigned long long)st.ctx0_entries, (unsigned long long)st.dict_elems);
 
 	for (int i = 0; i < ngpu; i++) x3h_ctx_destroy(ctxs[i]);
+	g_phase = 6;
 	free(iptr);
 	free(optr);
 	fclose(istream);
@@ -198,5 +250,9 @@ int main(int argc, char *argv[])
 	/* everything is written and every handle is released: leave without the HIP runtime's exit-time teardown (nothing of ours is left
 	 * for it to release) */
 	fflush(NULL);
+	g_phase = 7;
+	if (getenv("X3H_DEBUG")) fprintf(stderr, "[x3] ms: handles %.1f, read %.1f, library call %.1f, write %.1f, release + close %.1f\n", t_ctx - t_start, t_read - t_ctx,
+	                                 t_call - t_read, t_write - t_call, now_ms() - t_write);
+	if (getenv("X3_CLI_RUNTIME_TEARDOWN")) return 0; /* (diagnostics) leave through exit(): atexit handlers and the HIP runtime's static destructors run */
 	_exit(0);
 }

@@ -18,6 +18,9 @@
 #include <vector>
 
 extern thread_local int x3_last_hip;
+extern thread_local double x3_alloc_ms;   /* time spent in hipMalloc / hipFree by this thread's DevBuf::reserve calls (X3H_DEBUG reports it per call) */
+extern thread_local unsigned long long x3_alloc_bytes, x3_alloc_calls;
+double x3_now_ms();
 
 #define HIPCHK(expr)                                                   \
 	do {                                                               \
@@ -32,9 +35,11 @@ struct DevBuf {
 	int reserve(size_t bytes)
 	{
 		if (bytes <= cap) return X3H_OK;
+		const double t0 = x3_now_ms();
 		if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
 		size_t want = bytes + bytes / 8 + 4096;
 		hipError_t e = hipMalloc(&p, want);
+		x3_alloc_ms += x3_now_ms() - t0; x3_alloc_bytes += want; x3_alloc_calls++;
 		if (e != hipSuccess) { p = nullptr; x3_last_hip = (int)e; return X3H_E_NOMEM; }
 		cap = want;
 		return X3H_OK;
