@@ -43,6 +43,39 @@ def test_emulated_kernels_match_oracle(emu, oracle, name, data, kw):
     assert emu.compress(data, prm) == stream
 
 
+SEG_CASES = [
+    ("abra", b"abracadabra" * 30, dict(w_kib=1, t=2)),
+    ("english", synth.english_like(2600).tobytes(), dict(w_kib=1, t=4)),
+    ("zipf_rare_bytes", synth.zipf_bytes(1500).tobytes(), dict(w_kib=1, t=2)),          # most bytes occur fewer than T+1 times in a window: exact K
+    ("zeros_dense", bytes(1200), dict(w_kib=1, t=15)),                                 # one dense class + the padding zeros as occurrences
+    ("mr_like", synth.mr_like(3000).tobytes(), dict(w_kib=1, t=3)),
+    ("two_tiles_t1", synth.english_like(5000, seed=5).tobytes(), dict(w_kib=2, t=1)),   # more than one 4096-element tile per pass
+    ("one_byte", b"a", dict()),
+]
+
+
+@pytest.mark.parametrize("name,data,kw", SEG_CASES, ids=[c[0] for c in SEG_CASES])
+def test_emulated_per_chunk_scan_matches_oracle(emu, oracle, monkeypatch, name, data, kw):
+    """scan3.hip (K1 of many-chunk batches: one workgroup sorts and level-tests one chunk) forced on a single chunk: m[] == the oracle's
+    (backend.c:56-78) and the stream built on it == the oracle's"""
+    monkeypatch.setenv("X3H_SEG_MIN", "1")
+    prm, oprm = _lib.make_params(**kw), oracle_lib.params(**kw)
+    assert np.array_equal(np.frombuffer(emu.scan_m(data, prm), np.uint8), np.frombuffer(oracle.scan_m(data, oprm), np.uint8))
+    assert emu.compress(data, prm) == oracle.compress(data, oprm)
+
+
+def test_emulated_per_chunk_scan_batch(emu, oracle, monkeypatch):
+    """a ragged batch (empty chunk, one byte, text, zeros) through the per-chunk scan: every chunk's stream == the oracle's stream of that chunk"""
+    monkeypatch.setenv("X3H_SEG_MIN", "2")
+    parts = [synth.english_like(900, seed=2).tobytes(), b"", b"x", bytes(700), synth.zipf_bytes(800, offset=99).tobytes()]
+    data = np.frombuffer(b"".join(parts), np.uint8)
+    off = np.cumsum([0] + [len(p) for p in parts]).astype(np.uint64)
+    kw = dict(w_kib=1, t=3)
+    got = emu.compress_chunks(data, off, _lib.make_params(**kw))
+    for g, p in zip(got, parts):
+        assert g == oracle.compress(p, oracle_lib.params(**kw))
+
+
 def test_emulated_scan_counts(emu, oracle):
     data = synth.zipf_bytes(300).tobytes()
     cnt = emu.scan_counts(data, _lib.make_params(w_kib=1, t=2))

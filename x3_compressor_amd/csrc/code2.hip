@@ -403,13 +403,55 @@ __device__ static __forceinline__ uint4 x3_make_symbol(uint32_t cum, uint32_t fr
  * holds [nlo, nhi].  That happens at t = 30 - s with (nhi >> t) - (nlo >> t) <= 1 no longer satisfiable one level down, i.e. with
  * D = nhi - nlo = sf - 1 and b = its top bit:  s = clz(D) - 1 - carry, where carry = the carry into bit b of nlo + D == NOT bit b of
  * (nlo ^ nhi)  (bit b of D is 1).  Both kinds of shift are left shifts that scale the range: lo' = (nlo << s) mod 2^30, R' = sf << s.
- * One clz, one bit test and a subtract-with-borrow replace the E1/E2/E3 loops: 17 scalar instructions per symbol in all.
+ * One clz, one bit test and a subtract-with-borrow replace the E1/E2/E3 loops: 13 scalar instructions per symbol in all
+ * (x3_ac2_sym below; disassembly excerpt: profiles/r03_ac2_chain_disassembly.txt).
  * Nothing is written to the bit stream here, not even a record per symbol: the chain stores its STATE (lo, R) once per group of
  * X3_AC2_G = 8 symbols (at the slot of the group's first symbol); the emit stage re-runs the eight steps of every group in parallel
  * (x3_expand_records) to get the per-symbol intervals (nlo, nhi), and derives n (E1/E2 count), k (E3 count), the mScale bookkeeping
  * and the bit placement from those with prefix sums.  (A record store per symbol pair cost the chain 7 %.)
  * D != 0 always: sf >= step >= 2^29 / total, and a model total stays < 2^28 (a stream is at most 2^27 bytes, X3H_MAX_CHUNK).
  */
+/* ONE definition of a chain step for every user: the scalar-unit chain of x3_ac2_kernel, the emulator build of that kernel (tests/emu runs
+ * exactly this arithmetic, not a restatement) and the parallel re-run of a group in the emit stage (x3_chain_step).  Advances (lo, R) and
+ * returns the narrowed interval (nlo, nhi) with lo as the chain holds it (unreduced, see below).  The only build-specific piece is the
+ * borrow of the bit test: s_bitcmp0_b32 + s_subb_u32 on the scalar chain (two instructions, SCC in between), the same expression in C for
+ * per-thread values and under the emulator. */
+template <bool SALU> /* SALU: the values are wave-uniform and live in scalar registers (the chain of x3_ac2_kernel); else per-thread values */
+__device__ static __forceinline__ uint32_t x3_ac2_shift(uint32_t x, uint32_t cz)
+{
+	/* cz - 1 - NOT(bit (31 - cz) of x) */
+#ifndef X3_EMU
+	if (SALU) {
+		uint32_t sh;
+		const uint32_t t = 31u - cz;
+		asm("s_bitcmp0_b32 %1, %2\n\ts_subb_u32 %0, %3, 1" : "=s"(sh) : "s"(x), "s"(t), "s"(cz) : "scc");
+		return sh;
+	}
+#endif
+	return cz - 1 - (((x >> (31u - cz)) & 1u) ^ 1u);
+}
+template <bool SALU>
+__device__ static __forceinline__ uint2 x3_ac2_sym(uint32_t &lo, uint32_t &R, uint32_t cum, uint32_t fq, uint32_t m, uint32_t msh)
+{
+	const uint32_t step = (uint32_t)(((uint64_t)R * m) >> 32) >> msh;
+	const uint32_t sf = step * fq, D = sf - 1;
+	uint2 iv;
+	iv.x = lo + step * cum;
+	iv.y = iv.x + D;
+#ifndef X3_EMU
+	const uint32_t cz = (uint32_t)__builtin_clz(D); /* D != 0 always (see above): no guard instruction on the chain */
+#else
+	const uint32_t cz = (uint32_t)x3_clz32(D);
+#endif
+	const uint32_t sh = x3_ac2_shift<SALU>(iv.x ^ iv.y, cz);
+	/* both shifts in ONE s_lshl_b64 of the pair {sf (low word), nlo (high word)}: sf << sh stays below 2^32 (it is the renormalised
+	 * range), so nothing crosses into the high word, whose own top bits fall off as in a 32-bit shift */
+	const uint64_t pr = (((uint64_t)iv.x << 32) | sf) << sh;
+	lo = (uint32_t)(pr >> 32);
+	R = (uint32_t)pr;
+	return iv;
+}
+
 #define X3_AC2_G 8u   /* symbols per stored chain state */
 #define X3_SYM_PAD 72 /* readable operand entries behind the last symbol (the chain fetches one group of 8 ahead) */
 #ifndef X3_EMU
@@ -422,25 +464,14 @@ __device__ static __forceinline__ uint4 x3_make_symbol(uint32_t cum, uint32_t fr
  * The operand array has X3_SYM_PAD readable entries behind the last symbol, so the fetch one group ahead needs no clamping.
  * lo is NOT reduced mod 2^30 after the shift: the two stray bits (30, 31) never reach a bit the chain looks at (they cancel in
  * nlo ^ nhi at bit 30, the only place they could matter) and are shifted out or stay put; x3_expand_records re-runs the chain with
- * the same unreduced lo and takes the stray bits off the intervals it writes: 14 instructions per symbol + 1/8 store. */
+ * the same unreduced lo and takes the stray bits off the intervals it writes: 13 instructions per symbol + 1/8 store. */
 typedef uint32_t x3_u32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t x3_u32x4 __attribute__((ext_vector_type(4)));
 
 #define X3_AC2_SYM(Q, J, NLO, NHI)                                                                                              \
 	{                                                                                                                           \
-		const uint32_t cum = (Q)[4 * (J)], fq = (Q)[4 * (J) + 1], m = (Q)[4 * (J) + 2], msh = (Q)[4 * (J) + 3];                 \
-		const uint32_t step = (uint32_t)(((uint64_t)R * m) >> 32) >> msh;                                                       \
-		const uint32_t sf = step * fq, D = sf - 1;                                                                              \
-		NLO = lo + step * cum;                                                                                                  \
-		NHI = NLO + D;                                                                                                          \
-		const uint32_t cz = (uint32_t)__builtin_clz(D), x = NLO ^ NHI, t = 31u - cz;                                            \
-		uint32_t sh;                                                                                                            \
-		asm("s_bitcmp0_b32 %1, %2\n\ts_subb_u32 %0, %3, 1" : "=s"(sh) : "s"(x), "s"(t), "s"(cz) : "scc");                      \
-		/* both shifts in ONE s_lshl_b64 of the pair {sf (low word), NLO (high word)}: sf << sh stays below 2^32 (it is the renormalised   \
-		 * range), so nothing crosses into the high word, whose own top bits fall off as in a 32-bit shift */                         \
-		const uint64_t pr_ = (((uint64_t)NLO << 32) | sf) << sh;                                                                \
-		lo = (uint32_t)(pr_ >> 32);                                                                                             \
-		R = (uint32_t)pr_;                                                                                                      \
+		const uint2 iv_ = x3_ac2_sym<true>(lo, R, (Q)[4 * (J)], (Q)[4 * (J) + 1], (Q)[4 * (J) + 2], (Q)[4 * (J) + 3]);          \
+		NLO = iv_.x; NHI = iv_.y;                                                                                               \
 	}
 #define X3_AC2_STATE(OFF)                                                                                                       \
 	{                                                                                                                           \
@@ -518,7 +549,7 @@ __device__ static void x3_ac2_body(const X3Ac2Args &a)
 	}
 }
 #else
-/* functional restatement of the same formulas for the CPU emulator build (tests only) */
+/* the CPU emulator build (tests only): the same step function, one symbol at a time, no scalar-cache staging */
 __device__ static void x3_ac2_body(const X3Ac2Args &a)
 {
 	const uint32_t c = blockIdx.x, lane = x3_lane();
@@ -528,13 +559,8 @@ __device__ static void x3_ac2_body(const X3Ac2Args &a)
 	x3_wave_sync();
 	for (uint32_t y = 0; y < Y; y++) {
 		const uint4 q = a.sym[y0 + y];
-		const uint32_t step = (uint32_t)(((uint64_t)R * q.z) >> 32) >> q.w;
-		const uint32_t nlo = lo + step * q.x, sf = step * q.y, D = sf - 1, nhi = nlo + D;
-		const uint32_t cz = (uint32_t)x3_clz32(D), t = 31u - cz;
-		const uint32_t sh = cz - 1 - ((((nlo ^ nhi) >> t) & 1u) ^ 1u);
 		if (lane == 0 && (y % X3_AC2_G) == 0) { a.rec_nk[2 * (size_t)(y0 + y)] = lo; a.rec_nk[2 * (size_t)(y0 + y) + 1] = R; } /* the state before the group */
-		lo = nlo << sh; /* not reduced mod 2^30, like the device chain */
-		R = sf << sh;
+		(void)x3_ac2_sym<false>(lo, R, q.x, q.y, q.z, q.w); /* the device chain's own step function (lo not reduced mod 2^30) */
 	}
 	x3_wave_sync();
 	if (lane == 0) {
@@ -585,15 +611,9 @@ __device__ static __forceinline__ uint32_t x3_rec_k(uint32_t nlo, uint32_t nhi)
  * narrowed interval with the stray top bits of lo removed, advances (lo, R). */
 __device__ static __forceinline__ uint2 x3_chain_step(uint32_t &lo, uint32_t &R, const uint4 q)
 {
-	const uint32_t step = (uint32_t)(((uint64_t)R * q.z) >> 32) >> q.w;
-	const uint32_t nlo = lo + step * q.x, sf = step * q.y, D = sf - 1, nhi = nlo + D;
-	const uint32_t cz = (uint32_t)x3_clz32(D), t = 31u - cz;
-	const uint32_t sh = cz - 1 - ((((nlo ^ nhi) >> t) & 1u) ^ 1u);
 	const uint32_t stray = lo & 0xC0000000u;
-	uint2 r;
-	r.x = nlo - stray; r.y = nhi - stray;
-	lo = nlo << sh;
-	R = sf << sh;
+	uint2 r = x3_ac2_sym<false>(lo, R, q.x, q.y, q.z, q.w);
+	r.x -= stray; r.y -= stray;
 	return r;
 }
 
