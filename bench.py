@@ -57,6 +57,13 @@ def run_reference(sample: bytes, w_kib: int, t: int):
         return sec, open(o, "rb").read(), "port"
 
 
+def newest_profile(suffix):
+    """profiles/rNN_<suffix> of the latest round that has one (PMC numbers come from separate profiling passes, tools/r03_refresh.sh)"""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return c[-1] if c else None
+
+
 def timed(fn, sync):
     sync()
     t0 = time.perf_counter()
@@ -238,14 +245,14 @@ def main():
     # HBM bytes of the dominant kernel from SEPARATE rocprofv3 --pmc passes of this same command (tools/pmc_agg.py): only quoted when
     # that profile was taken with the same arguments and its kernel time agrees with this run's (else null: stale numbers are worse than none)
     traffic, traffic_src = None, None
-    pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if os.path.exists(pmc_path):
+    pmc_path = newest_profile("pmc_traffic.json")
+    if pmc_path:
         pmc = json.load(open(pmc_path))
         same_args = pmc.get("bench_args") == {"bytes": args.bytes, "w": args.w, "t": args.t}
         e = pmc.get("kernels", {}).get(dom)
         if same_args and e and abs(e.get("kernel_ms_per_step", 0) - kernels[dom]["ms"]) <= 0.1 * kernels[dom]["ms"]:
             traffic = e["hbm_bytes_per_step"]
-            traffic_src = "profiles/r02_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (per step = all launches of the kernel; FETCH doubled per MI355X_MICROARCH.md)"
+            traffic_src = f"profiles/{os.path.basename(pmc_path)}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (per step = all launches of the kernel; FETCH doubled per MI355X_MICROARCH.md)"
     path_bytes = S * W + N + comp  # the path's algorithmic bytes B_alg = S*W + N + C
     line.update({
         "config": {"workload": f"dickens-like: {N} bytes of synthetic English-like text, ONE x3 stream, -w {args.w} -t {args.t}, bit-exact x3 code stream",
@@ -332,13 +339,14 @@ def main():
             line["many_chunks_batch"]["decode_64KiB_streams"] = dict(decode_leg(d_fout, fstride, flens, 64 << 10), ratio=round(mtot / float(flens.sum()), 4),
                                                                  compress_value=round(mtot / fdt / 1e6, 2))
             del d_fout
-            tpath = os.path.join(ROOT, "profiles", "r02_many_chunks_pmc_traffic.json")
-            if os.path.exists(tpath):
+            tpath = newest_profile("many_chunks_pmc_traffic.json")
+            if tpath:
                 t = json.load(open(tpath))
                 if t.get("total_bytes") == mtot and abs(t.get("batch_ms", 0) - mdt * 1e3) <= 0.15 * mdt * 1e3:
                     line["many_chunks_batch"]["hbm_traffic"] = {"GB_per_batch": t["total"]["GB"], "bytes_per_input_byte": t["total"]["bytes_per_input_byte"],
                                                                 "avg_TBps_over_kernel_time": t["total"]["avg_TBps"], "frac_of_hbm_peak": round(t["total"]["avg_TBps"] * 1e12 / HBM_PEAK, 3),
-                                                                "source": "profiles/r02_many_chunks_pmc_traffic.json (separate rocprofv3 --pmc passes of tools/many_chunks_check.py on the same batch)"}
+                                                                "source": f"profiles/{os.path.basename(tpath)} (separate rocprofv3 --pmc passes of tools/many_chunks_check.py on the same batch)",
+                                                                "by_family_GB": {k: v["hbm_GB"] for k, v in list(t.get("groups", {}).items())[:8]}}
             del d_min, d_mout, d_tout
             # data with DENSE classes (sparse 16-bit samples: thousands of repeats of a gram inside every window): K1 refines such classes byte
             # by byte instead of sweeping them (scan2.hip) -- bounded, but the scan dominates
