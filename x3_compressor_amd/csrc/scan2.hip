@@ -58,6 +58,7 @@ struct X3WalkArgs {
 	const uint32_t *nactive;
 	uint8_t *m;
 	uint32_t total;              /* sorted entries */
+	uint32_t seg;                /* the list is a concatenation of per-chunk lists (scan3.hip): chunk c's entries are [byte_off, byte_off + len + 3), no padding positions */
 	uint32_t ncand;              /* W - 33 */
 };
 
@@ -83,9 +84,11 @@ __device__ static void x3_walk_body(const X3WalkArgs &a)
 #pragma unroll
 	for (int i = 0; i < 28; i++) cnt[i] = 0;
 	uint32_t done = 0, npad = 0;
-	for (uint32_t base = myj + 1; base < a.total && !done; base += X3_WAVE) {
+	uint32_t lend = a.total; /* one past the last list entry a walk from here may read */
+	if (a.seg) { const uint32_t e = a.dataend[p >> 8] + 3u; lend = e < lend ? e : lend; }
+	for (uint32_t base = myj + 1; base < lend && !done; base += X3_WAVE) {
 		const uint32_t j = base + lane;
-		uint32_t s = j < a.total ? a.S4[j] - a.back : NONE32; /* an end position < back wraps to a huge value: fails the window test like any out-of-class entry */
+		uint32_t s = j < lend ? a.S4[j] - a.back : NONE32; /* an end position < back wraps to a huge value: fails the window test like any out-of-class entry */
 		uint32_t lcp = 0;
 		bool inwin = false;
 		if (s != NONE32 && s <= wend && a.cls[j] == g) { inwin = true; lcp = 4 * a.kwords; } /* same class: the class's gram in common */
@@ -324,12 +327,17 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 	HIPCHK(hipStreamSynchronize(st));
 	X3WalkArgs wa;
 	wa.bytes = d_bytes; wa.S4 = S; wa.cls = ks4; wa.back = 3; wa.kwords = 1; wa.active_j = act_j; wa.active = act; wa.active_k = act_k; wa.nactive = d_nact; wa.m = d_m;
-	wa.total = Pn; wa.ncand = ncand; wa.padbits = padbits; wa.pad_dropped = 0; wa.dataend = dataend; wa.npos = Pn;
+	wa.total = Pn; wa.ncand = ncand; wa.padbits = padbits; wa.pad_dropped = seg ? 1u : 0u; wa.dataend = dataend; wa.npos = Pn; wa.seg = seg ? 1u : 0u;
 	launch_walk(wa, hcnt[0], st);
 	HIPCHK(hipGetLastError());
 	if (!hcnt[1]) return X3H_OK;
 
 	/* ---- dense classes: refine them byte by byte (header, step 4).  Element = START position from here on. ---- */
+	wa.seg = 0; /* the refined lists below are chip-wide again */
+	if (seg) { /* per-chunk lists end at len + 3 entries: what lies behind them in a slot becomes entries that are never a query, never inside a window */
+		uint32_t *S4w = S, *K4w = (uint32_t *)ks4;
+		x3_foreach(P, st, X3_LAMBDA(size_t j) { if ((uint32_t)j >= dataend[j >> 8] + 3u) { S4w[j] = 2u; K4w[j] = 0xFFFFFFFFu; } });
+	}
 	for (int i = 10; i < 21; i++) CHK(B.a[i].reserve((P + 8) * 4));
 	uint32_t *Lp = B.a[10].as<uint32_t>(), *Lc = B.a[11].as<uint32_t>(), *Np = B.a[12].as<uint32_t>(), *Nc = B.a[13].as<uint32_t>();
 	uint32_t *keep = B.a[14].as<uint32_t>(), *flg = B.a[15].as<uint32_t>(), *scn = B.a[16].as<uint32_t>();
@@ -344,7 +352,7 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 	size_t n = P;
 	for (uint32_t len = 4; len <= X3_MAXLEN && n > 0; len++) {
 		const uint32_t nn = (uint32_t)n, stamp = len;
-		const bool pad_dropped = len > 4; /* list 4 still holds the padding positions; the first compaction drops them and they are counted analytically from then on */
+		const bool pad_dropped = seg || len > 4; /* the chip-wide list 4 still holds the padding positions; the first compaction drops them and they are counted analytically from then on (per-chunk lists never held them) */
 		HIPCHK(hipMemsetAsync(d_nact, 0, 8, st));
 		/* the level test (gram length len): K-th next member of my class inside my window?  Then: finished by a sweep, or still dense */
 		x3_foreach(n, st, X3_LAMBDA(size_t j) {

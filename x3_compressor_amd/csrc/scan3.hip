@@ -14,7 +14,8 @@
  *   level l  on the list just written (ordered by the l-gram starting at p = q-(l-1), positions ascending inside a class):
  *            count_{l-1}(p) >= K  <=>  entry j+K has the same l-gram and lies inside p's window -- scan2.hip's O(1) test.  A level that
  *            passes adds one to a 2-BIT COUNTER of the position IN LDS (levels pass in order: the counter IS m for m <= 3), so m[] leaves
- *            the chip once, as coalesced bytes, instead of as one scattered byte store per level;
+ *            the chip once, as coalesced bytes, instead of as one scattered byte store per level.  The W padding zeros behind a chunk are
+ *            COUNTED where a window reaches them (seg_cpad), never sorted;
  *   list 4   (4-gram classes) and the positions whose 4-gram still repeats K times go to the walk kernel / the dense-class refinement of
  *            scan2.hip unchanged (same list layout: chunk c's list occupies the entries of its slot of the padded layout).
  * HBM traffic: 16 B per element and pass + the level reads, all of it sequential or in digit runs.
@@ -42,6 +43,13 @@ __device__ static __forceinline__ uint64_t seg_match8(uint32_t d, bool valid)
 	return mask;
 }
 
+/* Padding.  The W zero bytes behind a chunk take part in its windows (x3.c:579,590), but they are not sorted: the lists hold the END positions
+ * q < n + 3 only (every gram that starts inside the data).  An end position e >= n + 3 ends an all-zero gram of any length <= 4, so a query
+ * whose gram is all zero meets   cpad = #{ e in [n + 3, q + ncand] }   further occurrences behind everything the list shows it (they are the
+ * class's largest positions): "the K-th next occurrence lies inside the window"  <=>  cpad >= K, or entry j + (K - cpad) is of the class and
+ * inside the window. */
+__device__ static __forceinline__ uint32_t seg_cpad(uint32_t qrel, uint32_t ncand, uint32_t n) { const uint32_t we = qrel + ncand; return we >= n + 3u ? we - n - 2u : 0u; }
+
 /* the test of level lv (gram length lv) for entry j = `it` of list lv; `la` = entry j + T + 1 of the same list (position 0xFFFFFFFF when
  * there is none); list = list lv as (key, position) pairs.  Level 1 fixes K = min(T+1, count_0) (positions with a smaller K are marked in
  * `rbits`, their K goes to kexact); levels 2, 3 add one to the position's 2-bit counter when count_{lv-1} >= K. */
@@ -50,17 +58,24 @@ __device__ static __forceinline__ void seg_level(uint32_t lv, const uint2 it, co
 {
 	if (lv == 1u) {
 		const uint32_t prel = it.y - base;
-		if (prel >= n) return; /* padding: an occurrence, never a query */
+		if (prel >= n) return; /* a padding start: an occurrence, never a query */
 		const uint32_t kj = it.x & 0xFFu, wend = prel + ncand;
-		if ((la.x & 0xFFu) == kj && la.y - base <= wend) return; /* the (T+1)-th next occurrence of the byte is inside the window: K = T+1 */
-		uint32_t lo = 0, bnd = Tu; /* count them: binary search, predicate true at lo */
+		const uint32_t cpad = kj == 0u ? seg_cpad(prel, ncand, n) : 0u;
+		/* is the (T+1)-th next occurrence of the byte inside the window?  then K = T+1 */
+		if (cpad == 0u) { if ((la.x & 0xFFu) == kj && la.y - base <= wend) return; }
+		else {
+			if (cpad > Tu) return;
+			const uint32_t u = j + (Tu + 1u - cpad);
+			if (u < L) { const uint2 eu = list[u]; if ((eu.x & 0xFFu) == kj && eu.y - base <= wend) return; }
+		}
+		uint32_t lo = 0, bnd = Tu - cpad; /* count the listed ones: binary search, predicate true at lo */
 		if (j + bnd >= L) bnd = L - 1u - j;
 		while (lo < bnd) {
 			const uint32_t mid = (lo + bnd + 1u) >> 1;
 			const uint2 em = list[j + mid];
 			if ((em.x & 0xFFu) == kj && em.y - base <= wend) lo = mid; else bnd = mid - 1u;
 		}
-		kexact[it.y] = lo; /* == count_0 */
+		kexact[it.y] = lo + cpad; /* == count_0 */
 		atomicOr(&rbits[prel >> 5], 1u << (prel & 31u));
 		return;
 	}
@@ -68,14 +83,25 @@ __device__ static __forceinline__ void seg_level(uint32_t lv, const uint2 it, co
 	const uint32_t qrel = it.y - base;
 	if (qrel < back || qrel - back >= n) return; /* the gram starts before the chunk or in its padding */
 	const uint32_t prel = qrel - back, wend = qrel + ncand; /* both sides of the window test carry the same +back */
+	const uint32_t cpad = (it.x & msk) == 0u ? seg_cpad(qrel, ncand, n) : 0u;
 	/* first with K = T+1, from the list alone (K <= T+1: if even the (T+1)-th next occurrence is inside the window the level passes);
 	 * only if that fails can a smaller K matter, and only marked positions have one */
-	bool pass = ((la.x ^ it.x) & msk) == 0u && la.y - base <= wend;
+	bool pass;
+	if (cpad == 0u) pass = ((la.x ^ it.x) & msk) == 0u && la.y - base <= wend;
+	else if (cpad > Tu) pass = true;
+	else {
+		const uint32_t u = j + (Tu + 1u - cpad);
+		pass = false;
+		if (u < L) { const uint2 eu = list[u]; pass = ((eu.x ^ it.x) & msk) == 0u && eu.y - base <= wend; }
+	}
 	if (!pass && ((rbits[prel >> 5] >> (prel & 31u)) & 1u)) {
 		const uint32_t K = kexact[base + prel];
-		if (K >= 2u && j + K < L) { /* K < 2: count_0 < 2, nothing repeats */
-			const uint2 eu = list[j + K];
-			pass = ((eu.x ^ it.x) & msk) == 0u && eu.y - base <= wend;
+		if (K >= 2u) { /* K < 2: count_0 < 2, nothing repeats */
+			if (cpad >= K) pass = true;
+			else if (j + (K - cpad) < L) {
+				const uint2 eu = list[j + (K - cpad)];
+				pass = ((eu.x ^ it.x) & msk) == 0u && eu.y - base <= wend;
+			}
 		}
 	}
 	if (pass) atomicAdd(&mfield[prel >> 4], 1u << (2u * (prel & 15u)));
@@ -92,16 +118,15 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 	const uint32_t tid = threadIdx.x, lane = x3_lane(), wv = tid / X3_WAVE;
 	const X3Chunk ck = a.chunks[blockIdx.x];
 	const uint32_t n = ck.len, base = (uint32_t)ck.byte_off;
-	const uint32_t slot = (n + a.window + X3_PAD_EXTRA + 255u) & ~255u;
-	/* elements q = 0 .. L-1: every start position a window can reach (n-1 + ncand) is the start of an l-gram ending before L, l <= 4 */
-	const uint32_t L = n ? n + a.ncand + 3u : 0u;
+	/* elements q = 0 .. L-1: the END positions of every l-gram (l <= 4) that starts inside the data; the padding behind is counted, not sorted (seg_cpad) */
+	const uint32_t L = n ? n + 3u : 0u;
 	const uint32_t ncand = a.ncand, Tu = a.Tu;
 	uint2 *A = a.la + base, *Bq = a.lb + base;
 	uint32_t *S4 = a.S4 + base, *K4 = a.K4 + base;
 
-	/* entries of the slot behind the list: never a query, never inside a window, never in a class with a real entry's position */
-	for (uint32_t i = L + tid; i < slot; i += X3_SEG_THREADS) { S4[i] = 2u; K4[i] = 0xFFFFFFFFu; }
-	if (!n) return;
+	/* entries of the slot behind the list are never read: the walk kernel stops at the list's end, and scan2.hip turns everything from entry
+	 * len + 3 on into fillers before it refines dense classes -- which leaves the first three entries of an EMPTY chunk's slot to this kernel */
+	if (!n) { if (tid < 3u) { S4[tid] = 2u; K4[tid] = 0xFFFFFFFFu; } return; }
 
 	uint64_t tclk = a.prof ? x3_clock() : 0;
 #define SEG_MARK(k) do { if (a.prof && tid == 0) { const uint64_t now_ = x3_clock(); atomicAdd((unsigned long long *)&a.prof[k], (unsigned long long)(now_ - tclk)); tclk = now_; } } while (0)
@@ -255,11 +280,18 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 			const uint32_t qrel = ss[e] - base;
 			if (j < L && qrel >= 3u && qrel - 3u < n) {
 				const uint32_t prel = qrel - 3u, wend = qrel + ncand;
+				const uint32_t cpad = kk[e] == 0u ? seg_cpad(qrel, ncand, n) : 0u;
 				gp = base + prel;
-				bool pass = ku[e] == kk[e] && su[e] - base <= wend;
+				bool pass;
+				if (cpad == 0u) pass = ku[e] == kk[e] && su[e] - base <= wend;
+				else if (cpad > Tu) pass = true;
+				else { const uint32_t u = j + (Tu + 1u - cpad); pass = u < L && K4[u] == kk[e] && S4[u] - base <= wend; }
 				if (!pass && ((rbits[prel >> 5] >> (prel & 31u)) & 1u)) {
 					K = a.kexact[gp];
-					if (K >= 2u && j + K < L) pass = K4[j + K] == kk[e] && S4[j + K] - base <= wend;
+					if (K >= 2u) {
+						if (cpad >= K) pass = true;
+						else if (j + (K - cpad) < L) pass = K4[j + (K - cpad)] == kk[e] && S4[j + (K - cpad)] - base <= wend;
+					}
 				}
 				if (pass) {
 					atomicAdd(&mfield[prel >> 4], 1u << (2u * (prel & 15u)));
