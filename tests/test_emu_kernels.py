@@ -208,6 +208,14 @@ def test_emulated_pipelined_single_stream(emu_env, oracle, name, data, kw):
     assert ctx.compress(data, _lib.make_params(**kw)) == oracle.compress(data, oracle_lib.params(**kw))
 
 
+@pytest.mark.parametrize("name,data,kw", PIPE_CASES[1:], ids=[c[0] for c in PIPE_CASES[1:]])
+def test_emulated_pipelined_emit_behind_every_segment(emu_env, oracle, name, data, kw):
+    """X3H_SEG_EMIT=1: each coder segment's bits written behind its recurrence by one workgroup per stream (the default for 8 or more streams)
+    against the other form of the schedule's tail (operands and chain states gathered into the final layout, every bit emitted at the end)"""
+    ctx = emu_env(X3H_PIPE_MIN="1", X3H_SEG_EMIT="1")
+    assert ctx.compress(data, _lib.make_params(**kw)) == oracle.compress(data, oracle_lib.params(**kw))
+
+
 @pytest.mark.parametrize("marks", ["0.5", "0.1,0.2,0.3,0.4,0.5,0.6,0.7,0.8", "0.9,0.95", "garbage"])
 def test_emulated_pipelined_other_checkpoints(emu_env, oracle, marks):
     """X3H_PIPE_MARKS: one checkpoint, the maximum of eight, late ones, and a malformed list (keeps the default): same bytes"""
@@ -225,10 +233,11 @@ def test_emulated_fixed_point_modes(emu_env, oracle, pipe):
     assert ctx.last_stats.mode_iters > 0
 
 
-def test_emulated_pipelined_several_streams(emu_env, oracle):
+@pytest.mark.parametrize("seg_emit", ["0", "1"], ids=["bits-at-the-end", "bits-behind-every-segment"])
+def test_emulated_pipelined_several_streams(emu_env, oracle, seg_emit):
     """run_pipelined with a batch: ragged streams (an empty and a 2-byte one among them), per-stream checkpoints, per-stream coder segments
-    in the operand / state rings, gather into the final symbol layout"""
-    ctx = emu_env(X3H_PIPE_MIN="1")
+    in the operand / state rings, gather into the final symbol layout -- or, the other form of the tail, every segment's bits written behind it"""
+    ctx = emu_env(X3H_PIPE_MIN="1", X3H_SEG_EMIT=seg_emit)
     kw = dict(w_kib=2, t=8)
     parts = [synth.english_like(9000).tobytes(), b"", synth.zipf_bytes(3000).tobytes(), b"ab", synth.english_like(20000, seed=5).tobytes(), bytes(2500)]
     data = np.frombuffer(b"".join(parts), dtype=np.uint8)

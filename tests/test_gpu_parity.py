@@ -285,7 +285,8 @@ def test_pipelined_stream_equals_reference_golden(gpu_env, golden, name):
 
 
 @pytest.mark.parametrize("env", [dict(X3H_PIPE_MIN="0", X3H_MODES="serial"), dict(X3H_PIPE_MIN="0", X3H_MODES="fixed"),
-                                 dict(X3H_PIPE_MIN="1", X3H_MODES="serial")], ids=["classic-serial", "classic-fixed", "pipelined-serial"])
+                                 dict(X3H_PIPE_MIN="1", X3H_MODES="serial"), dict(X3H_PIPE_MIN="1", X3H_SEG_EMIT="1")],
+                         ids=["classic-serial", "classic-fixed", "pipelined-serial", "pipelined-emit-behind-every-segment"])
 def test_schedules_agree_on_a_long_stream(gpu, gpu_env, env):
     """3 MiB of text, -w 64 -t 256: the default schedule (pipelined, cost-model choice of the mode pass) against the forced others"""
     data = synth.english_like(3 << 20, seed=77).tobytes()

@@ -45,7 +45,11 @@ struct x3h_ctx {
 	double pipe_marks[X3_MAX_CKPT] = { 0.02, 0.08, 0.26, 0.62 }; /* where the parse publishes checkpoints (X3H_PIPE_MARKS: up to 8 ascending fractions) */
 	uint32_t pipe_nmarks = 4;
 	uint64_t pipe_min = (uint64_t)256 << 10; /* streams at least this long are pipelined (X3H_PIPE_MIN; 0: never): measured faster from 256 KiB up */
-	hipStream_t s_parse = nullptr, s_coder = nullptr;
+	hipStream_t s_parse = nullptr, s_coder = nullptr, s_emit = nullptr;
+	hipEvent_t ev_emit = nullptr;
+	int seg_emit = -1; /* pipelined schedule: 1 = each coder segment's bits are written behind it (one workgroup per stream), 0 = every bit after the last
+	                    * segment by chip-wide passes, -1 = by the batch: 8 or more streams of at most 16 MiB (config 4's shape) measured 8 ms faster the
+	                    * first way, one or a few longer streams 6-60 ms faster the second (X3H_SEG_EMIT overrides) */
 	hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr, ev_ready = nullptr, ev_cb[X3_MAX_CKPT + 1] = {}, ev_ce[X3_MAX_CKPT + 1] = {};
 	X3ParseCkpt *ckpt = nullptr; /* host-mapped, X3_CKPT_SLOTS per stream */
 	uint32_t ckpt_cap = 0;
@@ -131,6 +135,7 @@ extern "C" int x3h_ctx_create(x3h_ctx **out, int device)
 		if (ok && k && !*q) { for (uint32_t i = 0; i < k; i++) c->pipe_marks[i] = m[i]; c->pipe_nmarks = k; }
 	  } }
 	{ const char *e = getenv("X3H_PIPE_STREAMS"); if (e && *e) c->pipe_max_streams = atoi(e); }
+	{ const char *e = getenv("X3H_SEG_EMIT"); if (e && *e) c->seg_emit = *e != '0' ? 1 : 0; }
 	if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return X3H_E_HIP; }
 	for (int i = 0; i < 6; i++)
 		if (hipEventCreate(&c->ev[i]) != hipSuccess) { x3h_ctx_destroy(c); return X3H_E_HIP; }
@@ -161,6 +166,9 @@ extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 	if (c->ckpt) (void)hipHostFree((void *)c->ckpt);
 	if (c->s_parse) (void)hipStreamDestroy(c->s_parse);
 	if (c->s_coder) (void)hipStreamDestroy(c->s_coder);
+	if (c->s_emit) (void)hipStreamDestroy(c->s_emit);
+	if (c->ev_emit) (void)hipEventDestroy(c->ev_emit);
+	c->seg.emit_state.release();
 	hipEvent_t pev[] = { c->ev_p0, c->ev_p1, c->ev_ready };
 	for (hipEvent_t e : pev) if (e) (void)hipEventDestroy(e);
 	for (int i = 0; i <= X3_MAX_CKPT; i++) { if (c->ev_cb[i]) (void)hipEventDestroy(c->ev_cb[i]); if (c->ev_ce[i]) (void)hipEventDestroy(c->ev_ce[i]); }
@@ -272,6 +280,8 @@ static int pipe_setup(x3h_ctx *c)
 	if (c->s_parse) return X3H_OK;
 	HIPCHK(hipStreamCreate(&c->s_parse));
 	HIPCHK(hipStreamCreate(&c->s_coder));
+	HIPCHK(hipStreamCreate(&c->s_emit));
+	HIPCHK(hipEventCreate(&c->ev_emit));
 	HIPCHK(hipEventCreate(&c->ev_p0)); HIPCHK(hipEventCreate(&c->ev_p1)); HIPCHK(hipEventCreate(&c->ev_ready));
 	for (int i = 0; i <= X3_MAX_CKPT; i++) { HIPCHK(hipEventCreate(&c->ev_cb[i])); HIPCHK(hipEventCreate(&c->ev_ce[i])); }
 	return X3H_OK;
@@ -286,7 +296,7 @@ static int run_pipelined(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, ui
 	CHK(pipe_setup(c));
 	const int rc = run_pipelined_body(c, pa, d_bytes, tok_pos, tok_hb, tok_nb, tok_mb, d_out, ps);
 	if (rc != X3H_OK) { /* never return with the parse or a coder segment still running on the side streams */
-		(void)hipStreamSynchronize(c->s_parse); (void)hipStreamSynchronize(c->s_coder); (void)hipStreamSynchronize(c->stream);
+		(void)hipStreamSynchronize(c->s_parse); (void)hipStreamSynchronize(c->s_coder); (void)hipStreamSynchronize(c->s_emit); (void)hipStreamSynchronize(c->stream);
 	}
 	return rc;
 }
@@ -332,6 +342,12 @@ static int run_pipelined_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_byte
 
 	X3CodeSeg &seg = c->seg;
 	seg.final = false; seg.coder_stream = c->s_coder; seg.ev_ready = c->ev_ready; seg.coder_state = c->coder_state.as<uint32_t>();
+	{
+		uint64_t longest = 0;
+		for (uint32_t i = 0; i < nc; i++) if (c->hchunks[i].len > longest) longest = c->hchunks[i].len;
+		const bool by_segment = c->seg_emit < 0 ? (nc >= 8 && longest <= ((uint64_t)16 << 20)) : c->seg_emit != 0;
+		seg.emit_stream = by_segment ? c->s_emit : nullptr; seg.ev_emit_done = c->ev_emit;
+	}
 	seg.y_done.assign(nc, 0u); seg.ring_top = 0; seg.calls.clear(); seg.prev_ho.clear(); seg.prev_serial = false;
 	/* the workspace is sized ONCE, for the worst case (steps, hits + elements and new-fragment bytes are each <= input bytes): a
 	 * reallocation in mid-flight would wait for the running parse and coder (hipFree synchronises the device), and a token density
@@ -401,6 +417,13 @@ static int run_pipelined_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_byte
 	float ms = 0;
 	(void)hipEventElapsedTime(&ms, c->ev_p0, c->ev_p1); ps->ms_parse = ms;
 	for (int i = 0; i < nseg; i++) { (void)hipEventElapsedTime(&ms, c->ev_cb[i], c->ev_ce[i]); ps->ms_coder += ms; }
+	if (getenv("X3H_DEBUG")) { /* where the coder segments sit on the time line of the call (ms after the parse started) */
+		(void)hipStreamSynchronize(c->stream);
+		fprintf(stderr, "[x3h] pipelined: parse %.1f ms;", ps->ms_parse);
+		for (int i = 0; i < nseg; i++) { float b = 0, e = 0; (void)hipEventElapsedTime(&b, c->ev_p0, c->ev_cb[i]); (void)hipEventElapsedTime(&e, c->ev_p0, c->ev_ce[i]); fprintf(stderr, " coder segment %d: %.1f .. %.1f;", i, b, e); }
+		if (c->seg.emit_stream) { float e = 0; (void)hipEventElapsedTime(&e, c->ev_p0, c->ev_emit); fprintf(stderr, " last bits written %.1f", e); }
+		fprintf(stderr, "\n");
+	}
 	return X3H_OK;
 }
 

@@ -666,6 +666,11 @@ struct X3EmitArgs {
 	const uint32_t *npairs, *evfinal;
 	uint8_t *out;               /* streams are assembled with ORs into pre-zeroed slots */
 	X3CodeResult *result;
+	/* segment form (pipelined schedule of a few long streams): the symbols of stream c are [seg_off[c], seg_off[c] + seg_len[c]) of the operand /
+	 * state rings, the pending-bit count and the bit position come from and go back to carry[4c ..], flush + result only when last */
+	const uint32_t *seg_off, *seg_len;
+	uint32_t *carry;
+	uint32_t last;
 };
 
 __device__ static __forceinline__ uint32_t x3_wave_incl_maxscan_u32(uint32_t v)
@@ -683,18 +688,21 @@ __device__ static __forceinline__ uint32_t x3_wave_incl_maxscan_u32(uint32_t v)
 #endif
 }
 
+template <uint32_t NT> /* threads of the workgroup: 256 when a thousand streams share the chip, 1024 when a few long ones do */
 __device__ static void x3_emit_body(const X3EmitArgs &a)
 {
-	const uint32_t NW = X3_EMIT_THREADS / X3_WAVE;
-	X3_LDS uint32_t s_ksum[X3_EMIT_THREADS], s_tail[X3_EMIT_THREADS], s_lr[X3_EMIT_THREADS];
-	X3_LDS uint32_t s_w[3][X3_EMIT_THREADS / X3_WAVE];
+	const uint32_t NW = NT / X3_WAVE;
+	X3_LDS uint32_t s_ksum[NT], s_tail[NT], s_lr[NT];
+	X3_LDS uint32_t s_w[3][NT / X3_WAVE];
 	const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = x3_lane(), wave = tid / X3_WAVE;
-	const uint32_t first = a.yoc[c], end = a.yoc[c + 1];
+	uint32_t first, end;
+	if (a.seg_off) { first = a.seg_off[c]; end = first + a.seg_len[c]; } else { first = a.yoc[c]; end = a.yoc[c + 1]; }
 	uint32_t *out32 = (uint32_t *)(a.out + a.chunks[c].out_off);
 	const uint32_t capw = (uint32_t)(a.chunks[c].out_cap / 4);
 	uint32_t carry_pend = 0;
 	uint64_t carry_pos = 0;
-	for (uint32_t tb = first; tb < end; tb += X3_EMIT_THREADS * X3_AC2_G) {
+	if (a.carry) { carry_pend = a.carry[4 * c]; carry_pos = (uint64_t)a.carry[4 * c + 1] | ((uint64_t)a.carry[4 * c + 2] << 32); }
+	for (uint32_t tb = first; tb < end; tb += NT * X3_AC2_G) {
 		const uint32_t gi = tb + tid * X3_AC2_G;
 		const uint32_t cnt = gi >= end ? 0u : (end - gi < X3_AC2_G ? end - gi : X3_AC2_G);
 		uint32_t eb[X3_AC2_G], kq[X3_AC2_G];
@@ -768,12 +776,13 @@ __device__ static void x3_emit_body(const X3EmitArgs &a)
 			}
 		}
 		/* carries: pending after the tile's last thread, bits so far */
-		const uint32_t llr = s_lr[X3_EMIT_THREADS - 1], lks = s_ksum[X3_EMIT_THREADS - 1];
+		const uint32_t llr = s_lr[NT - 1], lks = s_ksum[NT - 1];
 		carry_pend = llr ? s_tail[llr - 1] + (lks - s_ksum[llr - 1]) : carry_pend + lks;
 		carry_pos += btot;
 		__syncthreads();
 	}
-	if (tid == 0) { /* ac_encode_flush (ac.c:115-126) + bio_close (bio.c:105-112) + result */
+	if (a.carry && tid == 0) { a.carry[4 * c] = carry_pend; a.carry[4 * c + 1] = (uint32_t)carry_pos; a.carry[4 * c + 2] = (uint32_t)(carry_pos >> 32); }
+	if (tid == 0 && (!a.carry || a.last)) { /* ac_encode_flush (ac.c:115-126) + bio_close (bio.c:105-112) + result */
 		uint64_t nbits = carry_pos;
 		if (a.final_lo[c] < 0x20000000u) {
 			x3_or_run(out32, capw, nbits + 1, 1u, carry_pend + 1); /* '0' then mScale+1 ones */
@@ -793,11 +802,21 @@ __device__ static void x3_emit_body(const X3EmitArgs &a)
 }
 
 #ifndef X3_EMU
-__global__ void __launch_bounds__(X3_EMIT_THREADS) x3_emit_kernel(X3EmitArgs a) { x3_emit_body(a); }
-static void launch_emit(const X3EmitArgs &a, uint32_t nchunks, hipStream_t st) { hipLaunchKernelGGL(x3_emit_kernel, dim3(nchunks), dim3(X3_EMIT_THREADS), 0, st, a); }
+__global__ void __launch_bounds__(X3_EMIT_THREADS) x3_emit_kernel(X3EmitArgs a) { x3_emit_body<X3_EMIT_THREADS>(a); }
+__global__ void __launch_bounds__(1024) x3_emit_wide_kernel(X3EmitArgs a) { x3_emit_body<1024>(a); }
+static void launch_emit(const X3EmitArgs &a, uint32_t nchunks, hipStream_t st, bool wide = false)
+{
+	if (wide) hipLaunchKernelGGL(x3_emit_wide_kernel, dim3(nchunks), dim3(1024), 0, st, a);
+	else hipLaunchKernelGGL(x3_emit_kernel, dim3(nchunks), dim3(X3_EMIT_THREADS), 0, st, a);
+}
 #else
-static void emit_tramp(void *p) { x3_emit_body(*(const X3EmitArgs *)p); }
-static void launch_emit(const X3EmitArgs &a, uint32_t nchunks, hipStream_t) { x3emu_launch(emit_tramp, (void *)&a, dim3(nchunks), dim3(X3_EMIT_THREADS)); }
+static void emit_tramp(void *p) { x3_emit_body<X3_EMIT_THREADS>(*(const X3EmitArgs *)p); }
+static void emit_wide_tramp(void *p) { x3_emit_body<1024>(*(const X3EmitArgs *)p); }
+static void launch_emit(const X3EmitArgs &a, uint32_t nchunks, hipStream_t, bool wide = false)
+{
+	if (wide) x3emu_launch(emit_wide_tramp, (void *)&a, dim3(nchunks), dim3(1024));
+	else x3emu_launch(emit_tramp, (void *)&a, dim3(nchunks), dim3(X3_EMIT_THREADS));
+}
 #endif
 
 /* ============================================================================================================
@@ -977,6 +996,24 @@ int x3_token_postpass(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk
 		const uint32_t c = find_chunk(d_eo, nc, (uint32_t)i);
 		tok_hb[i] -= base[4 * c]; tok_nb[i] -= base[4 * c + 1]; tok_mb[i] -= base[4 * c + 2]; tok_pos[i] -= base[4 * c + 3];
 	});
+	return X3H_OK;
+}
+
+/* the streams are assembled with ORs: zero every chunk's slot (one launch for the batch; out_off and out_cap are multiples of 4) */
+static int zero_output_slots(hipStream_t st, uint32_t nc, const X3Chunk *h_chunks, const X3Chunk *d_chunks, uint8_t *d_out)
+{
+	uint64_t maxcap = 0;
+	for (uint32_t c = 0; c < nc; c++) if (h_chunks[c].out_cap > maxcap) maxcap = h_chunks[c].out_cap;
+	const uint64_t per = (maxcap + 15) / 16;
+	x3_foreach((size_t)(per * nc), st, X3_LAMBDA(size_t i) {
+		const uint32_t c = (uint32_t)(i / per);
+		const uint64_t o = (uint64_t)(i % per) * 16, cap = d_chunks[c].out_cap;
+		if (o >= cap) return;
+		uint32_t *w = (uint32_t *)(d_out + d_chunks[c].out_off + o);
+		const uint32_t nw = cap - o >= 16 ? 4u : (uint32_t)((cap - o) / 4);
+		for (uint32_t k = 0; k < nw; k++) w[k] = 0;
+	});
+	HIPCHK(hipGetLastError());
 	return X3H_OK;
 }
 
@@ -1505,6 +1542,27 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		for (uint32_t c = 0; c < nc; c++) seg->y_done[c] += cl.len[c];
 		seg->ring_top += acc;
 		B.last.symbols = nYraw; B.last.chain_symbols = nYc;
+		if (seg->emit_stream) {
+			/* the bits of THIS segment, straight from the rings, behind its recurrence and beside the recurrence of the next one: the pending-bit
+			 * count and the bit position of every stream travel from launch to launch; the last launch flushes and writes the results */
+			if (kcall == 0) {
+				CHK(seg->emit_state.reserve((size_t)nc * 16));
+				HIPCHK(hipStreamWaitEvent(seg->emit_stream, seg->ev_ready, 0)); /* the stream table (out_off / out_cap) is in place */
+				HIPCHK(hipMemsetAsync(seg->emit_state.p, 0, (size_t)nc * 16, seg->emit_stream));
+				CHK(zero_output_slots(seg->emit_stream, nc, h_chunks, d_chunks, d_out));
+			}
+			HIPCHK(hipStreamWaitEvent(seg->emit_stream, seg->ev_coder_end, 0));
+			X3EmitArgs ea;
+			ea.yoc = nullptr; ea.sym = sy; ea.state = rec_nk; ea.final_lo = m_finallo; ea.chunks = d_chunks; ea.parsed = d_parsed;
+			ea.npairs = m_npairs; ea.evfinal = m_evfinal; ea.out = d_out; ea.result = d_result;
+			ea.seg_off = d_off; ea.seg_len = d_len; ea.carry = seg->emit_state.as<uint32_t>(); ea.last = final ? 1u : 0u;
+			launch_emit(ea, nc, seg->emit_stream, true);
+			HIPCHK(hipGetLastError());
+			if (!final) return X3H_OK;
+			HIPCHK(hipEventRecord(seg->ev_emit_done, seg->emit_stream));
+			HIPCHK(hipStreamWaitEvent(st, seg->ev_emit_done, 0));
+			return X3H_OK;
+		}
 		if (!final) return X3H_OK;
 		HIPCHK(hipStreamWaitEvent(st, seg->ev_coder_end, 0)); /* emission needs every chain state */
 		/* final symbol layout: the operands once more (one scatter) and the chain states of every segment gathered from the ring */
@@ -1529,24 +1587,13 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		sy = syf; rec_nk = recf;
 	}
 
-	{ /* the stream is assembled with ORs: zero every chunk's slot (one launch for the batch; out_off and out_cap are multiples of 4) */
-		uint64_t maxcap = 0;
-		for (uint32_t c = 0; c < nc; c++) if (h_chunks[c].out_cap > maxcap) maxcap = h_chunks[c].out_cap;
-		const uint64_t per = (maxcap + 15) / 16;
-		x3_foreach((size_t)(per * nc), st, X3_LAMBDA(size_t i) {
-			const uint32_t c = (uint32_t)(i / per);
-			const uint64_t o = (uint64_t)(i % per) * 16, cap = d_chunks[c].out_cap;
-			if (o >= cap) return;
-			uint32_t *w = (uint32_t *)(d_out + d_chunks[c].out_off + o);
-			const uint32_t nw = cap - o >= 16 ? 4u : (uint32_t)((cap - o) / 4);
-			for (uint32_t k = 0; k < nw; k++) w[k] = 0;
-		});
-	}
+	CHK(zero_output_slots(st, nc, h_chunks, d_chunks, d_out));
 	if (streamk) {
 		/* many streams: one workgroup per stream carries the pending-bit count and the bit position through its symbols */
 		X3EmitArgs ea;
 		ea.yoc = d_yoc; ea.sym = sy; ea.state = rec_nk; ea.final_lo = m_finallo; ea.chunks = d_chunks; ea.parsed = d_parsed;
 		ea.npairs = m_npairs; ea.evfinal = m_evfinal; ea.out = d_out; ea.result = d_result;
+		ea.seg_off = ea.seg_len = nullptr; ea.carry = nullptr; ea.last = 1;
 		launch_emit(ea, nc, st);
 		HIPCHK(hipGetLastError());
 	} else {

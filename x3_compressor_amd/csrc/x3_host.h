@@ -140,6 +140,9 @@ struct X3CodeSeg {
 	hipStream_t coder_stream = nullptr;
 	hipEvent_t ev_ready = nullptr, ev_coder_begin = nullptr, ev_coder_end = nullptr; /* symbols assembled (feature stream); around the recurrence (coder stream) */
 	uint32_t *coder_state = nullptr;  /* device: {lo, R} per stream, carried from segment to segment; {0, 0x80000000} before the first */
+	hipStream_t emit_stream = nullptr; /* the bits of a segment are written behind its recurrence, beside the recurrence of the next segment (nullptr: all of them after the last) */
+	hipEvent_t ev_emit_done = nullptr;
+	DevBuf emit_state;                /* per stream {pending bits, bit position lo, hi, -}: carried from segment to segment */
 	std::vector<uint32_t> y_done;     /* per stream: chain symbols already handed to the coder (a multiple of 8 until the final call)  */
 	uint64_t ring_top = 0;            /* bump pointer of the operand / state rings, in symbols                                     */
 	std::vector<X3CodeSegCall> calls; /* what every call put where                                                                 */
