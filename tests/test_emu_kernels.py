@@ -54,11 +54,14 @@ SEG_CASES = [
 ]
 
 
+@pytest.mark.parametrize("form", ["counters-in-lds", "counters-in-global-memory"])
 @pytest.mark.parametrize("name,data,kw", SEG_CASES, ids=[c[0] for c in SEG_CASES])
-def test_emulated_per_chunk_scan_matches_oracle(emu, oracle, monkeypatch, name, data, kw):
-    """scan3.hip (K1 of many-chunk batches: one workgroup sorts and level-tests one chunk) forced on a single chunk: m[] == the oracle's
-    (backend.c:56-78) and the stream built on it == the oracle's"""
+def test_emulated_per_chunk_scan_matches_oracle(emu, oracle, monkeypatch, name, data, kw, form):
+    """scan3.hip (K1 of many-chunk batches: one workgroup sorts and level-tests one chunk) forced on a single chunk, in both of its forms
+    (chunks up to 256 KiB / longer ones): m[] == the oracle's (backend.c:56-78) and the stream built on it == the oracle's"""
     monkeypatch.setenv("X3H_SEG_MIN", "1")
+    if form == "counters-in-global-memory":
+        monkeypatch.setenv("X3H_SEG_SMALL_MAX", "0")
     prm, oprm = _lib.make_params(**kw), oracle_lib.params(**kw)
     assert np.array_equal(np.frombuffer(emu.scan_m(data, prm), np.uint8), np.frombuffer(oracle.scan_m(data, oprm), np.uint8))
     assert emu.compress(data, prm) == oracle.compress(data, oprm)

@@ -177,7 +177,8 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 	}
 	uint64_t max_len = 0;
 	for (uint32_t c = 0; c < nc; c++) if (h_chunks[c].len > max_len) max_len = h_chunks[c].len;
-	const bool seg = x3_scan_seg_applies(nc, max_len); /* many chunks: one workgroup per chunk sorts and tests its own positions (scan3.hip) */
+	const int seg_form = x3_scan_seg_applies(nc, max_len); /* many chunks: one workgroup per chunk sorts and tests its own positions (scan3.hip) */
+	const bool seg = seg_form != 0;
 	for (int i = 0; i < 8; i++) CHK(B.a[i].reserve((P + 8) * (seg && i < 2 ? 8 : 4)));
 	CHK(B.a[9].reserve(((size_t)P / 32 + 2) * 4 + 64)); /* padding bitmap */
 	CHK(B.misc.reserve(64));
@@ -232,6 +233,8 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 		ga.S4 = B.a[2].as<uint32_t>(); ga.K4 = B.a[3].as<uint32_t>(); ga.m = d_m; ga.rare = rare; ga.kexact = kexact;
 		ga.act = act; ga.act_k = act_k; ga.act_j = act_j; ga.nact = d_nact;
 		ga.window = window; ga.ncand = ncand; ga.Tu = Tu; ga.dense_at = dense_at;
+		ga.gmf = nullptr;
+		if (seg_form == 2) { CHK(B.a[23].reserve(P / 4 + 64)); HIPCHK(hipMemsetAsync(B.a[23].p, 0, P / 4 + 64, st)); ga.gmf = B.a[23].as<uint32_t>(); }
 		if (getenv("X3H_DEBUG")) fprintf(stderr, "[x3h] scan: one workgroup per chunk (%u chunks, longest %llu)\n", nc, (unsigned long long)max_len);
 		ga.prof = nullptr;
 		const bool prof = getenv("X3H_SEG_PROF") != nullptr;

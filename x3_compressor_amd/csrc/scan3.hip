@@ -107,10 +107,13 @@ __device__ static __forceinline__ void seg_level(uint32_t lv, const uint2 it, co
 	if (pass) atomicAdd(&mfield[prel >> 4], 1u << (2u * (prel & 15u)));
 }
 
+/* BIG = false: chunks of at most X3_SEG_MAXLEN bytes, their level counters and small-K marks live in LDS; BIG = true: longer chunks, both
+ * live in global memory (a.gmf / a.rare, zeroed by the caller; the atomics execute in L2) */
+template <bool BIG>
 __device__ static void x3_segscan_body(const X3SegArgs &a)
 {
-	X3_LDS uint32_t mfield[X3_SEG_MAXLEN / 16];        /* 2 bits per position: levels 1..3 passed so far */
-	X3_LDS uint32_t rbits[X3_SEG_MAXLEN / 32];         /* positions whose K is below T+1 */
+	X3_LDS uint32_t mfield_l[BIG ? 1 : X3_SEG_MAXLEN / 16]; /* 2 bits per position: levels 1..3 passed so far */
+	X3_LDS uint32_t rbits_l[BIG ? 1 : X3_SEG_MAXLEN / 32];  /* positions whose K is below T+1 */
 	X3_LDS uint32_t cnt[256 * X3_SEG_WAVES];           /* [digit][wave]: counts, then exclusive prefix in tile-sorted order */
 	X3_LDS uint2 stage[X3_SEG_TILE];                   /* the tile in sorted order (phase 0: eight copies of the byte histogram) */
 	X3_LDS uint32_t bbase[256], bcur[256], wtot[X3_SEG_WAVES];
@@ -131,8 +134,12 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 	uint64_t tclk = a.prof ? x3_clock() : 0;
 #define SEG_MARK(k) do { if (a.prof && tid == 0) { const uint64_t now_ = x3_clock(); atomicAdd((unsigned long long *)&a.prof[k], (unsigned long long)(now_ - tclk)); tclk = now_; } } while (0)
 	uint32_t *hist = (uint32_t *)stage;
-	for (uint32_t i = tid; i < (n + 15u) / 16u; i += X3_SEG_THREADS) mfield[i] = 0u;
-	for (uint32_t i = tid; i < (n + 31u) / 32u; i += X3_SEG_THREADS) rbits[i] = 0u;
+	uint32_t *const mfield = BIG ? a.gmf + (base >> 4) : mfield_l; /* (slots are 256-byte aligned) */
+	uint32_t *const rbits = BIG ? a.rare + (base >> 5) : rbits_l;
+	if (!BIG) {
+		for (uint32_t i = tid; i < (n + 15u) / 16u; i += X3_SEG_THREADS) mfield[i] = 0u;
+		for (uint32_t i = tid; i < (n + 31u) / 32u; i += X3_SEG_THREADS) rbits[i] = 0u;
+	}
 	for (uint32_t i = tid; i < 8u * 256u; i += X3_SEG_THREADS) hist[i] = 0u;
 	__syncthreads();
 
@@ -326,30 +333,39 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 		}
 		*(uint4 *)(a.m + base + 16u * w) = make_uint4(o[0], o[1], o[2], o[3]); /* (the last word may spill <= 15 bytes into the slot's padding) */
 	}
-	for (uint32_t w = tid; w < (n + 31u) / 32u; w += X3_SEG_THREADS) a.rare[(base >> 5) + w] = rbits[w];
+	if (!BIG) for (uint32_t w = tid; w < (n + 31u) / 32u; w += X3_SEG_THREADS) a.rare[(base >> 5) + w] = rbits[w];
 }
 
 #ifndef X3_EMU
-__global__ void __launch_bounds__(X3_SEG_THREADS) x3_segscan_kernel(X3SegArgs a) { x3_segscan_body(a); }
+__global__ void __launch_bounds__(X3_SEG_THREADS) x3_segscan_kernel(X3SegArgs a) { x3_segscan_body<false>(a); }
+__global__ void __launch_bounds__(X3_SEG_THREADS) x3_segscan_big_kernel(X3SegArgs a) { x3_segscan_body<true>(a); }
 int x3_scan_seg_launch(const X3SegArgs &a, uint32_t nchunks, hipStream_t st)
 {
-	hipLaunchKernelGGL(x3_segscan_kernel, dim3(nchunks), dim3(X3_SEG_THREADS), 0, st, a);
+	if (a.gmf) hipLaunchKernelGGL(x3_segscan_big_kernel, dim3(nchunks), dim3(X3_SEG_THREADS), 0, st, a);
+	else hipLaunchKernelGGL(x3_segscan_kernel, dim3(nchunks), dim3(X3_SEG_THREADS), 0, st, a);
 	HIPCHK(hipGetLastError());
 	return X3H_OK;
 }
 #else
-static void segscan_tramp(void *p) { x3_segscan_body(*(const X3SegArgs *)p); }
+static void segscan_tramp(void *p) { x3_segscan_body<false>(*(const X3SegArgs *)p); }
+static void segscan_big_tramp(void *p) { x3_segscan_body<true>(*(const X3SegArgs *)p); }
 int x3_scan_seg_launch(const X3SegArgs &a, uint32_t nchunks, hipStream_t)
 {
-	x3emu_launch(segscan_tramp, (void *)&a, dim3(nchunks), dim3(X3_SEG_THREADS));
+	x3emu_launch(a.gmf ? segscan_big_tramp : segscan_tramp, (void *)&a, dim3(nchunks), dim3(X3_SEG_THREADS));
 	return X3H_OK;
 }
 #endif
 
-/* one workgroup per chunk pays off once there are enough chunks to fill the chip, and needs the chunk's level counters in LDS */
-bool x3_scan_seg_applies(uint32_t nchunks, uint64_t max_len)
+/* One workgroup per chunk pays off once there are enough chunks to fill the chip.  -> 0: no (the chip-wide sort of scan2.hip), 1: yes, the
+ * chunk's level counters fit LDS, 2: yes, with the counters in global memory (chunks up to X3_SEG_MAXLEN_BIG; needs enough of them that a
+ * quarter of the CUs are busy with one chunk each for the whole scan).  X3H_SEG_MIN=n moves the first threshold (tests), 0 turns it off. */
+int x3_scan_seg_applies(uint32_t nchunks, uint64_t max_len)
 {
-	uint32_t min_streams = X3_SEG_MIN_STREAMS;
-	if (const char *e = getenv("X3H_SEG_MIN")) { const int v = atoi(e); if (v >= 1) min_streams = (uint32_t)v; else if (v == 0 && *e == '0') return false; }
-	return nchunks >= min_streams && max_len <= X3_SEG_MAXLEN;
+	uint32_t min_streams = X3_SEG_MIN_STREAMS, min_big = X3_SEG_MIN_STREAMS_BIG;
+	if (const char *e = getenv("X3H_SEG_MIN")) { const int v = atoi(e); if (v >= 1) min_streams = min_big = (uint32_t)v; else if (v == 0 && *e == '0') return 0; }
+	uint64_t small_max = X3_SEG_MAXLEN;
+	if (const char *e = getenv("X3H_SEG_SMALL_MAX")) { const long long v = atoll(e); if (v >= 0) small_max = (uint64_t)v < X3_SEG_MAXLEN ? (uint64_t)v : X3_SEG_MAXLEN; } /* (tests: force the global-memory form) */
+	if (nchunks >= min_streams && max_len <= small_max) return 1;
+	if (nchunks >= min_big && max_len <= X3_SEG_MAXLEN_BIG) return 2;
+	return 0;
 }

@@ -89,6 +89,8 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 #ifndef X3_SEG_MIN_STREAMS
 #define X3_SEG_MIN_STREAMS 48u       /* fewer chunks: the chip-wide sort of scan2.hip */
 #endif
+#define X3_SEG_MAXLEN_BIG (1u << 20)     /* longer chunks (up to this) keep those counters in global memory */
+#define X3_SEG_MIN_STREAMS_BIG 224u      /* ... and need nearly a chunk per CU to beat the chip-wide sort (a 1 MiB chunk keeps its CU busy for 27 ms) */
 struct X3SegArgs {
 	const uint8_t *bytes;        /* padded chunks */
 	const X3Chunk *chunks;
@@ -96,11 +98,12 @@ struct X3SegArgs {
 	uint32_t *S4, *K4;           /* out: list 4 (END positions ordered by 4-gram) and its keys, same layout; slot tails hold fillers */
 	uint8_t *m;                  /* out: m[p] for levels 0..3 (the walk kernel raises it where the 4-gram repeats often enough) */
 	uint32_t *rare, *kexact;     /* out: positions with K < T+1 (bitmap, zeroed by the caller) and their K */
+	uint32_t *gmf;               /* nullptr: level counters in LDS; else 2 bits per position of the padded layout, zeroed by the caller (long chunks) */
 	uint32_t *act, *act_k, *act_j, *nact; /* out: positions for the walk kernel; nact[0] = their number, nact[1] = a dense class was met */
 	uint32_t window, ncand, Tu, dense_at;
 	uint64_t *prof;              /* nullptr, or 16 cycle counters: phase 0, passes 1-4, levels 1-4 (X3H_SEG_PROF, debugging) */
 };
-bool x3_scan_seg_applies(uint32_t nchunks, uint64_t max_len);
+int x3_scan_seg_applies(uint32_t nchunks, uint64_t max_len); /* 0: no, 1: counters in LDS, 2: counters in global memory */
 int x3_scan_seg_launch(const X3SegArgs &a, uint32_t nchunks, hipStream_t st);
 
 /* ---- v2 coding stage (code2.hip) ------------------------------------------------------------------------- */
