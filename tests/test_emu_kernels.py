@@ -377,7 +377,7 @@ def test_emulated_scan_dense_classes_and_padding(emu, oracle, name, data, kw):
 @pytest.mark.parametrize("name,data,kw", CASES + PIPE_CASES[2:4], ids=[c[0] for c in CASES] + ["english9k", "zipf4k"])
 def test_emulated_stream_kernels_forced(emu_env, oracle, name, data, kw):
     """X3H_STREAM_KERNELS=1: the per-stream LDS kernels on single streams (they are the default only for batches of >= 48 streams)"""
-    ctx = emu_env(X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0")
+    ctx = emu_env(X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0", X3H_ARRANGE="1" if len(data) % 2 else "0")
     assert ctx.compress(data, _lib.make_params(**kw)) == oracle.compress(data, oracle_lib.params(**kw))
 
 
@@ -397,7 +397,7 @@ def test_emulated_stream_kernels_batch_of_52(emu_env, oracle):
     kw = dict(w_kib=1, t=3)
     data = np.frombuffer(b"".join(parts), dtype=np.uint8)
     off = np.cumsum([0] + [len(p) for p in parts]).astype(np.uint64)
-    for env in (dict(), dict(X3H_CTX_SUB="3")):
+    for env in (dict(), dict(X3H_CTX_SUB="3"), dict(X3H_ARRANGE="1")):  # X3H_ARRANGE=1: hits arranged by one workgroup per stream (x3_arrange_kernel) instead of the chip-wide sort
         streams = emu_env(**env).compress_chunks(data, off, _lib.make_params(**kw))
         for i, (p, got) in enumerate(zip(parts, streams)):
             assert got == oracle.compress(p, oracle_lib.params(**kw)), f"{env}: stream {i}"

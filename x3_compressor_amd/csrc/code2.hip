@@ -1170,9 +1170,17 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 			CHK(B.stat.reserve((nA + 4) * 16));
 			uint4 *stat = B.stat.as<uint4>();
 			uint32_t npairs_total = 0;
-			x3_foreach(nH, st, X3_LAMBDA(size_t i) { iota[i] = (uint32_t)i; });
-			CHK(x3p_sort_pairs(B.tmp, h_c1, kA, iota, vA, nH, bits_for(nD), st)); /* by context1, time order inside */
-			x3_foreach(nH, st, X3_LAMBDA(size_t i) { tA[i] = h_tag[vA[i]]; });
+			/* by context1, time order inside: chip-wide stable radix sort (rocPRIM onesweep, 3.6 TB/s).  X3H_ARRANGE=1: one workgroup per stream, counting
+			 * sort on the stream-local key (x3_arrange_kernel, code3.hip) -- same order, measured SLOWER on the 1024-chunk batch (features 48 against
+			 * 40 ms: four wavefronts per stream walk their quarter as a chain of LDS round trips), so it stays an option, not the default */
+			bool seg_arrange = false;
+			if (const char *e = getenv("X3H_ARRANGE")) seg_arrange = e[0] == '1';
+			if (seg_arrange) CHK(x3_arrange_run(st, nc, d_ho, d_dof, maxDict, h_c1, h_tag, kA, vA, tA, T[7], T[8]));
+			else {
+				x3_foreach(nH, st, X3_LAMBDA(size_t i) { iota[i] = (uint32_t)i; });
+				CHK(x3p_sort_pairs(B.tmp, h_c1, kA, iota, vA, nH, bits_for(nD), st));
+				x3_foreach(nH, st, X3_LAMBDA(size_t i) { tA[i] = h_tag[vA[i]]; });
+			}
 			CHK(x3_ctx_stats_run(st, nc, maxDict, d_ho, d_dof, kA, vA, tA, stat));
 			x3_foreach(nH, st, X3_LAMBDA(size_t i) {
 				const uint4 r = stat[i];
@@ -1201,9 +1209,18 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 				}
 				G0[gh] = g;
 			});
-			HIPCHK(hipStreamSynchronize(st)); /* npairs_total */
-			CHK(x3p_sort_pairs(B.tmp, G0, kA, iota, vA, nH, bits_for(npairs_total ? npairs_total : 1), st)); /* by ctx0 (pair ordinal) */
-			x3_foreach(nH, st, X3_LAMBDA(size_t i) { tA[i] = h_tag[vA[i]]; });
+			std::vector<uint32_t> hnp(nc);
+			HIPCHK(hipMemcpyAsync(hnp.data(), m_npairs, (size_t)nc * 4, hipMemcpyDeviceToHost, st));
+			HIPCHK(hipStreamSynchronize(st)); /* npairs_total, pairs per stream */
+			uint64_t maxPairs = 1;
+			for (uint32_t c = 0; c < nc; c++) if (hnp[c] > maxPairs) maxPairs = hnp[c];
+			/* by ctx0 (pair ordinal; a stream's ordinals start at m_pairbase): the same segmented counting sort, two passes beyond 2048 pairs */
+			if (seg_arrange && maxPairs <= X3_ARRANGE_MAX_LOCAL) CHK(x3_arrange_run(st, nc, d_ho, m_pairbase, maxPairs, G0, h_tag, kA, vA, tA, T[7], T[8]));
+			else {
+				if (seg_arrange) x3_foreach(nH, st, X3_LAMBDA(size_t i) { iota[i] = (uint32_t)i; });
+				CHK(x3p_sort_pairs(B.tmp, G0, kA, iota, vA, nH, bits_for(npairs_total ? npairs_total : 1), st));
+				x3_foreach(nH, st, X3_LAMBDA(size_t i) { tA[i] = h_tag[vA[i]]; });
+			}
 			CHK(x3_ctx_stats_run(st, nc, maxDict, d_ho, d_dof, kA, vA, tA, stat));
 			x3_foreach(nH, st, X3_LAMBDA(size_t i) { const uint4 r = stat[i]; f0[i] = r.x; t0[i] = r.y; c0[i] = r.z; });
 		} else {

@@ -482,6 +482,94 @@ __device__ static void x3_tokens_body(const X3TokArgs &a)
 	}
 }
 
+
+/* ============================================================================================================
+ * Arranging a stream's hits by (context, time) -- what x3_ctxseg_kernel sweeps.  The context keys of a batch are stream-major (a stream's
+ * tags / pair ordinals are one contiguous range of the global numbering), so the arrangement is a SEGMENTED sort: one workgroup of four
+ * wavefronts per stream does one stable counting-sort pass on an 11-bit digit of the stream-local key.  Wavefront w takes the w-th quarter
+ * of the stream's hits (time order); LDS holds one counter row per wavefront, so after a scan over (digit, wavefront) every wavefront
+ * knows where its hits of each digit go and the rest is tiles of 64: lanes with the same digit found by ballots (wave_same_mask), rank =
+ * earlier lanes of the group, the group's first lane moves the wavefront's cursor.  Local keys beyond 2048 (tag-pair ordinals) take two
+ * passes, low digit first.  An alternative to the chip-wide iota + multi-pass radix sort of (key, index) pairs + gather of the hits' tags
+ * (X3H_ARRANGE=1); measured slower than those on the 1024-chunk batch (features 48 against 40 ms), so not the default.
+ * ============================================================================================================ */
+#define X3_ARR_WAVES 4u
+#define X3_ARR_THREADS (X3_ARR_WAVES * X3_WAVE)
+#ifndef X3_ARR_DBITS
+#define X3_ARR_DBITS 11 /* (the emulator build of the tests uses 8, so that small inputs take the two-pass form) */
+#endif
+#define X3_ARR_DIGITS (1u << X3_ARR_DBITS)
+#define X3_ARR_PER (X3_ARR_DIGITS / X3_ARR_THREADS) /* digits per thread in the scan */
+struct X3ArrangeArgs {
+	const uint32_t *ho;        /* nc+1: hit ranges                                                                           */
+	const uint32_t *kbase;     /* per stream: its first global key (first tag id / first pair ordinal)                       */
+	const uint32_t *kin;       /* per input entry: global key                                                                */
+	const uint32_t *vin;       /* per input entry: hit index; nullptr = the entry's own index (first pass)                   */
+	const uint32_t *h_tag;     /* per hit: global tag id; nullptr = not the last pass                                        */
+	uint32_t *kout, *vout, *tout; /* out, same ranges: key, hit index, and (last pass) the hit's tag                          */
+	uint32_t shift;            /* digit = ((key - kbase) >> shift) & (X3_ARR_DIGITS - 1)                                     */
+};
+
+__device__ static void x3_arrange_body(const X3ArrangeArgs &a)
+{
+	X3_LDS uint32_t cnt[X3_ARR_WAVES][X3_ARR_DIGITS]; /* counts, then each wavefront's cursor per digit */
+	X3_LDS uint32_t wtot[X3_ARR_WAVES];
+	const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = x3_lane(), wv = tid / X3_WAVE;
+	const uint32_t h0 = a.ho[c], h1 = a.ho[c + 1], kb = a.kbase[c];
+	const uint32_t nh = h1 - h0;
+	if (!nh) return;
+	const uint32_t per = (nh + X3_ARR_WAVES - 1) / X3_ARR_WAVES;
+	const uint32_t q0 = h0 + wv * per < h1 ? h0 + wv * per : h1, q1 = q0 + per < h1 ? q0 + per : h1; /* this wavefront's quarter */
+	const uint64_t below = ((uint64_t)1 << lane) - 1;
+	for (uint32_t i = tid; i < X3_ARR_WAVES * X3_ARR_DIGITS; i += X3_ARR_THREADS) (&cnt[0][0])[i] = 0u;
+	__syncthreads();
+	/* ---- histogram of the quarter (LDS atomics into the wavefront's own row) ---- */
+	for (uint32_t i = q0 + lane; i < q1; i += X3_WAVE) atomicAdd(&cnt[wv][((a.kin[i] - kb) >> a.shift) & (X3_ARR_DIGITS - 1u)], 1u);
+	__syncthreads();
+	/* ---- exclusive scan in (digit, wavefront) order: thread t owns digits [t * PER, (t + 1) * PER) of all four rows ---- */
+	{
+		static_assert(X3_ARR_PER >= 1 && X3_ARR_PER * X3_ARR_THREADS == X3_ARR_DIGITS, "digits per thread");
+		uint32_t v[X3_ARR_PER][X3_ARR_WAVES], s = 0;
+#pragma unroll
+		for (uint32_t d = 0; d < X3_ARR_PER; d++)
+#pragma unroll
+			for (uint32_t w = 0; w < X3_ARR_WAVES; w++) { v[d][w] = cnt[w][tid * X3_ARR_PER + d]; s += v[d][w]; }
+		const uint32_t incl = x3_wave_incl_scan_u32(s);
+		if (lane == X3_WAVE - 1u) wtot[wv] = incl;
+		__syncthreads();
+		uint32_t ex = h0 + incl - s;
+		for (uint32_t w = 0; w < wv; w++) ex += wtot[w];
+#pragma unroll
+		for (uint32_t d = 0; d < X3_ARR_PER; d++)
+#pragma unroll
+			for (uint32_t w = 0; w < X3_ARR_WAVES; w++) { cnt[w][tid * X3_ARR_PER + d] = ex; ex += v[d][w]; }
+	}
+	__syncthreads();
+	/* ---- stable scatter of the quarter, 64 entries per trip; the next trip's entries are in flight meanwhile ---- */
+	uint32_t nk = 0, nv = 0;
+	if (q0 + lane < q1) { nk = a.kin[q0 + lane]; nv = a.vin ? a.vin[q0 + lane] : q0 + lane; }
+	for (uint32_t base = q0; base < q1; base += X3_WAVE) {
+		const bool valid = base + lane < q1;
+		const uint32_t k = nk, v = nv;
+		{
+			const uint32_t nx = base + X3_WAVE + lane;
+			if (nx < q1) { nk = a.kin[nx]; nv = a.vin ? a.vin[nx] : nx; }
+		}
+		const uint32_t d = ((k - kb) >> a.shift) & (X3_ARR_DIGITS - 1u);
+		const uint64_t V = x3_ballot(valid);
+		const uint64_t M = wave_same_mask(d, X3_ARR_DBITS, V, valid);
+		const uint32_t cur = valid ? cnt[wv][d] : 0u;
+		x3_wave_order();
+		if (valid && (M & below) == 0) cnt[wv][d] = cur + (uint32_t)x3_popc64(M);
+		x3_wave_order();
+		if (valid) {
+			const uint32_t dst = cur + (uint32_t)x3_popc64(M & below);
+			a.kout[dst] = k; a.vout[dst] = v;
+			if (a.h_tag) a.tout[dst] = a.h_tag[v];
+		}
+	}
+}
+
 #ifndef X3_EMU
 __global__ void __launch_bounds__(X3_WAVE) x3_mtfrank_kernel_s(X3MtfArgs a) { x3_mtfrank_body<2048>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_mtfrank_kernel_l(X3MtfArgs a) { x3_mtfrank_body<16384>(a); }
@@ -492,9 +580,11 @@ __global__ void __launch_bounds__(X3_WAVE) x3_order0_kernel(X3Order0Args a) { x3
 __global__ void __launch_bounds__(X3_TOK_THREADS) x3_tokens_kernel(X3TokArgs a) { x3_tokens_body(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_idxstat_kernel_s(X3IdxStatArgs a) { x3_idxstat_body<2048>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_idxstat_kernel_l(X3IdxStatArgs a) { x3_idxstat_body<X3_STREAM_DMAX>(a); }
+__global__ void __launch_bounds__(X3_ARR_THREADS) x3_arrange_kernel(X3ArrangeArgs a) { x3_arrange_body(a); }
 #define X3_LAUNCH1(kern, args, nc, st) hipLaunchKernelGGL(kern, dim3(nc), dim3(X3_WAVE), 0, st, args)
 #else
 static void order0_tramp(void *p) { x3_order0_body(*(const X3Order0Args *)p); }
+static void arrange_tramp(void *p) { x3_arrange_body(*(const X3ArrangeArgs *)p); }
 static void tokens_tramp(void *p) { x3_tokens_body(*(const X3TokArgs *)p); }
 static void idxstat_tramp_s(void *p) { x3_idxstat_body<2048>(*(const X3IdxStatArgs *)p); }
 static void idxstat_tramp_l(void *p) { x3_idxstat_body<X3_STREAM_DMAX>(*(const X3IdxStatArgs *)p); }
@@ -587,5 +677,29 @@ int x3_tokens_run(hipStream_t st, uint32_t nc, const X3Chunk *d_chunks, const X3
 	x3emu_launch(tokens_tramp, (void *)&a, dim3(nc), dim3(X3_TOK_THREADS));
 #endif
 	HIPCHK(hipGetLastError());
+	return X3H_OK;
+}
+
+/* hits of every stream arranged by (key, time): kA = key, vA = hit, tA = the hit's tag.  max_local = largest stream-local key of the batch
+ * (decides one pass or two); tmpk / tmpv: nH-entry temporaries for the two-pass form */
+int x3_arrange_run(hipStream_t st, uint32_t nc, const uint32_t *d_ho, const uint32_t *kbase, uint64_t max_local, const uint32_t *key, const uint32_t *h_tag,
+                   uint32_t *kA, uint32_t *vA, uint32_t *tA, uint32_t *tmpk, uint32_t *tmpv)
+{
+	if (max_local >= (uint64_t)X3_ARR_DIGITS * X3_ARR_DIGITS) return X3H_E_INTERNAL; /* (the caller keeps the chip-wide sort for such a batch) */
+	X3ArrangeArgs a;
+	a.ho = d_ho; a.kbase = kbase;
+	const bool two = max_local >= X3_ARR_DIGITS;
+	for (int pass = 0; pass < (two ? 2 : 1); pass++) {
+		const bool last = pass == (two ? 1 : 0);
+		a.kin = pass == 0 ? key : tmpk; a.vin = pass == 0 ? nullptr : tmpv;
+		a.kout = last ? kA : tmpk; a.vout = last ? vA : tmpv; a.tout = tA; a.h_tag = last ? h_tag : nullptr;
+		a.shift = pass == 0 ? 0u : (uint32_t)X3_ARR_DBITS;
+#ifndef X3_EMU
+		hipLaunchKernelGGL(x3_arrange_kernel, dim3(nc), dim3(X3_ARR_THREADS), 0, st, a);
+#else
+		x3emu_launch(arrange_tramp, (void *)&a, dim3(nc), dim3(X3_ARR_THREADS));
+#endif
+		HIPCHK(hipGetLastError());
+	}
 	return X3H_OK;
 }

@@ -170,6 +170,12 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 bool x3_stream_kernels_fit(uint64_t max_dict);
 int x3_mtf_ranks_run(hipStream_t st, uint32_t nc, uint64_t max_dict, const uint32_t *d_eo, const uint32_t *d_dof, const uint32_t *e_tag,
                      const uint32_t *e_hit, uint32_t *h_rank);
+int x3_arrange_run(hipStream_t st, uint32_t nc, const uint32_t *d_ho, const uint32_t *kbase, uint64_t max_local, const uint32_t *key, const uint32_t *h_tag,
+                   uint32_t *kA, uint32_t *vA, uint32_t *tA, uint32_t *tmpk, uint32_t *tmpv);
+#ifndef X3_ARR_DBITS
+#define X3_ARR_DBITS 11
+#endif
+#define X3_ARRANGE_MAX_LOCAL (((uint64_t)1 << (2 * X3_ARR_DBITS)) - 1) /* largest stream-local key two passes cover */
 int x3_ctx_stats_run(hipStream_t st, uint32_t nc, uint64_t max_dict, const uint32_t *d_ho, const uint32_t *d_dof, const uint32_t *kA,
                      const uint32_t *vA, const uint32_t *tA, uint4 *stat /* per hit: {freq, total, cum, first hit | isfirst << 31} */);
 int x3_order0_run(hipStream_t st, uint32_t nc, const uint32_t *d_mo, const uint32_t *lval, uint32_t *lsm, uint32_t *leq,
