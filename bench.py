@@ -85,7 +85,20 @@ def chunk_batch(ctx, d_in, total, cb, prm, dev, reps=2):
     return best
 
 
+def emit_line(line):
+    """the ONE JSON line of the contract, on the process's real stdout (main() points fd 1 at stderr meanwhile: RCCL prints a version banner to
+    stdout when a communicator is made, and nothing but the line may appear there)"""
+    os.write(_REAL_STDOUT, (json.dumps(line) + "\n").encode())
+
+
+_REAL_STDOUT = 1
+
+
 def main():
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -215,7 +228,7 @@ def main():
             line["roofline"] = {"bound": "hbm", "kernel": "x3_ac2_kernel", "achieved": round(Yc * 16.5 / (kms * 1e-3) / 1e9, 3) if kms > 0 else None,
                                 "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(Yc * 16.5 / (kms * 1e-3) / HBM_PEAK, 7) if kms > 0 else None,
                                 "traffic": None, "note": "rank 0's coder recurrence (16 chains side by side); see the N=1 line for the dominant-kernel analysis"}
-            print(json.dumps(line))
+            emit_line(line)
         dist.destroy_process_group()
         return
 
@@ -445,7 +458,7 @@ def main():
             line["cpu_baseline_all_cores"] = {"value": round(ncpu * piece / wall / 1e6, 5), "unit": "MB/s", "cores": ncpu, "nproc": ncpu, "kind": res[0][2],
                                               "sample": f"{ncpu} reference processes side by side, each on its own {piece}-byte piece of the workload (independent chunks), wall clock",
                                               "seconds": round(wall, 3)}
-    print(json.dumps(line))
+    emit_line(line)
     if distributed:
         dist.destroy_process_group()
 
