@@ -491,6 +491,43 @@ def test_scan_dense_classes_equal_brute_force_kernel(gpu, monkeypatch):
         assert gpu.decompress(streams[i], len(p)) == p
 
 
+@pytest.mark.parametrize("env", [dict(X3H_SEG_MIN="1"), dict(X3H_SEG_MIN="1", X3H_SEG_SMALL_MAX="0"), dict(X3H_SEG_MIN="1", X3H_SEG_REFINE="0"),
+                                 dict(X3H_SEG_MIN="1", X3H_WALK_DENSE="48")],
+                         ids=["counters-in-lds", "counters-in-global-memory", "chip-wide-refinement", "dense-from-48-members"])
+def test_per_chunk_scan_equals_brute_force_kernel(gpu_env, monkeypatch, env):
+    """scan3.hip (K1 of many-chunk batches: one workgroup sorts, level-tests and -- dense classes -- refines one chunk) forced on single
+    chunks, against the brute-force window sweep of scan.hip: text, Zipf bytes (exact K for most positions), zero runs and padding counts,
+    sparse samples, periodic data, a four-letter alphabet at -t 1 (thousands of classes: three 9-bit passes in the refinement), windows
+    larger than the chunk, a chunk of exactly 256 KiB"""
+    monkeypatch.setenv("X3H_SCAN_V1", "1")
+    brute = _lib.X3Context(0)
+    monkeypatch.delenv("X3H_SCAN_V1")
+    rng = np.random.default_rng(44)
+    sparse = np.zeros(150_000, np.uint8)
+    sparse[rng.integers(0, 150_000, 7000)] = rng.integers(1, 4, 7000)
+    cases = [
+        (synth.english_like(120_000, seed=4).tobytes(), dict(w_kib=64, t=256)),
+        (synth.zipf_bytes(90_000, offset=12345).tobytes(), dict(w_kib=64, t=256)),
+        (synth.mr_like(262_144, seed=9).tobytes(), dict(w_kib=64, t=256)),
+        (sparse.tobytes(), dict(w_kib=32, t=64)),
+        (bytes(70_000), dict(w_kib=64, t=256)),
+        (synth.english_like(50_000).tobytes() + bytes(40_000) + b"tail", dict(w_kib=32, t=100)),
+        ((b"\0\0\0\1" * 30_000), dict(w_kib=16, t=40)),
+        (rng.integers(0, 4, 100_000, dtype=np.uint8).tobytes(), dict(w_kib=8, t=1)),
+        (rng.integers(0, 4, 60_000, dtype=np.uint8).tobytes(), dict(w_kib=64, t=3)),
+        (synth.english_like(30_000, seed=6).tobytes(), dict(w_kib=256, t=1024)),
+        (b"abc", dict(w_kib=8, t=16)),
+    ]
+    ctx = gpu_env(**env)
+    try:
+        for data, kw in cases:
+            prm = _lib.make_params(**kw)
+            a, b = ctx.scan_m(data, prm), brute.scan_m(data, prm)
+            assert np.array_equal(a, b), f"{kw}, {len(data)} bytes: first diff at {first_diff(a, b)}"
+    finally:
+        brute.close()
+
+
 def test_many_streams_with_one_oversized_dictionary(gpu, oracle):
     """50 streams, one of which has more dictionary elements (> 8192) than the LDS tables of the per-stream kernels hold: the whole batch
     takes the chip-wide passes instead (x3_code_v2_run derives the token prefix sums itself in that case) -- same bytes as stream by stream"""

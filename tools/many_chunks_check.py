@@ -21,7 +21,8 @@ d_in = torch.from_numpy(data).to(dev)
 stride = (cb + (cb >> 1) + 4096 + 3) & ~3
 d_out = torch.empty(stride * nch, dtype=torch.uint8, device=dev)
 ctx = _lib.X3Context(0)
-prm = _lib.make_params(w_kib=64, t=256)
+import os
+prm = _lib.make_params(w_kib=int(os.environ.get("MC_W", "64")), t=int(os.environ.get("MC_T", "256")))
 for it in range(3):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     lens, st = ctx.compress_chunks_dev(d_in.data_ptr(), off, prm, d_out.data_ptr(), stride)

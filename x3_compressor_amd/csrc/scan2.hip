@@ -220,20 +220,32 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 		dataend[b] = (uint32_t)(d_chunks[lo].byte_off + d_chunks[lo].len);
 	});
 	uint32_t dense_at = X3_WALK_DENSE;
-	if (const char *e = getenv("X3H_WALK_DENSE")) { const int v = atoi(e); if (v >= 2) dense_at = (uint32_t)v; } /* tuning / tests */
+	bool dense_env = false;
+	if (const char *e = getenv("X3H_WALK_DENSE")) { const int v = atoi(e); if (v >= 1) { dense_at = (uint32_t)v; dense_env = true; } } /* tuning / tests */
 	if (window > (1u << 24)) return X3H_E_ARG; /* K is kept in 24 bits */
 	/* K = min(T+1, count_0) and count_0 <= ncand: any T >= ncand behaves like T = ncand */
 	const uint32_t Tu = (uint32_t)T > ncand ? ncand : (uint32_t)T, Pn = (uint32_t)P;
+	{
+		/* per-chunk lists of chunks up to 256 KiB: the chunk's own workgroup refines its dense classes (x3_segrefine_kernel), which is cheaper than
+		 * sweeping a class's members position by position as soon as a class has the K members a level needs at all -- every class with a passing
+		 * member is refined (1024 x 256 KiB of text + Zipf bytes at -t 256: scan 21 -> 15 ms; mr-like samples: 57 -> 30 ms) */
+		const char *e = getenv("X3H_SEG_REFINE");
+		if (seg_form == 1 && !dense_env && !(e && e[0] == '0') && dense_at > Tu + 1u) dense_at = Tu + 1u;
+	}
 
 	uint32_t *S = nullptr;
 	const uint32_t *ks4 = nullptr;
+	X3SegArgs seg_args = {};
 	if (seg) {
-		X3SegArgs ga;
+		X3SegArgs &ga = seg_args;
 		ga.bytes = d_bytes; ga.chunks = d_chunks; ga.la = B.a[0].as<uint2>(); ga.lb = B.a[1].as<uint2>();
 		ga.S4 = B.a[2].as<uint32_t>(); ga.K4 = B.a[3].as<uint32_t>(); ga.m = d_m; ga.rare = rare; ga.kexact = kexact;
 		ga.act = act; ga.act_k = act_k; ga.act_j = act_j; ga.nact = d_nact;
 		ga.window = window; ga.ncand = ncand; ga.Tu = Tu; ga.dense_at = dense_at;
 		ga.gmf = nullptr;
+		CHK(B.a[13].reserve((size_t)nc * 4 + 64)); /* (a[10..20] are the chip-wide refinement's; it does not run behind the per-chunk one) */
+		HIPCHK(hipMemsetAsync(B.a[13].p, 0, (size_t)nc * 4, st));
+		ga.dense_chunk = B.a[13].as<uint32_t>();
 		if (seg_form == 2) { CHK(B.a[23].reserve(P / 4 + 64)); HIPCHK(hipMemsetAsync(B.a[23].p, 0, P / 4 + 64, st)); ga.gmf = B.a[23].as<uint32_t>(); }
 		if (getenv("X3H_DEBUG")) fprintf(stderr, "[x3h] scan: one workgroup per chunk (%u chunks, longest %llu)\n", nc, (unsigned long long)max_len);
 		ga.prof = nullptr;
@@ -334,6 +346,13 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 	launch_walk(wa, hcnt[0], st);
 	HIPCHK(hipGetLastError());
 	if (!hcnt[1]) return X3H_OK;
+	if (seg_form == 1) { /* dense classes of per-chunk lists: refined by the chunk's own workgroup (scan3.hip); X3H_SEG_REFINE=0: the chip-wide refinement below */
+		const char *e = getenv("X3H_SEG_REFINE");
+		if (!(e && e[0] == '0')) {
+			if (getenv("X3H_DEBUG")) fprintf(stderr, "[x3h] scan: dense classes refined per chunk\n");
+			return x3_scan_seg_refine_launch(seg_args, nc, st);
+		}
+	}
 
 	/* ---- dense classes: refine them byte by byte (header, step 4).  Element = START position from here on. ---- */
 	wa.seg = 0; /* the refined lists below are chip-wide again */

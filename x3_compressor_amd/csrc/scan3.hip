@@ -303,7 +303,7 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 				if (pass) {
 					atomicAdd(&mfield[prel >> 4], 1u << (2u * (prel & 15u)));
 					const uint32_t ud = j + a.dense_at;
-					if (ud < L && K4[ud] == kk[e] && S4[ud] - base <= wend && S4[ud] - base - 3u < n) a.nact[1] = 1u;
+					if (ud < L && K4[ud] == kk[e] && S4[ud] - base <= wend && S4[ud] - base - 3u < n) { a.nact[1] = 1u; a.dense_chunk[blockIdx.x] = 1u; }
 					else push = true;
 				}
 			}
@@ -336,9 +336,353 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 	if (!BIG) for (uint32_t w = tid; w < (n + 31u) / 32u; w += X3_SEG_THREADS) a.rare[(base >> 5) + w] = rbits[w];
 }
 
+
+/* ============================================================================================================
+ * Dense classes, refined by the chunk's own workgroup.  A 4-gram class with more than dense_at members inside some member's window (zero
+ * runs, sparse 16-bit samples, periodic data) is not swept by the walk kernel but extended one byte at a time (scan2.hip header, step 4):
+ * level test "the K-th next member of my class lies inside my window", classes without a passing member dropped, the rest split by the
+ * next byte with positions staying ascending inside a class.  scan2.hip does that chip-wide -- ten launches, two host round trips and a
+ * 26-bit pair sort per level, 28 levels.  The classes of ONE chunk number about a thousand at most (a class needs K members inside a
+ * window), so here one workgroup keeps a chunk's list in its two halves of the K1 list buffers and per level makes five sweeps over it:
+ *   test      entry j passes  <=>  entry j + K - cpad is of its class and inside its window (cpad: padding zeros counted, seg_cpad's rule in
+ *             start coordinates); a pass is recorded IN the entry (the level), its class marked in an LDS bitmap;
+ *   compact   entries of marked classes move on (new class number = rank of the class among the marked ones), the byte behind the gram
+ *             is attached; entries that leave write their m[] byte -- ONE store per position for the whole refinement;
+ *   sort      stable counting-sort passes on 9-bit digits of (class number << 8 | byte): two passes up to 1024 classes;
+ *   heads     neighbours with different (class, byte) start a class; a scan numbers the classes of the new list.
+ * Elements are START positions relative to the chunk from here on.  Entry = { position (19 bits) | byte << 19 | last level passed << 27,
+ * class number | all-zero gram << 31 }.
+ * ============================================================================================================ */
+#define X3_REF_DB 9u
+#define X3_REF_DIGITS (1u << X3_REF_DB)
+#define X3_REF_POS(x) ((x) & 0x7FFFFu)
+#define X3_REF_NOPOS 0x7FFFFu /* a gram that starts before the chunk: never a query, never inside a window (chunks are at most 2^18 bytes here) */
+#define X3_REF_BYTE(x) (((x) >> 19) & 0xFFu)
+#define X3_REF_LVL(x) ((x) >> 27)
+#define X3_REF_CLS(y) ((y) & 0x7FFFFFFFu)
+#define X3_REF_ZERO(y) ((y) >> 31)
+#define X3_REF_MAXPASS 3u /* 9-bit digits of (class number << 8 | byte): 27 bits, more than a chunk's entries can need */
+
+/* LDS atomics of a wavefront whose lanes mostly hit the SAME word (the zero class, the zero byte): if every participating lane names the same
+ * word, one lane does the update for all of them -- 64 same-address atomics serialise otherwise */
+__device__ static __forceinline__ void ref_wave_add(uint32_t *table, uint32_t idx, bool on)
+{
+	const uint64_t m = x3_ballot(on);
+	if (!m) return;
+	const uint32_t first = (uint32_t)x3_ctz64(m), i0 = x3_readlane_u32(idx, first);
+	if (x3_ballot(on && idx != i0) == 0) { if (x3_lane() == first) atomicAdd(&table[i0], (uint32_t)x3_popc64(m)); }
+	else if (on) atomicAdd(&table[idx], 1u);
+}
+__device__ static __forceinline__ void ref_wave_or(uint32_t *table, uint32_t idx, uint32_t bits, bool on)
+{
+	const uint64_t m = x3_ballot(on);
+	if (!m) return;
+	const uint32_t first = (uint32_t)x3_ctz64(m), i0 = x3_readlane_u32(idx, first), b0 = x3_readlane_u32(bits, first);
+	if (x3_ballot(on && (idx != i0 || bits != b0)) == 0) { if (x3_lane() == first) atomicOr(&table[i0], b0); }
+	else if (on) atomicOr(&table[idx], bits);
+}
+
+/* exclusive prefix of `v` over the workgroup's threads in thread order, plus the total; `wt` = X3_SEG_WAVES words of LDS; two barriers */
+__device__ static __forceinline__ uint32_t ref_block_excl(uint32_t v, uint32_t *wt, uint32_t lane, uint32_t wv, uint32_t &total)
+{
+	const uint32_t incl = x3_wave_incl_scan_u32(v);
+	__syncthreads(); /* (the previous use of wt is over) */
+	if (lane == X3_WAVE - 1u) wt[wv] = incl;
+	__syncthreads();
+	uint32_t ex = incl - v, tot = 0;
+	for (uint32_t w = 0; w < X3_SEG_WAVES; w++) { const uint32_t t = wt[w]; if (w < wv) ex += t; tot += t; }
+	total = tot;
+	return ex;
+}
+
+/* one stable counting-sort pass over list `in` (cnt entries) on digit (key >> sh) & 511 with key = class << 8 | byte; hist = this digit's
+ * histogram (512 counters, consumed); LDS: cnt_t (512 x 16 counters), stage (4096 entries), bcur (512), wt */
+__device__ static void ref_sort_pass(const uint2 *in, uint2 *out, uint32_t n, uint32_t sh, uint32_t *hist, uint32_t *cnt_t, uint2 *stage,
+                                     uint32_t *bcur, uint32_t *wt, uint32_t tid, uint32_t lane, uint32_t wv)
+{
+	/* bucket bases: exclusive scan of the histogram */
+	{
+		uint32_t tot;
+		const uint32_t h = tid < X3_REF_DIGITS ? hist[tid] : 0u;
+		const uint32_t ex = ref_block_excl(h, wt, lane, wv, tot);
+		if (tid < X3_REF_DIGITS) bcur[tid] = ex;
+	}
+	__syncthreads();
+	uint2 nx[X3_SEG_E];
+	{
+		const uint32_t i0 = wv * (X3_SEG_E * X3_WAVE) + lane;
+#pragma unroll
+		for (uint32_t e = 0; e < X3_SEG_E; e++) { if (i0 + e * X3_WAVE < n) nx[e] = in[i0 + e * X3_WAVE]; else { nx[e].x = 0u; nx[e].y = 0u; } }
+	}
+	for (uint32_t t0 = 0; t0 < n; t0 += X3_SEG_TILE) {
+		for (uint32_t k = 0; k < (X3_REF_DIGITS * X3_SEG_WAVES) / X3_SEG_THREADS; k++) cnt_t[tid * ((X3_REF_DIGITS * X3_SEG_WAVES) / X3_SEG_THREADS) + k] = 0u;
+		uint2 it[X3_SEG_E];
+		uint32_t rk[X3_SEG_E], dg[X3_SEG_E];
+		const uint32_t i0 = t0 + wv * (X3_SEG_E * X3_WAVE) + lane;
+#pragma unroll
+		for (uint32_t e = 0; e < X3_SEG_E; e++) {
+			it[e] = nx[e];
+			dg[e] = (uint32_t)(((((uint64_t)X3_REF_CLS(it[e].y)) << 8) | X3_REF_BYTE(it[e].x)) >> sh) & (X3_REF_DIGITS - 1u);
+		}
+		if (t0 + X3_SEG_TILE < n) { /* the next tile's entries are on their way while this one is ranked */
+#pragma unroll
+			for (uint32_t e = 0; e < X3_SEG_E; e++) { const uint32_t idx = i0 + X3_SEG_TILE + e * X3_WAVE; if (idx < n) nx[e] = in[idx]; else { nx[e].x = 0u; nx[e].y = 0u; } }
+		}
+		__syncthreads();
+#pragma unroll
+		for (uint32_t e = 0; e < X3_SEG_E; e++) {
+			const bool valid = i0 + e * X3_WAVE < n;
+			uint64_t mask = x3_ballot(valid);
+#pragma unroll
+			for (uint32_t b = 0; b < X3_REF_DB; b++) { const bool bit = (dg[e] >> b) & 1u; const uint64_t bal = x3_ballot(bit); mask &= bit ? bal : ~bal; }
+			const uint32_t lower = (uint32_t)x3_popc64(mask & (((uint64_t)1 << lane) - 1u));
+			const uint32_t prev = valid ? cnt_t[dg[e] * X3_SEG_WAVES + wv] : 0u;
+			x3_wave_order();
+			if (valid && lower == 0u) cnt_t[dg[e] * X3_SEG_WAVES + wv] = prev + (uint32_t)x3_popc64(mask);
+			x3_wave_order();
+			rk[e] = prev + lower;
+		}
+		__syncthreads();
+		{ /* exclusive scan of the counter table in (digit, wave) order: 8 counters per thread */
+			const uint32_t per = (X3_REF_DIGITS * X3_SEG_WAVES) / X3_SEG_THREADS;
+			uint32_t c[8], sum = 0, tot;
+#pragma unroll
+			for (uint32_t k = 0; k < 8; k++) { c[k] = k < per ? cnt_t[tid * per + k] : 0u; sum += c[k]; }
+			uint32_t ex = ref_block_excl(sum, wt, lane, wv, tot);
+#pragma unroll
+			for (uint32_t k = 0; k < 8; k++) if (k < per) { cnt_t[tid * per + k] = ex; ex += c[k]; }
+		}
+		__syncthreads();
+		const uint32_t tile_n = n - t0 < X3_SEG_TILE ? n - t0 : X3_SEG_TILE;
+		uint32_t delta = 0;
+		if (tid < X3_REF_DIGITS) delta = (tid + 1u < X3_REF_DIGITS ? cnt_t[(tid + 1u) * X3_SEG_WAVES] : tile_n) - cnt_t[tid * X3_SEG_WAVES];
+#pragma unroll
+		for (uint32_t e = 0; e < X3_SEG_E; e++) if (i0 + e * X3_WAVE < n) stage[cnt_t[dg[e] * X3_SEG_WAVES + wv] + rk[e]] = it[e];
+		__syncthreads();
+#pragma unroll
+		for (uint32_t e = 0; e < X3_SEG_E; e++) {
+			const uint32_t i = e * X3_SEG_THREADS + tid;
+			if (i < tile_n) {
+				const uint2 item = stage[i];
+				const uint32_t d = (uint32_t)(((((uint64_t)X3_REF_CLS(item.y)) << 8) | X3_REF_BYTE(item.x)) >> sh) & (X3_REF_DIGITS - 1u);
+				out[bcur[d] + (i - cnt_t[d * X3_SEG_WAVES])] = item;
+			}
+		}
+		__syncthreads();
+		if (tid < X3_REF_DIGITS) bcur[tid] += delta;
+	}
+	__syncthreads();
+}
+
+__device__ static void x3_segrefine_body(const X3SegArgs &a)
+{
+	X3_LDS uint32_t cnt_t[X3_REF_DIGITS * X3_SEG_WAVES];   /* 32 KiB */
+	X3_LDS uint2 stage[X3_SEG_TILE];                       /* 32 KiB */
+	X3_LDS uint32_t keepbits[X3_SEG_MAXLEN / 32 + 2];      /* one bit per class of the current list: a member passed this level */
+	X3_LDS uint32_t kpre[X3_SEG_MAXLEN / 32 + 2];          /* kept classes before each bitmap word */
+	X3_LDS uint32_t hist[X3_REF_MAXPASS][X3_REF_DIGITS], bcur[X3_REF_DIGITS], wt[X3_SEG_WAVES];
+	const uint32_t tid = threadIdx.x, lane = x3_lane(), wv = tid / X3_WAVE;
+	const uint32_t c = blockIdx.x;
+	if (!a.dense_chunk[c]) return; /* (uniform) no class of this chunk was dense */
+	const X3Chunk ck = a.chunks[c];
+	const uint32_t n = ck.len, base = (uint32_t)ck.byte_off, L = n + 3u;
+	const uint32_t ncand = a.ncand, Tu = a.Tu;
+	const uint8_t *bytes = a.bytes + base;
+	uint2 *A = a.la + base, *Bq = a.lb + base;
+	const uint32_t *S4 = a.S4 + base, *K4 = a.K4 + base;
+	const uint32_t *rare = a.rare;
+	uint8_t *mout = a.m + base;
+
+	/* ---- list 4 as { start position | zero flag, class number }: the class number of an entry = heads before it (a scan over the list) ---- */
+	{
+		uint32_t carry = 0;
+		for (uint32_t t0 = 0; t0 < L; t0 += X3_SEG_TILE) {
+			const uint32_t j0 = t0 + tid * X3_SEG_E;
+			uint32_t k[X3_SEG_E + 1], s[X3_SEG_E], hd = 0;
+			k[0] = j0 > 0 && j0 <= L ? K4[j0 - 1] : 0xFFFFFFFFu;
+#pragma unroll
+			for (uint32_t e = 0; e < X3_SEG_E; e++) { k[e + 1] = j0 + e < L ? K4[j0 + e] : 0u; s[e] = j0 + e < L ? S4[j0 + e] - base : 0u; }
+#pragma unroll
+			for (uint32_t e = 0; e < X3_SEG_E; e++) if (j0 + e < L && (j0 + e == 0 || k[e + 1] != k[e])) hd += 1u;
+			uint32_t tot;
+			uint32_t ord = carry + ref_block_excl(hd, wt, lane, wv, tot);
+#pragma unroll
+			for (uint32_t e = 0; e < X3_SEG_E; e++) {
+				if (j0 + e < L) {
+					if (j0 + e == 0 || k[e + 1] != k[e]) ord++;
+					uint2 en;
+					en.x = s[e] >= 3u ? s[e] - 3u : X3_REF_NOPOS; /* (an END position < 3: the gram starts before the chunk) */
+					en.y = (ord - 1u) | (k[e + 1] == 0u ? 0x80000000u : 0u);
+					A[j0 + e] = en;
+				}
+			}
+			carry += tot;
+		}
+	}
+	uint2 *cur = A, *oth = Bq;
+	uint32_t nl = L;
+	__syncthreads();
+
+	for (uint32_t len = 4; ; len++) {
+		/* ---- test: entry j passes level `len` ---- */
+		for (uint32_t i = tid; i < nl / 32u + 1u; i += X3_SEG_THREADS) keepbits[i] = 0u;
+		__syncthreads();
+		for (uint32_t j0 = 0; j0 < nl; j0 += X3_SEG_TILE) { /* uniform trip count: the class marks are wave operations */
+			uint2 ev[X3_SEG_E];
+			uint32_t Kv[X3_SEG_E];
+#pragma unroll
+			for (uint32_t q = 0; q < X3_SEG_E; q++) { /* the loads of four entries are in flight together */
+				const uint32_t j = j0 + q * X3_SEG_THREADS + tid;
+				if (j < nl) ev[q] = cur[j]; else { ev[q].x = X3_REF_NOPOS; ev[q].y = 0; }
+			}
+#pragma unroll
+			for (uint32_t q = 0; q < X3_SEG_E; q++) {
+				const uint32_t p = X3_REF_POS(ev[q].x), gp = base + p;
+				Kv[q] = Tu + 1u;
+				if (p < n && ((rare[gp >> 5] >> (gp & 31u)) & 1u)) Kv[q] = a.kexact[gp];
+			}
+#pragma unroll
+			for (uint32_t q = 0; q < X3_SEG_E; q++) {
+				const uint32_t j = j0 + q * X3_SEG_THREADS + tid;
+				const uint2 e = ev[q];
+				const uint32_t p = X3_REF_POS(e.x), K = Kv[q];
+				bool pass = p < n && K >= 2u; /* (p >= n: starts before the chunk; K < 2: nothing repeats) */
+				const uint32_t wend = p + ncand;
+				if (pass) {
+					const uint32_t cpad = (X3_REF_ZERO(e.y) && wend >= n) ? wend - n + 1u : 0u; /* padding START positions inside the window */
+					if (cpad < K) {
+						const uint32_t u = j + (K - cpad);
+						pass = false;
+						if (u < nl) { const uint2 eu = cur[u]; pass = eu.y == e.y && X3_REF_POS(eu.x) <= wend; }
+					}
+				}
+				bool dense = pass && len > 4u; /* a class that was dense at length 4 is refined to the end (scan2.hip) */
+				if (pass) {
+					if (len > 4u) cur[j].x = (e.x & 0x07FFFFFFu) | ((len - 1u) << 27); /* m >= len - 1 (level 3 is in m[] already) */
+					else {
+						const uint32_t ud = j + a.dense_at;
+						if (ud < nl) { const uint2 ed = cur[ud]; dense = ed.y == e.y && X3_REF_POS(ed.x) <= wend; }
+					}
+				}
+				ref_wave_or(keepbits, X3_REF_CLS(e.y) >> 5, 1u << (e.y & 31u), dense && len < X3_MAXLEN);
+			}
+		}
+		__syncthreads();
+		/* ---- kept classes before each bitmap word; none kept (or the last level): every entry leaves ---- */
+		uint32_t nkept_cls = 0;
+		{
+			const uint32_t nw = nl / 32u + 1u;
+			uint32_t carry = 0;
+			for (uint32_t w0 = 0; w0 < nw; w0 += X3_SEG_THREADS) {
+				const uint32_t w = w0 + tid;
+				const uint32_t pc = w < nw ? (uint32_t)__builtin_popcount(keepbits[w]) : 0u;
+				uint32_t tot;
+				const uint32_t ex = ref_block_excl(pc, wt, lane, wv, tot);
+				if (w < nw) kpre[w] = carry + ex;
+				carry += tot;
+			}
+			nkept_cls = carry;
+		}
+		__syncthreads();
+		/* ---- compact: entries of kept classes move on with the byte behind their gram; the others write their m[] ---- */
+		for (uint32_t i = tid; i < X3_REF_MAXPASS * X3_REF_DIGITS; i += X3_SEG_THREADS) (&hist[0][0])[i] = 0u;
+		__syncthreads();
+		uint32_t nnew = 0;
+		{
+			uint32_t carry = 0;
+			for (uint32_t t0 = 0; t0 < nl; t0 += X3_SEG_TILE) {
+				const uint32_t j0 = t0 + tid * X3_SEG_E;
+				uint2 e[X3_SEG_E];
+				uint32_t keep = 0, cntk = 0, okey[X3_SEG_E] = { 0, 0, 0, 0 };
+#pragma unroll
+				for (uint32_t q = 0; q < X3_SEG_E; q++) {
+					if (j0 + q < nl) {
+						e[q] = cur[j0 + q];
+						const bool kp = nkept_cls && X3_REF_POS(e[q].x) < n && ((keepbits[X3_REF_CLS(e[q].y) >> 5] >> (e[q].y & 31u)) & 1u);
+						if (kp) { keep |= 1u << q; cntk++; }
+						else if (X3_REF_POS(e[q].x) < n && X3_REF_LVL(e[q].x) >= 4u) mout[X3_REF_POS(e[q].x)] = (uint8_t)X3_REF_LVL(e[q].x);
+					}
+				}
+				uint32_t tot;
+				uint32_t dst = carry + ref_block_excl(cntk, wt, lane, wv, tot);
+#pragma unroll
+				for (uint32_t q = 0; q < X3_SEG_E; q++) {
+					if (keep & (1u << q)) {
+						const uint32_t p = X3_REF_POS(e[q].x), bt = bytes[p + len];
+						const uint32_t cl = X3_REF_CLS(e[q].y);
+						const uint32_t rank = kpre[cl >> 5] + (uint32_t)__builtin_popcount(keepbits[cl >> 5] & ((1u << (cl & 31u)) - 1u));
+						uint2 en;
+						en.x = (e[q].x & ~(0xFFu << 19)) | (bt << 19);
+						en.y = rank | ((X3_REF_ZERO(e[q].y) && !bt) ? 0x80000000u : 0u); /* all zero only while every byte is */
+						oth[dst++] = en;
+						const uint32_t key = (rank << 8) | bt;
+						okey[q] = key;
+					}
+				}
+#pragma unroll
+				for (uint32_t q = 0; q < X3_SEG_E; q++)
+#pragma unroll
+					for (uint32_t ps = 0; ps < X3_REF_MAXPASS; ps++) ref_wave_add(hist[ps], (okey[q] >> (ps * X3_REF_DB)) & (X3_REF_DIGITS - 1u), (keep >> q) & 1u);
+				carry += tot;
+			}
+			nnew = carry;
+		}
+		__syncthreads();
+		if (!nnew) break;
+		/* ---- sort by (class number, byte): positions stay ascending inside a (class, byte) group; as many 9-bit passes as the class numbers need ---- */
+		uint2 *src = oth, *dst2 = cur;
+		{
+			uint32_t keybits = 8u;
+			while (keybits < 27u && ((nkept_cls - 1u) >> (keybits - 8u))) keybits++;
+			const uint32_t npass = (keybits + X3_REF_DB - 1u) / X3_REF_DB;
+			for (uint32_t ps = 0; ps < npass; ps++) {
+				ref_sort_pass(src, dst2, nnew, ps * X3_REF_DB, hist[ps], cnt_t, stage, bcur, wt, tid, lane, wv);
+				uint2 *t = src; src = dst2; dst2 = t;
+			}
+		}
+		/* ---- heads: neighbours with a different (class, byte) start a class; number the classes of the new list (src -> dst2) ---- */
+		{
+			uint32_t carry = 0;
+			for (uint32_t t0 = 0; t0 < nnew; t0 += X3_SEG_TILE) {
+				const uint32_t j0 = t0 + tid * X3_SEG_E;
+				uint2 e[X3_SEG_E + 1];
+				uint32_t hd = 0;
+				if (j0 > 0 && j0 <= nnew) e[0] = src[j0 - 1]; else { e[0].x = 0; e[0].y = 0xFFFFFFFFu; }
+#pragma unroll
+				for (uint32_t q = 0; q < X3_SEG_E; q++) { if (j0 + q < nnew) e[q + 1] = src[j0 + q]; else { e[q + 1].x = 0; e[q + 1].y = 0; } }
+#pragma unroll
+				for (uint32_t q = 0; q < X3_SEG_E; q++)
+					if (j0 + q < nnew && (j0 + q == 0 || e[q + 1].y != e[q].y || X3_REF_BYTE(e[q + 1].x) != X3_REF_BYTE(e[q].x))) hd += 1u;
+				uint32_t tot;
+				uint32_t ord = carry + ref_block_excl(hd, wt, lane, wv, tot);
+#pragma unroll
+				for (uint32_t q = 0; q < X3_SEG_E; q++) {
+					if (j0 + q < nnew) {
+						if (j0 + q == 0 || e[q + 1].y != e[q].y || X3_REF_BYTE(e[q + 1].x) != X3_REF_BYTE(e[q].x)) ord++;
+						uint2 en = e[q + 1];
+						en.y = (ord - 1u) | (en.y & 0x80000000u);
+						dst2[j0 + q] = en;
+					}
+				}
+				carry += tot;
+			}
+		}
+		cur = dst2; oth = src;
+		nl = nnew;
+		__syncthreads();
+	}
+}
+
 #ifndef X3_EMU
 __global__ void __launch_bounds__(X3_SEG_THREADS) x3_segscan_kernel(X3SegArgs a) { x3_segscan_body<false>(a); }
 __global__ void __launch_bounds__(X3_SEG_THREADS) x3_segscan_big_kernel(X3SegArgs a) { x3_segscan_body<true>(a); }
+__global__ void __launch_bounds__(X3_SEG_THREADS) x3_segrefine_kernel(X3SegArgs a) { x3_segrefine_body(a); }
+int x3_scan_seg_refine_launch(const X3SegArgs &a, uint32_t nchunks, hipStream_t st)
+{
+	hipLaunchKernelGGL(x3_segrefine_kernel, dim3(nchunks), dim3(X3_SEG_THREADS), 0, st, a);
+	HIPCHK(hipGetLastError());
+	return X3H_OK;
+}
 int x3_scan_seg_launch(const X3SegArgs &a, uint32_t nchunks, hipStream_t st)
 {
 	if (a.gmf) hipLaunchKernelGGL(x3_segscan_big_kernel, dim3(nchunks), dim3(X3_SEG_THREADS), 0, st, a);
@@ -349,6 +693,12 @@ int x3_scan_seg_launch(const X3SegArgs &a, uint32_t nchunks, hipStream_t st)
 #else
 static void segscan_tramp(void *p) { x3_segscan_body<false>(*(const X3SegArgs *)p); }
 static void segscan_big_tramp(void *p) { x3_segscan_body<true>(*(const X3SegArgs *)p); }
+static void segrefine_tramp(void *p) { x3_segrefine_body(*(const X3SegArgs *)p); }
+int x3_scan_seg_refine_launch(const X3SegArgs &a, uint32_t nchunks, hipStream_t)
+{
+	x3emu_launch(segrefine_tramp, (void *)&a, dim3(nchunks), dim3(X3_SEG_THREADS));
+	return X3H_OK;
+}
 int x3_scan_seg_launch(const X3SegArgs &a, uint32_t nchunks, hipStream_t)
 {
 	x3emu_launch(a.gmf ? segscan_big_tramp : segscan_tramp, (void *)&a, dim3(nchunks), dim3(X3_SEG_THREADS));

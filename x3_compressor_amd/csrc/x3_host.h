@@ -99,12 +99,14 @@ struct X3SegArgs {
 	uint8_t *m;                  /* out: m[p] for levels 0..3 (the walk kernel raises it where the 4-gram repeats often enough) */
 	uint32_t *rare, *kexact;     /* out: positions with K < T+1 (bitmap, zeroed by the caller) and their K */
 	uint32_t *gmf;               /* nullptr: level counters in LDS; else 2 bits per position of the padded layout, zeroed by the caller (long chunks) */
-	uint32_t *act, *act_k, *act_j, *nact; /* out: positions for the walk kernel; nact[0] = their number, nact[1] = a dense class was met */
+	uint32_t *act, *act_k, *act_j, *nact; /* out: positions for the walk kernel; nact[0] = their number, nact[1] = a dense class was met, nact[2] = the per-chunk refinement gave up */
+	uint32_t *dense_chunk;       /* out, per chunk (zeroed by the caller): a class of this chunk is dense -> x3_segrefine_kernel */
 	uint32_t window, ncand, Tu, dense_at;
 	uint64_t *prof;              /* nullptr, or 16 cycle counters: phase 0, passes 1-4, levels 1-4 (X3H_SEG_PROF, debugging) */
 };
 int x3_scan_seg_applies(uint32_t nchunks, uint64_t max_len); /* 0: no, 1: counters in LDS, 2: counters in global memory */
 int x3_scan_seg_launch(const X3SegArgs &a, uint32_t nchunks, hipStream_t st);
+int x3_scan_seg_refine_launch(const X3SegArgs &a, uint32_t nchunks, hipStream_t st); /* dense classes of every marked chunk, by the chunk's own workgroup */
 
 /* ---- v2 coding stage (code2.hip) ------------------------------------------------------------------------- */
 struct X3Code2Stats { double ms_features, ms_modes, ms_coder, ms_emit; uint64_t symbols, chain_symbols; int mode_iters; /* fixed-point iterations of the mode choice (0: serial kernel, < 0: not converged, serial kernel ran) */ };
