@@ -44,7 +44,11 @@ def ctx_for(env):
 ENVS = [dict(), dict(X3H_PIPE_MIN="1"), dict(X3H_PIPE_MIN="1", X3H_MODES="fixed"), dict(X3H_PIPE_MIN="0", X3H_MODES="serial"), dict(X3H_PIPE_MIN="0", X3H_MODES="fixed"),
         dict(X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0"), dict(X3H_STREAM_KERNELS="0"), dict(X3H_WALK_DENSE="16"), dict(X3H_WALK_DENSE="40", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0"),
         dict(X3H_PIPE_MIN="1", X3H_MODES="serial"), dict(X3H_CTX_SUB="3"), dict(X3H_PIPE_MIN="1", X3H_PIPE_MARKS="0.1,0.2,0.3,0.4,0.5,0.6,0.7,0.8"),
-        dict(X3H_PIPE_MIN="1", X3H_PIPE_MARKS="0.6")]
+        dict(X3H_PIPE_MIN="1", X3H_PIPE_MARKS="0.6"),
+        # round 3: K1 by one workgroup per chunk (scan3.hip) on batches of any size, in both forms, with the per-chunk / chip-wide dense refinement;
+        # segment-wise bit emission; per-stream arrangement
+        dict(X3H_SEG_MIN="1"), dict(X3H_SEG_MIN="1", X3H_SEG_SMALL_MAX="0"), dict(X3H_SEG_MIN="1", X3H_WALK_DENSE="12"), dict(X3H_SEG_MIN="1", X3H_SEG_REFINE="0", X3H_WALK_DENSE="12"),
+        dict(X3H_SEG_MIN="2", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0"), dict(X3H_PIPE_MIN="1", X3H_SEG_EMIT="1"), dict(X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0", X3H_ARRANGE="1")]
 t0, cases = time.time(), 0
 while time.time() - t0 < budget:
     nch = int(rng.choice([1, 1, 1, 2, 3, 7, 40, 60, 130, 300]))   # >= 48: the per-stream kernels of code3.hip; 300: above the switch to the small-LDS kernel variants
