@@ -178,7 +178,7 @@ extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 	for (DevBuf &b : c->s2.a) b.release();
 	c->s2.misc.release();
 	for (DevBuf &b : c->c2.y) b.release();
-	c->c2.yraw.release(); c->c2.csbsmall.release(); c->c2.stat.release();
+	c->c2.yraw.release(); c->c2.csbsmall.release(); c->c2.stat.release(); c->c2.stat0.release();
 	for (DevBuf &b : c->c2.ms) b.release();
 	for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
 	if (c->stream) (void)hipStreamDestroy(c->stream);

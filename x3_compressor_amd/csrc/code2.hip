@@ -195,6 +195,7 @@ struct X3ModesArgs {
 	const X3ParseResult *parsed;
 	const uint32_t *ho, *dof;          /* per chunk: first hit, first tag */
 	const uint32_t *f0, *t0, *f1, *t1; /* per hit: freq/total in ctx0 and ctx1 (freq 0 == tag absent) */
+	uint32_t fs;                       /* stride of those four in words: 1 = plain arrays, 4 = fields of the per-hit records the context kernel stores */
 	const uint32_t *rank, *dk, *step;  /* per hit: MTF rank, dictionary size at that step, step index */
 	uint32_t *idxfreq;                 /* per tag slot (by rank), pre-set to 1: spill area for ranks >= X3_IDXF_LDS */
 	uint32_t *mode;                    /* out per hit: the chosen event (E_CTX0 / E_CTX1 / E_IDX1) */
@@ -242,7 +243,7 @@ __device__ static __forceinline__ void x3_modes_loop(const X3ModesArgs &a, uint3
 	{
 		const bool in0 = first + lane < H;
 		const uint32_t g0 = h0 + first + lane;
-		nf0 = in0 ? a.f0[g0] : 0; nt0 = in0 ? a.t0[g0] : 1; nf1 = in0 ? a.f1[g0] : 0; nt1 = in0 ? a.t1[g0] : 1;
+		nf0 = in0 ? a.f0[(size_t)g0 * a.fs] : 0; nt0 = in0 ? a.t0[(size_t)g0 * a.fs] : 1; nf1 = in0 ? a.f1[(size_t)g0 * a.fs] : 0; nt1 = in0 ? a.t1[(size_t)g0 * a.fs] : 1;
 		nr = in0 ? a.rank[g0] : 0; nd = in0 ? a.dk[g0] : 1; ns = in0 ? a.step[g0] : 0;
 	}
 	for (uint32_t base = first; base < H; base += X3_WAVE) {
@@ -252,7 +253,7 @@ __device__ static __forceinline__ void x3_modes_loop(const X3ModesArgs &a, uint3
 		{
 			const bool inn = base + X3_WAVE + lane < H;
 			const uint32_t gn = g + X3_WAVE;
-			nf0 = inn ? a.f0[gn] : 0; nt0 = inn ? a.t0[gn] : 1; nf1 = inn ? a.f1[gn] : 0; nt1 = inn ? a.t1[gn] : 1;
+			nf0 = inn ? a.f0[(size_t)gn * a.fs] : 0; nt0 = inn ? a.t0[(size_t)gn * a.fs] : 1; nf1 = inn ? a.f1[(size_t)gn * a.fs] : 0; nt1 = inn ? a.t1[(size_t)gn * a.fs] : 1;
 			nr = inn ? a.rank[gn] : 0; nd = inn ? a.dk[gn] : 1; ns = inn ? a.step[gn] : 0;
 		}
 		const float q0 = vf0 ? (float)vf0 / (float)vt0 : 0.f; /* (float)freq / (float)total of the context item; 0 == absent */
@@ -1166,9 +1167,11 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		if (streamk) {
 			/* ---- many streams: context statistics by one wavefront per stream (code3.hip); the context1 pass also finds the first use
 			 *      of every (context1, tag), which IS the tag-pair map (tag_pair.c:100-130: ordinal = rank of the first occurrence) ---- */
-			uint32_t *iota = T[0], *kA = T[1], *vA = T[2], *tA = T[3], *first = T[4], *pf = T[5], *P = T[6];
+			uint32_t *iota = T[0], *kA = T[1], *vA = T[2], *tA = T[3], *pf = T[5], *P = T[6];
 			CHK(B.stat.reserve((nA + 4) * 16));
-			uint4 *stat = B.stat.as<uint4>();
+			CHK(B.stat0.reserve((nA + 4) * 16));
+			uint4 *stat = B.stat.as<uint4>(), *stat0 = B.stat0.as<uint4>(); /* per hit {freq, total, cum, first}: context1 / context0.  Read in place by the mode kernel and the symbol
+			                                                                  * selection (no unpacking into six arrays: 60 bytes per hit less traffic) */
 			uint32_t npairs_total = 0;
 			/* by context1, time order inside: chip-wide stable radix sort (rocPRIM onesweep, 3.6 TB/s).  X3H_ARRANGE=1: one workgroup per stream, counting
 			 * sort on the stream-local key (x3_arrange_kernel, code3.hip) -- same order, measured SLOWER on the 1024-chunk batch (features 48 against
@@ -1182,10 +1185,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 				x3_foreach(nH, st, X3_LAMBDA(size_t i) { tA[i] = h_tag[vA[i]]; });
 			}
 			CHK(x3_ctx_stats_run(st, nc, maxDict, d_ho, d_dof, kA, vA, tA, stat));
-			x3_foreach(nH, st, X3_LAMBDA(size_t i) {
-				const uint4 r = stat[i];
-				f1[i] = r.x; t1[i] = r.y; c1[i] = r.z; first[i] = r.w & 0x7FFFFFFFu; pf[i] = r.w >> 31;
-			});
+			x3_foreach(nH, st, X3_LAMBDA(size_t i) { pf[i] = stat[i].w >> 31; }); /* this hit put its (context1, tag) pair into the map */
 			CHK(x3p_excl_scan(B.tmp, pf, P, nH, st));
 			HIPCHK(hipMemcpyAsync(&npairs_total, P + nH, 4, hipMemcpyDeviceToHost, st));
 			x3_foreach(nc, st, X3_LAMBDA(size_t c) {
@@ -1194,7 +1194,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 				m_first00[c] = NONE32; m_ord00[c] = 0;
 			});
 			x3_foreach(nH, st, X3_LAMBDA(size_t i) {
-				h_pair[i] = P[first[i]];
+				h_pair[i] = P[stat[i].w & 0x7FFFFFFFu]; /* ordinal of the pair = rank of the hit that first used it */
 				if (pf[i]) { /* the pair (0,0) of the stream: both contexts after a new fragment (x3.c:424-425) */
 					const uint32_t c = find_chunk(d_ho, nc, (uint32_t)i), z = d_dof[c];
 					if (h_tag[i] == z && h_c1[i] == z) { m_first00[c] = (uint32_t)i; m_ord00[c] = P[i]; }
@@ -1221,8 +1221,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 				CHK(x3p_sort_pairs(B.tmp, G0, kA, iota, vA, nH, bits_for(npairs_total ? npairs_total : 1), st));
 				x3_foreach(nH, st, X3_LAMBDA(size_t i) { tA[i] = h_tag[vA[i]]; });
 			}
-			CHK(x3_ctx_stats_run(st, nc, maxDict, d_ho, d_dof, kA, vA, tA, stat));
-			x3_foreach(nH, st, X3_LAMBDA(size_t i) { const uint4 r = stat[i]; f0[i] = r.x; t0[i] = r.y; c0[i] = r.z; });
+			CHK(x3_ctx_stats_run(st, nc, maxDict, d_ho, d_dof, kA, vA, tA, stat0));
 		} else {
 		/* ---- tag-pair ordinals (tag_pair.c) and the ctx0 group of every hit (x3.c:139-147) ---- */
 			uint32_t npairs_total = 0;
@@ -1300,7 +1299,11 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		if (!done) {
 			X3ModesArgs ma;
 			ma.parsed = d_parsed; ma.ho = d_ho; ma.dof = d_dof;
-			ma.f0 = f0; ma.t0 = t0; ma.f1 = f1; ma.t1 = t1; ma.rank = h_rank; ma.dk = h_dk; ma.step = h_step;
+			ma.f0 = f0; ma.t0 = t0; ma.f1 = f1; ma.t1 = t1; ma.fs = 1; ma.rank = h_rank; ma.dk = h_dk; ma.step = h_step;
+			if (streamk) { /* the context kernel's records, read in place: {freq, total, cum, first} per hit */
+				const uint32_t *r0 = (const uint32_t *)B.stat0.p, *r1 = (const uint32_t *)B.stat.p;
+				ma.f0 = r0; ma.t0 = r0 + 1; ma.f1 = r1; ma.t1 = r1 + 1; ma.fs = 4;
+			}
 			ma.idxfreq = idxf; ma.mode = mode;
 			ma.pe0 = ma.pe1 = ma.ilist_rank = ma.ilist_hit = ma.evfinal = nullptr;
 			ma.state = nullptr; ma.resume = 0;
@@ -1387,9 +1390,15 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 
 		/* ---- the tag / index symbol of every hit ---- */
 		uint32_t *scum = T[0], *sfreq = T[1], *stot = T[2]; /* zi/ci/key are dead now */
+		const uint4 *recs0 = streamk ? B.stat0.as<uint4>() : nullptr, *recs1 = streamk ? B.stat.as<uint4>() : nullptr;
 		x3_foreach(nH, st, X3_LAMBDA(size_t i) {
 			const uint32_t m = mode[i];
 			uint32_t cu, fq, to;
+			if (recs0) { /* many streams: the context kernel's records in place */
+				if (m == X3_E_CTX0) { const uint4 r = recs0[i]; cu = r.z; fq = r.x; to = r.y; }
+				else if (m == X3_E_CTX1) { const uint4 r = recs1[i]; cu = r.z; fq = r.x; to = r.y; }
+				else { cu = rcum[i]; fq = rfreq[i]; to = itot[i]; }
+			} else
 			if (m == X3_E_CTX0) { cu = c0[i]; fq = f0[i]; to = t0[i]; }
 			else if (m == X3_E_CTX1) { cu = c1[i]; fq = f1[i]; to = t1[i]; }
 			else { cu = rcum[i]; fq = rfreq[i]; to = itot[i]; }

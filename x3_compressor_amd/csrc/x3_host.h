@@ -115,7 +115,7 @@ struct X3Code2Bufs {
 	DevBuf tmp, offs, chunkmeta;
 	DevBuf a[48]; /* u32 work arrays of max(hits, events)+4 entries */
 	DevBuf idxfreq, hsym, maxred, csbsmall;
-	DevBuf stat;  /* per hit {freq, total, cum, first}: what a per-stream context kernel (code3.hip) stores in one go */
+	DevBuf stat, stat0;  /* per hit {freq, total, cum, first} in context1 / context0: what a per-stream context kernel (code3.hip) stores in one go */
 	hipEvent_t ev[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
 	hipStream_t side = nullptr;                       /* batches of many streams: the move-to-front ranks run beside the context statistics */
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
