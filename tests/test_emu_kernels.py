@@ -54,8 +54,8 @@ SEG_CASES = [
 ]
 
 
-@pytest.mark.parametrize("form", ["counters-in-lds", "counters-in-global-memory"])
-@pytest.mark.parametrize("name,data,kw", SEG_CASES, ids=[c[0] for c in SEG_CASES])
+@pytest.mark.parametrize("name,data,kw,form", [c + ("counters-in-lds",) for c in SEG_CASES] + [c + ("counters-in-global-memory",) for c in SEG_CASES[1:4]],
+                         ids=[c[0] + "-lds" for c in SEG_CASES] + [c[0] + "-global" for c in SEG_CASES[1:4]])
 def test_emulated_per_chunk_scan_matches_oracle(emu, oracle, monkeypatch, name, data, kw, form):
     """scan3.hip (K1 of many-chunk batches: one workgroup sorts and level-tests one chunk) forced on a single chunk, in both of its forms
     (chunks up to 256 KiB / longer ones): m[] == the oracle's (backend.c:56-78) and the stream built on it == the oracle's"""
@@ -397,7 +397,12 @@ def test_emulated_stream_kernels_batch_of_52(emu_env, oracle):
     kw = dict(w_kib=1, t=3)
     data = np.frombuffer(b"".join(parts), dtype=np.uint8)
     off = np.cumsum([0] + [len(p) for p in parts]).astype(np.uint64)
-    for env in (dict(), dict(X3H_CTX_SUB="3"), dict(X3H_ARRANGE="1")):  # X3H_ARRANGE=1: hits arranged by one workgroup per stream (x3_arrange_kernel) instead of the chip-wide sort
+    # (K1 by one emulated 1024-thread workgroup per chunk costs ~1.5 s a chunk: it has its own tests above, here the chip-wide scan runs)
+    for env in (dict(X3H_SEG_MIN="1000"), dict(X3H_SEG_MIN="1000", X3H_CTX_SUB="3")):
         streams = emu_env(**env).compress_chunks(data, off, _lib.make_params(**kw))
         for i, (p, got) in enumerate(zip(parts, streams)):
             assert got == oracle.compress(p, oracle_lib.params(**kw)), f"{env}: stream {i}"
+    # X3H_ARRANGE=1: hits arranged by one workgroup per stream (x3_arrange_kernel) instead of the chip-wide sort -- on the first ten streams (emulator time)
+    few = emu_env(X3H_ARRANGE="1", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0").compress_chunks(data[:int(off[10])], off[:11], _lib.make_params(**kw))
+    for i in range(10):
+        assert few[i] == oracle.compress(parts[i], oracle_lib.params(**kw)), f"per-stream arrangement: stream {i}"
