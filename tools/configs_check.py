@@ -1,14 +1,19 @@
 """All five BASELINE.json configs at full size on one GPU (synthetic stand-ins for Silesia; config 4 = one GPU's share of the 128 chunks).
 Prints one line per config: bytes, device ms, MB/s, ratio, and the checks made."""
-import sys, time
+import hashlib, json, sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
 from x3_compressor_amd import _lib, synth
 import oracle_lib
 
 ctx = _lib.X3Context(0)
-SILESIA = dict(dickens=10192446, mozilla=51220480, mr=9970564, nci=33553445, ooffice=6152192, osdb=10085684, reymont=6627202,
-               samba=21606400, sao=7251944, webster=41458703, xray=8474240, xml=5345280)
+SILESIA = synth.SILESIA
+MAN = json.load(open('tests/golden/manifest_sha.json'))  # sha256 of the REAL reference's streams (tests/golden/make_golden_sha.py)
+
+
+def pinned(name, stream):
+    e = MAN.get(name)
+    return None if e is None else (len(stream) == e["output_len"] and hashlib.sha256(stream).hexdigest() == e["output_sha256"])
 
 
 def line(name, nbytes, st, out_bytes, extra=""):
@@ -25,16 +30,16 @@ line("1: 64 KiB text, -w 8 -t 16", len(d), st, len(s), f"== CPU oracle stream: {
 d = synth.english_like(SILESIA["dickens"]).tobytes()
 for _ in range(2):
     s = ctx.compress(d, _lib.make_params(w_kib=64, t=256)); st = ctx.last_stats
-line("2: 10.2 MB text, -w 64 -t 256 (host buffers)", len(d), st, len(s))
+line("2: 10.2 MB text, -w 64 -t 256 (host buffers)", len(d), st, len(s), f"sha256 == real reference: {pinned('cfg2_full_english10192446_w64_t256', s)}")
 
 # config 3: 12 independent streams with the Silesia sizes, -w 256 -t 1024
 sizes = list(SILESIA.values())
-parts = [synth.english_like(n, seed=1000 + i) if i % 3 else synth.zipf_bytes(n, offset=i << 26) for i, n in enumerate(sizes)]
+parts = [synth.config3_part(i) for i in range(len(sizes))]
 data = np.concatenate(parts); off = np.cumsum([0] + sizes).astype(np.uint64)
 for _ in range(2):
     streams = ctx.compress_chunks(data, off, _lib.make_params(w_kib=256, t=1024)); st = ctx.last_stats
-chk = ctx.decompress(streams[11], sizes[11]) == parts[11].tobytes()
-line("3: 12 streams with the Silesia sizes, -w 256 -t 1024", int(off[-1]), st, sum(map(len, streams)), f"pipelined {st.pipelined}; stream 11 decodes back: {chk}")
+oks = [pinned(f"cfg3_full_{i:02d}_{nm}{sizes[i]}_w256_t1024", streams[i]) for i, nm in enumerate(SILESIA)]
+line("3: 12 streams with the Silesia sizes, -w 256 -t 1024", int(off[-1]), st, sum(map(len, streams)), f"pipelined {st.pipelined}; streams with sha256 == real reference: {sum(1 for o in oks if o)} of 12 (differ: {sum(1 for o in oks if o is False)})")
 
 # config 4 (one GPU's share): 16 chunks x 8 MiB of the Zipf stream, -w 64 -t 256
 nch, cb = 16, 8 << 20
@@ -44,8 +49,8 @@ for _ in range(2):
 line("4: 16 x 8 MiB Zipf (1/8 of the 1 GiB), -w 64 -t 256", nch * cb, st, sum(map(len, streams)), f"pipelined {st.pipelined}")
 
 # config 5: mr-sized stream, -w 512 -t 4096, compress + decompress round trip
-d = synth.english_like(SILESIA["mr"], seed=5).tobytes()
+d = synth.mr_like(synth.MR_BYTES).tobytes()
 for _ in range(2):
     s = ctx.compress(d, _lib.make_params(w_kib=512, t=4096)); st = ctx.last_stats
 t0 = time.time(); back = ctx.decompress(s, len(d)); dt = time.time() - t0
-line("5: 10.0 MB, -w 512 -t 4096, round trip", len(d), st, len(s), f"decode {ctx.last_stats.ms_code:.0f} ms ({len(d)/dt/1e6:.2f} MB/s), round trip ok: {back == d}")
+line("5: 10.0 MB of mr-like samples, -w 512 -t 4096, round trip", len(d), st, len(s), f"sha256 == real reference: {pinned(f'cfg5_full_mr{len(d)}_w512_t4096', s)}; decode {ctx.last_stats.ms_code:.0f} ms ({len(d)/dt/1e6:.2f} MB/s), round trip ok: {back == d}")
