@@ -83,6 +83,41 @@ int main()
 		uint8_t junk[64]; for (int i = 0; i < 64; i++) junk[i] = (uint8_t)(i * 37 + 11);
 		REQUIRE(x3h_decompress(ctx, junk, 64, back.data(), back.size(), &bl, nullptr) != X3H_OK);
 	}
+	/* round 3: K1 by one workgroup per chunk (scan3.hip) in both of its forms with its dense-class refinement (X3_WALK_DENSE is 6 in this build),
+	 * bits written behind every coder segment, hits arranged by one workgroup per stream -- a ragged batch, each stream against the oracle */
+	{
+		struct { const char *k, *v; } envs[][3] = {
+			{ { "X3H_SEG_MIN", "1" }, { "X3H_SEG_EMIT", "1" }, { "X3H_PIPE_MIN", "1" } },
+			{ { "X3H_SEG_MIN", "1" }, { "X3H_SEG_SMALL_MAX", "0" }, { "X3H_PIPE_MIN", "0" } },
+			{ { "X3H_STREAM_KERNELS", "1" }, { "X3H_ARRANGE", "1" }, { "X3H_PIPE_MIN", "0" } },
+		};
+		const int kinds[] = { 0, 2, 4, 0 };
+		const size_t lens[] = { 450, 300, 300, 0 };
+		const int NS = 4;
+		std::vector<uint8_t> all;
+		std::vector<uint64_t> off(1, 0);
+		for (int i = 0; i < NS; i++) { std::vector<uint8_t> v = make_input(kinds[i], lens[i]); all.insert(all.end(), v.begin(), v.end()); off.push_back(all.size()); }
+		x3h_params p; x3h_default_params(&p); p.window_bytes = 1024; p.max_match_count = 3;
+		x3o_params op = { 1024, 3, 4, 0, 0 };
+		for (auto &env : envs) {
+			unsetenv("X3H_PIPE_MIN");
+			for (auto &kv : env) if (kv.k) setenv(kv.k, kv.v, 1);
+			x3h_ctx *e = nullptr;
+			REQUIRE(x3h_ctx_create(&e, 0) == X3H_OK);
+			const uint64_t stride = 8192;
+			std::vector<uint8_t> out(stride * NS);
+			uint64_t lens_out[NS];
+			REQUIRE(x3h_compress_chunks(e, &p, all.data(), off.data(), NS, out.data(), stride, lens_out, nullptr) == X3H_OK);
+			for (int i = 0; i < NS; i++) {
+				std::vector<uint8_t> want(x3o_compress_bound(lens[i]));
+				size_t wl = 0;
+				REQUIRE(x3o_compress(&op, all.data() + off[(size_t)i], lens[i], want.data(), want.size(), &wl, nullptr) == X3O_OK);
+				REQUIRE(lens_out[i] == wl && same(out.data() + (size_t)i * stride, want.data(), wl));
+			}
+			x3h_ctx_destroy(e);
+			for (auto &kv : env) if (kv.k) unsetenv(kv.k);
+		}
+	}
 	x3h_ctx_destroy(pctx); x3h_ctx_destroy(ctx2); x3h_ctx_destroy(ctx);
 	printf("asan_selftest ok\n");
 	return 0;
