@@ -330,6 +330,13 @@ def main():
                 "value": round(mtot / mdt / 1e6, 2), "unit": "MB/s", "ms": round(mdt * 1e3, 2), "ratio": round(mtot / float(mlens.sum()), 4),
                 "stage_ms": {"scan": round(mst.ms_scan, 2), "parse": round(mst.ms_parse, 2), "features": round(mst.ms_features, 2),
                              "modes": round(mst.ms_modes, 2), "coder": round(mst.ms_coder, 2), "emit": round(mst.ms_emit, 2)}}
+            # K1 of this batch is the one HBM-bound hand-written kernel family of the path (scan3.hip: per-chunk radix sort + level tests, dense classes
+            # refined by the same workgroup): algorithmic bytes = 80 per list element (8 keys out + 4 passes x 16 + 8 for the level-4 re-read), n + 3 elements per chunk
+            k1_alg = 80 * (mtot + 3 * (len(moff) - 1))
+            line["many_chunks_batch"]["k1_roofline"] = {"bound": "hbm", "kernel": "x3_segscan_kernel (+ x3_segrefine_kernel / x3_walk_kernel: stage_ms.scan)", "algorithmic_bytes": k1_alg,
+                                                        "achieved": round(k1_alg / (mst.ms_scan * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                                        "frac": round(k1_alg / (mst.ms_scan * 1e-3) / HBM_PEAK, 4),
+                                                        "note": "HIP events around the scan stage on the library's stream; PMC traffic of the kernel itself: hbm_traffic.by_family_GB"}
             tdt, tlens, tst, _, d_tout, _ = chunk_batch(ctx, d_min[:q], q, mcb, prm, dev)  # the text half alone (round 1 measured tiled text)
             line["many_chunks_batch"]["text_only"] = {"total_bytes": q, "value": round(q / tdt / 1e6, 2), "unit": "MB/s", "ratio": round(q / float(tlens.sum()), 4)}
             # decoder (x3.c:285-353), one wavefront per stream: the whole fresh batch decoded back as ONE batch, streams and bytes resident in HBM
