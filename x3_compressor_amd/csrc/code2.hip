@@ -204,6 +204,8 @@ struct X3ModesArgs {
 	uint32_t *pe0, *pe1;               /* out per hit: model_events freq of E_CTX0 / E_CTX1 before the hit (x3.c:176-177)            */
 	uint32_t *ilist_rank, *ilist_hit;  /* out: the IDX1-coded hits of stream c in time order, at [ho[c], ho[c] + evfinal[4c+3])          */
 	uint32_t *evfinal;                 /* out per chunk: the three model_events freqs after the last hit, and the number of IDX1 hits */
+	uint32_t *nzl, *nnoop;             /* optional (with pe0): per hit, the stream's earlier hits whose tag / index symbol is a no-op for the coder (model total 1:
+	                                    * x3_make_symbol); per chunk, how many there are -- the compacted symbol index of every step follows without a scan */
 	/* optional (state != nullptr; growing prefixes of a few long streams): the chain's state after the last hit is saved per stream
 	 * {E0, E1, E2, nidx, hits done, table entries, 0, 0, table...} (stride X3_MODES_STATE_STRIDE words), and a later call on a longer prefix
 	 * resumes behind the hits already decided instead of starting over (their modes are in `mode` already) */
@@ -236,6 +238,7 @@ __device__ static __forceinline__ void x3_modes_loop(const X3ModesArgs &a, uint3
                                                      uint32_t first = 0, const uint32_t *st0 = nullptr, uint32_t *st1 = nullptr)
 {
 	uint32_t E0 = 1024, E1 = 1024, E2 = 1, nidx = 0; /* model_events freqs (x3.c:239-241), IDX1 uses so far */
+	uint32_t nnoop = 0;                              /* hits so far whose symbol is coded under a model total of 1 */
 	if (st0) { E0 = st0[0]; E1 = st0[1]; E2 = st0[2]; nidx = st0[3]; } /* resumed behind `first` hits */
 	const uint64_t below = ((uint64_t)1 << lane) - 1;
 	/* features of the next block are fetched while this block is decided (a lone wave cannot hide the load latency otherwise) */
@@ -323,6 +326,12 @@ __device__ static __forceinline__ void x3_modes_loop(const X3ModesArgs &a, uint3
 			 * the stream's IDX1-coded hits as a list (rank, hit) in time order for x3_idxstat_kernel */
 			if (in) { a.pe0[g] = E0 + (uint32_t)x3_popc64(m0 & below); a.pe1[g] = E1 + (uint32_t)x3_popc64(m1 & below); }
 			if (in && fin == X3_E_IDX1) { const uint32_t j = h0 + nidx + (uint32_t)x3_popc64(m2 & below); a.ilist_rank[j] = vr; a.ilist_hit[j] = g; }
+			if (a.nzl) { /* total of the model the hit's symbol is coded under: the context's, or model_index1's = elements + earlier IDX1 uses */
+				const uint32_t tsel = fin == X3_E_CTX0 ? vt0 : fin == X3_E_CTX1 ? vt1 : vd + nidx + (uint32_t)x3_popc64(m2 & below);
+				const uint64_t NZ = x3_ballot(in && tsel <= 1u);
+				if (in) a.nzl[g] = nnoop + (uint32_t)x3_popc64(NZ & below);
+				nnoop += (uint32_t)x3_popc64(NZ);
+			}
 		}
 		if (in) {
 			a.mode[g] = fin;
@@ -334,6 +343,7 @@ __device__ static __forceinline__ void x3_modes_loop(const X3ModesArgs &a, uint3
 		x3_wave_sync();
 	}
 	if (a.evfinal && lane == 0) { uint32_t *ef = a.evfinal + 4 * blockIdx.x; ef[0] = E0; ef[1] = E1; ef[2] = E2; ef[3] = nidx; }
+	if (EMIT && a.nnoop && lane == 0) a.nnoop[blockIdx.x] = nnoop;
 	if (st1 && lane == 0) { st1[0] = E0; st1[1] = E1; st1[2] = E2; st1[3] = nidx; st1[4] = H; st1[5] = Dc; }
 }
 
@@ -1084,7 +1094,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	uint32_t *f0 = A[10], *t0 = A[11], *c0 = A[12], *f1 = A[13], *t1 = A[14], *c1 = A[15];
 	uint32_t *mode = A[16], *rfreq = A[17], *itot = A[18], *rcum = A[19];
 	uint32_t **T = A + 20; /* 28 temporaries */
-	uint32_t *m_evfinal = m_ord00 + nc, *m_finallo = m_evfinal + 4 * nc; /* per chunk: 4 + 1 words */
+	uint32_t *m_evfinal = m_ord00 + nc, *m_finallo = m_evfinal + 4 * nc, *m_nnoop = m_finallo + nc; /* per chunk: 4 + 1 + 1 words */
 
 	/* A batch of many streams whose dictionaries fit the LDS tables gets the per-stream kernels of code3.hip (one wavefront per stream,
 	 * tables in LDS) instead of chip-wide sorts and partitions; X3H_STREAM_KERNELS=0/1 forces either form (both give the same bytes). */
@@ -1305,7 +1315,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 				ma.f0 = r0; ma.t0 = r0 + 1; ma.f1 = r1; ma.t1 = r1 + 1; ma.fs = 4;
 			}
 			ma.idxfreq = idxf; ma.mode = mode;
-			ma.pe0 = ma.pe1 = ma.ilist_rank = ma.ilist_hit = ma.evfinal = nullptr;
+			ma.pe0 = ma.pe1 = ma.ilist_rank = ma.ilist_hit = ma.evfinal = nullptr; ma.nzl = ma.nnoop = nullptr;
 			ma.state = nullptr; ma.resume = 0;
 			if (seg) {
 				/* growing prefixes: the serial chain continues where the previous call stopped.  The hit arrays are laid out by the CURRENT
@@ -1327,7 +1337,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 				}
 				seg->prev_ho = ho; seg->prev_serial = true;
 			}
-			if (streamk) { ma.pe0 = T[26]; ma.pe1 = T[27]; ma.ilist_rank = T[2]; ma.ilist_hit = T[3]; ma.evfinal = m_evfinal; }
+			if (streamk) { ma.pe0 = T[26]; ma.pe1 = T[27]; ma.ilist_rank = T[2]; ma.ilist_hit = T[3]; ma.evfinal = m_evfinal; ma.nzl = T[4]; ma.nnoop = m_nnoop; }
 			launch_modes(ma, nc, st, maxDict);
 			/* model_index1 as the IDX1-coded hits saw it (x3.c:187-188): one wavefront per stream, the table and its running sums in LDS */
 			if (streamk) CHK(x3_idxstat_run(st, nc, maxDict, d_ho, m_evfinal, T[2], T[3], h_dk, rfreq, rcum, itot));
@@ -1388,17 +1398,11 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 
 		}
 
-		/* ---- the tag / index symbol of every hit ---- */
+		/* ---- the tag / index symbol of every hit (many streams: picked by the assembly pass below straight from the context kernel's records) ---- */
 		uint32_t *scum = T[0], *sfreq = T[1], *stot = T[2]; /* zi/ci/key are dead now */
-		const uint4 *recs0 = streamk ? B.stat0.as<uint4>() : nullptr, *recs1 = streamk ? B.stat.as<uint4>() : nullptr;
-		x3_foreach(nH, st, X3_LAMBDA(size_t i) {
+		if (!streamk) x3_foreach(nH, st, X3_LAMBDA(size_t i) {
 			const uint32_t m = mode[i];
 			uint32_t cu, fq, to;
-			if (recs0) { /* many streams: the context kernel's records in place */
-				if (m == X3_E_CTX0) { const uint4 r = recs0[i]; cu = r.z; fq = r.x; to = r.y; }
-				else if (m == X3_E_CTX1) { const uint4 r = recs1[i]; cu = r.z; fq = r.x; to = r.y; }
-				else { cu = rcum[i]; fq = rfreq[i]; to = itot[i]; }
-			} else
 			if (m == X3_E_CTX0) { cu = c0[i]; fq = f0[i]; to = t0[i]; }
 			else if (m == X3_E_CTX1) { cu = c1[i]; fq = f1[i]; to = t1[i]; }
 			else { cu = rcum[i]; fq = rfreq[i]; to = itot[i]; }
@@ -1408,6 +1412,8 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		x3_foreach(nc, st, X3_LAMBDA(size_t c) { m_npairs[c] = 0; m_evfinal[4 * c] = 1024; m_evfinal[4 * c + 1] = 1024; m_evfinal[4 * c + 2] = 1; m_evfinal[4 * c + 3] = 0; });
 	}
 	const uint32_t *hs_cum = T[0], *hs_freq = T[1], *hs_tot = T[2], *pe0 = T[26], *pe1 = T[27];
+	const bool inplace = streamk && nH > 0; /* many streams: symbols picked from the context kernel's records, no-op counts from the mode kernel */
+	const uint4 *recs0 = inplace ? B.stat0.as<uint4>() : nullptr, *recs1 = inplace ? B.stat.as<uint4>() : nullptr;
 
 	/* ---- new fragments: model_match_size (32 symbols) and model_chars (256 symbols) are adaptive order-0 models
 	 *      (x3.c:259-267): cum_freq = symbol + #{earlier smaller}, freq = 1 + #{earlier equal}, total = alphabet + index ---- */
@@ -1465,7 +1471,10 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	 * raw list first: they need the compacted index of every raw symbol to find the NEW ones (a prefix of the raw list compacts to a
 	 * prefix of the compacted list). */
 	uint32_t *nzf = T[3], *nzb = T[4];
-	if (!seg) {
+	if (!seg && inplace) {
+		/* nzb[hit] = no-ops among the STREAM's earlier hits (mode kernel); the streams' totals give the compacted offsets: one small serial pass */
+		x3_foreach(1, st, X3_LAMBDA(size_t) { uint32_t acc = 0; for (uint32_t c = 0; c <= nc; c++) { d_yoc[c] = d_yo[c] - acc; if (c < nc) acc += m_nnoop[c]; } });
+	} else if (!seg) {
 		HIPCHK(hipMemsetAsync(nzb, 0, 4, st));
 		if (nH > 0) {
 			x3_foreach(nH, st, X3_LAMBDA(size_t gh) { nzf[gh] = hs_tot[gh] <= 1u ? 1u : 0u; });
@@ -1481,12 +1490,20 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		const uint64_t base = d_chunks[c].elem_off;
 		const uint32_t info = tok_info[base + k], hb = tok_hb[base + k] - tokb[4 * c], mb = tok_mb[base + k] - tokb[4 * c + 2];
 		uint32_t yi = d_yo[c] + 2 * k + mb;
-		if (direct) yi -= nzb[d_ho[c] + hb]; /* == d_yoc[c] + 2k + mb - (no-ops among the stream's earlier hits) */
+		if (inplace) yi = d_yoc[c] + 2 * k + mb - (hb < d_ho[c + 1] - d_ho[c] ? nzb[d_ho[c] + hb] : m_nnoop[c]); /* nzb: stream-local here (mode kernel); behind the last hit: the stream's total */
+		else if (direct) yi -= nzb[d_ho[c] + hb]; /* == d_yoc[c] + 2k + mb - (no-ops among the stream's earlier hits) */
 		const uint32_t evtotal = 2051u + k; /* model_events: 1024+1024+1+1+1 (x3.c:236-244), +1 per step */
 		if (!(info & X3_TOK_MISS)) {
 			const uint32_t gh = d_ho[c] + hb, m = mode[gh], e0 = pe0[gh], e1 = pe1[gh];
 			const uint32_t e2 = 2049u + hb - e0 - e1; /* every hit bumps exactly one of the three */
 			sdst[yi] = x3_make_symbol(m == X3_E_CTX0 ? 0u : m == X3_E_CTX1 ? e0 : e0 + e1, m == X3_E_CTX0 ? e0 : m == X3_E_CTX1 ? e1 : e2, evtotal);
+			if (inplace) {
+				uint32_t cu, fq, to;
+				if (m == X3_E_CTX0) { const uint4 r = recs0[gh]; cu = r.z; fq = r.x; to = r.y; }
+				else if (m == X3_E_CTX1) { const uint4 r = recs1[gh]; cu = r.z; fq = r.x; to = r.y; }
+				else { cu = rcum[gh]; fq = rfreq[gh]; to = itot[gh]; }
+				if (to > 1u) sdst[yi + 1] = x3_make_symbol(cu, fq, to);
+			} else
 			if (!direct || hs_tot[gh] > 1u) sdst[yi + 1] = x3_make_symbol(hs_cum[gh], hs_freq[gh], hs_tot[gh]);
 		} else {
 			const uint32_t len = info & 0x3Fu, mk = k - hb; /* mk = new fragments before this one */
