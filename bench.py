@@ -398,53 +398,62 @@ def main():
         # config 3: twelve independent streams with the Silesia sizes (every third Zipf bytes, the others English-like text), -w 256 -t 1024,
         # ONE batch; every stream's sha256 is compared with the real reference's inside the run
         if not args.no_config35:
-            prm3 = _lib.make_params(w_kib=256, t=1024)
-            names3 = list(synth.SILESIA)
-            parts = [synth.config3_part(i) for i in range(len(names3))]
-            sizes3 = [int(p.size) for p in parts]
-            tot3 = sum(sizes3)
-            d_3in = torch.from_numpy(np.concatenate(parts)).to(dev)
-            off3 = np.concatenate([[0], np.cumsum(sizes3)]).astype(np.uint64)
-            stride3 = (max(sizes3) + (max(sizes3) >> 2) + 4096 + 3) & ~3
-            d_3out = torch.empty(stride3 * len(sizes3), dtype=torch.uint8, device=dev)
-            best3 = None
-            for it in range(2):
-                dt3, (lens3, st3) = timed(lambda: ctx.compress_chunks_dev(d_3in.data_ptr(), off3, prm3, d_3out.data_ptr(), stride3), torch.cuda.synchronize)
-                if best3 is None or dt3 < best3[0]:
-                    best3 = (dt3, st3)
-            h3 = d_3out.cpu().numpy()
-            oks = [sha_matches(f"cfg3_full_{i:02d}_{nm}{sizes3[i]}_w256_t1024", h3[i * stride3:i * stride3 + int(lens3[i])].tobytes()) for i, nm in enumerate(names3)]
-            assert all(o is not False for o in oks), f"config 3: stream(s) {[names3[i] for i, o in enumerate(oks) if o is False]} differ from the real reference's"
-            line["config3_full"] = {"streams": len(sizes3), "total_bytes": tot3, "args": "-w 256 -t 1024", "value": round(tot3 / best3[0] / 1e6, 3), "unit": "MB/s",
-                                    "ms": round(best3[0] * 1e3, 1), "ratio": round(tot3 / float(lens3.sum()), 4), "pipelined": int(best3[1].pipelined),
-                                    "parse_steps": int(best3[1].steps), "streams_sha256_equal_reference": sum(1 for o in oks if o), "streams_not_pinned": sum(1 for o in oks if o is None),
-                                    "stage_ms": {"scan": round(best3[1].ms_scan, 1), "parse": round(best3[1].ms_parse, 1), "features": round(best3[1].ms_features, 1),
-                                                 "modes": round(best3[1].ms_modes, 1), "coder": round(best3[1].ms_coder, 1)},
-                                    "content": "synthetic stand-ins with the 12 Silesia file sizes (synth.config3_part)"}
-            del d_3in, d_3out, h3, parts
+            try:
+                prm3 = _lib.make_params(w_kib=256, t=1024)
+                names3 = list(synth.SILESIA)
+                parts = [synth.config3_part(i) for i in range(len(names3))]
+                sizes3 = [int(p.size) for p in parts]
+                tot3 = sum(sizes3)
+                d_3in = torch.from_numpy(np.concatenate(parts)).to(dev)
+                off3 = np.concatenate([[0], np.cumsum(sizes3)]).astype(np.uint64)
+                stride3 = (max(sizes3) + (max(sizes3) >> 2) + 4096 + 3) & ~3
+                d_3out = torch.empty(stride3 * len(sizes3), dtype=torch.uint8, device=dev)
+                best3 = None
+                for it in range(2):
+                    dt3, (lens3, st3) = timed(lambda: ctx.compress_chunks_dev(d_3in.data_ptr(), off3, prm3, d_3out.data_ptr(), stride3), torch.cuda.synchronize)
+                    if best3 is None or dt3 < best3[0]:
+                        best3 = (dt3, st3)
+                h3 = d_3out.cpu().numpy()
+                oks = [sha_matches(f"cfg3_full_{i:02d}_{nm}{sizes3[i]}_w256_t1024", h3[i * stride3:i * stride3 + int(lens3[i])].tobytes()) for i, nm in enumerate(names3)]
+                bad3 = [names3[i] for i, o in enumerate(oks) if o is False]
+                if bad3:  # a stream that differs from the reference's voids THIS leg (its number is not reported); the headline has its own hard check above
+                    print(f"bench.py: config 3: stream(s) {bad3} differ from the real reference's -- leg marked invalid", file=sys.stderr)
+                line["config3_full"] = {"valid": False, "streams_that_differ_from_the_reference": bad3} if bad3 else {"streams": len(sizes3), "total_bytes": tot3, "args": "-w 256 -t 1024", "value": round(tot3 / best3[0] / 1e6, 3), "unit": "MB/s",
+                                        "ms": round(best3[0] * 1e3, 1), "ratio": round(tot3 / float(lens3.sum()), 4), "pipelined": int(best3[1].pipelined),
+                                        "parse_steps": int(best3[1].steps), "streams_sha256_equal_reference": sum(1 for o in oks if o), "streams_not_pinned": sum(1 for o in oks if o is None),
+                                        "stage_ms": {"scan": round(best3[1].ms_scan, 1), "parse": round(best3[1].ms_parse, 1), "features": round(best3[1].ms_features, 1),
+                                                     "modes": round(best3[1].ms_modes, 1), "coder": round(best3[1].ms_coder, 1)},
+                                        "content": "synthetic stand-ins with the 12 Silesia file sizes (synth.config3_part)"}
+                del d_3in, d_3out, h3, parts
 
-            # config 5: mr-sized stream of mr-like 16-bit samples, -w 512 -t 4096, compress + GPU decode round trip
-            prm5 = _lib.make_params(w_kib=512, t=4096)
-            d5 = synth.mr_like(synth.MR_BYTES)
-            d_5in = torch.from_numpy(d5).to(dev)
-            stride5 = (2 * d5.size + 4096 + 3) & ~3
-            d_5out = torch.empty(stride5, dtype=torch.uint8, device=dev)
-            off5 = np.array([0, d5.size], dtype=np.uint64)
-            ctx.compress_chunks_dev(d_5in.data_ptr(), off5, prm5, d_5out.data_ptr(), stride5)
-            dt5, (lens5, st5) = timed(lambda: ctx.compress_chunks_dev(d_5in.data_ptr(), off5, prm5, d_5out.data_ptr(), stride5), torch.cuda.synchronize)
-            s5 = d_5out[:int(lens5[0])].cpu().numpy().tobytes()
-            ok5 = sha_matches(f"cfg5_full_mr{d5.size}_w512_t4096", s5)
-            assert ok5 is not False, "config 5: the GPU stream differs from the real reference's"
-            d_5back = torch.empty(d5.size, dtype=torch.uint8, device=dev)
-            ioff5 = np.array([0, (len(s5) + 3) & ~3], dtype=np.uint64)
-            ddt5, (dl5, dst5) = timed(lambda: ctx.decompress_chunks_dev(d_5out.data_ptr(), ioff5, d_5back.data_ptr(), off5), torch.cuda.synchronize)
-            line["config5_round_trip"] = {"bytes": int(d5.size), "args": "-w 512 -t 4096", "compress_value": round(d5.size / dt5 / 1e6, 3), "compress_ms": round(dt5 * 1e3, 1),
-                                          "decode_value": round(d5.size / ddt5 / 1e6, 3), "decode_ms": round(ddt5 * 1e3, 1), "unit": "MB/s", "ratio": round(d5.size / len(s5), 4),
-                                          "parse_steps": int(st5.steps), "stream_sha256_equals_reference": ok5,
-                                          "round_trip_ok": bool(int(dl5[0]) == d5.size and torch.equal(d_5back, d_5in)),
-                                          "content": "mr-like 16-bit samples (synth.mr_like), the size of Silesia 'mr'"}
-            assert line["config5_round_trip"]["round_trip_ok"], "config 5: the GPU decoder does not reproduce the input"
-            del d_5in, d_5out, d_5back
+                # config 5: mr-sized stream of mr-like 16-bit samples, -w 512 -t 4096, compress + GPU decode round trip
+                prm5 = _lib.make_params(w_kib=512, t=4096)
+                d5 = synth.mr_like(synth.MR_BYTES)
+                d_5in = torch.from_numpy(d5).to(dev)
+                stride5 = (2 * d5.size + 4096 + 3) & ~3
+                d_5out = torch.empty(stride5, dtype=torch.uint8, device=dev)
+                off5 = np.array([0, d5.size], dtype=np.uint64)
+                ctx.compress_chunks_dev(d_5in.data_ptr(), off5, prm5, d_5out.data_ptr(), stride5)
+                dt5, (lens5, st5) = timed(lambda: ctx.compress_chunks_dev(d_5in.data_ptr(), off5, prm5, d_5out.data_ptr(), stride5), torch.cuda.synchronize)
+                s5 = d_5out[:int(lens5[0])].cpu().numpy().tobytes()
+                ok5 = sha_matches(f"cfg5_full_mr{d5.size}_w512_t4096", s5)
+                if ok5 is False:
+                    print("bench.py: config 5: the GPU stream differs from the real reference's -- leg marked invalid", file=sys.stderr)
+                d_5back = torch.empty(d5.size, dtype=torch.uint8, device=dev)
+                ioff5 = np.array([0, (len(s5) + 3) & ~3], dtype=np.uint64)
+                ddt5, (dl5, dst5) = timed(lambda: ctx.decompress_chunks_dev(d_5out.data_ptr(), ioff5, d_5back.data_ptr(), off5), torch.cuda.synchronize)
+                line["config5_round_trip"] = {"bytes": int(d5.size), "args": "-w 512 -t 4096", "compress_value": round(d5.size / dt5 / 1e6, 3), "compress_ms": round(dt5 * 1e3, 1),
+                                              "decode_value": round(d5.size / ddt5 / 1e6, 3), "decode_ms": round(ddt5 * 1e3, 1), "unit": "MB/s", "ratio": round(d5.size / len(s5), 4),
+                                              "parse_steps": int(st5.steps), "stream_sha256_equals_reference": ok5,
+                                              "round_trip_ok": bool(int(dl5[0]) == d5.size and torch.equal(d_5back, d_5in)),
+                                              "content": "mr-like 16-bit samples (synth.mr_like), the size of Silesia 'mr'"}
+                if ok5 is False or not line["config5_round_trip"]["round_trip_ok"]:
+                    line["config5_round_trip"] = {"valid": False, "stream_sha256_equals_reference": ok5, "round_trip_ok": line["config5_round_trip"]["round_trip_ok"]}
+                del d_5in, d_5out, d_5back
+            except Exception as e:  # a secondary leg must not take the line with it
+                print(f"bench.py: config 3 / 5 legs failed: {e!r}", file=sys.stderr)
+                line.setdefault("config3_full", {"valid": False, "error": repr(e)})
+                line.setdefault("config5_round_trip", {"valid": False, "error": repr(e)})
 
     if not args.no_cpu:
         # CPU baseline, this box's host cores: (1) one core on a bounded prefix of THE workload (the reference is single-threaded);
