@@ -123,6 +123,12 @@ def test_cli_chunked_container_round_trip(tmp_path, oracle):
     r = run(["-z", "-w", "64", "-t", "256", "--chunk-kib", "256", "--gpus", "0,0", str(f), str(z2)])
     assert r.returncode == 0 and z2.read_bytes() == z.read_bytes()
     assert run(["-d", "-f", "--gpus", "0,0", str(z2), str(b)]).returncode == 0 and b.read_bytes() == data
+    z4 = tmp_path / "small_batches.x3c"   # --batch-mib: the chunks coded 1 MiB at a time (bounds the workspace; default 64): same container
+    r = run(["-z", "-w", "64", "-t", "256", "--chunk-kib", "64", "--batch-mib", "1", str(f), str(z4)])
+    assert r.returncode == 0, r.stderr.decode()
+    r = run(["-z", "-w", "64", "-t", "256", "--chunk-kib", "64", str(f), str(tmp_path / "default_batches.x3c")])
+    assert r.returncode == 0 and z4.read_bytes() == (tmp_path / "default_batches.x3c").read_bytes()
+    assert run(["-d", "-f", "--batch-mib", "1", str(z4), str(b)]).returncode == 0 and b.read_bytes() == data
     z3 = tmp_path / "one.x3"
     assert run(["-z", "-w", "64", "-t", "256", "--chunk-kib", "1024", str(f), str(z3)]).returncode == 0
     assert run(["-z", "-w", "64", "-t", "256", str(f)]).returncode == 0            # -> in.x3, the plain single stream

@@ -363,6 +363,22 @@ def test_container_from_hip_streams(gpu, oracle):
     assert e.value.status == -3
 
 
+def test_sub_batch_size_set_per_handle(gpu):
+    """x3h_ctx_set_batch_bytes: the chunks of a batch coded (and decoded) a sub-batch at a time -- what the CLI does to keep a short-lived process's
+    workspace small -- give the same streams as one batch; values below 1 MiB are refused"""
+    data = synth.english_like(3 << 20, seed=21)
+    off = np.arange(0, (3 << 20) + 1, 96 << 10, dtype=np.uint64)
+    prm = _lib.make_params(w_kib=16, t=32)
+    want = gpu.compress_chunks(data, off, prm)
+    with _lib.X3Context(0) as small:
+        assert small.lib.x3h_ctx_set_batch_bytes(small._h, 1 << 20) == 0
+        assert small.lib.x3h_ctx_set_batch_bytes(small._h, 1000) == -1
+        got = small.compress_chunks(data, off, prm)
+        assert got == want
+        back = small.decompress_chunks(got, [int(off[i + 1] - off[i]) for i in range(len(off) - 1)])
+        assert b"".join(back) == data.tobytes()
+
+
 def test_container_through_rccl_equals_host_staged_container(gpu):
     """x3h_compress_container_rccl: streams stay in HBM, one ncclSend/ncclRecv group concatenates them behind the header on the root GPU.
     On a one-GPU machine the block is sent to itself through RCCL; the bytes must equal x3h_compress_container's; two handles on ONE GPU are
