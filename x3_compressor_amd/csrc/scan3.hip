@@ -11,14 +11,17 @@
  *   pass l   one stable counting-sort pass on key byte l-1 in tiles of 4096 elements: per wavefront a ballot match gives every lane its
  *            rank among the lanes with the same digit, a [digit][wave] counter table in LDS and one workgroup scan turn that into the
  *            tile-sorted order, the tile is staged in LDS and leaves as coalesced runs, one run per digit;
- *   level l  on the list just written (ordered by the l-gram starting at p = q-(l-1), positions ascending inside a class):
- *            count_{l-1}(p) >= K  <=>  entry j+K has the same l-gram and lies inside p's window -- scan2.hip's O(1) test.  A level that
- *            passes adds one to a 2-BIT COUNTER of the position IN LDS (levels pass in order: the counter IS m for m <= 3), so m[] leaves
- *            the chip once, as coalesced bytes, instead of as one scattered byte store per level.  The W padding zeros behind a chunk are
- *            COUNTED where a window reaches them (seg_cpad), never sorted;
- *   list 4   (4-gram classes) and the positions whose 4-gram still repeats K times go to the walk kernel / the dense-class refinement of
- *            scan2.hip unchanged (same list layout: chunk c's list occupies the entries of its slot of the padded layout).
- * HBM traffic: 16 B per element and pass + the level reads, all of it sequential or in digit runs.
+ *   level l  tested on the entries of list l WHILE pass l+1 reads them (level 4: one more sweep over list 4): count_{l-1}(p) >= K  <=>
+ *            entry j+K has the same l-gram and lies inside p's window -- scan2.hip's O(1) test.  A level that passes adds one to a 2-BIT
+ *            COUNTER of the position IN LDS (levels pass in order: the counter IS m for m <= 3), so m[] leaves the chip once, as coalesced
+ *            bytes, instead of as one scattered byte store per level.  The W padding zeros behind a chunk are COUNTED where a window reaches
+ *            them (seg_cpad), never sorted;
+ *   deeper   the positions whose 4-gram still repeats K times: x3_segrefine_kernel below extends the classes byte by byte (levels 5..32) with
+ *            the same workgroup-per-chunk machinery -- every class with a passing member for chunks up to 256 KiB; longer chunks (level
+ *            counters in global memory) hand list 4 to the walk kernel / the chip-wide refinement of scan2.hip (same list layout: chunk
+ *            c's list occupies the entries of its slot of the padded layout).
+ * HBM traffic: 16 B per element and pass + 8 B of keys + the level-4 sweep, all of it sequential or in digit runs (80 B per element
+ * algorithmic; measured 2.2x that: short digit runs pay whole sectors).
  */
 #include "x3_host.h"
 
