@@ -116,8 +116,10 @@ extern "C" int x3h_ctx_create(x3h_ctx **out, int device)
 	if (!out) return X3H_E_ARG;
 	*out = nullptr;
 	int n = 0;
+	const double t_c0 = x3_now_ms();
 	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return X3H_E_NO_DEVICE;
 	if (device < 0 || device >= n) return X3H_E_ARG;
+	const double t_c1 = x3_now_ms();
 	HIPCHK(hipSetDevice(device));
 	x3h_ctx *c = new (std::nothrow) x3h_ctx();
 	if (!c) return X3H_E_NOMEM;
@@ -136,9 +138,12 @@ extern "C" int x3h_ctx_create(x3h_ctx **out, int device)
 	  } }
 	{ const char *e = getenv("X3H_PIPE_STREAMS"); if (e && *e) c->pipe_max_streams = atoi(e); }
 	{ const char *e = getenv("X3H_SEG_EMIT"); if (e && *e) c->seg_emit = *e != '0' ? 1 : 0; }
+	const double t_c2 = x3_now_ms();
 	if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return X3H_E_HIP; }
+	const double t_c3 = x3_now_ms();
 	for (int i = 0; i < 6; i++)
 		if (hipEventCreate(&c->ev[i]) != hipSuccess) { x3h_ctx_destroy(c); return X3H_E_HIP; }
+	if (getenv("X3H_DEBUG")) fprintf(stderr, "[x3h] handle: device count (runtime start) %.1f ms, set device %.1f, stream %.1f, events %.1f\n", t_c1 - t_c0, t_c2 - t_c1, t_c3 - t_c2, x3_now_ms() - t_c3);
 	*out = c;
 	return X3H_OK;
 }
