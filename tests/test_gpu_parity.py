@@ -442,6 +442,7 @@ def test_stream_kernels_agree_with_chipwide_passes(gpu_env):
     old = gpu_env(X3H_STREAM_KERNELS="0").compress_chunks(data, off, prm)
     assert new == old
     assert gpu_env(X3H_STREAM_KERNELS="1", X3H_ARRANGE="1").compress_chunks(data, off, prm) == old  # hits arranged by one workgroup per stream (x3_arrange_kernel)
+    assert gpu_env(X3H_AC2_WIDE="1").compress_chunks(data, off, prm) == old   # coder chains four to a workgroup (default from 513 streams), ragged last workgroup
     big = synth.english_like(3 << 20, seed=77).tobytes()
     assert gpu_env(X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0").compress(big, prm) == gpu_env(X3H_STREAM_KERNELS="0", X3H_PIPE_MIN="0").compress(big, prm)
 

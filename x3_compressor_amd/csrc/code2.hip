@@ -388,6 +388,7 @@ struct X3Ac2Args {
 	uint32_t *final_lo;                   /* out per chunk */
 	const uint32_t *seg_off, *seg_len;    /* nullptr: whole streams (yo).  Else per stream: first symbol (ring coordinate) and count of this segment */
 	uint32_t *seg_state;                  /* ... and {lo, R} per stream, in / out */
+	uint32_t nstreams;                    /* the wide launch form (several wavefronts = streams per workgroup) guards its stream index with this */
 };
 
 /* range / total as a multiply-shift (Granlund-Montgomery, N = 31): L = ceil(log2 total) >= 1, m = ceil(2^(31+L)/total) in [2^31, 2^32),
@@ -502,9 +503,9 @@ typedef uint32_t x3_u32x4 __attribute__((ext_vector_type(4)));
 	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_load_dwordx16 %0, %4, %5\n\ts_load_dwordx16 %1, %4, %5+0x40"                         \
 	             : "=&s"(N0), "=&s"(N1), "+s"(C0), "+s"(C1) : "s"(symp), "n"(OFF) : "memory")
 
-__device__ static void x3_ac2_body(const X3Ac2Args &a)
+__device__ static void x3_ac2_body(const X3Ac2Args &a, const uint32_t c)
 {
-	const uint32_t c = blockIdx.x, lane = x3_lane();
+	const uint32_t lane = x3_lane();
 	uint32_t y0, Y, lo = 0, R = 0x80000000u; /* ac_init, ac.c:35-41: [0, 0x7FFFFFFF] */
 	if (a.seg_off) { y0 = x3_uniform(a.seg_off[c]); Y = x3_uniform(a.seg_len[c]); lo = x3_uniform(a.seg_state[2 * c]); R = x3_uniform(a.seg_state[2 * c + 1]); }
 	else { y0 = x3_uniform(a.yo[c]); Y = x3_uniform(a.yo[c + 1]) - y0; }
@@ -561,9 +562,9 @@ __device__ static void x3_ac2_body(const X3Ac2Args &a)
 }
 #else
 /* the CPU emulator build (tests only): the same step function, one symbol at a time, no scalar-cache staging */
-__device__ static void x3_ac2_body(const X3Ac2Args &a)
+__device__ static void x3_ac2_body(const X3Ac2Args &a, const uint32_t c)
 {
-	const uint32_t c = blockIdx.x, lane = x3_lane();
+	const uint32_t lane = x3_lane();
 	uint32_t y0, Y, lo = 0, R = 0x80000000u;
 	if (a.seg_off) { y0 = a.seg_off[c]; Y = a.seg_len[c]; lo = a.seg_state[2 * c]; R = a.seg_state[2 * c + 1]; }
 	else { y0 = a.yo[c]; Y = a.yo[c + 1] - y0; }
@@ -586,7 +587,13 @@ __global__ void __launch_bounds__(X3_WAVE) x3_modes_kernel(X3ModesArgs a) { x3_m
 __global__ void __launch_bounds__(X3_WAVE) x3_modes_many_kernel(X3ModesArgs a) { x3_modes_body<X3_IDXF_LDS_SMALL, false>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_modes_stream_kernel_s(X3ModesArgs a) { x3_modes_body<2048, true>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_modes_stream_kernel_l(X3ModesArgs a) { x3_modes_body<X3_STREAM_DMAX, true>(a); }
-__global__ void __launch_bounds__(X3_WAVE) x3_ac2_kernel(X3Ac2Args a) { x3_ac2_body(a); }
+__global__ void __launch_bounds__(X3_WAVE) x3_ac2_kernel(X3Ac2Args a) { x3_ac2_body(a, blockIdx.x); }
+/* four streams per workgroup, one per wavefront: the wavefronts of a workgroup are spread over the CU's four SIMDs */
+__global__ void __launch_bounds__(4 * X3_WAVE) x3_ac2_wide_kernel(X3Ac2Args a)
+{
+	const uint32_t c = x3_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
+	if (c < a.nstreams) x3_ac2_body(a, c);
+}
 static void launch_modes(const X3ModesArgs &a, uint32_t nchunks, hipStream_t st, uint64_t max_dict)
 {
 	if (a.pe0) { /* many streams, model state handed out by the kernel: a table (and its running sums) that holds every rank */
@@ -598,12 +605,22 @@ static void launch_modes(const X3ModesArgs &a, uint32_t nchunks, hipStream_t st,
 	if (nchunks > 256) hipLaunchKernelGGL(x3_modes_many_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, a);
 	else hipLaunchKernelGGL(x3_modes_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, a);
 }
-static void launch_ac2(const X3Ac2Args &a, uint32_t nchunks, hipStream_t st) { hipLaunchKernelGGL(x3_ac2_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, a); }
+/* One-wavefront workgroups are not spread evenly over a CU's four SIMDs: with four chains per CU (1024 streams) two of them share a SIMD's
+ * issue slot and a symbol costs 49 ns instead of 25; as four wavefronts of ONE workgroup they get a SIMD each (31.5 ns; 8 per CU: 52 against
+ * 73; tools/exp/ac2_wide.sh).  Up to two streams per CU the narrow form keeps every chain on its own CU.  X3H_AC2_WIDE = smallest stream
+ * count that takes the wide form (0: never). */
+static void launch_ac2(X3Ac2Args a, uint32_t nchunks, hipStream_t st)
+{
+	static const uint32_t wide_min = getenv("X3H_AC2_WIDE") ? (uint32_t)atoi(getenv("X3H_AC2_WIDE")) : 513u;
+	a.nstreams = nchunks;
+	if (wide_min && nchunks >= wide_min) hipLaunchKernelGGL(x3_ac2_wide_kernel, dim3((nchunks + 3) / 4), dim3(4 * X3_WAVE), 0, st, a);
+	else hipLaunchKernelGGL(x3_ac2_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, a);
+}
 __device__ static __forceinline__ uint32_t x3_brev32(uint32_t v) { return __brev(v); }
 #else
 static void modes_tramp(void *p) { x3_modes_body<X3_IDXF_LDS, false>(*(const X3ModesArgs *)p); }
 static void modes_stream_tramp(void *p) { x3_modes_body<X3_STREAM_DMAX, true>(*(const X3ModesArgs *)p); }
-static void ac2_tramp(void *p) { x3_ac2_body(*(const X3Ac2Args *)p); }
+static void ac2_tramp(void *p) { x3_ac2_body(*(const X3Ac2Args *)p, blockIdx.x); }
 static void launch_modes(const X3ModesArgs &a, uint32_t nchunks, hipStream_t, uint64_t) { x3emu_launch(a.pe0 ? modes_stream_tramp : modes_tramp, (void *)&a, dim3(nchunks), dim3(X3_WAVE)); }
 static void launch_ac2(const X3Ac2Args &a, uint32_t nchunks, hipStream_t) { x3emu_launch(ac2_tramp, (void *)&a, dim3(nchunks), dim3(X3_WAVE)); }
 static inline uint32_t x3_brev32(uint32_t v) { uint32_t r = 0; for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i); return r; }
@@ -1194,7 +1211,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 				CHK(x3p_sort_pairs(B.tmp, h_c1, kA, iota, vA, nH, bits_for(nD), st));
 				x3_foreach(nH, st, X3_LAMBDA(size_t i) { tA[i] = h_tag[vA[i]]; });
 			}
-			CHK(x3_ctx_stats_run(st, nc, maxDict, d_ho, d_dof, kA, vA, tA, stat));
+			CHK(x3_ctx_stats_run(st, nc, maxDict, nH, d_ho, d_dof, kA, vA, tA, stat));
 			x3_foreach(nH, st, X3_LAMBDA(size_t i) { pf[i] = stat[i].w >> 31; }); /* this hit put its (context1, tag) pair into the map */
 			CHK(x3p_excl_scan(B.tmp, pf, P, nH, st));
 			HIPCHK(hipMemcpyAsync(&npairs_total, P + nH, 4, hipMemcpyDeviceToHost, st));
@@ -1231,7 +1248,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 				CHK(x3p_sort_pairs(B.tmp, G0, kA, iota, vA, nH, bits_for(npairs_total ? npairs_total : 1), st));
 				x3_foreach(nH, st, X3_LAMBDA(size_t i) { tA[i] = h_tag[vA[i]]; });
 			}
-			CHK(x3_ctx_stats_run(st, nc, maxDict, d_ho, d_dof, kA, vA, tA, stat0));
+			CHK(x3_ctx_stats_run(st, nc, maxDict, nH, d_ho, d_dof, kA, vA, tA, stat0));
 		} else {
 		/* ---- tag-pair ordinals (tag_pair.c) and the ctx0 group of every hit (x3.c:139-147) ---- */
 			uint32_t npairs_total = 0;

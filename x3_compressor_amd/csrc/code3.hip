@@ -78,15 +78,11 @@ struct X3MtfArgs {
 	uint32_t *h_rank;          /* out per hit                                            */
 };
 
-template <uint32_t DMAX>
-__device__ static void x3_mtfrank_body(const X3MtfArgs &a)
+/* the events [e0, e1) of one stream, 64 per trip, on the list (lst, pos0) that holds Dcur elements when the range starts */
+__device__ static __forceinline__ void x3_mtf_tiles(const X3MtfArgs &a, uint16_t *lst, uint16_t *pos0, const uint32_t e0, const uint32_t e1, uint32_t Dcur,
+                                                    const uint32_t dof, const uint32_t lane)
 {
-	X3_LDS uint16_t lst[DMAX];
-	X3_LDS uint16_t pos0[DMAX];
-	const uint32_t c = blockIdx.x, lane = x3_lane();
-	const uint32_t e0 = a.eo[c], e1 = a.eo[c + 1], dof = a.dof[c];
 	const uint64_t bit = (uint64_t)1 << lane, below = bit - 1, above = ~(below | bit);
-	uint32_t Dcur = 0;
 	uint32_t nt_ = 0, nh_ = 0;
 	if (e0 + lane < e1) { nt_ = a.e_tag[e0 + lane] - dof; nh_ = a.e_hit[e0 + lane]; }
 	for (uint32_t base = e0; base < e1; base += X3_WAVE) {
@@ -149,6 +145,67 @@ __device__ static void x3_mtfrank_body(const X3MtfArgs &a)
 	}
 }
 
+template <uint32_t DMAX>
+__device__ static void x3_mtfrank_body(const X3MtfArgs &a)
+{
+	X3_LDS uint16_t lst[DMAX];
+	X3_LDS uint16_t pos0[DMAX];
+	const uint32_t c = blockIdx.x, lane = x3_lane();
+	x3_mtf_tiles(a, lst, pos0, a.eo[c], a.eo[c + 1], 0, a.dof[c], lane);
+}
+
+/* The same ranks with a stream's events cut into X3_MTFP_WAVES time ranges, one wavefront each (one workgroup per stream; dictionaries of at
+ * most X3_MTFP_DMAX elements).  The list at the start of a range is the elements that exist by then in order of their last touch, latest
+ * first: (1) every wavefront records the last touch (insertion included) of each element inside ITS range and counts its insertions;
+ * (2) a running maximum over the earlier ranges gives each wavefront the last touch before its range, the running count the number of
+ * elements; (3) an element's position = how many elements were touched later (last touches are distinct events); (4) the tile loop above.
+ * One lone wavefront per stream walks ~1 500 tiles at ~5 us each (a chain of ballots and LDS round trips); the eight ranges overlap them. */
+#define X3_MTFP_WAVES 8u
+#define X3_MTFP_DMAX 512u
+__device__ static void x3_mtfrank_par_body(const X3MtfArgs &a)
+{
+	X3_LDS uint32_t tab[X3_MTFP_WAVES][X3_MTFP_DMAX];   /* (1) last touch + 1 inside range w, 0: none; after (2): last touch + 1 before range w */
+	X3_LDS uint16_t lstw[X3_MTFP_WAVES][X3_MTFP_DMAX];
+	X3_LDS uint16_t pos0w[X3_MTFP_WAVES][X3_MTFP_DMAX];
+	X3_LDS uint32_t nnew[X3_MTFP_WAVES];
+	const uint32_t c = blockIdx.x, lane = x3_lane(), wv = threadIdx.x / X3_WAVE;
+	const uint32_t e0 = a.eo[c], e1 = a.eo[c + 1], dof = a.dof[c];
+	const uint32_t per = (((e1 - e0 + X3_MTFP_WAVES - 1) / X3_MTFP_WAVES) + X3_WAVE - 1) & ~(X3_WAVE - 1);
+	const uint32_t s0 = e0 + wv * per < e1 ? e0 + wv * per : e1, s1 = s0 + per < e1 ? s0 + per : e1; /* (per * 8 < 2^32: a stream has < 2^28 events) */
+	for (uint32_t i = lane; i < X3_MTFP_DMAX; i += X3_WAVE) tab[wv][i] = 0;
+	x3_wave_sync();
+	uint32_t cnt_new = 0;
+	for (uint32_t base = s0; base < s1; base += X3_WAVE) {
+		const uint32_t i = base + lane;
+		const bool valid = i < s1;
+		const uint32_t t = valid ? a.e_tag[i] - dof : 0u;
+		const bool isnew = valid && a.e_hit[i] == NONE32;
+		if (valid) atomicMax(&tab[wv][t], i - e0 + 1);
+		cnt_new += (uint32_t)x3_popc64(x3_ballot(isnew));
+	}
+	if (lane == 0) nnew[wv] = cnt_new;
+	__syncthreads();
+	for (uint32_t t = threadIdx.x; t < X3_MTFP_DMAX; t += X3_MTFP_WAVES * X3_WAVE) { /* (2), in place */
+		uint32_t run = 0;
+		for (uint32_t w = 0; w < X3_MTFP_WAVES; w++) { const uint32_t own = tab[w][t]; tab[w][t] = run; run = own > run ? own : run; }
+	}
+	uint32_t Dcur = 0;
+	for (uint32_t w = 0; w < wv; w++) Dcur += nnew[w];
+	__syncthreads();
+	uint16_t *const lst = lstw[wv], *const pos0 = pos0w[wv];
+	if (s0 < s1) {
+		for (uint32_t tb = 0; tb < Dcur; tb += X3_WAVE) { /* (3) */
+			const uint32_t t = tb + lane;
+			const uint32_t mine = t < Dcur ? tab[wv][t] : 0xFFFFFFFFu;
+			uint32_t later = 0;
+			for (uint32_t u = 0; u < Dcur; u++) later += tab[wv][u] > mine ? 1u : 0u;
+			if (t < Dcur) { lst[later] = (uint16_t)t; pos0[t] = (uint16_t)later; }
+		}
+		x3_wave_sync();
+		x3_mtf_tiles(a, lst, pos0, s0, s1, Dcur, dof, lane);
+	}
+}
+
 /* ============================================================================================================
  * Context statistics.  Hits arranged by (context, time) -- arrangement A of code2.hip: kA = context key, vA = hit.  A stream's hits
  * are one contiguous range of the arrangement (context keys are stream-major), so one wavefront per stream sweeps it in tiles of 64.
@@ -170,6 +227,9 @@ struct X3CtxSegArgs {
 	uint4 *stat;               /* out per hit: {freq, total, cum, first | isfirst << 31}  */
 	uint32_t dbits_max;        /* bits that cover every local tag of the batch            */
 	uint32_t nsub;             /* wavefronts per stream: wavefront r takes the contexts that START in the r-th part of the range (contexts are independent) */
+	uint32_t nc;               /* streams */
+	uint32_t xcd;              /* 1: workgroup b works for stream 8 * (b / 8 / nsub) + b % 8 -- all wavefronts of a stream on ONE XCD (workgroups go to the XCDs
+	                              round-robin), so the stream's scattered 16-byte results meet in that XCD's L2 and leave it as whole lines */
 };
 
 /* lane i gets lane i-1's value (lane 0: its own) */
@@ -190,7 +250,13 @@ __device__ static void x3_ctxseg_body(const X3CtxSegArgs &a)
 	X3_LDS uint32_t lfirst[DMAX];    /* position -> hit that added the item                       */
 	X3_LDS uint32_t lfreq[DMAX];     /* position -> freq                                          */
 	X3_LDS uint32_t lpre[DMAX];      /* position -> cum_freq = sum of the freqs before it (count_cum_freqs, ac.c:6-18), as of the tile's start */
-	const uint32_t c = blockIdx.x / a.nsub, sub = blockIdx.x % a.nsub, lane = x3_lane();
+	const uint32_t lane = x3_lane();
+	uint32_t c = blockIdx.x / a.nsub, sub = blockIdx.x % a.nsub;
+	if (a.xcd) {
+		const uint32_t q = blockIdx.x >> 3;
+		c = ((q / a.nsub) << 3) + (blockIdx.x & 7u); sub = q % a.nsub;
+		if (c >= a.nc) return;
+	}
 	const uint32_t c0 = a.ho[c], c1 = a.ho[c + 1], dof = a.dof[c];
 	const uint64_t bit = (uint64_t)1 << lane, below = bit - 1;
 	const int tbits = (int)a.dbits_max; /* covers tags and list positions alike (a list holds each tag once) */
@@ -573,6 +639,7 @@ __device__ static void x3_arrange_body(const X3ArrangeArgs &a)
 #ifndef X3_EMU
 __global__ void __launch_bounds__(X3_WAVE) x3_mtfrank_kernel_s(X3MtfArgs a) { x3_mtfrank_body<2048>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_mtfrank_kernel_l(X3MtfArgs a) { x3_mtfrank_body<16384>(a); }
+__global__ void __launch_bounds__(X3_MTFP_WAVES * X3_WAVE) x3_mtfrank_par_kernel(X3MtfArgs a) { x3_mtfrank_par_body(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_ctxseg_kernel_t(X3CtxSegArgs a) { x3_ctxseg_body<512>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_ctxseg_kernel_s(X3CtxSegArgs a) { x3_ctxseg_body<2048>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_ctxseg_kernel_l(X3CtxSegArgs a) { x3_ctxseg_body<8192>(a); }
@@ -593,6 +660,7 @@ static void idxstat_tramp_l(void *p) { x3_idxstat_body<X3_STREAM_DMAX>(*(const X
 #define x3_order0_kernel order0_tramp
 static void mtf_tramp_s(void *p) { x3_mtfrank_body<2048>(*(const X3MtfArgs *)p); }
 static void mtf_tramp_l(void *p) { x3_mtfrank_body<16384>(*(const X3MtfArgs *)p); }
+static void mtf_tramp_par(void *p) { x3_mtfrank_par_body(*(const X3MtfArgs *)p); }
 static void ctx_tramp_t(void *p) { x3_ctxseg_body<512>(*(const X3CtxSegArgs *)p); }
 static void ctx_tramp_s(void *p) { x3_ctxseg_body<2048>(*(const X3CtxSegArgs *)p); }
 static void ctx_tramp_l(void *p) { x3_ctxseg_body<8192>(*(const X3CtxSegArgs *)p); }
@@ -612,28 +680,41 @@ int x3_mtf_ranks_run(hipStream_t st, uint32_t nc, uint64_t max_dict, const uint3
 {
 	X3MtfArgs a;
 	a.eo = d_eo; a.dof = d_dof; a.e_tag = e_tag; a.e_hit = e_hit; a.h_rank = h_rank;
-	if (max_dict <= 2048) X3_LAUNCH1(x3_mtfrank_kernel_s, a, nc, st);
+	bool par = max_dict <= X3_MTFP_DMAX;
+	if (const char *e = getenv("X3H_MTF_PAR")) par = par && atoi(e) != 0;
+	if (par) {
+#ifndef X3_EMU
+		hipLaunchKernelGGL(x3_mtfrank_par_kernel, dim3(nc), dim3(X3_MTFP_WAVES * X3_WAVE), 0, st, a);
+#else
+		x3emu_launch(mtf_tramp_par, (void *)&a, dim3(nc), dim3(X3_MTFP_WAVES * X3_WAVE));
+#endif
+	} else if (max_dict <= 2048) X3_LAUNCH1(x3_mtfrank_kernel_s, a, nc, st);
 	else X3_LAUNCH1(x3_mtfrank_kernel_l, a, nc, st);
 	HIPCHK(hipGetLastError());
 	return X3H_OK;
 }
 
-int x3_ctx_stats_run(hipStream_t st, uint32_t nc, uint64_t max_dict, const uint32_t *d_ho, const uint32_t *d_dof, const uint32_t *kA,
+int x3_ctx_stats_run(hipStream_t st, uint32_t nc, uint64_t max_dict, uint64_t nhits, const uint32_t *d_ho, const uint32_t *d_dof, const uint32_t *kA,
                      const uint32_t *vA, const uint32_t *tA, uint4 *stat)
 {
 	X3CtxSegArgs a;
 	a.ho = d_ho; a.dof = d_dof; a.kA = kA; a.vA = vA; a.tA = tA; a.stat = stat;
 	uint32_t b = 1; while (b < 32 && (max_dict >> b)) b++;
 	a.dbits_max = b;
-	/* contexts are independent, so a stream's range is cut (at context boundaries) over several wavefronts: enough of them to keep a few
-	 * per SIMD in flight -- the kernel is a chain of LDS round trips per tile, only occupancy hides them */
-	uint32_t nsub = nc >= 4096 ? 1u : 4096u / nc;
-	if (nsub > 16) nsub = 16;
-	if (const char *e = getenv("X3H_CTX_SUB")) { const int v = atoi(e); if (v >= 1 && v <= 64) nsub = (uint32_t)v; }
-	a.nsub = nsub;
-	if (max_dict <= 512) X3_LAUNCH1(x3_ctxseg_kernel_t, a, nc * nsub, st);
-	else if (max_dict <= 2048) X3_LAUNCH1(x3_ctxseg_kernel_s, a, nc * nsub, st);
-	else X3_LAUNCH1(x3_ctxseg_kernel_l, a, nc * nsub, st);
+	/* contexts are independent, so a stream's range is cut (at context boundaries) over several wavefronts -- MANY of them: ~512 hits each, and
+	 * all wavefronts of a stream on one XCD (see X3CtxSegArgs::xcd).  The kernel's cost is its scattered 16-byte result stores (without them it
+	 * takes half the time): with a handful of wavefronts per stream the chip works on every stream's 1-2 MB of results at once, no cache holds
+	 * them and every store is its own HBM write; with a stream's results finished by ~100 wavefronts within microseconds the lines fill in L2
+	 * (1024 x 256 KiB of text: features 28 -> 20 ms; tools/exp/ctx_xcd.sh) */
+	uint64_t want = nc ? (nhits / nc + 511) / 512 : 1;
+	uint32_t nsub = want < 1 ? 1u : want > 1024 ? 1024u : (uint32_t)want;
+	if (const char *e = getenv("X3H_CTX_SUB")) { const int v = atoi(e); if (v >= 1 && v <= 1024) nsub = (uint32_t)v; }
+	a.nsub = nsub; a.nc = nc; a.xcd = nc >= 8 ? 1u : 0u;
+	if (const char *e = getenv("X3H_CTX_XCD")) a.xcd = atoi(e) ? 1u : 0u;
+	const uint32_t nblk = a.xcd ? ((nc + 7u) & ~7u) * nsub : nc * nsub;
+	if (max_dict <= 512) X3_LAUNCH1(x3_ctxseg_kernel_t, a, nblk, st);
+	else if (max_dict <= 2048) X3_LAUNCH1(x3_ctxseg_kernel_s, a, nblk, st);
+	else X3_LAUNCH1(x3_ctxseg_kernel_l, a, nblk, st);
 	HIPCHK(hipGetLastError());
 	return X3H_OK;
 }

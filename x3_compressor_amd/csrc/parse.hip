@@ -58,6 +58,16 @@ __device__ static __forceinline__ bool x3_eq_bytes(const uint8_t *b, uint32_t gp
 	return true;
 }
 
+/* eight bytes of an LDS byte array at any offset, little-endian: three aligned dword reads + funnel shifts */
+__device__ static __forceinline__ uint64_t x3_lds_load8(const uint8_t *sp, uint32_t i)
+{
+	const uint32_t *w = (const uint32_t *)(sp + (i & ~3u));
+	const uint32_t sh = (i & 3u) * 8u;
+	const uint32_t a = w[0], b = w[1], c = w[2];
+	const uint32_t lo = sh ? (a >> sh) | (b << (32u - sh)) : a, hi = sh ? (b >> sh) | (c << (32u - sh)) : b;
+	return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
 /* state shared by the workgroup */
 struct ParseShared {
 	uint32_t p, blk, D, lenmask, hlog, flag, ntok, hits, mbytes;
@@ -69,7 +79,7 @@ template <uint32_t PB>
 __device__ static void x3_parse_body(const X3ParseArgs &a)
 {
 	constexpr uint32_t PBL = PB + 32, PBB = PB + 64;
-	X3_LDS uint8_t sb[PBB + 8];
+	alignas(16) X3_LDS uint8_t sb[PBB + 8];
 	X3_LDS uint8_t sL[PBL];
 	X3_LDS uint32_t sE[PBL];
 	X3_LDS uint8_t sM[PB];
@@ -81,6 +91,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 	X3_LDS uint16_t sHT[X3_LDS_HT];
 	X3_LDS uint32_t sDpos[X3_LDS_DICT];
 	X3_LDS uint8_t sDlen[X3_LDS_DICT];
+	X3_LDS uint2 sD8[X3_LDS_DICT];   /* the first eight bytes of each mirrored element (zero beyond its length): most candidates are settled without touching global memory */
 	X3_LDS ParseShared S;
 
 	const X3Chunk ck = a.chunks[blockIdx.x];
@@ -123,7 +134,10 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 						for (uint32_t e = sHT[slot]; e != 0; slot = (slot + 1) & hmask, e = sHT[slot]) {
 							const uint32_t tag = e - 1;
 							if (sDlen[tag] != l) continue;
-							if (x3_eq_bytes(b, sDpos[tag], sb + i, l)) { best = l; btag = tag; break; }
+							const uint2 d8 = sD8[tag];
+							const uint64_t m8 = l >= 8 ? ~(uint64_t)0 : (((uint64_t)1 << (8 * l)) - 1);
+							if ((((uint64_t)d8.x | ((uint64_t)d8.y << 32)) ^ x3_lds_load8(sb, i)) & m8) continue; /* (not this element: an exact table, so the probe goes on) */
+							if (l <= 8 || x3_eq_bytes(b, sDpos[tag] + 8, sb + i + 8, l - 8)) { best = l; btag = tag; break; }
 						}
 					} else {
 						for (uint32_t e = ht[slot]; e != 0; slot = (slot + 1) & hmask, e = ht[slot]) {
@@ -267,7 +281,12 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 					if (lane == 0) {
 						dpos[ntag] = p;
 						dlen[ntag] = (uint8_t)len;
-						if (ntag < X3_LDS_DICT) { sDpos[ntag] = p; sDlen[ntag] = (uint8_t)len; }
+						if (ntag < X3_LDS_DICT) {
+							sDpos[ntag] = p; sDlen[ntag] = (uint8_t)len;
+							uint64_t v8 = 0;
+							for (uint32_t k = 0; k < len && k < 8; k++) v8 |= (uint64_t)sb[idx + k] << (8 * k);
+							sD8[ntag] = make_uint2((uint32_t)v8, (uint32_t)(v8 >> 32));
+						}
 						if (!rebuild) {
 							uint32_t h = FNV_OFF;
 							for (uint32_t k = 0; k < len; k++) h = (h ^ sb[idx + k]) * FNV_MUL;

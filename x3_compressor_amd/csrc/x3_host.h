@@ -178,7 +178,7 @@ int x3_arrange_run(hipStream_t st, uint32_t nc, const uint32_t *d_ho, const uint
 #define X3_ARR_DBITS 11
 #endif
 #define X3_ARRANGE_MAX_LOCAL (((uint64_t)1 << (2 * X3_ARR_DBITS)) - 1) /* largest stream-local key two passes cover */
-int x3_ctx_stats_run(hipStream_t st, uint32_t nc, uint64_t max_dict, const uint32_t *d_ho, const uint32_t *d_dof, const uint32_t *kA,
+int x3_ctx_stats_run(hipStream_t st, uint32_t nc, uint64_t max_dict, uint64_t nhits, const uint32_t *d_ho, const uint32_t *d_dof, const uint32_t *kA,
                      const uint32_t *vA, const uint32_t *tA, uint4 *stat /* per hit: {freq, total, cum, first hit | isfirst << 31} */);
 int x3_order0_run(hipStream_t st, uint32_t nc, const uint32_t *d_mo, const uint32_t *lval, uint32_t *lsm, uint32_t *leq,
                   const uint32_t *d_bo, const uint32_t *bval, uint32_t *bsm, uint32_t *beq);
