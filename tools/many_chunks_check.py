@@ -23,9 +23,9 @@ d_out = torch.empty(stride * nch, dtype=torch.uint8, device=dev)
 ctx = _lib.X3Context(0)
 import os
 prm = _lib.make_params(w_kib=int(os.environ.get("MC_W", "64")), t=int(os.environ.get("MC_T", "256")))
-for it in range(3):
+for it in range(int(os.environ.get('MC_RUNS', '3'))):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     lens, st = ctx.compress_chunks_dev(d_in.data_ptr(), off, prm, d_out.data_ptr(), stride)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
-    print(f"run {it}: {nch} chunks x {cb>>10} KiB = {total>>20} MiB: wall {dt*1e3:.0f} ms -> {total/dt/1e6:.1f} MB/s | device ms: scan {st.ms_scan:.0f} parse {st.ms_parse:.0f} code {st.ms_code:.0f} (features {st.ms_features:.0f} modes {st.ms_modes:.0f} coder {st.ms_coder:.0f} emit {st.ms_emit:.0f}) ratio {total/float(lens.sum()):.3f}", flush=True)
+    print(f"run {it}: {nch} chunks x {cb>>10} KiB = {total>>20} MiB: wall {dt*1e3:.1f} ms -> {total/dt/1e6:.1f} MB/s | device ms: scan {st.ms_scan:.1f} parse {st.ms_parse:.1f} code {st.ms_code:.1f} (features {st.ms_features:.1f} modes {st.ms_modes:.1f} coder {st.ms_coder:.1f} emit {st.ms_emit:.1f}) ratio {total/float(lens.sum()):.3f}", flush=True)
 print("mem GB", torch.cuda.mem_get_info()[0] / 1e9, "free of", torch.cuda.mem_get_info()[1] / 1e9)

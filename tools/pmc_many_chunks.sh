@@ -8,6 +8,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   echo "$c pass done"
 done
 F=$(find gpurun_out/pm_FETCH_SIZE -name '*counter_collection.csv' | head -1); W=$(find gpurun_out/pm_WRITE_SIZE -name '*counter_collection.csv' | head -1)
+PMC_SPLIT=1 python3 tools/pmc_traffic.py batch $F $W ${OUT%.json}_by_pass.json 268435456 > /dev/null
 python3 tools/pmc_traffic.py batch $F $W $OUT 268435456 && python3 -c "
 import json; t=json.load(open('$OUT')); print(json.dumps(t['total'])); [print(f'{k:44s}', v) for k,v in list(t['groups'].items())[:14]]"
 rm -rf gpurun_out/pm_FETCH_SIZE gpurun_out/pm_WRITE_SIZE

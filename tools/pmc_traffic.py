@@ -8,9 +8,20 @@ import csv, json, sys
 from collections import defaultdict
 
 
+import os, re
+SPLIT = os.environ.get("PMC_SPLIT") == "1"   # every element-wise pass (lambda number in its host function) and every rocPRIM kernel on its own line
+
+
 def family(n):
     if "x3_foreach" in n:
-        return "foreach:" + n.split("x3_foreach_kernel<")[1].split("(")[0]
+        fam = "foreach:" + n.split("x3_foreach_kernel<")[1].split("(")[0]
+        if SPLIT:
+            m = re.findall(r"lambda\(unsigned long\)#(\d+)", n)
+            fam += "#" + (m[-1] if m else "?")
+        return fam
+    if SPLIT and "rocprim" in n:
+        m = re.search(r"detail::(\w+)<", n.split("trampoline_kernel<")[-1]) if "trampoline_kernel" in n else re.search(r"detail::(\w+)", n)
+        return "rocprim:" + (m.group(1) if m else "other")
     if "rocprim" in n or "rocclr" in n:
         return "rocprim:" + ("sort" if "radix" in n else "scan" if "scan" in n else "other") if "rocprim" in n else "runtime fill/copy"
     return n.split("(")[0]

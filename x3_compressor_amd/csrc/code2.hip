@@ -389,6 +389,8 @@ struct X3Ac2Args {
 	const uint32_t *seg_off, *seg_len;    /* nullptr: whole streams (yo).  Else per stream: first symbol (ring coordinate) and count of this segment */
 	uint32_t *seg_state;                  /* ... and {lo, R} per stream, in / out */
 	uint32_t nstreams;                    /* the wide launch form (several wavefronts = streams per workgroup) guards its stream index with this */
+	uint32_t compact;                     /* 1: the state of group g of stream c goes to slot (first symbol >> 3) + c + g (consecutive 8-byte stores that fill whole
+	                                         lines) instead of the slot of the group's first symbol (one 8-byte store per 64 bytes) -- whole-stream form only */
 };
 
 /* range / total as a multiply-shift (Granlund-Montgomery, N = 31): L = ceil(log2 total) >= 1, m = ceil(2^(31+L)/total) in [2^31, 2^32),
@@ -493,7 +495,7 @@ typedef uint32_t x3_u32x4 __attribute__((ext_vector_type(4)));
 #define X3_AC2_GROUP(Q0, Q1, OFF)                                                                                               \
 	{                                                                                                                           \
 		uint32_t nl_, nh_;                                                                                                      \
-		X3_AC2_STATE(OFF)                                                                                                       \
+		X3_AC2_STATE((OFF) * SST)                                                                                                     \
 		X3_AC2_SYM(Q0, 0, nl_, nh_) X3_AC2_SYM(Q0, 1, nl_, nh_) X3_AC2_SYM(Q0, 2, nl_, nh_) X3_AC2_SYM(Q0, 3, nl_, nh_)          \
 		X3_AC2_SYM(Q1, 0, nl_, nh_) X3_AC2_SYM(Q1, 1, nl_, nh_) X3_AC2_SYM(Q1, 2, nl_, nh_) X3_AC2_SYM(Q1, 3, nl_, nh_)          \
 		(void)nl_; (void)nh_;                                                                                                   \
@@ -503,14 +505,16 @@ typedef uint32_t x3_u32x4 __attribute__((ext_vector_type(4)));
 	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_load_dwordx16 %0, %4, %5\n\ts_load_dwordx16 %1, %4, %5+0x40"                         \
 	             : "=&s"(N0), "=&s"(N1), "+s"(C0), "+s"(C1) : "s"(symp), "n"(OFF) : "memory")
 
+template <bool CP> /* CP: compact state slots (X3Ac2Args::compact) */
 __device__ static void x3_ac2_body(const X3Ac2Args &a, const uint32_t c)
 {
+	constexpr uint32_t SST = CP ? 8u : 64u; /* bytes from one group's state to the next */
 	const uint32_t lane = x3_lane();
 	uint32_t y0, Y, lo = 0, R = 0x80000000u; /* ac_init, ac.c:35-41: [0, 0x7FFFFFFF] */
 	if (a.seg_off) { y0 = x3_uniform(a.seg_off[c]); Y = x3_uniform(a.seg_len[c]); lo = x3_uniform(a.seg_state[2 * c]); R = x3_uniform(a.seg_state[2 * c + 1]); }
 	else { y0 = x3_uniform(a.yo[c]); Y = x3_uniform(a.yo[c + 1]) - y0; }
 	uint64_t symp = (uint64_t)(a.sym + y0);
-	uint64_t recp = (uint64_t)((uint2 *)a.rec_nk + y0);
+	uint64_t recp = (uint64_t)((uint2 *)a.rec_nk + (CP ? (y0 >> 3) + c : y0));
 	const uint32_t G = Y >> 3; /* whole groups of 8 symbols */
 	if (G) {
 		x3_u32x16 A0, A1, B0, B1;
@@ -527,13 +531,13 @@ __device__ static void x3_ac2_body(const X3Ac2Args &a, const uint32_t c)
 			X3_AC2_FETCH(B0, B1, A0, A1, 128);
 			X3_AC2_GROUP(A0, A1, 0)
 			X3_AC2_FETCH(A0, A1, B0, B1, 256);
-			X3_AC2_GROUP(B0, B1, 64)
+			X3_AC2_GROUP(B0, B1, 1)
 			X3_AC2_FETCH(B0, B1, A0, A1, 384);
-			X3_AC2_GROUP(A0, A1, 128)
+			X3_AC2_GROUP(A0, A1, 2)
 			X3_AC2_FETCH(A0, A1, B0, B1, 512);
-			X3_AC2_GROUP(B0, B1, 192)
+			X3_AC2_GROUP(B0, B1, 3)
 			symp += 512;
-			recp += 256;
+			recp += 4 * SST;
 		}
 		for (; g < G; g++) { /* < 4 leftover groups; A holds the current one */
 			X3_AC2_FETCH(B0, B1, A0, A1, 128);
@@ -541,7 +545,7 @@ __device__ static void x3_ac2_body(const X3Ac2Args &a, const uint32_t c)
 			asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(B0), "+s"(B1) : : "memory"); /* landed: only now may the registers be copied */
 			A0 = B0; A1 = B1;
 			symp += 128;
-			recp += 64;
+			recp += SST;
 		}
 		asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : : "v"(dummy) : "memory"); /* the last prefetches */
 	}
@@ -562,6 +566,7 @@ __device__ static void x3_ac2_body(const X3Ac2Args &a, const uint32_t c)
 }
 #else
 /* the CPU emulator build (tests only): the same step function, one symbol at a time, no scalar-cache staging */
+template <bool CP>
 __device__ static void x3_ac2_body(const X3Ac2Args &a, const uint32_t c)
 {
 	const uint32_t lane = x3_lane();
@@ -571,7 +576,10 @@ __device__ static void x3_ac2_body(const X3Ac2Args &a, const uint32_t c)
 	x3_wave_sync();
 	for (uint32_t y = 0; y < Y; y++) {
 		const uint4 q = a.sym[y0 + y];
-		if (lane == 0 && (y % X3_AC2_G) == 0) { a.rec_nk[2 * (size_t)(y0 + y)] = lo; a.rec_nk[2 * (size_t)(y0 + y) + 1] = R; } /* the state before the group */
+		if (lane == 0 && (y % X3_AC2_G) == 0) { /* the state before the group */
+			const size_t slot = CP ? (size_t)(y0 >> 3) + c + y / X3_AC2_G : (size_t)(y0 + y);
+			a.rec_nk[2 * slot] = lo; a.rec_nk[2 * slot + 1] = R;
+		}
 		(void)x3_ac2_sym<false>(lo, R, q.x, q.y, q.z, q.w); /* the device chain's own step function (lo not reduced mod 2^30) */
 	}
 	x3_wave_sync();
@@ -587,12 +595,18 @@ __global__ void __launch_bounds__(X3_WAVE) x3_modes_kernel(X3ModesArgs a) { x3_m
 __global__ void __launch_bounds__(X3_WAVE) x3_modes_many_kernel(X3ModesArgs a) { x3_modes_body<X3_IDXF_LDS_SMALL, false>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_modes_stream_kernel_s(X3ModesArgs a) { x3_modes_body<2048, true>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_modes_stream_kernel_l(X3ModesArgs a) { x3_modes_body<X3_STREAM_DMAX, true>(a); }
-__global__ void __launch_bounds__(X3_WAVE) x3_ac2_kernel(X3Ac2Args a) { x3_ac2_body(a, blockIdx.x); }
+__global__ void __launch_bounds__(X3_WAVE) x3_ac2_kernel(X3Ac2Args a) { x3_ac2_body<false>(a, blockIdx.x); }
+__global__ void __launch_bounds__(X3_WAVE) x3_ac2_compact_kernel(X3Ac2Args a) { x3_ac2_body<true>(a, blockIdx.x); }
 /* four streams per workgroup, one per wavefront: the wavefronts of a workgroup are spread over the CU's four SIMDs */
 __global__ void __launch_bounds__(4 * X3_WAVE) x3_ac2_wide_kernel(X3Ac2Args a)
 {
 	const uint32_t c = x3_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
-	if (c < a.nstreams) x3_ac2_body(a, c);
+	if (c < a.nstreams) x3_ac2_body<false>(a, c);
+}
+__global__ void __launch_bounds__(4 * X3_WAVE) x3_ac2_wide_compact_kernel(X3Ac2Args a)
+{
+	const uint32_t c = x3_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
+	if (c < a.nstreams) x3_ac2_body<true>(a, c);
 }
 static void launch_modes(const X3ModesArgs &a, uint32_t nchunks, hipStream_t st, uint64_t max_dict)
 {
@@ -613,14 +627,18 @@ static void launch_ac2(X3Ac2Args a, uint32_t nchunks, hipStream_t st)
 {
 	static const uint32_t wide_min = getenv("X3H_AC2_WIDE") ? (uint32_t)atoi(getenv("X3H_AC2_WIDE")) : 513u;
 	a.nstreams = nchunks;
-	if (wide_min && nchunks >= wide_min) hipLaunchKernelGGL(x3_ac2_wide_kernel, dim3((nchunks + 3) / 4), dim3(4 * X3_WAVE), 0, st, a);
+	if (a.seg_off) a.compact = 0;
+	if (wide_min && nchunks >= wide_min) {
+		if (a.compact) hipLaunchKernelGGL(x3_ac2_wide_compact_kernel, dim3((nchunks + 3) / 4), dim3(4 * X3_WAVE), 0, st, a);
+		else hipLaunchKernelGGL(x3_ac2_wide_kernel, dim3((nchunks + 3) / 4), dim3(4 * X3_WAVE), 0, st, a);
+	} else if (a.compact) hipLaunchKernelGGL(x3_ac2_compact_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, a);
 	else hipLaunchKernelGGL(x3_ac2_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, a);
 }
 __device__ static __forceinline__ uint32_t x3_brev32(uint32_t v) { return __brev(v); }
 #else
 static void modes_tramp(void *p) { x3_modes_body<X3_IDXF_LDS, false>(*(const X3ModesArgs *)p); }
 static void modes_stream_tramp(void *p) { x3_modes_body<X3_STREAM_DMAX, true>(*(const X3ModesArgs *)p); }
-static void ac2_tramp(void *p) { x3_ac2_body(*(const X3Ac2Args *)p, blockIdx.x); }
+static void ac2_tramp(void *p) { const X3Ac2Args &a = *(const X3Ac2Args *)p; if (a.compact && !a.seg_off) x3_ac2_body<true>(a, blockIdx.x); else x3_ac2_body<false>(a, blockIdx.x); }
 static void launch_modes(const X3ModesArgs &a, uint32_t nchunks, hipStream_t, uint64_t) { x3emu_launch(a.pe0 ? modes_stream_tramp : modes_tramp, (void *)&a, dim3(nchunks), dim3(X3_WAVE)); }
 static void launch_ac2(const X3Ac2Args &a, uint32_t nchunks, hipStream_t) { x3emu_launch(ac2_tramp, (void *)&a, dim3(nchunks), dim3(X3_WAVE)); }
 static inline uint32_t x3_brev32(uint32_t v) { uint32_t r = 0; for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i); return r; }
@@ -660,6 +678,30 @@ __device__ static __forceinline__ void x3_or_bits(uint32_t *out32, uint32_t capw
 	}
 }
 
+/* the same into a buffer of `nw` words whose bit 0 is bit `bitpos` = 0 (LDS: the tile buffer of x3_emit_body) */
+__device__ static __forceinline__ void x3_or_bits_buf(uint32_t *buf, uint32_t nw, uint32_t bitpos, uint32_t val, uint32_t nbits)
+{
+	if (!nbits) return;
+	if (nbits < 32) val &= (1u << nbits) - 1;
+	const uint32_t w = bitpos >> 5, sh = bitpos & 31u;
+	const uint32_t v0 = val << sh;
+	if (v0 && w < nw) atomicOr(&buf[w], v0);
+	if (sh && sh + nbits > 32) {
+		const uint32_t v1 = val >> (32 - sh);
+		if (v1 && w + 1 < nw) atomicOr(&buf[w + 1], v1);
+	}
+}
+__device__ static __forceinline__ void x3_or_run_buf(uint32_t *buf, uint32_t nw, uint32_t bitpos, uint32_t bit, uint32_t count)
+{
+	if (!bit) return;
+	while (count) {
+		const uint32_t c = count < 32 ? count : 32;
+		x3_or_bits_buf(buf, nw, bitpos, 0xFFFFFFFFu, c);
+		bitpos += c;
+		count -= c;
+	}
+}
+
 /* a run of `count` equal bits */
 __device__ static __forceinline__ void x3_or_run(uint32_t *out32, uint32_t capw, uint64_t bitpos, uint32_t bit, uint32_t count)
 {
@@ -684,6 +726,7 @@ __device__ static __forceinline__ void x3_or_run(uint32_t *out32, uint32_t capw,
  * Then ac_encode_flush (ac.c:115-126), bio_close's word padding (bio.c:105-112) and the stream's result record.
  * ============================================================================================================ */
 #define X3_EMIT_THREADS 256u
+#define X3_EMIT_LDSW 2048u  /* words of a tile's output assembled in LDS (a tile of 2048 symbols emits ~100 words; a tile with more than this ORs straight into memory) */
 struct X3EmitArgs {
 	const uint32_t *yoc;        /* nc+1: symbol ranges (no-op symbols already dropped) */
 	const uint4 *sym;           /* per symbol: {cum, freq, magic, shift}               */
@@ -699,6 +742,7 @@ struct X3EmitArgs {
 	const uint32_t *seg_off, *seg_len;
 	uint32_t *carry;
 	uint32_t last;
+	uint32_t compact;           /* the states lie in compact slots (X3Ac2Args::compact) */
 };
 
 __device__ static __forceinline__ uint32_t x3_wave_incl_maxscan_u32(uint32_t v)
@@ -722,6 +766,7 @@ __device__ static void x3_emit_body(const X3EmitArgs &a)
 	const uint32_t NW = NT / X3_WAVE;
 	X3_LDS uint32_t s_ksum[NT], s_tail[NT], s_lr[NT];
 	X3_LDS uint32_t s_w[3][NT / X3_WAVE];
+	X3_LDS uint32_t s_bits[X3_EMIT_LDSW]; /* the tile's bits, assembled here and written out as whole words (zero between tiles) */
 	const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = x3_lane(), wave = tid / X3_WAVE;
 	uint32_t first, end;
 	if (a.seg_off) { first = a.seg_off[c]; end = first + a.seg_len[c]; } else { first = a.yoc[c]; end = a.yoc[c + 1]; }
@@ -730,13 +775,15 @@ __device__ static void x3_emit_body(const X3EmitArgs &a)
 	uint32_t carry_pend = 0;
 	uint64_t carry_pos = 0;
 	if (a.carry) { carry_pend = a.carry[4 * c]; carry_pos = (uint64_t)a.carry[4 * c + 1] | ((uint64_t)a.carry[4 * c + 2] << 32); }
+	for (uint32_t i = tid; i < X3_EMIT_LDSW; i += NT) s_bits[i] = 0;
 	for (uint32_t tb = first; tb < end; tb += NT * X3_AC2_G) {
 		const uint32_t gi = tb + tid * X3_AC2_G;
 		const uint32_t cnt = gi >= end ? 0u : (end - gi < X3_AC2_G ? end - gi : X3_AC2_G);
 		uint32_t eb[X3_AC2_G], kq[X3_AC2_G];
 		uint32_t ktot = 0, tail = 0, has_reset = 0, nsum = 0, pinner = 0;
 		if (cnt) {
-			uint32_t lo = a.state[2 * (size_t)gi], R = a.state[2 * (size_t)gi + 1];
+			const size_t slot = a.compact ? (size_t)(first >> 3) + c + ((gi - first) >> 3) : (size_t)gi;
+			uint32_t lo = a.state[2 * slot], R = a.state[2 * slot + 1];
 #pragma unroll
 			for (uint32_t j = 0; j < X3_AC2_G; j++) {
 				eb[j] = 1; kq[j] = 0;
@@ -783,24 +830,48 @@ __device__ static void x3_emit_body(const X3EmitArgs &a)
 		uint32_t bbase = 0, btot = 0;
 		for (uint32_t w = 0; w < NW; w++) { if (w < wave) bbase += s_w[2][w]; btot += s_w[2][w]; }
 		uint64_t bp = carry_pos + bbase + bs_w - bits;
-		/* ---- write ---- */
-		uint32_t pd = incoming;
+		/* ---- write ----  A tile's bits are one contiguous range of the stream: they are ORed together in LDS and leave as whole words (plain
+		 * stores; the first and the last word are shared with the neighbouring tiles: OR).  Straight into memory a tile's ~2 500 atomic ORs
+		 * meet on ~100 words of one L2 channel and the kernel waits for them. */
+		const uint64_t w0 = carry_pos >> 5;
+		const uint32_t nw = (uint32_t)(((carry_pos + btot + 31) >> 5) - w0);
+		const bool inlds = nw <= X3_EMIT_LDSW; /* (uniform) */
+		const uint32_t rb = (uint32_t)(bp - (w0 << 5)); /* my first bit inside the buffer (used when inlds: < 32 * X3_EMIT_LDSW) */
+		uint32_t pd = incoming, rp = rb;
 #pragma unroll
 		for (uint32_t j = 0; j < X3_AC2_G; j++) {
 			if (j < cnt) {
 				const uint32_t n = 31u - (uint32_t)x3_clz32(eb[j]);
 				if (n >= 1) {
 					const uint32_t rev = eb[j] ^ (1u << n);
-					if (!pd) x3_or_bits(out32, capw, bp, rev, n);
-					else {
-						x3_or_bits(out32, capw, bp, rev & 1u, 1);
-						x3_or_run(out32, capw, bp + 1, (rev & 1u) ^ 1u, pd);
-						x3_or_bits(out32, capw, bp + 1 + pd, rev >> 1, n - 1);
+					if (inlds) {
+						if (!pd) x3_or_bits_buf(s_bits, nw, rp, rev, n);
+						else {
+							x3_or_bits_buf(s_bits, nw, rp, rev & 1u, 1);
+							x3_or_run_buf(s_bits, nw, rp + 1, (rev & 1u) ^ 1u, pd);
+							x3_or_bits_buf(s_bits, nw, rp + 1 + pd, rev >> 1, n - 1);
+						}
+						rp += n + pd;
+					} else {
+						if (!pd) x3_or_bits(out32, capw, bp, rev, n);
+						else {
+							x3_or_bits(out32, capw, bp, rev & 1u, 1);
+							x3_or_run(out32, capw, bp + 1, (rev & 1u) ^ 1u, pd);
+							x3_or_bits(out32, capw, bp + 1 + pd, rev >> 1, n - 1);
+						}
+						bp += n + pd;
 					}
-					bp += n + pd;
 					pd = 0;
 				}
 				pd += kq[j];
+			}
+		}
+		if (inlds) {
+			__syncthreads();
+			for (uint32_t i = tid; i < nw; i += NT) {
+				const uint32_t v = s_bits[i];
+				s_bits[i] = 0; /* ready for the next tile (whose ORs come behind its own barriers) */
+				if (v && w0 + i < capw) { if (i == 0 || i + 1 == nw) atomicOr(&out32[w0 + i], v); else out32[w0 + i] = v; }
 			}
 		}
 		/* carries: pending after the tile's last thread, bits so far */
@@ -1194,7 +1265,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		if (streamk) {
 			/* ---- many streams: context statistics by one wavefront per stream (code3.hip); the context1 pass also finds the first use
 			 *      of every (context1, tag), which IS the tag-pair map (tag_pair.c:100-130: ordinal = rank of the first occurrence) ---- */
-			uint32_t *iota = T[0], *kA = T[1], *vA = T[2], *tA = T[3], *pf = T[5], *P = T[6];
+			uint32_t *iota = T[0], *kA = T[1], *vA = T[2], *tA = T[3], *P = T[6];
 			CHK(B.stat.reserve((nA + 4) * 16));
 			CHK(B.stat0.reserve((nA + 4) * 16));
 			uint4 *stat = B.stat.as<uint4>(), *stat0 = B.stat0.as<uint4>(); /* per hit {freq, total, cum, first}: context1 / context0.  Read in place by the mode kernel and the symbol
@@ -1205,31 +1276,27 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 			 * 40 ms: four wavefronts per stream walk their quarter as a chain of LDS round trips), so it stays an option, not the default */
 			bool seg_arrange = false;
 			if (const char *e = getenv("X3H_ARRANGE")) seg_arrange = e[0] == '1';
+			bool ctx_gather = true; /* the context kernel fetches the tags of its arrangement itself (X3H_CTX_GATHER=0: an element-wise pass writes them out first) */
+			if (const char *e = getenv("X3H_CTX_GATHER")) ctx_gather = e[0] != '0';
 			if (seg_arrange) CHK(x3_arrange_run(st, nc, d_ho, d_dof, maxDict, h_c1, h_tag, kA, vA, tA, T[7], T[8]));
 			else {
 				x3_foreach(nH, st, X3_LAMBDA(size_t i) { iota[i] = (uint32_t)i; });
 				CHK(x3p_sort_pairs(B.tmp, h_c1, kA, iota, vA, nH, bits_for(nD), st));
-				x3_foreach(nH, st, X3_LAMBDA(size_t i) { tA[i] = h_tag[vA[i]]; });
+				if (!ctx_gather) x3_foreach(nH, st, X3_LAMBDA(size_t i) { tA[i] = h_tag[vA[i]]; });
 			}
-			CHK(x3_ctx_stats_run(st, nc, maxDict, nH, d_ho, d_dof, kA, vA, tA, stat));
-			x3_foreach(nH, st, X3_LAMBDA(size_t i) { pf[i] = stat[i].w >> 31; }); /* this hit put its (context1, tag) pair into the map */
-			CHK(x3p_excl_scan(B.tmp, pf, P, nH, st));
+			HIPCHK(hipMemsetAsync(m_first00, 0xFF, (size_t)nc * 4, st)); /* NONE32: the stream never uses the pair (0, 0) */
+			CHK(x3_ctx_stats_run(st, nc, maxDict, nH, d_ho, d_dof, kA, vA, ctx_gather && !seg_arrange ? nullptr : tA, h_tag, stat, m_first00));
+			/* P[i] = hits before i that put their (context1, tag) pair into the map -- the scan reads the flag out of the records (no flag array) */
+			CHK(x3p_excl_scan_top_bit_w(B.tmp, stat, P, nH, st));
 			HIPCHK(hipMemcpyAsync(&npairs_total, P + nH, 4, hipMemcpyDeviceToHost, st));
 			x3_foreach(nc, st, X3_LAMBDA(size_t c) {
 				m_pairbase[c] = P[d_ho[c]];
 				m_npairs[c] = P[d_ho[c + 1]] - P[d_ho[c]];
-				m_first00[c] = NONE32; m_ord00[c] = 0;
-			});
-			x3_foreach(nH, st, X3_LAMBDA(size_t i) {
-				h_pair[i] = P[stat[i].w & 0x7FFFFFFFu]; /* ordinal of the pair = rank of the hit that first used it */
-				if (pf[i]) { /* the pair (0,0) of the stream: both contexts after a new fragment (x3.c:424-425) */
-					const uint32_t c = find_chunk(d_ho, nc, (uint32_t)i), z = d_dof[c];
-					if (h_tag[i] == z && h_c1[i] == z) { m_first00[c] = (uint32_t)i; m_ord00[c] = P[i]; }
-				}
+				m_ord00[c] = m_first00[c] != NONE32 ? P[m_first00[c]] : 0u; /* the pair (0,0) of the stream: both contexts after a new fragment (x3.c:424-425); found by the context kernel */
 			});
 			x3_foreach(nH, st, X3_LAMBDA(size_t gh) {
 				uint32_t g;
-				if (h_pv[gh]) g = h_pair[gh - 1]; /* (prev_context1, context1) is the pair the previous hit registered */
+				if (h_pv[gh]) g = P[stat[gh - 1].w & 0x7FFFFFFFu]; /* (prev_context1, context1) is the pair the previous hit registered: its ordinal = rank of the hit that first used it */
 				else {
 					const uint32_t c = find_chunk(d_ho, nc, (uint32_t)gh);
 					g = (m_first00[c] != NONE32 && m_first00[c] < gh) ? m_ord00[c] : m_pairbase[c]; /* unknown pair -> context 0 */
@@ -1246,9 +1313,9 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 			else {
 				if (seg_arrange) x3_foreach(nH, st, X3_LAMBDA(size_t i) { iota[i] = (uint32_t)i; });
 				CHK(x3p_sort_pairs(B.tmp, G0, kA, iota, vA, nH, bits_for(npairs_total ? npairs_total : 1), st));
-				x3_foreach(nH, st, X3_LAMBDA(size_t i) { tA[i] = h_tag[vA[i]]; });
+				if (!ctx_gather) x3_foreach(nH, st, X3_LAMBDA(size_t i) { tA[i] = h_tag[vA[i]]; });
 			}
-			CHK(x3_ctx_stats_run(st, nc, maxDict, nH, d_ho, d_dof, kA, vA, tA, stat0));
+			CHK(x3_ctx_stats_run(st, nc, maxDict, nH, d_ho, d_dof, kA, vA, ctx_gather && !(seg_arrange && maxPairs <= X3_ARRANGE_MAX_LOCAL) ? nullptr : tA, h_tag, stat0, nullptr));
 		} else {
 		/* ---- tag-pair ordinals (tag_pair.c) and the ctx0 group of every hit (x3.c:139-147) ---- */
 			uint32_t npairs_total = 0;
@@ -1552,7 +1619,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 
 	/* ---- serial pass 2: interval recurrence ---- */
 	X3Ac2Args aa;
-	aa.yo = d_yoc; aa.sym = sy; aa.rec_nk = rec_nk; aa.final_lo = m_finallo;
+	aa.yo = d_yoc; aa.sym = sy; aa.rec_nk = rec_nk; aa.final_lo = m_finallo; aa.compact = (!seg && streamk) ? 1u : 0u;
 	aa.seg_off = aa.seg_len = nullptr; aa.seg_state = nullptr;
 	if (nH == 0) HIPCHK(hipEventRecord(B.ev[2], st));
 	if (!seg) {
@@ -1615,7 +1682,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 			X3EmitArgs ea;
 			ea.yoc = nullptr; ea.sym = sy; ea.state = rec_nk; ea.final_lo = m_finallo; ea.chunks = d_chunks; ea.parsed = d_parsed;
 			ea.npairs = m_npairs; ea.evfinal = m_evfinal; ea.out = d_out; ea.result = d_result;
-			ea.seg_off = d_off; ea.seg_len = d_len; ea.carry = seg->emit_state.as<uint32_t>(); ea.last = final ? 1u : 0u;
+			ea.seg_off = d_off; ea.seg_len = d_len; ea.carry = seg->emit_state.as<uint32_t>(); ea.last = final ? 1u : 0u; ea.compact = 0;
 			launch_emit(ea, nc, seg->emit_stream, true);
 			HIPCHK(hipGetLastError());
 			if (!final) return X3H_OK;
@@ -1653,7 +1720,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		X3EmitArgs ea;
 		ea.yoc = d_yoc; ea.sym = sy; ea.state = rec_nk; ea.final_lo = m_finallo; ea.chunks = d_chunks; ea.parsed = d_parsed;
 		ea.npairs = m_npairs; ea.evfinal = m_evfinal; ea.out = d_out; ea.result = d_result;
-		ea.seg_off = ea.seg_len = nullptr; ea.carry = nullptr; ea.last = 1;
+		ea.seg_off = ea.seg_len = nullptr; ea.carry = nullptr; ea.last = 1; ea.compact = seg ? 0u : 1u;
 		launch_emit(ea, nc, st);
 		HIPCHK(hipGetLastError());
 	} else {
@@ -1757,7 +1824,7 @@ int x3_coder_chain_run(X3Code2Bufs &B, hipStream_t st, const uint32_t *h_cum, co
 	HIPCHK(hipMemcpyAsync(d_yo, yo, 8, hipMemcpyHostToDevice, st));
 	x3_foreach(n, st, X3_LAMBDA(size_t i) { sy[i] = x3_make_symbol(d_cum[i], d_freq[i], d_tot[i]); });
 	X3Ac2Args aa;
-	aa.yo = d_yo; aa.sym = sy; aa.rec_nk = rec; aa.final_lo = d_yo + 4; aa.seg_off = aa.seg_len = nullptr; aa.seg_state = nullptr;
+	aa.yo = d_yo; aa.sym = sy; aa.rec_nk = rec; aa.final_lo = d_yo + 4; aa.seg_off = aa.seg_len = nullptr; aa.seg_state = nullptr; aa.compact = 0;
 	launch_ac2(aa, 1, st);
 	HIPCHK(hipGetLastError());
 	std::vector<uint32_t> all(2 * (n + 1));

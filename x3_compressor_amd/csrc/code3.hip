@@ -223,8 +223,10 @@ struct X3CtxSegArgs {
 	const uint32_t *ho;        /* nc+1: hit ranges (== ranges of the arrangement)         */
 	const uint32_t *dof;       /* per chunk: first global tag id                          */
 	const uint32_t *kA, *vA;   /* arrangement by (context, time): context key, hit        */
-	const uint32_t *tA;        /* ... and the hit's global tag id                         */
+	const uint32_t *tA;        /* ... and the hit's global tag id; or nullptr and          */
+	const uint32_t *h_tag;     /* ... the tags by hit: the kernel fetches h_tag[vA[.]] itself, vA two tiles ahead, the tags one (no gather pass, no tA array) */
 	uint4 *stat;               /* out per hit: {freq, total, cum, first | isfirst << 31}  */
+	uint32_t *first00;         /* context1 launch: per stream, the hit that first uses the pair (element 0 in context 0) -- x3.c:424-425; preset to NONE32.  Else nullptr */
 	uint32_t dbits_max;        /* bits that cover every local tag of the batch            */
 	uint32_t nsub;             /* wavefronts per stream: wavefront r takes the contexts that START in the r-th part of the range (contexts are independent) */
 	uint32_t nc;               /* streams */
@@ -284,15 +286,23 @@ __device__ static void x3_ctxseg_body(const X3CtxSegArgs &a)
 	for (uint32_t i = lane; i < DMAX; i += X3_WAVE) tpos[i] = NONE16;
 	bool open = false;
 	uint32_t open_g = 0, open_k = 0, open_total = 0;
-	uint32_t ng_ = 0, nh_ = 0, nt_ = 0;
-	if (h0 + lane < h1) { ng_ = a.kA[h0 + lane]; nh_ = a.vA[h0 + lane]; nt_ = a.tA[h0 + lane]; }
+	uint32_t ng_ = 0, nh_ = 0, nt_ = 0, nh2_ = 0;
+	if (h0 + lane < h1) { ng_ = a.kA[h0 + lane]; nh_ = a.vA[h0 + lane]; if (a.tA) nt_ = a.tA[h0 + lane]; }
+	if (!a.tA) {
+		if (h0 + X3_WAVE + lane < h1) nh2_ = a.vA[h0 + X3_WAVE + lane];
+		if (h0 + lane < h1) nt_ = a.h_tag[nh_];
+	}
 	x3_wave_sync();
 	for (uint32_t base = h0; base < h1; base += X3_WAVE) {
 		const bool valid = base + lane < h1;
 		const uint32_t g = ng_, hit = nh_, t = valid ? nt_ - dof : 0u;
 		{ /* the next tile's records are in flight while this one is resolved */
 			const uint32_t nx = base + X3_WAVE + lane;
-			if (nx < h1) { ng_ = a.kA[nx]; nh_ = a.vA[nx]; nt_ = a.tA[nx]; }
+			if (a.tA) { if (nx < h1) { ng_ = a.kA[nx]; nh_ = a.vA[nx]; nt_ = a.tA[nx]; } }
+			else {
+				if (nx < h1) { ng_ = a.kA[nx]; nh_ = nh2_; nt_ = a.h_tag[nh2_]; } /* nh2_ was fetched a tile ago */
+				if (nx + X3_WAVE < h1) nh2_ = a.vA[nx + X3_WAVE];
+			}
 		}
 		const uint64_t V = x3_ballot(valid);
 		const uint32_t nvalid = (uint32_t)x3_popc64(V);
@@ -331,6 +341,7 @@ __device__ static void x3_ctxseg_body(const X3CtxSegArgs &a)
 			uint4 r;
 			r.x = freq; r.y = total; r.z = cum; r.w = (known ? lfirst[cp] : hit_fl) | (isnew ? 0x80000000u : 0u);
 			a.stat[hit] = r;
+			if (a.first00 && isnew && t == 0u && g == dof) a.first00[c] = hit;
 		}
 		/* ---- carry the last context of the tile if it goes on in the next one ---- */
 		const uint32_t sl = 63u - (uint32_t)x3_clz64(S);               /* first lane of the tile's last segment */
@@ -695,10 +706,10 @@ int x3_mtf_ranks_run(hipStream_t st, uint32_t nc, uint64_t max_dict, const uint3
 }
 
 int x3_ctx_stats_run(hipStream_t st, uint32_t nc, uint64_t max_dict, uint64_t nhits, const uint32_t *d_ho, const uint32_t *d_dof, const uint32_t *kA,
-                     const uint32_t *vA, const uint32_t *tA, uint4 *stat)
+                     const uint32_t *vA, const uint32_t *tA, const uint32_t *h_tag, uint4 *stat, uint32_t *first00)
 {
 	X3CtxSegArgs a;
-	a.ho = d_ho; a.dof = d_dof; a.kA = kA; a.vA = vA; a.tA = tA; a.stat = stat;
+	a.ho = d_ho; a.dof = d_dof; a.kA = kA; a.vA = vA; a.tA = tA; a.h_tag = h_tag; a.stat = stat; a.first00 = first00;
 	uint32_t b = 1; while (b < 32 && (max_dict >> b)) b++;
 	a.dbits_max = b;
 	/* contexts are independent, so a stream's range is cut (at context boundaries) over several wavefronts -- MANY of them: ~512 hits each, and

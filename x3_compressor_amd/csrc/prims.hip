@@ -10,6 +10,7 @@
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 int x3p_sort_pairs(DevBuf &tmp, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, int bits, hipStream_t st)
 {
@@ -35,6 +36,17 @@ int x3p_sort_pairs_bits(DevBuf &tmp, const uint32_t *kin, uint32_t *kout, const 
 
 int x3p_excl_scan(DevBuf &tmp, const uint32_t *in, uint32_t *out, size_t n, hipStream_t st)
 {
+	size_t need = 0;
+	HIPCHK(rocprim::exclusive_scan(nullptr, need, in, out, 0u, n + 1, rocprim::plus<uint32_t>(), st));
+	CHK(tmp.reserve(need));
+	HIPCHK(rocprim::exclusive_scan(tmp.p, need, in, out, 0u, n + 1, rocprim::plus<uint32_t>(), st));
+	return X3H_OK;
+}
+
+struct X3TopBitW { __device__ __host__ uint32_t operator()(const uint4 &r) const { return r.w >> 31; } };
+int x3p_excl_scan_top_bit_w(DevBuf &tmp, const uint4 *rec, uint32_t *out, size_t n, hipStream_t st)
+{
+	auto in = rocprim::make_transform_iterator(rec, X3TopBitW());
 	size_t need = 0;
 	HIPCHK(rocprim::exclusive_scan(nullptr, need, in, out, 0u, n + 1, rocprim::plus<uint32_t>(), st));
 	CHK(tmp.reserve(need));
@@ -84,6 +96,13 @@ int x3p_excl_scan(DevBuf &, const uint32_t *in, uint32_t *out, size_t n, hipStre
 {
 	uint32_t acc = 0;
 	for (size_t i = 0; i <= n; i++) { uint32_t v = i < n ? in[i] : 0; out[i] = acc; acc += v; }
+	return X3H_OK;
+}
+
+int x3p_excl_scan_top_bit_w(DevBuf &, const uint4 *rec, uint32_t *out, size_t n, hipStream_t)
+{
+	uint32_t acc = 0;
+	for (size_t i = 0; i <= n; i++) { out[i] = acc; if (i < n) acc += rec[i].w >> 31; }
 	return X3H_OK;
 }
 

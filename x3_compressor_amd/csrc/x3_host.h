@@ -73,6 +73,7 @@ int x3p_sort_pairs(DevBuf &tmp, const uint32_t *kin, uint32_t *kout, const uint3
 int x3p_sort_pairs_bits(DevBuf &tmp, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, int begin_bit, int end_bit, hipStream_t st);
 /* out[i] = sum in[0..i) for i in [0,n]; `in` must have n+1 readable entries (in[n] is ignored), out n+1 writable */
 int x3p_excl_scan(DevBuf &tmp, const uint32_t *in, uint32_t *out, size_t n, hipStream_t st);
+int x3p_excl_scan_top_bit_w(DevBuf &tmp, const uint4 *rec, uint32_t *out, size_t n, hipStream_t st); /* out[i] = #{ j < i : rec[j].w >> 31 }, i <= n (rec[n] is read, not used) */
 /* out[i] = max in[0..i] */
 int x3p_incl_max_scan(DevBuf &tmp, const uint32_t *in, uint32_t *out, size_t n, hipStream_t st);
 
@@ -179,7 +180,7 @@ int x3_arrange_run(hipStream_t st, uint32_t nc, const uint32_t *d_ho, const uint
 #endif
 #define X3_ARRANGE_MAX_LOCAL (((uint64_t)1 << (2 * X3_ARR_DBITS)) - 1) /* largest stream-local key two passes cover */
 int x3_ctx_stats_run(hipStream_t st, uint32_t nc, uint64_t max_dict, uint64_t nhits, const uint32_t *d_ho, const uint32_t *d_dof, const uint32_t *kA,
-                     const uint32_t *vA, const uint32_t *tA, uint4 *stat /* per hit: {freq, total, cum, first hit | isfirst << 31} */);
+                     const uint32_t *vA, const uint32_t *tA, const uint32_t *h_tag, uint4 *stat, uint32_t *first00 /* per hit: {freq, total, cum, first hit | isfirst << 31} */);
 int x3_order0_run(hipStream_t st, uint32_t nc, const uint32_t *d_mo, const uint32_t *lval, uint32_t *lsm, uint32_t *leq,
                   const uint32_t *d_bo, const uint32_t *bval, uint32_t *bsm, uint32_t *beq);
 int x3_idxstat_run(hipStream_t st, uint32_t nc, uint64_t max_dict, const uint32_t *d_ho, const uint32_t *evfinal, const uint32_t *lrank,
