@@ -333,6 +333,30 @@ def test_decode_batch_of_many_streams(gpu):
         assert streams[i] == gpu.compress(parts[i], prm), f"stream {i}"
 
 
+def test_batch_above_512_streams_equals_oracle_and_the_narrow_forms(gpu, gpu_env, oracle):
+    """600 ragged streams (text, Zipf, 16-bit samples, zeros; empty ones): from 513 streams on the coder chains run four to a workgroup
+    (x3_ac2_wide_compact_kernel); the batch also takes the time-ranged move-to-front kernel, the context kernel with ~512-hit ranges on one XCD and
+    its own tag gather, compact coder states and LDS-assembled output.  Same bytes as the oracle (sampled) and as the forms they replaced."""
+    import oracle_lib
+    rng = np.random.default_rng(600)
+    parts = []
+    for i in range(600):
+        n = int(rng.integers(0, 24_000)) if i % 50 else 0
+        kind = i % 4
+        parts.append(synth.english_like(n, seed=900 + i).tobytes() if kind == 0 else synth.zipf_bytes(n, offset=777 * i).tobytes() if kind == 1
+                     else synth.mr_like(n, seed=i).tobytes() if kind == 2 else bytes(n))
+    parts[7] = synth.english_like(300_000, seed=5).tobytes()          # one stream of many tiles (and time ranges of several thousand events)
+    data = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    off = np.cumsum([0] + [len(p) for p in parts]).astype(np.uint64)
+    prm = _lib.make_params(w_kib=64, t=256)
+    got = gpu.compress_chunks(data, off, prm)
+    for i in (0, 1, 2, 3, 7, 50, 301, 598, 599):
+        assert got[i] == oracle.compress(parts[i], oracle_lib.params(w_kib=64, t=256)), f"stream {i}"
+    old = gpu_env(X3H_AC2_WIDE="0", X3H_MTF_PAR="0", X3H_CTX_GATHER="0", X3H_CTX_SUB="4", X3H_CTX_XCD="0").compress_chunks(data, off, prm)
+    assert got == old
+    assert gpu.decompress_chunks(got, [len(p) for p in parts]) == parts
+
+
 # ---- chunking behind the C boundary: container, several handles, sub-batches cut on the padded layout ---------------------------------
 def test_container_from_hip_streams(gpu, oracle):
     """HIP streams -> X3C1 container (x3h_compress_container) -> unpack -> every chunk == the oracle's stream of that chunk ->

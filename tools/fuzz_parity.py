@@ -48,10 +48,14 @@ ENVS = [dict(), dict(X3H_PIPE_MIN="1"), dict(X3H_PIPE_MIN="1", X3H_MODES="fixed"
         # round 3: K1 by one workgroup per chunk (scan3.hip) on batches of any size, in both forms, with the per-chunk / chip-wide dense refinement;
         # segment-wise bit emission; per-stream arrangement
         dict(X3H_SEG_MIN="1"), dict(X3H_SEG_MIN="1", X3H_SEG_SMALL_MAX="0"), dict(X3H_SEG_MIN="1", X3H_WALK_DENSE="12"), dict(X3H_SEG_MIN="1", X3H_SEG_REFINE="0", X3H_WALK_DENSE="12"),
-        dict(X3H_SEG_MIN="2", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0"), dict(X3H_PIPE_MIN="1", X3H_SEG_EMIT="1"), dict(X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0", X3H_ARRANGE="1")]
+        dict(X3H_SEG_MIN="2", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0"), dict(X3H_PIPE_MIN="1", X3H_SEG_EMIT="1"), dict(X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0", X3H_ARRANGE="1"),
+        # round 3, second half: coder chains four to a workgroup (default from 513 streams), context kernel with / without its own tag gather and XCD mapping,
+        # move-to-front ranks by one wavefront per stream instead of eight time ranges
+        dict(X3H_AC2_WIDE="1", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0"), dict(X3H_CTX_GATHER="0"), dict(X3H_CTX_SUB="64", X3H_CTX_XCD="0"), dict(X3H_CTX_SUB="1", X3H_CTX_XCD="1"),
+        dict(X3H_MTF_PAR="0"), dict(X3H_MTF_PAR="0", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0", X3H_CTX_GATHER="0")]
 t0, cases = time.time(), 0
 while time.time() - t0 < budget:
-    nch = int(rng.choice([1, 1, 1, 2, 3, 7, 40, 60, 130, 300]))   # >= 48: the per-stream kernels of code3.hip; 300: above the switch to the small-LDS kernel variants
+    nch = int(rng.choice([1, 1, 1, 2, 3, 7, 40, 60, 130, 300, 600]))   # >= 48: the per-stream kernels of code3.hip; 300: above the switch to the small-LDS kernel variants
     sizes = [int(rng.integers(0, 3000)) for _ in range(nch)] if nch > 100 else [int(rng.integers(0, 9000)) for _ in range(nch)] if nch > 45 else [int(rng.choice([0, 1, 2, 31, 32, 33, 200, 2047, 2048, 2049, 5000, 20000, 70000])) if rng.random() < 0.5 else int(rng.integers(0, 30000)) for _ in range(nch)]
     w = int(rng.choice([0, 1, 1, 2, 4, 8, 8, 16, 64]))
     kw = dict(w_kib=w, t=int(rng.choice([0, 1, 2, 3, 8, 15, 16, 64, 256, 5000])), m=int(rng.choice([0, 1, 4, 4, 4, 9])),

@@ -625,7 +625,8 @@ static void launch_modes(const X3ModesArgs &a, uint32_t nchunks, hipStream_t st,
  * count that takes the wide form (0: never). */
 static void launch_ac2(X3Ac2Args a, uint32_t nchunks, hipStream_t st)
 {
-	static const uint32_t wide_min = getenv("X3H_AC2_WIDE") ? (uint32_t)atoi(getenv("X3H_AC2_WIDE")) : 513u;
+	const char *we = getenv("X3H_AC2_WIDE"); /* (read per launch: the tests switch it inside one process) */
+	const uint32_t wide_min = we ? (uint32_t)atoi(we) : 513u;
 	a.nstreams = nchunks;
 	if (a.seg_off) a.compact = 0;
 	if (wide_min && nchunks >= wide_min) {
@@ -726,7 +727,9 @@ __device__ static __forceinline__ void x3_or_run(uint32_t *out32, uint32_t capw,
  * Then ac_encode_flush (ac.c:115-126), bio_close's word padding (bio.c:105-112) and the stream's result record.
  * ============================================================================================================ */
 #define X3_EMIT_THREADS 256u
-#define X3_EMIT_LDSW 2048u  /* words of a tile's output assembled in LDS (a tile of 2048 symbols emits ~100 words; a tile with more than this ORs straight into memory) */
+#ifndef X3_EMIT_LDSW
+#define X3_EMIT_LDSW 2048u
+#endif                      /* words of a tile's output assembled in LDS (a tile of 2048 symbols emits ~100 words; a tile with more than this ORs straight into memory) */
 struct X3EmitArgs {
 	const uint32_t *yoc;        /* nc+1: symbol ranges (no-op symbols already dropped) */
 	const uint4 *sym;           /* per symbol: {cum, freq, magic, shift}               */
