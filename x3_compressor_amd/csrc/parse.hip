@@ -29,6 +29,7 @@
 #define X3_LDS_HT_LOG2 11u
 #define X3_LDS_HT (1u << X3_LDS_HT_LOG2) /* the mirror is used while the table has at most this many slots ... */
 #define X3_LDS_DICT (X3_LDS_HT / 2)      /* ... i.e. at most this many elements */
+static_assert(X3_LDS_DICT < 2048, "a mirror entry holds tag + 1 in 11 bits beside the element's length - 1 in 5");
 
 #define FNV_OFF 2166136261u
 #define FNV_MUL 16777619u
@@ -88,7 +89,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 	X3_LDS uint16_t sAi[PB];   /* anchors of the current walk: cached index where a stride of hits starts ... */
 	X3_LDS uint32_t sAt[PB];   /* ... and the token index of its first hit */
 	/* LDS mirror of the dictionary while it is small (the usual case at large -t): hash table, element position / length */
-	X3_LDS uint16_t sHT[X3_LDS_HT];
+	X3_LDS uint16_t sHT[X3_LDS_HT];   /* the table's mirror: 0 = empty, else tag + 1 (11 bits: at most X3_LDS_DICT elements) | (length - 1) << 11 */
 	X3_LDS uint32_t sDpos[X3_LDS_DICT];
 	X3_LDS uint8_t sDlen[X3_LDS_DICT];
 	X3_LDS uint2 sD8[X3_LDS_DICT];   /* the first eight bytes of each mirrored element (zero beyond its length): most candidates are settled without touching global memory */
@@ -126,17 +127,18 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 			const uint32_t maxlen = lenmask ? 32 - (uint32_t)x3_clz32(lenmask) : 0;
 			for (uint32_t i = tid; i < PBL; i += X3_PARSE_THREADS) {
 				uint32_t h = FNV_OFF, best = 0, btag = 0;
+				const uint64_t my8 = x3_lds_load8(sb, i); /* the position's first eight bytes, compared with the mirrored elements' */
 				for (uint32_t l = 1; l <= maxlen; l++) {
 					h = (h ^ sb[i + l - 1]) * FNV_MUL;
 					if (!((lenmask >> (l - 1)) & 1)) continue;
 					uint32_t slot = ht_slot(h, l, hlog);
 					if (hlog <= X3_LDS_HT_LOG2) { /* wave-uniform: the whole dictionary is mirrored in LDS */
+						const uint64_t m8 = l >= 8 ? ~(uint64_t)0 : (((uint64_t)1 << (8 * l)) - 1);
 						for (uint32_t e = sHT[slot]; e != 0; slot = (slot + 1) & hmask, e = sHT[slot]) {
-							const uint32_t tag = e - 1;
-							if (sDlen[tag] != l) continue;
+							if ((e >> 11) != l - 1) continue; /* the entry carries its element's length: tag + 1 | (length - 1) << 11 */
+							const uint32_t tag = (e & 0x7FFu) - 1;
 							const uint2 d8 = sD8[tag];
-							const uint64_t m8 = l >= 8 ? ~(uint64_t)0 : (((uint64_t)1 << (8 * l)) - 1);
-							if ((((uint64_t)d8.x | ((uint64_t)d8.y << 32)) ^ x3_lds_load8(sb, i)) & m8) continue; /* (not this element: an exact table, so the probe goes on) */
+							if ((((uint64_t)d8.x | ((uint64_t)d8.y << 32)) ^ my8) & m8) continue; /* (not this element: an exact table, so the probe goes on) */
 							if (l <= 8 || x3_eq_bytes(b, sDpos[tag] + 8, sb + i + 8, l - 8)) { best = l; btag = tag; break; }
 						}
 					} else {
@@ -168,7 +170,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 				}
 				if (hlog <= X3_LDS_HT_LOG2) { /* same content as the global table (identical probe order is not needed: exact lookups) */
 					__syncthreads();
-					for (uint32_t i = tid; i <= hmask; i += X3_PARSE_THREADS) sHT[i] = (uint16_t)ht[i];
+					for (uint32_t i = tid; i <= hmask; i += X3_PARSE_THREADS) { const uint32_t e = ht[i]; sHT[i] = e ? (uint16_t)(e | ((uint32_t)(sDlen[e - 1] - 1u) << 11)) : (uint16_t)0; }
 				}
 			}
 			const uint32_t first = S.p - blk; /* positions before the parse pointer are never read again */
@@ -294,7 +296,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 							uint32_t slot = ht_slot(h, len, hlog);
 							while (ht[slot] != 0) slot = (slot + 1) & hmask;
 							ht[slot] = ntag + 1;
-							if (hlog <= X3_LDS_HT_LOG2) sHT[slot] = (uint16_t)(ntag + 1);
+							if (hlog <= X3_LDS_HT_LOG2) sHT[slot] = (uint16_t)((ntag + 1) | ((len - 1) << 11));
 						}
 						S.new_pos = p; S.new_len = len; S.new_tag = ntag; S.rebuild = rebuild;
 					}
