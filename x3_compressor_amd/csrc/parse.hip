@@ -29,6 +29,7 @@
 #define X3_LDS_HT_LOG2 11u
 #define X3_LDS_HT (1u << X3_LDS_HT_LOG2) /* the mirror is used while the table has at most this many slots ... */
 #define X3_LDS_DICT (X3_LDS_HT / 2)      /* ... i.e. at most this many elements */
+#define X3_BLOOM_WORDS 8u
 static_assert(X3_LDS_DICT < 2048, "a mirror entry holds tag + 1 in 11 bits beside the element's length - 1 in 5");
 
 #define FNV_OFF 2166136261u
@@ -93,6 +94,8 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 	X3_LDS uint32_t sDpos[X3_LDS_DICT];
 	X3_LDS uint8_t sDlen[X3_LDS_DICT];
 	X3_LDS uint2 sD8[X3_LDS_DICT];   /* the first eight bytes of each mirrored element (zero beyond its length): most candidates are settled without touching global memory */
+	X3_LDS uint32_t sBloom[32][X3_BLOOM_WORDS]; /* per element length: a 256-bit filter on the top bits of the element's FNV hash -- a probe whose bit is clear has no element to find
+	                                              * (the filter never forgets: the dictionary only grows) */
 	X3_LDS ParseShared S;
 
 	const X3Chunk ck = a.chunks[blockIdx.x];
@@ -112,6 +115,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 	}
 	for (uint32_t i = tid; i < (1u << (X3_HT_LOG2_MIN < ck.ht_log2_max ? X3_HT_LOG2_MIN : ck.ht_log2_max)); i += X3_PARSE_THREADS) ht[i] = 0;
 	for (uint32_t i = tid; i < X3_LDS_HT; i += X3_PARSE_THREADS) sHT[i] = 0;
+	for (uint32_t i = tid; i < 32u * X3_BLOOM_WORDS; i += X3_PARSE_THREADS) (&sBloom[0][0])[i] = 0;
 	__syncthreads();
 
 	uint64_t cyc_fill = 0, cyc_patch = 0, cyc_table = 0, cyc_walk = 0, t_prev = x3_clock();
@@ -131,6 +135,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 				for (uint32_t l = 1; l <= maxlen; l++) {
 					h = (h ^ sb[i + l - 1]) * FNV_MUL;
 					if (!((lenmask >> (l - 1)) & 1)) continue;
+					if (!((sBloom[l - 1][h >> 29] >> ((h >> 24) & 31u)) & 1u)) continue; /* no element of this length with these hash bits: skip the table (a random LDS / L2 access) */
 					uint32_t slot = ht_slot(h, l, hlog);
 					if (hlog <= X3_LDS_HT_LOG2) { /* wave-uniform: the whole dictionary is mirrored in LDS */
 						const uint64_t m8 = l >= 8 ? ~(uint64_t)0 : (((uint64_t)1 << (8 * l)) - 1);
@@ -289,9 +294,10 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 							for (uint32_t k = 0; k < len && k < 8; k++) v8 |= (uint64_t)sb[idx + k] << (8 * k);
 							sD8[ntag] = make_uint2((uint32_t)v8, (uint32_t)(v8 >> 32));
 						}
+						uint32_t h = FNV_OFF;
+						for (uint32_t k = 0; k < len; k++) h = (h ^ sb[idx + k]) * FNV_MUL;
+						sBloom[len - 1][h >> 29] |= 1u << ((h >> 24) & 31u);
 						if (!rebuild) {
-							uint32_t h = FNV_OFF;
-							for (uint32_t k = 0; k < len; k++) h = (h ^ sb[idx + k]) * FNV_MUL;
 							const uint32_t hmask = (1u << hlog) - 1;
 							uint32_t slot = ht_slot(h, len, hlog);
 							while (ht[slot] != 0) slot = (slot + 1) & hmask;
