@@ -112,6 +112,16 @@ __device__ static __forceinline__ void seg_level(uint32_t lv, const uint2 it, co
 
 /* BIG = false: chunks of at most X3_SEG_MAXLEN bytes, their level counters and small-K marks live in LDS; BIG = true: longer chunks, both
  * live in global memory (a.gmf / a.rare, zeroed by the caller; the atomics execute in L2) */
+/* element q of a chunk's list 0: key = the four bytes ENDING at q (byte q in bits 0-7, q-1 in 8-15, ...; bytes before the buffer read as 0 --
+ * before a later slot they are the previous slot's zero tail), value = the global position */
+__device__ static __forceinline__ uint2 seg_gen(const uint8_t *bytes, uint32_t base, uint32_t q)
+{
+	uint32_t w;
+	if (base + q >= 3u) __builtin_memcpy(&w, bytes + (base + q - 3u), 4); /* (an unaligned dword load) */
+	else { __builtin_memcpy(&w, bytes, 4); w <<= 8u * (3u - q); }
+	return make_uint2(seg_bswap(w), base + q);
+}
+
 template <bool BIG>
 __device__ static void x3_segscan_body(const X3SegArgs &a)
 {
@@ -146,28 +156,16 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 	for (uint32_t i = tid; i < 8u * 256u; i += X3_SEG_THREADS) hist[i] = 0u;
 	__syncthreads();
 
-	/* ---- phase 0: keys + byte histogram.  Four elements per thread from two aligned dwords. ---- */
+	/* ---- phase 0: the byte histogram (the digit of element q in pass 1 is byte q; bytes behind the data read as the zeros they are).  The
+	 * (key, position) pairs themselves are never written out: pass 1 makes them from the input bytes as it reads (seg_gen). ---- */
 	{
-		const uint32_t *w32 = (const uint32_t *)(a.bytes + base); /* slots are 256-byte aligned; bytes before slot c > 0 are slot c-1's zero tail */
+		const uint32_t *w32 = (const uint32_t *)(a.bytes + base); /* slots are 256-byte aligned */
 		uint32_t *hmine = hist + (lane & 7u) * 256u;
 		for (uint32_t q4 = tid * 4u; q4 < L; q4 += X3_SEG_THREADS * 4u) {
 			const uint32_t w1 = w32[q4 >> 2];
-			const uint32_t w0 = (base + q4) ? w32[(int32_t)(q4 >> 2) - 1] : 0u;
-			const uint64_t v = (uint64_t)w0 | ((uint64_t)w1 << 32);
-			uint2 e[4];
 #pragma unroll
-			for (uint32_t k = 0; k < 4; k++) {
-				e[k].x = seg_bswap((uint32_t)(v >> (8u * (k + 1u)))); /* byte q in bits 0-7, q-1 in 8-15, q-2, q-3 */
-				e[k].y = base + q4 + k;
-				if (q4 + k < L) atomicAdd(&hmine[e[k].x & 0xFFu], 1u);
-			}
-			if (q4 + 4u <= L) {
-				uint4 *d4 = (uint4 *)(A + q4);
-				d4[0] = make_uint4(e[0].x, e[0].y, e[1].x, e[1].y);
-				d4[1] = make_uint4(e[2].x, e[2].y, e[3].x, e[3].y);
-			} else {
-				for (uint32_t k = 0; k < 4 && q4 + k < L; k++) A[q4 + k] = e[k];
-			}
+			for (uint32_t k = 0; k < 4; k++)
+				if (q4 + k < L) atomicAdd(&hmine[(w1 >> (8u * k)) & 0xFFu], 1u);
 		}
 	}
 	__syncthreads();
@@ -200,7 +198,7 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 		{
 			const uint32_t i0 = wv * (X3_SEG_E * X3_WAVE) + lane;
 #pragma unroll
-			for (uint32_t e = 0; e < X3_SEG_E; e++) nx[e] = i0 + e * X3_WAVE < L ? in[i0 + e * X3_WAVE] : none;
+			for (uint32_t e = 0; e < X3_SEG_E; e++) nx[e] = i0 + e * X3_WAVE < L ? (l == 1u ? seg_gen(a.bytes, base, i0 + e * X3_WAVE) : in[i0 + e * X3_WAVE]) : none;
 		}
 		for (uint32_t t0 = 0; t0 < L; t0 += X3_SEG_TILE) {
 			*(uint4 *)&cnt[tid * 4u] = make_uint4(0u, 0u, 0u, 0u);
@@ -211,7 +209,7 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 			for (uint32_t e = 0; e < X3_SEG_E; e++) it[e] = nx[e];
 			if (t0 + X3_SEG_TILE < L) { /* the next tile's entries are on their way while this one is ranked */
 #pragma unroll
-				for (uint32_t e = 0; e < X3_SEG_E; e++) { const uint32_t idx = i0 + X3_SEG_TILE + e * X3_WAVE; nx[e] = idx < L ? in[idx] : none; }
+				for (uint32_t e = 0; e < X3_SEG_E; e++) { const uint32_t idx = i0 + X3_SEG_TILE + e * X3_WAVE; nx[e] = idx < L ? (l == 1u ? seg_gen(a.bytes, base, idx) : in[idx]) : none; }
 			}
 			if (lv) {
 #pragma unroll
