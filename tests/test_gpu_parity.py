@@ -335,7 +335,7 @@ def test_decode_batch_of_many_streams(gpu):
 
 def test_batch_above_512_streams_equals_oracle_and_the_narrow_forms(gpu, gpu_env, oracle):
     """600 ragged streams (text, Zipf, 16-bit samples, zeros; empty ones): from 513 streams on the coder chains run four to a workgroup
-    (x3_ac2_wide_compact_kernel); the batch also takes the time-ranged move-to-front kernel, the context kernel with ~512-hit ranges on one XCD and
+    (x3_ac2_wide_compact_kernel); the batch also takes the time-ranged move-to-front and index-model kernels, the context kernel with ~512-hit ranges on one XCD and
     its own tag gather, compact coder states and LDS-assembled output.  Same bytes as the oracle (sampled) and as the forms they replaced."""
     import oracle_lib
     rng = np.random.default_rng(600)
@@ -352,7 +352,7 @@ def test_batch_above_512_streams_equals_oracle_and_the_narrow_forms(gpu, gpu_env
     got = gpu.compress_chunks(data, off, prm)
     for i in (0, 1, 2, 3, 7, 50, 301, 598, 599):
         assert got[i] == oracle.compress(parts[i], oracle_lib.params(w_kib=64, t=256)), f"stream {i}"
-    old = gpu_env(X3H_AC2_WIDE="0", X3H_MTF_PAR="0", X3H_CTX_GATHER="0", X3H_CTX_SUB="4", X3H_CTX_XCD="0").compress_chunks(data, off, prm)
+    old = gpu_env(X3H_AC2_WIDE="0", X3H_MTF_PAR="0", X3H_IDX_PAR="0", X3H_CTX_GATHER="0", X3H_CTX_SUB="4", X3H_CTX_XCD="0").compress_chunks(data, off, prm)
     assert got == old
     assert gpu.decompress_chunks(got, [len(p) for p in parts]) == parts
 

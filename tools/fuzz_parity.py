@@ -52,7 +52,7 @@ ENVS = [dict(), dict(X3H_PIPE_MIN="1"), dict(X3H_PIPE_MIN="1", X3H_MODES="fixed"
         # round 3, second half: coder chains four to a workgroup (default from 513 streams), context kernel with / without its own tag gather and XCD mapping,
         # move-to-front ranks by one wavefront per stream instead of eight time ranges
         dict(X3H_AC2_WIDE="1", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0"), dict(X3H_CTX_GATHER="0"), dict(X3H_CTX_SUB="64", X3H_CTX_XCD="0"), dict(X3H_CTX_SUB="1", X3H_CTX_XCD="1"),
-        dict(X3H_MTF_PAR="0"), dict(X3H_MTF_PAR="0", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0", X3H_CTX_GATHER="0")]
+        dict(X3H_MTF_PAR="0", X3H_IDX_PAR="0"), dict(X3H_MTF_PAR="0", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0", X3H_CTX_GATHER="0"), dict(X3H_IDX_PAR="0", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0")]
 t0, cases = time.time(), 0
 while time.time() - t0 < budget:
     nch = int(rng.choice([1, 1, 1, 2, 3, 7, 40, 60, 130, 300, 600]))   # >= 48: the per-stream kernels of code3.hip; 300: above the switch to the small-LDS kernel variants

@@ -439,25 +439,23 @@ struct X3IdxStatArgs {
 	uint32_t dbits_max;
 };
 
-template <uint32_t DMAX>
-__device__ static void x3_idxstat_body(const X3IdxStatArgs &a)
+/* list entries [lo, hi) of the stream whose list starts at i0, on counters (hist) and running sums (pre) that hold the entries before lo:
+ * live up to rank rmax when `started`, untouched otherwise */
+__device__ static __forceinline__ void x3_idxstat_tiles(const X3IdxStatArgs &a, uint32_t *hist, uint32_t *pre, const uint32_t i0, const uint32_t lo, const uint32_t hi,
+                                                        uint32_t rmax, bool started, const uint32_t lane)
 {
-	X3_LDS uint32_t hist[DMAX];
-	X3_LDS uint32_t pre[DMAX];
-	const uint32_t c = blockIdx.x, lane = x3_lane();
-	const uint32_t i0 = a.ho[c], n = a.evfinal[4 * c + 3];
 	const uint64_t below = ((uint64_t)1 << lane) - 1;
 	const int bits = (int)a.dbits_max;
-	uint32_t rmax = 0; /* ranks seen so far are <= rmax: only that part of the tables is live */
-	for (uint32_t base = 0; base < n; base += X3_WAVE) {
-		const bool valid = base + lane < n;
+	for (uint32_t base = lo; base < hi; base += X3_WAVE) {
+		const bool valid = base + lane < hi;
 		const uint32_t r = valid ? a.lrank[i0 + base + lane] : 0u, hit = valid ? a.lhit[i0 + base + lane] : 0u;
 		const uint32_t tmax = wave_max_u32(r);
-		if (base == 0 || tmax > rmax) { /* grow the live part (zero counters, running sums continue flat) */
-			const uint32_t from = base == 0 ? 0u : rmax + 1, flat = base == 0 ? 0u : pre[rmax] + hist[rmax];
+		if (!started || tmax > rmax) { /* grow the live part (zero counters, running sums continue flat) */
+			const uint32_t from = !started ? 0u : rmax + 1, flat = !started ? 0u : pre[rmax] + hist[rmax];
 			x3_wave_sync();
 			for (uint32_t q = from + lane; q <= tmax; q += X3_WAVE) { hist[q] = 0; pre[q] = flat; }
-			if (tmax > rmax || base == 0) rmax = tmax;
+			if (tmax > rmax || !started) rmax = tmax;
+			started = true;
 			x3_wave_sync();
 		}
 		const uint64_t V = x3_ballot(valid);
@@ -481,6 +479,65 @@ __device__ static void x3_idxstat_body(const X3IdxStatArgs &a)
 		}
 		x3_wave_sync();
 	}
+}
+
+template <uint32_t DMAX>
+__device__ static void x3_idxstat_body(const X3IdxStatArgs &a)
+{
+	X3_LDS uint32_t hist[DMAX];
+	X3_LDS uint32_t pre[DMAX];
+	const uint32_t c = blockIdx.x, lane = x3_lane();
+	x3_idxstat_tiles(a, hist, pre, a.ho[c], 0, a.evfinal[4 * c + 3], 0, false, lane);
+}
+
+/* The same with a stream's list cut into X3_IDXP_WAVES time ranges, one wavefront each (ranks below X3_IDXP_DMAX, i.e. dictionaries of at most that
+ * many elements): the counters are additive, so the state at the start of a range is the sum of the earlier ranges' counts -- every wavefront
+ * counts its range, a running sum over the wavefronts (in place) turns the counts into start states, the running sums over the ranks follow,
+ * then the tile loop above.  One lone wavefront per stream is a chain of LDS round trips per tile; the ranges overlap them. */
+#define X3_IDXP_WAVES 8u
+#define X3_IDXP_DMAX 512u
+__device__ static void x3_idxstat_par_body(const X3IdxStatArgs &a)
+{
+	X3_LDS uint32_t histw[X3_IDXP_WAVES][X3_IDXP_DMAX];
+	X3_LDS uint32_t prew[X3_IDXP_WAVES][X3_IDXP_DMAX];
+	X3_LDS uint32_t wmax[X3_IDXP_WAVES]; /* largest rank inside the range + 1; 0: the range is empty */
+	const uint32_t c = blockIdx.x, lane = x3_lane(), wv = threadIdx.x / X3_WAVE;
+	const uint32_t i0 = a.ho[c], n = a.evfinal[4 * c + 3];
+	const uint32_t per = (((n + X3_IDXP_WAVES - 1) / X3_IDXP_WAVES) + X3_WAVE - 1) & ~(X3_WAVE - 1);
+	const uint32_t lo = wv * per < n ? wv * per : n, hi = lo + per < n ? lo + per : n;
+	for (uint32_t i = lane; i < X3_IDXP_DMAX; i += X3_WAVE) histw[wv][i] = 0;
+	x3_wave_sync();
+	uint32_t mx = 0;
+	for (uint32_t base = lo; base < hi; base += X3_WAVE) {
+		const bool valid = base + lane < hi;
+		const uint32_t r = valid ? a.lrank[i0 + base + lane] : 0u;
+		if (valid) atomicAdd(&histw[wv][r], 1u);
+		const uint32_t t = wave_max_u32(valid ? r + 1u : 0u);
+		mx = t > mx ? t : mx;
+	}
+	if (lane == 0) wmax[wv] = mx;
+	__syncthreads();
+	for (uint32_t r = threadIdx.x; r < X3_IDXP_DMAX; r += X3_IDXP_WAVES * X3_WAVE) { /* counts of the earlier ranges, in place */
+		uint32_t run = 0;
+		for (uint32_t w = 0; w < X3_IDXP_WAVES; w++) { const uint32_t own = histw[w][r]; histw[w][r] = run; run += own; }
+	}
+	uint32_t seen = 0; /* largest rank before my range, + 1 */
+	for (uint32_t w = 0; w < wv; w++) seen = wmax[w] > seen ? wmax[w] : seen;
+	__syncthreads();
+	if (lo >= hi) return;
+	uint32_t *const hist = histw[wv], *const pre = prew[wv];
+	if (seen) {
+		uint32_t carry = 0;
+		for (uint32_t pb = 0; pb < seen; pb += X3_WAVE) {
+			const uint32_t q = pb + lane;
+			const uint32_t h = q < seen ? hist[q] : 0u;
+			const uint32_t incl = x3_wave_incl_scan_u32(h) + carry;
+			if (q < seen) pre[q] = incl - h;
+			carry = x3_readlane_u32(incl, X3_WAVE - 1);
+		}
+		x3_wave_sync();
+	}
+	x3_idxstat_tiles(a, hist, pre, i0, lo, hi, seen ? seen - 1u : 0u, seen != 0u, lane);
 }
 
 /* ============================================================================================================
@@ -658,6 +715,7 @@ __global__ void __launch_bounds__(X3_WAVE) x3_order0_kernel(X3Order0Args a) { x3
 __global__ void __launch_bounds__(X3_TOK_THREADS) x3_tokens_kernel(X3TokArgs a) { x3_tokens_body(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_idxstat_kernel_s(X3IdxStatArgs a) { x3_idxstat_body<2048>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_idxstat_kernel_l(X3IdxStatArgs a) { x3_idxstat_body<X3_STREAM_DMAX>(a); }
+__global__ void __launch_bounds__(X3_IDXP_WAVES * X3_WAVE) x3_idxstat_par_kernel(X3IdxStatArgs a) { x3_idxstat_par_body(a); }
 __global__ void __launch_bounds__(X3_ARR_THREADS) x3_arrange_kernel(X3ArrangeArgs a) { x3_arrange_body(a); }
 #define X3_LAUNCH1(kern, args, nc, st) hipLaunchKernelGGL(kern, dim3(nc), dim3(X3_WAVE), 0, st, args)
 #else
@@ -666,6 +724,7 @@ static void arrange_tramp(void *p) { x3_arrange_body(*(const X3ArrangeArgs *)p);
 static void tokens_tramp(void *p) { x3_tokens_body(*(const X3TokArgs *)p); }
 static void idxstat_tramp_s(void *p) { x3_idxstat_body<2048>(*(const X3IdxStatArgs *)p); }
 static void idxstat_tramp_l(void *p) { x3_idxstat_body<X3_STREAM_DMAX>(*(const X3IdxStatArgs *)p); }
+static void idxstat_tramp_par(void *p) { x3_idxstat_par_body(*(const X3IdxStatArgs *)p); }
 #define x3_idxstat_kernel_s idxstat_tramp_s
 #define x3_idxstat_kernel_l idxstat_tramp_l
 #define x3_order0_kernel order0_tramp
@@ -749,7 +808,15 @@ int x3_idxstat_run(hipStream_t st, uint32_t nc, uint64_t max_dict, const uint32_
 	a.ho = d_ho; a.evfinal = evfinal; a.lrank = lrank; a.lhit = lhit; a.h_dk = h_dk; a.rfreq = rfreq; a.rcum = rcum; a.itot = itot;
 	uint32_t b = 1; while (b < 32 && (max_dict >> b)) b++;
 	a.dbits_max = b;
-	if (max_dict <= 2048) X3_LAUNCH1(x3_idxstat_kernel_s, a, nc, st);
+	bool par = max_dict <= X3_IDXP_DMAX; /* (a rank is below the stream's dictionary size) */
+	if (const char *e = getenv("X3H_IDX_PAR")) par = par && atoi(e) != 0;
+	if (par) {
+#ifndef X3_EMU
+		hipLaunchKernelGGL(x3_idxstat_par_kernel, dim3(nc), dim3(X3_IDXP_WAVES * X3_WAVE), 0, st, a);
+#else
+		x3emu_launch(idxstat_tramp_par, (void *)&a, dim3(nc), dim3(X3_IDXP_WAVES * X3_WAVE));
+#endif
+	} else if (max_dict <= 2048) X3_LAUNCH1(x3_idxstat_kernel_s, a, nc, st);
 	else X3_LAUNCH1(x3_idxstat_kernel_l, a, nc, st);
 	HIPCHK(hipGetLastError());
 	return X3H_OK;
