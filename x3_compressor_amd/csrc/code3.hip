@@ -544,10 +544,10 @@ __device__ static void x3_idxstat_par_body(const X3IdxStatArgs &a)
  * Token walk.  K2 leaves one word per parse step (tag of the hit element, or fragment length + "already present" flag); the coding
  * stage indexes with running counts over that list: hits / inserted elements / new-fragment bytes / input position before each step
  * (x3.c:394,422: p += len), and needs per-hit and per-touch records (context1 = previous tag or 0 after a new fragment, x3.c:389-390,
- * 424-425).  One workgroup per stream walks its tokens in tiles of 256 with the four counts carried from tile to tile -- instead of
+ * 424-425).  One workgroup per stream walks its tokens in tiles of 1024 with the four counts carried from tile to tile -- instead of
  * four chip-wide scans plus two passes that find every step's stream by binary search.  Counts are stream-relative.
  * ============================================================================================================ */
-#define X3_TOK_THREADS 256u
+#define X3_TOK_THREADS 1024u
 struct X3TokArgs {
 	const X3Chunk *chunks;
 	const X3ParseResult *parsed;
@@ -578,7 +578,7 @@ __device__ static void x3_tokens_body(const X3TokArgs &a)
 		const uint32_t mb = in && (info & X3_TOK_MISS) ? (info & 0x3Fu) : 0u;
 		const uint32_t ln = hit ? (uint32_t)a.dict_len[base + info] : mb;
 		const uint64_t Hm = x3_ballot(hit), Nm = x3_ballot(nw);
-		const uint32_t pk_w = x3_wave_incl_scan_u32(mb | ln << 16); /* both sums stay below 2^16 inside a tile (256 x 32) */
+		const uint32_t pk_w = x3_wave_incl_scan_u32(mb | ln << 16); /* both sums stay below 2^16 inside a tile (1024 x 32) */
 		if (lane == X3_WAVE - 1) { s_w[0][wave] = (uint32_t)x3_popc64(Hm); s_w[1][wave] = (uint32_t)x3_popc64(Nm); s_w[2][wave] = pk_w; }
 		__syncthreads();
 		uint32_t hbw = 0, nbw = 0, pkw = 0, hbt = 0, nbt = 0, pkt = 0;
