@@ -726,7 +726,7 @@ __device__ static __forceinline__ void x3_or_run(uint32_t *out32, uint32_t capw,
  *   bit offset of a thread   = sum scan of the bits the threads write (n + the pending bits in front of each emitting symbol).
  * Then ac_encode_flush (ac.c:115-126), bio_close's word padding (bio.c:105-112) and the stream's result record.
  * ============================================================================================================ */
-#define X3_EMIT_THREADS 256u
+#define X3_EMIT_THREADS 1024u
 #ifndef X3_EMIT_LDSW
 #define X3_EMIT_LDSW 2048u
 #endif                      /* words of a tile's output assembled in LDS (a tile of 2048 symbols emits ~100 words; a tile with more than this ORs straight into memory) */
