@@ -716,7 +716,7 @@ __device__ static __forceinline__ void x3_or_run(uint32_t *out32, uint32_t capw,
 }
 
 /* ============================================================================================================
- * Bit emission for batches of many streams: ONE workgroup per stream walks the stream's symbols in tiles of 256 groups (2048 symbols)
+ * Bit emission for batches of many streams: ONE workgroup per stream walks the stream's symbols in tiles of 1024 groups (8192 symbols)
  * and carries the pending-bit count (mScale, ac.c:49-74) and the bit position from tile to tile -- instead of chip-wide passes
  * (re-run groups, two scans, pending, lengths, scan, OR-writer) over arrays keyed by stream.  Per tile a thread re-runs the eight
  * chain steps of its group from the state x3_ac2_kernel stored (x3_chain_step), keeps (n, emitted bits, k) of its symbols in registers,
@@ -726,10 +726,10 @@ __device__ static __forceinline__ void x3_or_run(uint32_t *out32, uint32_t capw,
  *   bit offset of a thread   = sum scan of the bits the threads write (n + the pending bits in front of each emitting symbol).
  * Then ac_encode_flush (ac.c:115-126), bio_close's word padding (bio.c:105-112) and the stream's result record.
  * ============================================================================================================ */
-#define X3_EMIT_THREADS 1024u
+#define X3_EMIT_THREADS 1024u /* (512: 3.2 ms, 256: 3.4 ms on the 1024-stream mix) */
 #ifndef X3_EMIT_LDSW
-#define X3_EMIT_LDSW 2048u
-#endif                      /* words of a tile's output assembled in LDS (a tile of 2048 symbols emits ~100 words; a tile with more than this ORs straight into memory) */
+#define X3_EMIT_LDSW 4096u
+#endif                      /* words of a tile's output assembled in LDS: 16 bits per symbol of a tile of 8192 (text emits ~1.4); a tile with more ORs straight into memory */
 struct X3EmitArgs {
 	const uint32_t *yoc;        /* nc+1: symbol ranges (no-op symbols already dropped) */
 	const uint4 *sym;           /* per symbol: {cum, freq, magic, shift}               */
