@@ -398,11 +398,15 @@ def test_emulated_stream_kernels_batch_of_52(emu_env, oracle):
     data = np.frombuffer(b"".join(parts), dtype=np.uint8)
     off = np.cumsum([0] + [len(p) for p in parts]).astype(np.uint64)
     # (K1 by one emulated 1024-thread workgroup per chunk costs ~1.5 s a chunk: it has its own tests above, here the chip-wide scan runs)
-    for env in (dict(X3H_SEG_MIN="1000"), dict(X3H_SEG_MIN="1000", X3H_CTX_SUB="3")):
-        streams = emu_env(**env).compress_chunks(data, off, _lib.make_params(**kw))
-        for i, (p, got) in enumerate(zip(parts, streams)):
-            assert got == oracle.compress(p, oracle_lib.params(**kw)), f"{env}: stream {i}"
+    want = [oracle.compress(p, oracle_lib.params(**kw)) for p in parts]
+    streams = emu_env(X3H_SEG_MIN="1000").compress_chunks(data, off, _lib.make_params(**kw))
+    for i, got in enumerate(streams):
+        assert got == want[i], f"stream {i}"
+    # a fixed number of wavefronts per stream in the context kernel, no XCD mapping -- on the first sixteen streams (emulator time)
+    sub = emu_env(X3H_SEG_MIN="1000", X3H_CTX_SUB="3", X3H_CTX_XCD="0", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0").compress_chunks(data[:int(off[16])], off[:17], _lib.make_params(**kw))
+    for i in range(16):
+        assert sub[i] == want[i], f"X3H_CTX_SUB=3: stream {i}"
     # X3H_ARRANGE=1: hits arranged by one workgroup per stream (x3_arrange_kernel) instead of the chip-wide sort -- on the first ten streams (emulator time)
     few = emu_env(X3H_ARRANGE="1", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0").compress_chunks(data[:int(off[10])], off[:11], _lib.make_params(**kw))
     for i in range(10):
-        assert few[i] == oracle.compress(parts[i], oracle_lib.params(**kw)), f"per-stream arrangement: stream {i}"
+        assert few[i] == want[i], f"per-stream arrangement: stream {i}"

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def test_asan_ubsan_selftest():
-    r = subprocess.run(["make", "-C", os.path.join(HERE, "emu"), "asan"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run(["make", "-j8", "-C", os.path.join(HERE, "emu"), "asan"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "asan_selftest ok" in r.stdout
     assert "ERROR: AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr
