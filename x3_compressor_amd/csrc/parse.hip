@@ -31,7 +31,7 @@
 #define X3_LDS_DICT (X3_LDS_HT / 2)      /* ... i.e. at most this many elements */
 #define X3_BLOOM_WORDS 8u
 #ifndef X3_PARSE_HMASK
-#define X3_PARSE_HMASK 0xFFFFFFFFu /* bits of the element hash a candidate must match (the emulator build of the tests keeps 3 bits: collisions, and with them the exact second search, happen all the time) */
+#define X3_PARSE_HMASK 0xFFFFu /* of the 16 hash bits in a table entry, those a candidate must match (the emulator build of the tests keeps 3 bits: collisions, and with them the exact second search, happen all the time) */
 #endif
 static_assert(X3_LDS_DICT < 2048, "a mirror entry holds tag + 1 in 11 bits beside the element's length - 1 in 5");
 
@@ -93,7 +93,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 	X3_LDS uint16_t sAi[PB];   /* anchors of the current walk: cached index where a stride of hits starts ... */
 	X3_LDS uint32_t sAt[PB];   /* ... and the token index of its first hit */
 	/* LDS mirror of the dictionary while it is small (the usual case at large -t): hash table, element position / length */
-	X3_LDS uint16_t sHT[X3_LDS_HT];   /* the table's mirror: 0 = empty, else tag + 1 (11 bits: at most X3_LDS_DICT elements) | (length - 1) << 11 */
+	X3_LDS uint32_t sHT[X3_LDS_HT];   /* the table's mirror: 0 = empty, else tag + 1 (11 bits: at most X3_LDS_DICT elements) | (length - 1) << 11 | (top 16 bits of the element's hash) << 16 */
 	X3_LDS uint32_t sDpos[X3_LDS_DICT];
 	X3_LDS uint8_t sDlen[X3_LDS_DICT];
 	X3_LDS uint2 sD8[X3_LDS_DICT];   /* the first eight bytes of each mirrored element (zero beyond its length): most candidates are settled without touching global memory */
@@ -136,10 +136,11 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 			for (uint32_t i = tid; i < PBL; i += X3_PARSE_THREADS) {
 				uint32_t best = 0, btag = 0;
 				const uint64_t my8 = x3_lds_load8(sb, i); /* the position's first eight bytes, compared with the mirrored elements' */
-				/* Mirrored dictionary: a candidate longer than eight bytes is accepted on its 32-bit hash (sDh, in LDS) and only the LONGEST one is compared
-				 * byte by byte with the element in global memory, once the search is over -- on zero-heavy data every one of 24-32 lengths hits at every
-				 * position, and comparing each of them was 80 % of the parse (config 5: 717 of 900 Mcycles).  Should that one comparison fail (a hash
-				 * collision), the position is searched again with every candidate compared in full: the result is exact either way.
+				/* Mirrored dictionary: a candidate is accepted on the 16 hash bits its table entry carries (one LDS access per probe) and only the LONGEST
+				 * one is compared -- first 8 bytes in LDS, the rest with the element in global memory -- once the search is over.  On zero-heavy data
+				 * every one of 24-32 lengths hits at every position, and comparing each of them was 80 % of the parse (config 5: 717 of 900 Mcycles).
+				 * Should that one comparison fail (a hash collision, ~2^-16 per probe), the position is searched again with every candidate compared in
+				 * full: the result is exact either way.
 				 * (Probing from the longest length down with an early exit -- the hash of l bytes from the hash of l + 1 by undoing an FNV step -- was
 				 * measured too: it walks the hash twice and is slower on text, 8.9 against 8.2 ms per 1024 chunks, and no faster on zero-heavy data.) */
 				for (uint32_t pass = 0; pass < 2; pass++) {
@@ -153,13 +154,13 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 						if (hlog <= X3_LDS_HT_LOG2) { /* wave-uniform: the whole dictionary is mirrored in LDS */
 							const uint64_t m8 = l >= 8 ? ~(uint64_t)0 : (((uint64_t)1 << (8 * l)) - 1);
 							for (uint32_t e = sHT[slot]; e != 0; slot = (slot + 1) & hmask, e = sHT[slot]) {
-								if ((e >> 11) != l - 1) continue; /* the entry carries its element's length: tag + 1 | (length - 1) << 11 */
+								if (((e >> 11) & 31u) != l - 1) continue; /* the entry carries its element's length and 16 bits of its hash */
 								const uint32_t tag = (e & 0x7FFu) - 1;
-								const uint2 d8 = sD8[tag];
-								if ((((uint64_t)d8.x | ((uint64_t)d8.y << 32)) ^ my8) & m8) continue; /* (not this element: an exact table, so the probe goes on) */
-								if (l > 8) {
-									if (pass == 0) { if ((sDh[tag] ^ h) & X3_PARSE_HMASK) continue; }
-									else if (!x3_eq_bytes(b, sDpos[tag] + 8, sb + i + 8, l - 8)) continue;
+								if (pass == 0) { if (((e ^ h) >> 16) & X3_PARSE_HMASK) continue; } /* first search: ONE LDS access per probe, candidates accepted on the hash bits */
+								else {
+									const uint2 d8 = sD8[tag];
+									if ((((uint64_t)d8.x | ((uint64_t)d8.y << 32)) ^ my8) & m8) continue; /* (not this element: an exact table, so the probe goes on) */
+									if (l > 8 && !x3_eq_bytes(b, sDpos[tag] + 8, sb + i + 8, l - 8)) continue;
 								}
 								best = l; btag = tag; break;
 							}
@@ -171,7 +172,11 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 							}
 						}
 					}
-					if (pass == 0 && hlog <= X3_LDS_HT_LOG2 && best > 8 && !x3_eq_bytes(b, sDpos[btag] + 8, sb + i + 8, best - 8)) continue; /* (a collision: once more, exactly) */
+					if (pass == 0 && hlog <= X3_LDS_HT_LOG2 && best) { /* the one candidate that counts, compared in full */
+						const uint2 d8 = sD8[btag];
+						const uint64_t m8 = best >= 8 ? ~(uint64_t)0 : (((uint64_t)1 << (8 * best)) - 1);
+						if (((((uint64_t)d8.x | ((uint64_t)d8.y << 32)) ^ my8) & m8) || (best > 8 && !x3_eq_bytes(b, sDpos[btag] + 8, sb + i + 8, best - 8))) continue; /* (a collision: once more, exactly) */
+					}
 					break;
 				}
 				sL[i] = (uint8_t)best;
@@ -195,7 +200,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 				}
 				if (hlog <= X3_LDS_HT_LOG2) { /* same content as the global table (identical probe order is not needed: exact lookups) */
 					__syncthreads();
-					for (uint32_t i = tid; i <= hmask; i += X3_PARSE_THREADS) { const uint32_t e = ht[i]; sHT[i] = e ? (uint16_t)(e | ((uint32_t)(sDlen[e - 1] - 1u) << 11)) : (uint16_t)0; }
+					for (uint32_t i = tid; i <= hmask; i += X3_PARSE_THREADS) { const uint32_t e = ht[i]; sHT[i] = e ? (e | ((uint32_t)(sDlen[e - 1] - 1u) << 11) | (sDh[e - 1] & 0xFFFF0000u)) : 0u; }
 				}
 			}
 			const uint32_t first = S.p - blk; /* positions before the parse pointer are never read again */
@@ -323,7 +328,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 							uint32_t slot = ht_slot(h, len, hlog);
 							while (ht[slot] != 0) slot = (slot + 1) & hmask;
 							ht[slot] = ntag + 1;
-							if (hlog <= X3_LDS_HT_LOG2) sHT[slot] = (uint16_t)((ntag + 1) | ((len - 1) << 11));
+							if (hlog <= X3_LDS_HT_LOG2) sHT[slot] = (ntag + 1) | ((len - 1) << 11) | (h & 0xFFFF0000u);
 						}
 						S.new_pos = p; S.new_len = len; S.new_tag = ntag; S.rebuild = rebuild;
 					}
