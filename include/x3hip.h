@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define X3H_ABI_VERSION 5 /* 2: x3h_stats grew (mode_iters, chain_symbols, pipelined); 3: X3C1 container + multi-device batch entries; 4: x3h_decompress_chunks_dev; 5: x3h_compress_container_rccl */
+#define X3H_ABI_VERSION 6 /* 2: x3h_stats grew (mode_iters, chain_symbols, pipelined); 3: X3C1 container + multi-device batch entries; 4: x3h_decompress_chunks_dev; 5: x3h_compress_container_rccl; 6: x3h_stats.est_bits + x3h_ctx_set_estimates */
 
 /* status codes (the reference abort()s on every error: file.c:9-18, x3.c:515,547,554,583) */
 enum {
@@ -70,6 +70,9 @@ typedef struct x3h_stats {
 	uint64_t chain_symbols; /* symbols the coder recurrence processed (coded_symbols minus the no-op ones)   */
 	uint64_t pipelined;     /* 1: single-stream schedule with overlapped stages (ms_parse, ms_features,      */
 	                        /*    ms_modes, ms_coder are then per-stage sums that overlap inside ms_total)    */
+	double   est_bits[4];   /* sizes[E_CTX0..E_NEW] of x3.c:43: the estimated code length per event class, -log2f(prob) summed
+	                         * per stream in IEEE single IN CODING ORDER like the reference (x3.c:52-55,192-193,253-266), the streams of a
+	                         * batch added up in double.  Only filled after x3h_ctx_set_estimates(ctx, 1); zeros otherwise.            */
 } x3h_stats;
 
 typedef struct x3h_ctx x3h_ctx; /* one per GPU: device, stream, growable workspace */
@@ -88,6 +91,10 @@ void x3h_ctx_destroy(x3h_ctx *ctx);
  * HBM per input byte of a sub-batch.  A short-lived process (the CLI) wants it small: the driver hands out memory that an earlier process
  * freed at ~40 GB/s only, so a 90 GB workspace costs two seconds right behind another process.  Output does not depend on it.        */
 int  x3h_ctx_set_batch_bytes(x3h_ctx *ctx, uint64_t input_bytes);
+/* on != 0: compress calls on this handle also fill x3h_stats.est_bits (the float size estimates behind the "output stream size",
+ * "codestream size", "est. compression ratio" and "event sizes" lines of x3.c:664-691).  Off by default: the sums are one more
+ * per-stream chain (a float accumulator per event class, in coding order), which runs beside the coder on its own HIP stream.  */
+int  x3h_ctx_set_estimates(x3h_ctx *ctx, int on);
 
 /* Whole path, host buffers.  Replaces   create(); bio_open(); ac_init(); compress(ptr,size,&bio);
  * ac_encode_flush(); bio_close();   (x3.c:562,593-604).  `in` needs no padding (the W zero bytes of

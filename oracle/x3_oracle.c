@@ -11,6 +11,7 @@
 #include "x3_oracle.h"
 
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 
 /* ------------------------------------------------------------------------------------------------
@@ -438,6 +439,7 @@ typedef struct {
 	fmodel m_events, m_len, m_chars, m_index;
 	accoder ac;
 	uint64_t events[X3O_E_LAST];
+	float sizes[4]; /* x3.c:43 */
 	int oom;
 } codec;
 
@@ -524,17 +526,21 @@ static void put_hit(codec *c, bitw *w, uint32_t prev_context1, uint32_t context1
 		fm_inc(&c->m_index, index);
 	}
 	c->events[mode]++;
+	c->sizes[mode] += -log2f(best); /* x3.c:52-55,192-193: prob_to_bits of the chosen product, summed in float */
 	learn_tag(c, c0, c1, context1, tag);
 }
 
 /* encode_match, x3.c:251-270 */
 static void put_new(codec *c, bitw *w, const uint8_t *p, size_t len)
 {
+	c->sizes[X3O_E_NEW] += -log2f(fm_prob(&c->m_events, X3O_E_NEW)); /* x3.c:253,259,264: one term per coded symbol, before the model learns it */
 	fm_encode(&c->ac, w, &c->m_events, X3O_E_NEW);
 	fm_inc(&c->m_events, X3O_E_NEW);
+	c->sizes[X3O_E_NEW] += -log2f(fm_prob(&c->m_len, len - 1));
 	fm_encode(&c->ac, w, &c->m_len, len - 1);
 	fm_inc(&c->m_len, len - 1);
 	for (size_t k = 0; k < len; k++) {
+		c->sizes[X3O_E_NEW] += -log2f(fm_prob(&c->m_chars, p[k]));
 		fm_encode(&c->ac, w, &c->m_chars, p[k]);
 		fm_inc(&c->m_chars, p[k]);
 	}
@@ -720,6 +726,7 @@ static int compress_impl(const x3o_params *prm, const uint8_t *in, size_t n, con
 		stats->dict_elems = c.d.n;
 		stats->ctx0_entries = c.pairs.n;
 		stats->steps = steps;
+		for (int i = 0; i < 4; i++) stats->sizes[i] = c.sizes[i];
 	}
 	free(b);
 	codec_free(&c);

@@ -41,6 +41,8 @@ typedef struct {
 	uint64_t dict_elems;         /* dict_get_elems(), x3.c:693                                  */
 	uint64_t ctx0_entries;       /* tag_pair_get_elems(), x3.c:693                              */
 	uint64_t steps;              /* parse steps = hits + misses (x3.c:669)                      */
+	float    sizes[4];           /* x3.c:43: estimated bits per event class, accumulated in IEEE single IN CODING ORDER:
+	                              * sizes[mode] += -log2f(prob) per hit (x3.c:192-193), per coded symbol of a new fragment (x3.c:253-266) */
 } x3o_stats;
 
 /* Token trace of the parse (one entry per parse step, x3.c:379-429):

@@ -16,7 +16,8 @@ class Params(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("events", C.c_uint64 * 5), ("dict_elems", C.c_uint64), ("ctx0_entries", C.c_uint64), ("steps", C.c_uint64)]
+    _fields_ = [("events", C.c_uint64 * 5), ("dict_elems", C.c_uint64), ("ctx0_entries", C.c_uint64), ("steps", C.c_uint64),
+                ("sizes", C.c_float * 4)]
 
 
 def params(w_kib=8, t=15, m=4, n=0, x=0):

@@ -410,3 +410,31 @@ def test_emulated_stream_kernels_batch_of_52(emu_env, oracle):
     few = emu_env(X3H_ARRANGE="1", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0").compress_chunks(data[:int(off[10])], off[:11], _lib.make_params(**kw))
     for i in range(10):
         assert few[i] == want[i], f"per-stream arrangement: stream {i}"
+
+
+@pytest.mark.parametrize("env", [{}, dict(X3H_PIPE_MIN="1"), dict(X3H_PIPE_MIN="1", X3H_SEG_EMIT="1"), dict(X3H_STREAM_KERNELS="1")],
+                         ids=["stage-after-stage", "pipelined", "pipelined-segment-emit", "stream-kernels"])
+def test_emulated_size_estimates_match_oracle(oracle, monkeypatch, env):
+    """x3h_stats.est_bits (x3h_ctx_set_estimates; x3.c:43,192-193,253-266): the terms made by the symbol assembly pass and summed per stream in coding
+    order by x3_est_kernel, under every schedule -- equal to the oracle's accumulators, which equal the real reference's statistics lines
+    (tests/test_oracle_golden.py).  On the CPU the term -log2(double) -> float and glibc's log2f may differ by an ulp: 1e-6 relative."""
+    subprocess.run(["make", "-C", os.path.join(HERE, "emu")], check=True, capture_output=True)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    with _lib.X3Context(0, library=EMU_SO) as ctx:
+        ctx.set_estimates(True)
+        for data, kw in ((synth.english_like(2600).tobytes(), dict(w_kib=1, t=4)), (synth.zipf_bytes(1500).tobytes(), dict(w_kib=1, t=2)),
+                         (bytes(1200), dict(w_kib=1, t=15)), (b"", dict()), (b"a", dict())):
+            want, ost = oracle.compress(data, oracle_lib.params(**kw), want_stats=True)
+            assert ctx.compress(data, _lib.make_params(**kw)) == want
+            got = list(ctx.last_stats.est_bits)
+            assert all(abs(g - w) <= 1e-6 * max(abs(w), 1.0) for g, w in zip(got, ost.sizes)), (got, list(ost.sizes))
+        parts = [synth.english_like(900, seed=2).tobytes(), b"", b"x", synth.zipf_bytes(800, offset=99).tobytes()]
+        off = np.cumsum([0] + [len(p) for p in parts]).astype(np.uint64)
+        ctx.compress_chunks(np.frombuffer(b"".join(parts), np.uint8), off, _lib.make_params(w_kib=1, t=3))
+        got = list(ctx.last_stats.est_bits)
+        want = [0.0] * 4
+        for p in parts:
+            _, ost = oracle.compress(p, oracle_lib.params(w_kib=1, t=3), want_stats=True)
+            want = [a + float(b) for a, b in zip(want, ost.sizes)]
+        assert all(abs(g - w) <= 1e-6 * max(abs(w), 1.0) for g, w in zip(got, want)), (got, want)

@@ -80,6 +80,51 @@ def test_cli_stdin_stdout_and_statistics(tmp_path, golden):
     assert run(["-z", "-g", "99", str(f), str(tmp_path / "h.x3")]).returncode != 0   # no such device
 
 
+@pytest.mark.parametrize("name", ["gpl16k_default", "cfg1_english64k_w8_t16", "cfg2_english32k_w64_t256", "cfg4_zipf32k_w64_t256", "records_w8_t16", "zeros5000"])
+def test_cli_statistics_block_equals_reference(tmp_path, golden, name):
+    """the whole statistics block of x3.c:662-693 -- the float size estimates included (x3h_stats.est_bits: -log2f(prob) summed in single precision
+    in coding order, x3.c:43,192-193,253-266) -- against the stderr of the REAL reference (oracle/_ref/x3) on the same input: every number within
+    1e-3 relative (the terms differ from glibc's log2f by an ulp now and then), the integer lines character by character."""
+    c = golden[name]
+    ref = golden_util.reference_stderr(c["data"], c["args"])
+    if ref is None:
+        pytest.skip("oracle/_ref/x3 not present")
+    i = tmp_path / "in"
+    i.write_bytes(c["data"])
+    r = run(["-z", *c["args"], str(i), str(tmp_path / "out.x3")])
+    assert r.returncode == 0, r.stderr.decode()
+    mine = r.stderr.decode()
+    got, want = golden_util.estimate_lines_of(mine), golden_util.estimate_lines_of(ref)
+    assert len(got) == len(want) == 4
+    for g, w in zip(got, want):
+        gn, wn = golden_util.numbers_of(g), golden_util.numbers_of(w)
+        assert len(gn) == len(wn) and all(abs(a - b) <= 1e-3 * max(abs(b), 1.0) for a, b in zip(gn, wn)), (g, w)
+    clean = lambda t: [l.replace("\x1b[37;1m", "").replace("\x1b[0m", "") for l in t.splitlines()]
+    for prefix in ("input stream size", "dictionary:", "real compression ratio", "number of events", "context entries"):
+        assert [l for l in clean(mine) if l.startswith(prefix)] == [l for l in clean(ref) if l.startswith(prefix)], prefix
+
+
+def test_cli_says_when_it_writes_a_container_the_reference_cannot_read(tmp_path):
+    """x3.c:577-611 codes any input as ONE stream; this build's longest stream is X3H_MAX_CHUNK (128 MiB): a larger input without --chunk-kib
+    becomes an X3C1 container, and the CLI must say that the reference's `x3 -d` cannot read it.  (zeros: cheap to code, 129 MiB)"""
+    f, z, b = tmp_path / "big", tmp_path / "big.x3", tmp_path / "back"
+    n = (129 << 20) + 5
+    with open(f, "wb") as fh:
+        fh.truncate(n)
+    r = run(["-z", "-w", "8", "-t", "16", str(f)])
+    assert r.returncode == 0, r.stderr.decode()
+    assert b"NOTE" in r.stderr and b"cannot read this output" in r.stderr
+    blob = z.read_bytes()
+    assert blob[:4] == b"X3C1"
+    r = run(["-d", str(z), str(b)])
+    assert r.returncode == 0, r.stderr.decode()
+    assert os.path.getsize(b) == n and not any(open(b, "rb").read(1 << 20))
+    small = tmp_path / "small"
+    small.write_bytes(b"abc" * 1000)
+    r = run(["-z", str(small)])
+    assert r.returncode == 0 and b"NOTE" not in r.stderr
+
+
 def test_cli_large_file_round_trip_pinned_to_reference(tmp_path):
     """a 5 MiB file (> 2 MiB of compressed stream: the raw-stream decode path must size and grow its output buffer within
     X3H_MAX_CHUNK); the stream's sha256 is the REAL reference's (tests/golden/manifest_sha.json)"""

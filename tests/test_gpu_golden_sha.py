@@ -86,6 +86,76 @@ def test_long_streams_decode_back(inputs):
             assert b == d, n
 
 
+PINNED4 = (0, 1, 15, 64, 127)   # chunks of config 4's 128 x 8 MiB Zipf stream with a reference stream in the manifest
+CHUNK4 = 8 << 20
+
+
+def _pinned4(chunk):
+    return MAN[f"cfg4_zipf_chunk{chunk}_8m_w64_t256"]
+
+
+def test_config4_share_in_the_form_that_is_timed():
+    """BASELINE config 4 as bench.py times it on every GPU: ONE batch of 16 x 8 MiB chunks of the Zipf stream (rank 0's share, chunks 0..15), inputs
+    and streams resident in HBM (x3h_compress_chunks_dev), under the DEFAULT schedule -- for this shape the pipelined one with each coder segment's
+    bits written behind it (api.hip run_pipelined, X3H_SEG_EMIT by batch shape).  The pinned chunks 0, 1, 15 must equal the real reference's
+    `x3 -z -w 64 -t 256` of that chunk alone (x3.c:372-434,593-611)."""
+    import numpy as np
+    import torch
+    per = 16
+    data = synth.zipf_bytes(per * CHUNK4)
+    prm = _lib.make_params(w_kib=64, t=256)
+    off = np.arange(0, (per + 1) * CHUNK4, CHUNK4, dtype=np.uint64)
+    stride = (CHUNK4 + (CHUNK4 >> 2) + 4096 + 3) & ~3
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(data).to(dev)
+    d_out = torch.empty(stride * per, dtype=torch.uint8, device=dev)
+    with _lib.X3Context(0) as ctx:
+        lens, st = ctx.compress_chunks_dev(d_in.data_ptr(), off, prm, d_out.data_ptr(), stride)
+        torch.cuda.synchronize()
+        assert st.pipelined == 1, "16 x 8 MiB is a few-long-streams batch: the overlapped schedule is its default"
+        for c in (c for c in PINNED4 if c < per):
+            e = _pinned4(c)
+            got = d_out[c * stride:c * stride + int(lens[c])].cpu().numpy().tobytes()
+            assert len(got) == e["output_len"], f"chunk {c}: {len(got)} bytes, the reference wrote {e['output_len']}"
+            assert hashlib.sha256(got).hexdigest() == e["output_sha256"], f"chunk {c}"
+        # and decoded back as one batch, streams and bytes in HBM
+        ioff = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        d_cmp = torch.cat([d_out[i * stride:i * stride + int(lens[i])] for i in range(per)])
+        d_back = torch.empty(per * CHUNK4, dtype=torch.uint8, device=dev)
+        dl, _ = ctx.decompress_chunks_dev(d_cmp.data_ptr(), ioff, d_back.data_ptr(), off)
+        torch.cuda.synchronize()
+        assert int(dl.sum()) == per * CHUNK4 and torch.equal(d_back, d_in)
+
+
+def test_container_rccl_over_every_gpu_of_the_box():
+    """x3h_compress_container_rccl with ndevices == x3h_device_count(): every GPU codes its contiguous block of config-4 chunks, ONE RCCL
+    send/receive group concatenates the blocks on GPU 0.  Bytes must equal the host-staged container's, and the pinned chunks the real
+    reference's streams.  Skipped on a one-GPU box (the one-rank self-send is test_container_through_rccl_equals_host_staged_container)."""
+    lib = _lib.load_library()
+    ndev = int(lib.x3h_device_count())
+    if ndev < 2:
+        pytest.skip("one GPU: the multi-rank gather cannot run here")
+    ndev = min(ndev, 8)
+    per = 2  # chunks per GPU: 16 MiB each, the pinned chunks 0 and 1 are on GPU 0
+    data = synth.zipf_bytes(ndev * per * CHUNK4).tobytes()
+    prm = _lib.make_params(w_kib=64, t=256)
+    ctxs = [_lib.X3Context(d) for d in range(ndev)]
+    try:
+        got = _lib.compress_container(ctxs, data, prm, CHUNK4, rccl=True)
+        want = _lib.compress_container(ctxs, data, prm, CHUNK4)
+        assert got == want
+        from x3_compressor_amd import container
+        _, chunks = container.unpack(got)
+        assert len(chunks) == ndev * per
+        for c in (c for c in PINNED4 if c < len(chunks)):
+            assert hashlib.sha256(chunks[c][1]).hexdigest() == _pinned4(c)["output_sha256"], f"chunk {c}"
+        assert _lib.decompress_container(ctxs, got, len(data)) == data
+    finally:
+        lib.x3h_rccl_release()
+        for c in ctxs:
+            c.close()
+
+
 def test_window_smaller_than_input_cases_are_distinct():
     """the small cfg3/cfg5 vectors of manifest.json are the same bytes (16 KiB inside either window); these are not"""
     assert len({MAN[n]["output_sha256"] for n in CASES}) == len(CASES)

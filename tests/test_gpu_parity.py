@@ -90,6 +90,38 @@ def test_stream_equals_oracle_on_seeded_input(gpu, oracle, name, make, kw):
     assert gs.ctx0_entries == st.ctx0_entries and gs.steps == st.steps
 
 
+@pytest.mark.parametrize("env", [{}, dict(X3H_PIPE_MIN="1"), dict(X3H_PIPE_MIN="1", X3H_SEG_EMIT="1"), dict(X3H_STREAM_KERNELS="1")],
+                         ids=["stage-after-stage", "pipelined", "pipelined-segment-emit", "stream-kernels"])
+def test_size_estimates_equal_oracle(gpu_env, oracle, env):
+    """x3h_stats.est_bits (x3h_ctx_set_estimates): the reference's float accumulators sizes[] (x3.c:43,192-193,253-266) under every schedule.
+    The oracle's are bit-identical to the real reference's (tests/test_oracle_golden.py); the GPU's terms are -log2 in double rounded to single, which
+    differs from glibc's log2f by an ulp once in a while: 1e-6 relative."""
+    ctx = gpu_env(**env)
+    ctx.set_estimates(True)
+    for data, kw in ((synth.english_like(200_000, seed=3).tobytes(), dict(w_kib=8, t=16)),
+                     (synth.zipf_bytes(120_000, offset=7 << 20).tobytes(), dict(w_kib=64, t=256)),
+                     (synth.mr_like(150_000, seed=5).tobytes(), dict(w_kib=8, t=15)), (b"", dict()), (b"a", dict())):
+        want, ost = oracle.compress(data, oracle_lib.params(**kw), want_stats=True)
+        assert ctx.compress(data, _lib.make_params(**kw)) == want
+        got = list(ctx.last_stats.est_bits)
+        for g, w in zip(got, ost.sizes):
+            assert abs(g - w) <= 1e-6 * max(abs(w), 1.0), (got, list(ost.sizes))
+    # a batch: the streams' accumulators added up
+    text = synth.english_like(300_000, seed=11)
+    off = np.array([0, 100_000, 100_000, 220_000, 300_000], dtype=np.uint64)
+    prm = _lib.make_params(w_kib=8, t=16)
+    ctx.compress_chunks(text, off, prm)
+    got = list(ctx.last_stats.est_bits)
+    want = [0.0] * 4
+    for i in range(4):
+        _, ost = oracle.compress(text[int(off[i]):int(off[i + 1])].tobytes(), oracle_lib.params(w_kib=8, t=16), want_stats=True)
+        want = [a + float(b) for a, b in zip(want, ost.sizes)]
+    assert all(abs(g - w) <= 1e-6 * max(abs(w), 1.0) for g, w in zip(got, want)), (got, want)
+    ctx.set_estimates(False)
+    ctx.compress(text[:50_000], prm)
+    assert list(ctx.last_stats.est_bits) == [0.0] * 4
+
+
 def test_chunks_are_independent_streams(gpu, oracle):
     """chunk output == `x3 -z` of that chunk alone; ragged sizes incl. an empty chunk."""
     data = synth.english_like(70000).tobytes()

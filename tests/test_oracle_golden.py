@@ -33,6 +33,18 @@ def test_closed_form_m_equals_faithful_selection(oracle, golden, name):
     assert oracle.compress(c["data"], prm, via_m=m) == c["expect"]
 
 
+@pytest.mark.parametrize("name", [n for n in CASES if n not in SLOW and n != "empty"])
+def test_oracle_size_estimates_equal_reference_statistics(oracle, golden, name):
+    """x3.c:43,192-193,253-266: the four float accumulators `sizes[]` (one -log2f(prob) per hit / per coded symbol of a new fragment, summed in
+    single precision in coding order) -- the oracle's must reproduce the REAL reference's four statistics lines character by character."""
+    c = golden[name]
+    err = golden_util.reference_stderr(c["data"], c["args"])
+    if err is None:
+        pytest.skip("oracle/_ref/x3 not built (needs /root/reference)")
+    _, st = oracle.compress(c["data"], oracle_lib.params_from_args(c["args"]), want_stats=True)
+    assert golden_util.estimate_lines_from_sizes(list(st.sizes), len(c["data"])) == golden_util.estimate_lines_of(err)
+
+
 def test_trace_is_consistent(oracle, golden):
     c = golden["gpl16k_default"]
     prm = oracle_lib.params_from_args(c["args"])

@@ -20,13 +20,13 @@ ABI_SYMBOLS = (
     "x3h_compress_chunks_dev", "x3h_decompress", "x3h_decompress_chunks", "x3h_decompress_chunks_dev", "x3h_scan_m", "x3h_scan_counts", "x3h_parse",
     "x3h_compress_chunks_multi", "x3h_decompress_chunks_multi", "x3h_container_header_bytes", "x3h_container_write_header",
     "x3h_container_probe", "x3h_container_table", "x3h_container_bound", "x3h_compress_container", "x3h_decompress_container",
-    "x3h_coder_chain", "x3h_compress_container_rccl", "x3h_rccl_release", "x3h_ctx_set_batch_bytes",
+    "x3h_coder_chain", "x3h_compress_container_rccl", "x3h_rccl_release", "x3h_ctx_set_batch_bytes", "x3h_ctx_set_estimates",
 )
 
 TOK_MISS, TOK_DUP = 0x80000000, 0x40000000
 
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 NOT_A_CONTAINER = 1  # x3h_container_probe: the bytes are one raw x3 stream
 
 
@@ -40,11 +40,12 @@ class Stats(C.Structure):
                 ("steps", C.c_uint64), ("ms_total", C.c_double), ("ms_scan", C.c_double), ("ms_parse", C.c_double),
                 ("ms_code", C.c_double), ("ms_copy", C.c_double), ("ms_features", C.c_double), ("ms_modes", C.c_double),
                 ("ms_coder", C.c_double), ("ms_emit", C.c_double), ("coded_symbols", C.c_uint64), ("mode_iters", C.c_int64),
-                ("chain_symbols", C.c_uint64), ("pipelined", C.c_uint64)]
+                ("chain_symbols", C.c_uint64), ("pipelined", C.c_uint64), ("est_bits", C.c_double * 4)]
 
     def as_dict(self):
-        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "events"}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("events", "est_bits")}
         d["events"] = list(self.events)
+        d["est_bits"] = list(self.est_bits)
         return d
 
 
@@ -103,6 +104,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     lib.x3h_compress_container_rccl.argtypes = lib.x3h_compress_container.argtypes
     lib.x3h_rccl_release.restype = None
     lib.x3h_ctx_set_batch_bytes.argtypes = [C.c_void_p, C.c_uint64]
+    lib.x3h_ctx_set_estimates.argtypes = [C.c_void_p, C.c_int]
     return lib
 
 
@@ -153,6 +155,10 @@ class X3Context:
 
     def __exit__(self, *exc):
         self.close()
+
+    def set_estimates(self, on: bool = True):
+        """x3h_ctx_set_estimates: compress calls also fill Stats.est_bits (the float size estimates of x3.c:43,192-193,253-266)."""
+        self._check(self.lib.x3h_ctx_set_estimates(self._h, 1 if on else 0))
 
     def _check(self, status):
         if status != 0:

@@ -156,6 +156,13 @@ extern "C" int x3h_ctx_set_batch_bytes(x3h_ctx *c, uint64_t input_bytes)
 	return X3H_OK;
 }
 
+extern "C" int x3h_ctx_set_estimates(x3h_ctx *c, int on)
+{
+	if (!c) return X3H_E_ARG;
+	c->c2.want_est = on != 0;
+	return X3H_OK;
+}
+
 extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 {
 	if (!c) return;
@@ -168,6 +175,8 @@ extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 	for (DevBuf *b : bufs) b->release();
 	c->coder_state.release(); c->prefix_result.release(); c->srcoff.release(); c->ckpt_pos.release(); c->seg.meta.release(); c->seg.modes_state.release(); c->seg.mode_prev.release();
 	c->c2.yfin.release(); c->c2.yfinrec.release();
+	c->c2.est_val.release(); c->c2.est_cls.release(); c->c2.est_out.release();
+	if (c->c2.est_stream) { (void)hipStreamSynchronize(c->c2.est_stream); (void)hipStreamDestroy(c->c2.est_stream); (void)hipEventDestroy(c->c2.ev_est_fork); (void)hipEventDestroy(c->c2.ev_est_done); }
 	if (c->ckpt) (void)hipHostFree((void *)c->ckpt);
 	if (c->s_parse) (void)hipStreamDestroy(c->s_parse);
 	if (c->s_coder) (void)hipStreamDestroy(c->s_coder);
@@ -535,9 +544,16 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 		                   sa.bytes, tok_pos, pa.tok_info, tok_hb, tok_nb, tok_mb, d_out, c->cresult.as<X3CodeResult>(), nullptr,
 		                   tokens_in_code ? pa.dict_len : nullptr));
 	}
+	std::vector<float> hest;
+	if (c->c2.est_pending) { /* the size estimates ran beside the coder on their own stream */
+		HIPCHK(hipStreamWaitEvent(c->stream, c->c2.ev_est_done, 0));
+		c->c2.est_pending = false;
+		hest.resize((size_t)nc * 4);
+	}
 	HIPCHK(hipEventRecord(c->ev[5], c->stream));
 	c->hcode.resize((size_t)nc);
 	HIPCHK(hipMemcpyAsync(c->hcode.data(), c->cresult.p, (size_t)nc * sizeof(X3CodeResult), hipMemcpyDeviceToHost, c->stream));
+	if (!hest.empty()) HIPCHK(hipMemcpyAsync(hest.data(), c->c2.est_out.p, hest.size() * 4, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 
 	int rc = X3H_OK;
@@ -562,6 +578,7 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 			stats->dict_elems += c->hparse[(size_t)i].dict_elems;
 			stats->ctx0_entries += c->hcode[(size_t)i].pairs;
 			stats->steps += c->hparse[(size_t)i].ntok;
+			if (!hest.empty()) for (int e = 0; e < 4; e++) stats->est_bits[e] += (double)hest[(size_t)i * 4 + e];
 		}
 		float ms = 0;
 		(void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); stats->ms_copy = ms;
@@ -600,6 +617,7 @@ static void stats_add(x3h_stats &acc, const x3h_stats &part)
 	acc.ms_total += part.ms_total; acc.ms_scan += part.ms_scan; acc.ms_parse += part.ms_parse; acc.ms_code += part.ms_code; acc.ms_copy += part.ms_copy;
 	acc.ms_features += part.ms_features; acc.ms_modes += part.ms_modes; acc.ms_coder += part.ms_coder; acc.ms_emit += part.ms_emit;
 	acc.mode_iters += part.mode_iters; acc.chain_symbols += part.chain_symbols; acc.pipelined |= part.pipelined;
+	for (int e = 0; e < 4; e++) acc.est_bits[e] += part.est_bits[e];
 }
 
 static int run(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage upto, x3h_stats *stats)

@@ -25,6 +25,7 @@
  */
 #include "x3_host.h"
 
+#include <math.h>
 #include <vector>
 
 #define NONE32 0xFFFFFFFFu
@@ -1051,6 +1052,46 @@ static int modes_fixed_point(X3Code2Bufs &B, hipStream_t st, size_t nH, uint32_t
 }
 
 /* ============================================================================================================
+ * Size estimates (the reference's `sizes[]`, x3.c:43): sizes[mode] += -log2f(prob) per hit (x3.c:52-55,192-193) and per coded symbol of a
+ * new fragment (x3.c:253-266), accumulated in IEEE single IN CODING ORDER -- float addition is not associative, and past 2^24 bits the
+ * reference's accumulator drops every term below half an ulp, which the printed estimates inherit.  The terms are made by the symbol
+ * assembly pass (x3_est_term: the same float expression as the mode choice, -log2 in double rounded to single); here one wavefront per
+ * stream replays the four accumulators: 64 terms are loaded at once, then taken lane by lane in order.
+ * ============================================================================================================ */
+#define X3_EST_NONE 0xFFu
+__device__ static __forceinline__ float x3_est_term(float prob) { return (float)(-log2((double)prob)); }
+
+struct X3EstArgs { const uint32_t *range; const float *val; const uint8_t *cls; float *out; };
+
+__device__ static void x3_est_body(const X3EstArgs &a)
+{
+	const uint32_t c = blockIdx.x, lane = x3_lane();
+	const uint32_t y0 = a.range[c], y1 = a.range[c + 1];
+	float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+	for (uint32_t base = y0; base < y1; base += X3_WAVE) {
+		const uint32_t y = base + lane;
+		const uint32_t k = y < y1 ? a.cls[y] : X3_EST_NONE;
+		const float v = k != X3_EST_NONE ? a.val[y] : 0.f;
+		uint64_t m = x3_ballot(k != X3_EST_NONE);
+		while (m) {
+			const uint32_t l = (uint32_t)x3_ctz64(m);
+			m &= m - 1;
+			const uint32_t kl = x3_readlane_u32(k, l);
+			const float vl = __uint_as_float(x3_readlane_u32(__float_as_uint(v), l));
+			if (kl == 0) acc0 += vl; else if (kl == 1) acc1 += vl; else if (kl == 2) acc2 += vl; else acc3 += vl;
+		}
+	}
+	if (lane == 0) { float *o = a.out + 4 * (size_t)c; o[0] = acc0; o[1] = acc1; o[2] = acc2; o[3] = acc3; }
+}
+#ifndef X3_EMU
+__global__ void __launch_bounds__(X3_WAVE) x3_est_kernel(X3EstArgs a) { x3_est_body(a); }
+static void launch_est(const X3EstArgs &a, uint32_t nchunks, hipStream_t st) { hipLaunchKernelGGL(x3_est_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, a); }
+#else
+static void est_tramp(void *p) { x3_est_body(*(const X3EstArgs *)p); }
+static void launch_est(const X3EstArgs &a, uint32_t nchunks, hipStream_t) { x3emu_launch(est_tramp, (void *)&a, dim3(nchunks), dim3(X3_WAVE)); }
+#endif
+
+/* ============================================================================================================
  * K2 post-pass: the parse walker only emits one word per step (tag or fragment length); positions and the running
  * counts the coding stage indexes with are prefix sums over that list.
  *   tok_pos = sum of earlier step lengths (dict_len of the tag / fragment length)      (x3.c:394,422: p += len)
@@ -1571,6 +1612,15 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	}
 	uint4 *sdst = seg ? syr : sy;
 	const bool direct = !seg;
+	/* size estimates (optional): one term per coded symbol slot of this layout, written by the assembly pass below */
+	const bool est = B.want_est && final;
+	float *est_val = nullptr;
+	uint8_t *est_cls = nullptr;
+	if (B.want_est) { /* (sized on every call of a growing prefix, filled by the final one: nothing is reallocated while the coder runs) */
+		CHK(B.est_val.reserve((nYres + 4) * 4)); CHK(B.est_cls.reserve(nYres + 4)); CHK(B.est_out.reserve((size_t)nc * 16 + 16));
+		if (!B.est_stream) { HIPCHK(hipStreamCreate(&B.est_stream)); HIPCHK(hipEventCreate(&B.ev_est_fork)); HIPCHK(hipEventCreate(&B.ev_est_done)); }
+		if (est) { est_val = B.est_val.as<float>(); est_cls = B.est_cls.as<uint8_t>(); HIPCHK(hipMemsetAsync(est_cls, X3_EST_NONE, nY + 4, st)); }
+	}
 	x3_foreach(nS, st, X3_LAMBDA(size_t gs) {
 		const uint32_t c = find_chunk(d_so, nc, (uint32_t)gs);
 		const uint32_t k = (uint32_t)gs - d_so[c];
@@ -1584,22 +1634,36 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 			const uint32_t gh = d_ho[c] + hb, m = mode[gh], e0 = pe0[gh], e1 = pe1[gh];
 			const uint32_t e2 = 2049u + hb - e0 - e1; /* every hit bumps exactly one of the three */
 			sdst[yi] = x3_make_symbol(m == X3_E_CTX0 ? 0u : m == X3_E_CTX1 ? e0 : e0 + e1, m == X3_E_CTX0 ? e0 : m == X3_E_CTX1 ? e1 : e2, evtotal);
+			uint32_t tfq, tto;
 			if (inplace) {
 				uint32_t cu, fq, to;
 				if (m == X3_E_CTX0) { const uint4 r = recs0[gh]; cu = r.z; fq = r.x; to = r.y; }
 				else if (m == X3_E_CTX1) { const uint4 r = recs1[gh]; cu = r.z; fq = r.x; to = r.y; }
 				else { cu = rcum[gh]; fq = rfreq[gh]; to = itot[gh]; }
 				if (to > 1u) sdst[yi + 1] = x3_make_symbol(cu, fq, to);
-			} else
-			if (!direct || hs_tot[gh] > 1u) sdst[yi + 1] = x3_make_symbol(hs_cum[gh], hs_freq[gh], hs_tot[gh]);
+				tfq = fq; tto = to;
+			} else {
+				if (!direct || hs_tot[gh] > 1u) sdst[yi + 1] = x3_make_symbol(hs_cum[gh], hs_freq[gh], hs_tot[gh]);
+				tfq = hs_freq[gh]; tto = hs_tot[gh];
+			}
+			if (est_cls) { /* x3.c:152-172,192-193: the chosen product, evaluated as the reference evaluates it */
+				const float pe = (float)(m == X3_E_CTX0 ? e0 : m == X3_E_CTX1 ? e1 : e2) / (float)evtotal;
+				est_val[yi] = x3_est_term(pe * ((float)tfq / (float)tto));
+				est_cls[yi] = (uint8_t)m;
+			}
 		} else {
 			const uint32_t len = info & 0x3Fu, mk = k - hb; /* mk = new fragments before this one */
 			sdst[yi] = x3_make_symbol(2049u + hb, 1u + mk, evtotal); /* E_NEW */
 			const uint32_t gm = d_mo[c] + mk;
 			sdst[yi + 1] = x3_make_symbol((len - 1) + lsm[gm], 1u + leq[gm], 32u + mk);
+			if (est_cls) { /* x3.c:253,259: event and length symbol */
+				est_val[yi] = x3_est_term((float)(1u + mk) / (float)evtotal); est_cls[yi] = X3_E_NEW;
+				est_val[yi + 1] = x3_est_term((float)(1u + leq[gm]) / (float)(32u + mk)); est_cls[yi + 1] = X3_E_NEW;
+			}
 			for (uint32_t j = 0; j < len; j++) {
 				const uint32_t gb = d_bo[c] + mb + j;
 				sdst[yi + 2 + j] = x3_make_symbol(bval[gb] + bsm[gb], 1u + beq[gb], 256u + mb + j);
+				if (est_cls) { est_val[yi + 2 + j] = x3_est_term((float)(1u + beq[gb]) / (float)(256u + mb + j)); est_cls[yi + 2 + j] = X3_E_NEW; } /* x3.c:264 */
 			}
 		}
 	});
@@ -1607,6 +1671,17 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		const uint32_t yi = (direct ? d_yoc[c + 1] : d_yo[c + 1]) - 1, evtotal = 2051u + d_parsed[c].ntok;
 		sdst[yi] = x3_make_symbol(evtotal - 1, 1, evtotal);
 	});
+	B.est_pending = false;
+	if (est) { /* the four float accumulators of every stream, on their own HIP stream beside the coder; api.hip joins it (est_pending) */
+		X3EstArgs ea;
+		ea.range = direct ? d_yoc : d_yo; ea.val = est_val; ea.cls = est_cls; ea.out = B.est_out.as<float>();
+		HIPCHK(hipEventRecord(B.ev_est_fork, st));
+		HIPCHK(hipStreamWaitEvent(B.est_stream, B.ev_est_fork, 0));
+		launch_est(ea, nc, B.est_stream);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipEventRecord(B.ev_est_done, B.est_stream));
+		B.est_pending = true;
+	}
 
 	uint32_t *kf = Yv[5], *Pk = Yv[6];
 	if (seg) {

@@ -126,6 +126,12 @@ struct X3Code2Bufs {
 	DevBuf yfin, yfinrec; /* pipelined schedule, final call: operands / chain states gathered into the final symbol layout */
 	DevBuf pp[4]; /* token post-pass temporaries */
 	DevBuf ms[16]; /* u32 arrays over new-fragment lengths / bytes */
+	/* size estimates (x3h_ctx_set_estimates; x3.c:43,192-193,253-266): one float term and one class byte per coded symbol, summed per stream and
+	 * class in coding order by x3_est_kernel on its own HIP stream (beside the coder); est_out = 4 floats per stream */
+	bool want_est = false, est_pending = false;
+	DevBuf est_val, est_cls, est_out;
+	hipStream_t est_stream = nullptr;
+	hipEvent_t ev_est_fork = nullptr, ev_est_done = nullptr;
 };
 
 
