@@ -43,7 +43,7 @@ def test_library_is_gfx950_only():
 
 
 def test_scalar_entry_points(lib):
-    assert lib.x3h_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.x3h_abi_version() == _lib.ABI_VERSION == 6
     assert lib.x3h_strerror(0) == b"ok" and b"output" in lib.x3h_strerror(-3)
     assert lib.x3h_compress_bound(0) >= 4 and lib.x3h_compress_bound(1000) >= 2000
     p = _lib.Params()
