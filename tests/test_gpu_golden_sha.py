@@ -36,9 +36,15 @@ def inputs():
     return get
 
 
-@pytest.mark.parametrize("env", [{}, {"X3H_PIPE_MIN": "0"}], ids=["default-schedule", "stage-after-stage"])
-@pytest.mark.parametrize("name", CASES)
-def test_stream_sha_equals_reference(monkeypatch, inputs, name, env):
+SCHEDULES = {"default-schedule": {}, "stage-after-stage": {"X3H_PIPE_MIN": "0"}, "prefix-wise-pipelined": {"X3H_SLICED": "0"}}
+# every case under the default schedule (K3 in slices for these sizes) and stage after stage; the prefix-wise pipelined schedule of rounds 1-3 (what a
+# dictionary beyond the sliced kernels' tables falls back to) on the cases that take seconds, not minutes
+RUNS = [(n, s) for n in CASES for s in ("default-schedule", "stage-after-stage")] + [(n, "prefix-wise-pipelined") for n in CASES if n not in LONG]
+
+
+@pytest.mark.parametrize("name,sched", RUNS, ids=[f"{s}-{n}" for n, s in RUNS])
+def test_stream_sha_equals_reference(monkeypatch, inputs, name, sched):
+    env = SCHEDULES[sched]
     e = MAN[name]
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -48,9 +54,11 @@ def test_stream_sha_equals_reference(monkeypatch, inputs, name, env):
     assert len(got) == e["output_len"], f"{name}: {len(got)} bytes, the reference wrote {e['output_len']}"
     assert hashlib.sha256(got).hexdigest() == e["output_sha256"]
     if not env and e["input_len"] >= (256 << 10):
-        assert st.pipelined == 1
-    if env:
+        assert st.pipelined in (1, 2)   # an overlapped schedule: 2 = in slices with carried state (code4.hip), 1 = prefix-wise (run_pipelined)
+    if env.get("X3H_PIPE_MIN") == "0":
         assert st.pipelined == 0
+    if env.get("X3H_SLICED") == "0" and e["input_len"] >= (256 << 10):
+        assert st.pipelined == 1
     if name in PAST_2_24:
         # model_events.total = 2051 + steps is no longer exact as a float here (x3.c:152-172,236-244; ac.c:108-113)
         assert st.steps > (1 << 24), st.steps
@@ -96,8 +104,8 @@ def _pinned4(chunk):
 
 def test_config4_share_in_the_form_that_is_timed():
     """BASELINE config 4 as bench.py times it on every GPU: ONE batch of 16 x 8 MiB chunks of the Zipf stream (rank 0's share, chunks 0..15), inputs
-    and streams resident in HBM (x3h_compress_chunks_dev), under the DEFAULT schedule -- for this shape the pipelined one with each coder segment's
-    bits written behind it (api.hip run_pipelined, X3H_SEG_EMIT by batch shape).  The pinned chunks 0, 1, 15 must equal the real reference's
+    and streams resident in HBM (x3h_compress_chunks_dev), under the DEFAULT schedule -- for this shape K3 in slices with carried state (code4.hip, api.hip run_sliced:
+    parse | feature stages | coder | bit emission of a stream's slices overlap on four HIP streams).  The pinned chunks 0, 1, 15 must equal the real reference's
     `x3 -z -w 64 -t 256` of that chunk alone (x3.c:372-434,593-611)."""
     import numpy as np
     import torch
@@ -112,7 +120,7 @@ def test_config4_share_in_the_form_that_is_timed():
     with _lib.X3Context(0) as ctx:
         lens, st = ctx.compress_chunks_dev(d_in.data_ptr(), off, prm, d_out.data_ptr(), stride)
         torch.cuda.synchronize()
-        assert st.pipelined == 1, "16 x 8 MiB is a few-long-streams batch: the overlapped schedule is its default"
+        assert st.pipelined == 2, "16 x 8 MiB is a few-long-streams batch: the sliced, overlapped schedule is its default"
         for c in (c for c in PINNED4 if c < per):
             e = _pinned4(c)
             got = d_out[c * stride:c * stride + int(lens[c])].cpu().numpy().tobytes()

@@ -51,12 +51,23 @@ struct x3h_ctx {
 	                    * segment by chip-wide passes, -1 = by the batch: 8 or more streams of at most 16 MiB (config 4's shape) measured 8 ms faster the
 	                    * first way, one or a few longer streams 6-60 ms faster the second (X3H_SEG_EMIT overrides) */
 	hipEvent_t ev_p0 = nullptr, ev_p1 = nullptr, ev_ready = nullptr, ev_cb[X3_MAX_CKPT + 1] = {}, ev_ce[X3_MAX_CKPT + 1] = {};
+	/* K3 in slices (code4.hip; run_sliced): the default overlapped schedule wherever every stream's dictionary fits the per-stream LDS tables */
+	int sliced = 1;                               /* X3H_SLICED=0: never */
+	uint64_t sliced_min = (uint64_t)96 << 10;     /* X3H_SLICED_MIN: longest stream of the batch at least this long */
+	int sliced_max_streams = 192;                 /* X3H_SLICED_STREAMS: beyond, every CU has a stream of every stage anyway (stage after stage) */
+	double slice_marks[X3_MAX_CKPT] = { 0.02, 0.05, 0.10, 0.17, 0.26, 0.36, 0.47, 0.59, 0.72, 0.86 }; /* X3H_SLICE_MARKS: small slices first (the coder starts early), then ~12 % each */
+	uint32_t slice_nmarks = 10;
+	X3SliceRun sr;
+	hipEvent_t ev_sf[X3S_MAX_SLICES + 2] = {}, ev_sb[X3S_MAX_SLICES + 2] = {}, ev_se[X3S_MAX_SLICES + 2] = {}, ev_s0 = nullptr;
+	hipStream_t s_side = nullptr;
+	hipEvent_t ev_sfork = nullptr, ev_sjoin = nullptr;
 	X3ParseCkpt *ckpt = nullptr; /* host-mapped, X3_CKPT_SLOTS per stream */
 	uint32_t ckpt_cap = 0;
 	X3CodeSeg seg;
 	DevBuf coder_state, prefix_result, srcoff, ckpt_pos;
 	uint64_t batch_bytes = (uint64_t)512 << 20; /* X3H_BATCH_BYTES: input bytes of one sub-batch (the workspace is ~350 B per input byte) */
 	uint64_t dec_batch_bytes = (uint64_t)512 << 20; /* X3H_DEC_BATCH_BYTES */
+	bool dec_batch_from_env = false;
 	uint64_t batch_pad_bytes = (uint64_t)2 << 30; /* X3H_BATCH_PAD_BYTES: padded layout of one sub-batch (K1 needs < 2^32 - 256) */
 	uint64_t pad_total = 0;
 	DevBuf mtf, idxfreq, ctx1, ctx0, items, pkey, pval, out, counts;
@@ -126,7 +137,7 @@ extern "C" int x3h_ctx_create(x3h_ctx **out, int device)
 	c->device = device;
 	{ const char *e = getenv("X3H_SCAN_V1"); c->scan_v1 = e && *e && *e != '0'; }
 	{ const char *e = getenv("X3H_BATCH_BYTES"); if (e && atoll(e) > 0) c->batch_bytes = (uint64_t)atoll(e); }
-	{ const char *e = getenv("X3H_DEC_BATCH_BYTES"); if (e && atoll(e) > 0) c->dec_batch_bytes = (uint64_t)atoll(e); }
+	{ const char *e = getenv("X3H_DEC_BATCH_BYTES"); if (e && atoll(e) > 0) { c->dec_batch_bytes = (uint64_t)atoll(e); c->dec_batch_from_env = true; } }
 	{ const char *e = getenv("X3H_BATCH_PAD_BYTES"); if (e && atoll(e) > 0) c->batch_pad_bytes = (uint64_t)atoll(e); }
 	if (c->batch_pad_bytes > 0xF0000000ull) c->batch_pad_bytes = 0xF0000000ull;
 	{ const char *e = getenv("X3H_PIPE_MIN"); if (e && *e) c->pipe_min = (uint64_t)atoll(e); }
@@ -137,6 +148,15 @@ extern "C" int x3h_ctx_create(x3h_ctx **out, int device)
 		if (ok && k && !*q) { for (uint32_t i = 0; i < k; i++) c->pipe_marks[i] = m[i]; c->pipe_nmarks = k; }
 	  } }
 	{ const char *e = getenv("X3H_PIPE_STREAMS"); if (e && *e) c->pipe_max_streams = atoi(e); }
+	{ const char *e = getenv("X3H_SLICED"); if (e && *e) c->sliced = *e != '0'; }
+	{ const char *e = getenv("X3H_SLICED_MIN"); if (e && *e) c->sliced_min = (uint64_t)atoll(e); }
+	{ const char *e = getenv("X3H_SLICED_STREAMS"); if (e && *e) c->sliced_max_streams = atoi(e); }
+	{ const char *e = getenv("X3H_SLICE_MARKS");
+	  if (e && *e) {
+		double m[X3_MAX_CKPT]; uint32_t k = 0; const char *q = e; bool ok = true;
+		while (*q && k < X3_MAX_CKPT) { char *end = nullptr; const double v = strtod(q, &end); if (end == q || v <= (k ? m[k - 1] : 0.0) || v >= 1.0) { ok = false; break; } m[k++] = v; q = end; if (*q == ',') q++; }
+		if (ok && k && !*q) { for (uint32_t i = 0; i < k; i++) c->slice_marks[i] = m[i]; c->slice_nmarks = k; }
+	  } }
 	{ const char *e = getenv("X3H_SEG_EMIT"); if (e && *e) c->seg_emit = *e != '0' ? 1 : 0; }
 	const double t_c2 = x3_now_ms();
 	if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return X3H_E_HIP; }
@@ -151,8 +171,11 @@ extern "C" int x3h_ctx_create(x3h_ctx **out, int device)
 extern "C" int x3h_ctx_set_batch_bytes(x3h_ctx *c, uint64_t input_bytes)
 {
 	if (!c || input_bytes < ((uint64_t)1 << 20)) return X3H_E_ARG;
+	if (input_bytes > ((uint64_t)1 << 40)) input_bytes = (uint64_t)1 << 40; /* more than any GPU holds: "no sub-batches" */
 	c->batch_bytes = input_bytes;
-	c->dec_batch_bytes = 2 * input_bytes; /* the decoder cuts on output capacity, at ~150 B of workspace per byte; its rate is streams in flight x the per-stream rate */
+	/* the decoder cuts on output capacity, at ~150 B of workspace per byte; its rate is streams in flight x the per-stream rate.  An explicit
+	 * X3H_DEC_BATCH_BYTES from the environment stays in force. */
+	if (!c->dec_batch_from_env) c->dec_batch_bytes = 2 * input_bytes;
 	return X3H_OK;
 }
 
@@ -175,6 +198,10 @@ extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 	for (DevBuf *b : bufs) b->release();
 	c->coder_state.release(); c->prefix_result.release(); c->srcoff.release(); c->ckpt_pos.release(); c->seg.meta.release(); c->seg.modes_state.release(); c->seg.mode_prev.release();
 	c->c2.yfin.release(); c->c2.yfinrec.release();
+	c->sr.release();
+	for (uint32_t i = 0; i < X3S_MAX_SLICES + 2; i++) { if (c->ev_sf[i]) (void)hipEventDestroy(c->ev_sf[i]); if (c->ev_sb[i]) (void)hipEventDestroy(c->ev_sb[i]); if (c->ev_se[i]) (void)hipEventDestroy(c->ev_se[i]); }
+	if (c->ev_s0) (void)hipEventDestroy(c->ev_s0);
+	if (c->s_side) { (void)hipStreamDestroy(c->s_side); (void)hipEventDestroy(c->ev_sfork); (void)hipEventDestroy(c->ev_sjoin); }
 	c->c2.est_val.release(); c->c2.est_cls.release(); c->c2.est_out.release();
 	if (c->c2.est_stream) { (void)hipStreamSynchronize(c->c2.est_stream); (void)hipStreamDestroy(c->c2.est_stream); (void)hipEventDestroy(c->c2.ev_est_fork); (void)hipEventDestroy(c->c2.ev_est_done); }
 	if (c->ckpt) (void)hipHostFree((void *)c->ckpt);
@@ -441,6 +468,202 @@ static int run_pipelined_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_byte
 	return X3H_OK;
 }
 
+/* ------------------------------------------------------------------------------------------------------------
+ * K2 + K3 in SLICES (code4.hip): the parse of every stream runs on its own HIP stream and publishes checkpoints (host-mapped records) as it crosses its
+ * marks; for every mark -- taken one by one -- the host queues the feature stages of the SLICE between the previous mark and this one (carried state, no
+ * recomputation: a slice costs what the slice costs), the coder recurrence of the slice's symbols on a third stream and their bit emission on a fourth.
+ * The host never waits for the device inside the loop: every launch is sized from the checkpoint records.
+ * Returns X3S_FALLBACK (> 0) when a dictionary outgrew the sliced kernels' LDS tables: the parse has finished by then, nothing of the slices is kept, the
+ * caller runs the coding stage of the whole batch stage after stage.
+ * ------------------------------------------------------------------------------------------------------------ */
+#define X3S_FALLBACK 1000
+
+static int sliced_setup(x3h_ctx *c)
+{
+	CHK(pipe_setup(c));
+	if (c->s_side) return X3H_OK;
+	HIPCHK(hipStreamCreate(&c->s_side));
+	HIPCHK(hipEventCreate(&c->ev_sfork)); HIPCHK(hipEventCreate(&c->ev_sjoin)); HIPCHK(hipEventCreate(&c->ev_s0));
+	for (uint32_t i = 0; i < X3S_MAX_SLICES + 2; i++) { HIPCHK(hipEventCreate(&c->ev_sf[i])); HIPCHK(hipEventCreate(&c->ev_sb[i])); HIPCHK(hipEventCreate(&c->ev_se[i])); }
+	return X3H_OK;
+}
+
+static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, uint8_t *d_out, PipeStats *ps, std::vector<float> *est)
+{
+	const uint32_t nc = (uint32_t)c->hchunks.size();
+	const uint32_t nmarks = c->slice_nmarks;
+	if (c->ckpt_cap < nc) {
+		if (c->ckpt) (void)hipHostFree((void *)c->ckpt);
+		c->ckpt = nullptr; c->ckpt_cap = 0;
+		HIPCHK(hipHostMalloc((void **)&c->ckpt, sizeof(X3ParseCkpt) * X3_CKPT_SLOTS * nc, hipHostMallocMapped | hipHostMallocCoherent));
+		c->ckpt_cap = nc;
+	}
+	memset((void *)c->ckpt, 0, sizeof(X3ParseCkpt) * X3_CKPT_SLOTS * nc);
+	/* marks: fractions of every stream's length, at least 8 KiB apart and 8 KiB from either end -- the parse looks at its marks once per block of 2048
+	 * positions, so every mark is published by its own block (none is skipped, none falls together with the end of the stream) and a slice is bounded
+	 * by the distance of two marks + two blocks */
+	std::vector<uint32_t> pos((size_t)nc * X3_MAX_CKPT, 0xFFFFFFFFu);
+	uint64_t slice_bytes = 0;
+	uint32_t min_gap = 8192;
+	if (const char *e = getenv("X3H_SLICE_GAP")) { const int v = atoi(e); if (v > 0) min_gap = (uint32_t)v; } /* (tests: small inputs in many slices; a skipped mark merges two slices, a slice beyond the bound falls back) */
+	for (uint32_t i = 0; i < nc; i++) {
+		const uint32_t n = c->hchunks[i].len;
+		uint32_t prev = 0, gap = 0, used = 0; /* the marks a stream keeps are its marks 0, 1, ...: the parse waits for them in that order */
+		for (uint32_t k = 0; k < nmarks; k++) {
+			const uint32_t q = (uint32_t)((double)n * c->slice_marks[k]);
+			if (q >= prev + min_gap && (uint64_t)q + min_gap <= n) { pos[(size_t)i * X3_MAX_CKPT + used++] = q; if (q - prev > gap) gap = q - prev; prev = q; }
+		}
+		if (n - prev > gap) gap = n - prev;
+		slice_bytes += (uint64_t)gap + 2 * (X3_PARSE_PB + 64) + 16;
+	}
+	CHK(c->ckpt_pos.reserve(pos.size() * 4));
+	HIPCHK(hipMemcpyAsync(c->ckpt_pos.p, pos.data(), pos.size() * 4, hipMemcpyHostToDevice, c->stream));
+	CHK(x3s_begin(c->sr, c->stream, nc, c->hchunks.data(), slice_bytes, slice_bytes));
+	CHK(x3_zero_output_slots(c->stream, nc, c->hchunks.data(), c->chunks.as<X3Chunk>(), d_out));
+	void *dck = nullptr;
+	HIPCHK(hipHostGetDevicePointer(&dck, (void *)c->ckpt, 0));
+	pa.ckpt = (X3ParseCkpt *)dck; pa.ckpt_pos = c->ckpt_pos.as<uint32_t>(); pa.nckpt = nmarks;
+	HIPCHK(hipEventRecord(c->ev_ready, c->stream));
+	HIPCHK(hipStreamWaitEvent(c->s_parse, c->ev_ready, 0));
+	HIPCHK(hipStreamWaitEvent(c->s_coder, c->ev_ready, 0));
+	HIPCHK(hipStreamWaitEvent(c->s_emit, c->ev_ready, 0));
+	HIPCHK(hipEventRecord(c->ev_p0, c->s_parse));
+	x3k_launch_parse(&pa, nc, c->s_parse);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(c->ev_p1, c->s_parse));
+
+	X3SliceRun &R = c->sr;
+	uint32_t *sm = R.small.as<uint32_t>();
+	struct Bound { uint32_t t, h, d, mb, p; };
+	std::vector<Bound> prev(nc, Bound{ 0, 0, 0, 0, 0 }), cur(nc);
+	std::vector<int> avail(nc, -1); /* newest record taken per stream: -1 none, mark index, X3_MAX_CKPT = done */
+	std::vector<char> ended(nc, 0);
+	std::vector<X3Slice> hs(nc);
+	int next = 0, nslice = 0;
+	bool parse_done = false, fallback = false;
+	uint64_t max_dict = 1;
+	for (;;) {
+		int lowest = X3_MAX_CKPT;
+		for (uint32_t i = 0; i < nc; i++) {
+			const X3ParseCkpt *ck = c->ckpt + (size_t)i * X3_CKPT_SLOTS;
+			if (avail[i] < X3_MAX_CKPT) {
+				int best = avail[i];
+				for (int k = avail[i] + 1; k < (int)nmarks; k++) { if (ck[k].seq == (uint32_t)k + 1) { best = k; if (k >= next) break; } }
+				if ((best < next || best == avail[i]) && ck[X3_MAX_CKPT].seq == X3_MAX_CKPT + 1) best = X3_MAX_CKPT; /* no mark left to take: the stream is done */
+				avail[i] = best;
+			}
+			if (avail[i] < lowest) lowest = avail[i];
+		}
+		if (lowest < next && lowest < X3_MAX_CKPT) {
+			if (!parse_done) {
+				const hipError_t q = hipEventQuery(c->ev_p1);
+				if (q == hipSuccess) parse_done = true;
+				else if (q != hipErrorNotReady) { x3_last_hip = (int)q; return X3H_E_HIP; } /* the parse kernel faulted: do not spin on it */
+			}
+			continue; /* spin: a checkpoint is picked up at once (the waits are milliseconds) */
+		}
+		const bool final = lowest == X3_MAX_CKPT;
+		next = lowest + 1;
+		/* this slice of every stream: from where the previous one ended to the newest record taken */
+		uint32_t sh = 0, se = 0, smi = 0, sb = 0, ss = 0, sy = 0;
+		for (uint32_t i = 0; i < nc; i++) {
+			const X3ParseCkpt *ck = c->ckpt + (size_t)i * X3_CKPT_SLOTS;
+			Bound b = prev[i];
+			if (avail[i] >= 0) { const X3ParseCkpt &r = ck[avail[i]]; b.t = r.ntok; b.h = r.hits; b.d = r.dict_elems; b.mb = r.miss_bytes; b.p = r.p; }
+			cur[i] = b;
+			if (b.d > max_dict) max_dict = b.d;
+			X3Slice &s = hs[i];
+			s.t0 = prev[i].t; s.t1 = b.t; s.h0 = prev[i].h; s.h1 = b.h; s.d0 = prev[i].d; s.d1 = b.d; s.mb0 = prev[i].mb; s.mb1 = b.mb; s.p0 = prev[i].p;
+			s.sh = sh; s.se = se; s.sm = smi; s.sb = sb; s.ss = ss; s.sy = sy;
+			s.last = (avail[i] == X3_MAX_CKPT && !ended[i]) ? 1u : 0u;
+			if (s.last) ended[i] = 1;
+			sh += s.h1 - s.h0; se += (s.h1 - s.h0) + (s.d1 - s.d0); smi += (s.t1 - s.t0) - (s.h1 - s.h0); sb += s.mb1 - s.mb0; ss += s.t1 - s.t0;
+			sy += 2 * (s.t1 - s.t0) + (s.mb1 - s.mb0) + s.last;
+		}
+		if (max_dict > X3S_DMAX || ss > slice_bytes) { fallback = true; break; } /* (the second: cannot happen, see the marks above) */
+		if (nslice >= (int)X3S_MAX_SLICES + 1) return X3H_E_INTERNAL;
+		uint32_t *d_segoff = nullptr, *d_seglen = nullptr;
+		HIPCHK(hipEventRecord(c->ev_sb[nslice], c->stream));
+		CHK(x3s_slice(R, c->stream, c->s_side, c->ev_sfork, c->ev_sjoin, c->chunks.as<X3Chunk>(), hs, max_dict, d_bytes, pa.tok_info, pa.dict_len, final,
+		              c->c2.want_est, &d_segoff, &d_seglen));
+		if (c->c2.want_est) { /* the reference's float accumulators (x3.c:43), continued in coding order: one more chain per stream, on the feature stream */
+			X3EstArgs ea;
+			ea.range = nullptr; ea.val = R.est_val.as<float>(); ea.cls = R.est_cls.as<uint8_t>(); ea.out = (float *)(sm + X3S_EST * nc);
+			ea.seg_first = sm + X3S_ESTFIRST * nc; ea.seg_count = sm + X3S_ESTCNT * nc;
+			CHK(x3s_est_launch(ea, nc, c->stream));
+		}
+		HIPCHK(hipEventRecord(c->ev_sf[nslice], c->stream));
+		/* coder recurrence of the slice's symbols, then their bits (both carry their state per stream from launch to launch) */
+		HIPCHK(hipStreamWaitEvent(c->s_coder, c->ev_sf[nslice], 0));
+		HIPCHK(hipEventRecord(c->ev_cb[nslice % (X3_MAX_CKPT + 1)], c->s_coder));
+		CHK(x3s_ac2_launch(R.sym.as<uint4>(), R.states.as<uint32_t>(), sm + X3S_FINALLO * nc, d_segoff, d_seglen, sm + X3S_CODER * nc, nc, c->s_coder));
+		HIPCHK(hipEventRecord(c->ev_se[nslice], c->s_coder));
+		HIPCHK(hipStreamWaitEvent(c->s_emit, c->ev_se[nslice], 0));
+		X3EmitArgs ea;
+		ea.yoc = nullptr; ea.sym = R.sym.as<uint4>(); ea.state = R.states.as<uint32_t>(); ea.final_lo = sm + X3S_FINALLO * nc; ea.chunks = c->chunks.as<X3Chunk>(); ea.parsed = nullptr;
+		ea.npairs = sm + X3S_NPAIRS * nc; ea.evfinal = sm + X3S_EVFINAL * nc; ea.out = d_out; ea.result = c->cresult.as<X3CodeResult>();
+		ea.seg_off = d_segoff; ea.seg_len = d_seglen; ea.carry = sm + X3S_EMITCARRY * nc; ea.last = final ? 1u : 0u; ea.compact = 0;
+		ea.ntok = sm + X3S_NTOK * nc; ea.nhits = sm + X3S_NHITS * nc;
+		CHK(x3s_emit_launch(ea, nc, c->s_emit));
+		prev = cur;
+		nslice++;
+		if (final) break;
+	}
+	if (fallback) { /* nothing of the slices is kept: wait for everything in flight, the caller codes the batch stage after stage */
+		HIPCHK(hipStreamSynchronize(c->s_parse)); HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipStreamSynchronize(c->s_side));
+		HIPCHK(hipStreamSynchronize(c->s_coder)); HIPCHK(hipStreamSynchronize(c->s_emit));
+		return X3S_FALLBACK;
+	}
+	HIPCHK(hipEventRecord(c->ev_emit, c->s_emit));
+	HIPCHK(hipStreamWaitEvent(c->stream, c->ev_emit, 0));
+	/* results: what the parse counted (its own records) and, if asked for, the size estimates */
+	c->hparse.resize(nc);
+	HIPCHK(hipStreamSynchronize(c->s_parse));
+	HIPCHK(hipMemcpyAsync(c->hparse.data(), c->presult.p, (size_t)nc * sizeof(X3ParseResult), hipMemcpyDeviceToHost, c->stream));
+	std::vector<uint32_t> hstat(nc);
+	HIPCHK(hipMemcpyAsync(hstat.data(), sm + X3S_STATUS * nc, (size_t)nc * 4, hipMemcpyDeviceToHost, c->stream));
+	if (est && c->c2.want_est) { est->resize((size_t)nc * 4); HIPCHK(hipMemcpyAsync(est->data(), sm + X3S_EST * nc, (size_t)nc * 16, hipMemcpyDeviceToHost, c->stream)); }
+	HIPCHK(hipStreamSynchronize(c->stream));
+	for (uint32_t i = 0; i < nc; i++) if (hstat[i] != X3_ST_OK) return X3H_E_INTERNAL;
+	float ms = 0;
+	(void)hipEventElapsedTime(&ms, c->ev_p0, c->ev_p1); ps->ms_parse = ms;
+	for (int i = 0; i < nslice; i++) {
+		(void)hipEventElapsedTime(&ms, c->ev_sb[i], c->ev_sf[i]); ps->ms_features += ms;
+		(void)hipEventElapsedTime(&ms, c->ev_sf[i], c->ev_se[i]); /* (includes the wait of a segment for its predecessor) */
+	}
+	{ /* coder: first segment's begin to last segment's end minus nothing -- the segments of a stream follow each other without a gap when the pipeline is fed */
+		float tot = 0;
+		for (int i = 0; i < nslice && i <= X3_MAX_CKPT; i++) { (void)hipEventElapsedTime(&ms, c->ev_cb[i % (X3_MAX_CKPT + 1)], c->ev_se[i]); tot += ms; }
+		ps->ms_coder = tot;
+	}
+	ps->mode_iters = 0;
+	c->c2.last.symbols = 0; c->c2.last.chain_symbols = 0;
+	{
+		std::vector<uint32_t> yc(nc);
+		HIPCHK(hipMemcpy(yc.data(), sm + X3S_YCNT * nc, (size_t)nc * 4, hipMemcpyDeviceToHost));
+		uint64_t y = 0, raw = 0;
+		for (uint32_t i = 0; i < nc; i++) { y += yc[i]; raw += 2ull * c->hparse[i].ntok + c->hparse[i].miss_bytes + 1; }
+		c->c2.last.symbols = raw; c->c2.last.chain_symbols = y;
+	}
+	if (getenv("X3H_DEBUG")) {
+		fprintf(stderr, "[x3h] sliced: %d slices, parse %.1f ms;", nslice, ps->ms_parse);
+		for (int i = 0; i < nslice && i <= X3_MAX_CKPT; i++) { float f0 = 0, f1 = 0, b = 0, e = 0; (void)hipEventElapsedTime(&f0, c->ev_p0, c->ev_sb[i]); (void)hipEventElapsedTime(&f1, c->ev_p0, c->ev_sf[i]);
+			(void)hipEventElapsedTime(&b, c->ev_p0, c->ev_cb[i % (X3_MAX_CKPT + 1)]); (void)hipEventElapsedTime(&e, c->ev_p0, c->ev_se[i]); fprintf(stderr, " [%d] features %.2f..%.2f coder %.2f..%.2f;", i, f0, f1, b, e); }
+		{ float e = 0; (void)hipEventElapsedTime(&e, c->ev_p0, c->ev_emit); fprintf(stderr, " last bits written %.2f\n", e); }
+	}
+	return X3H_OK;
+}
+
+static int run_sliced(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, uint8_t *d_out, PipeStats *ps, std::vector<float> *est)
+{
+	CHK(sliced_setup(c));
+	const int rc = run_sliced_body(c, pa, d_bytes, d_out, ps, est);
+	if (rc != X3H_OK && rc != X3S_FALLBACK) { /* never return with work in flight on the side streams */
+		(void)hipStreamSynchronize(c->s_parse); (void)hipStreamSynchronize(c->s_coder); (void)hipStreamSynchronize(c->s_emit); (void)hipStreamSynchronize(c->s_side); (void)hipStreamSynchronize(c->stream);
+	}
+	return rc;
+}
+
 static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage upto, x3h_stats *stats)
 {
 	if (!c || !io.offsets || io.nchunks <= 0 || (!io.src && io.offsets[io.nchunks] != io.offsets[0])) return X3H_E_ARG;
@@ -485,7 +708,12 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 
 	/* ---- K2 ---- */
 	/* pipelined schedule: a few long streams (the serial chains dominate); many short ones run stage after stage (the chip-wide passes dominate) */
-	const bool pipe = upto == STAGE_CODE && nc <= c->pipe_max_streams && c->pipe_min && max_len >= c->pipe_min &&
+	/* K3 in slices (code4.hip) wherever it applies: up to a few streams per CU, the longest one long enough for a few slices (dictionaries beyond the sliced
+	 * kernels' LDS tables fall back inside run_sliced) */
+	uint64_t elems_total = 0;
+	for (int i = 0; i < nc; i++) elems_total += (uint64_t)c->hchunks[(size_t)i].len + 16;
+	bool sliced = upto == STAGE_CODE && c->sliced && c->pipe_min /* (X3H_PIPE_MIN=0: stage after stage, whatever the batch) */ && nc <= c->sliced_max_streams && max_len >= c->sliced_min && elems_total < ((uint64_t)1 << 29);
+	const bool pipe = !sliced && upto == STAGE_CODE && nc <= c->pipe_max_streams && c->pipe_min && max_len >= c->pipe_min &&
 	                  c->pad_total <= ((uint64_t)320 << 20); /* worst-case workspace of the pipelined schedule: ~330 B per input byte */
 	X3ParseArgs pa;
 	pa.ckpt = nullptr; pa.nckpt = 0;
@@ -498,7 +726,7 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 	pa.factor1 = prm.factor1; pa.factor2 = prm.factor2; pa.nl_mode = prm.nl_mode;
 	/* batches of many streams: the coding stage walks the tokens itself (one workgroup per stream, code3.hip) */
 	const bool tokens_in_code = !pipe && upto == STAGE_CODE && (uint32_t)nc >= X3_STREAM_MIN_STREAMS;
-	if (!pipe) {
+	if (!pipe && !sliced) {
 		x3k_launch_parse(&pa, (uint32_t)nc, c->stream);
 		HIPCHK(hipGetLastError());
 		if (!tokens_in_code)
@@ -536,7 +764,23 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 	HIPCHK(hipMemcpyAsync(c->chunks.p, c->hchunks.data(), (size_t)nc * sizeof(X3Chunk), hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipEventRecord(c->ev[4], c->stream));
 	PipeStats ps;
-	if (pipe) {
+	std::vector<float> hest;
+	bool fell_back = false;
+	if (sliced) {
+		const int r = run_sliced(c, pa, sa.bytes, d_out, &ps, &hest);
+		if (r == X3S_FALLBACK) { /* a dictionary outgrew the sliced kernels: the parse is complete, the coding stage runs stage after stage */
+			fell_back = true; sliced = false; hest.clear();
+			c->hparse.resize((size_t)nc);
+			HIPCHK(hipMemcpyAsync(c->hparse.data(), c->presult.p, (size_t)nc * sizeof(X3ParseResult), hipMemcpyDeviceToHost, c->stream));
+			HIPCHK(hipStreamSynchronize(c->stream));
+			pa.ckpt = nullptr; pa.nckpt = 0;
+			if (!tokens_in_code)
+				CHK(x3_token_postpass(c->c2, c->stream, nc, c->hchunks.data(), c->chunks.as<X3Chunk>(), pa.result, pa.tok_info, pa.dict_len, tok_pos, tok_hb, tok_nb, tok_mb, 0, false));
+			CHK(x3_code_v2_run(c->c2, c->stream, nc, c->hchunks.data(), c->chunks.as<X3Chunk>(), c->hparse.data(), pa.result,
+			                   sa.bytes, tok_pos, pa.tok_info, tok_hb, tok_nb, tok_mb, d_out, c->cresult.as<X3CodeResult>(), nullptr,
+			                   tokens_in_code ? pa.dict_len : nullptr));
+		} else CHK(r);
+	} else if (pipe) {
 		CHK(run_pipelined(c, pa, sa.bytes, tok_pos, tok_hb, tok_nb, tok_mb, d_out, &ps));
 	} else {
 		/* parallel feature extraction (sorts / scans / count-smaller-before) + two thin serial passes (code2.hip) */
@@ -544,7 +788,6 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 		                   sa.bytes, tok_pos, pa.tok_info, tok_hb, tok_nb, tok_mb, d_out, c->cresult.as<X3CodeResult>(), nullptr,
 		                   tokens_in_code ? pa.dict_len : nullptr));
 	}
-	std::vector<float> hest;
 	if (c->c2.est_pending) { /* the size estimates ran beside the coder on their own stream */
 		HIPCHK(hipStreamWaitEvent(c->stream, c->c2.ev_est_done, 0));
 		c->c2.est_pending = false;
@@ -553,7 +796,7 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 	HIPCHK(hipEventRecord(c->ev[5], c->stream));
 	c->hcode.resize((size_t)nc);
 	HIPCHK(hipMemcpyAsync(c->hcode.data(), c->cresult.p, (size_t)nc * sizeof(X3CodeResult), hipMemcpyDeviceToHost, c->stream));
-	if (!hest.empty()) HIPCHK(hipMemcpyAsync(hest.data(), c->c2.est_out.p, hest.size() * 4, hipMemcpyDeviceToHost, c->stream));
+	if (!hest.empty() && !sliced) HIPCHK(hipMemcpyAsync(hest.data(), c->c2.est_out.p, hest.size() * 4, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 
 	int rc = X3H_OK;
@@ -586,7 +829,7 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 		(void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); stats->ms_parse = ms;
 		(void)hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); stats->ms_code = ms;
 		(void)hipEventElapsedTime(&ms, c->ev[0], c->ev[5]); stats->ms_total = ms;
-		if (!pipe && c->c2.ev[4]) {
+		if (!pipe && !sliced && c->c2.ev[4]) {
 			(void)hipEventElapsedTime(&ms, c->c2.ev[0], c->c2.ev[1]); stats->ms_features = ms;
 			(void)hipEventElapsedTime(&ms, c->c2.ev[1], c->c2.ev[2]); stats->ms_modes = ms;
 			(void)hipEventElapsedTime(&ms, c->c2.ev[3], c->c2.ev[4]); stats->ms_coder = ms;
@@ -595,11 +838,12 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 			stats->mode_iters = c->c2.last.mode_iters;
 			stats->chain_symbols = c->c2.last.chain_symbols;
 		}
-		if (pipe) { /* overlapped stages: each from its own events (their sum exceeds ms_total) */
+		if (pipe || sliced) { /* overlapped stages: each from its own events (their sum exceeds ms_total) */
 			stats->ms_parse = ps.ms_parse; stats->ms_features = ps.ms_features; stats->ms_modes = ps.ms_modes; stats->ms_coder = ps.ms_coder;
 			stats->ms_emit = 0; stats->mode_iters = ps.mode_iters; stats->coded_symbols = c->c2.last.symbols;
-			stats->chain_symbols = c->c2.last.chain_symbols; stats->pipelined = 1;
+			stats->chain_symbols = c->c2.last.chain_symbols; stats->pipelined = sliced ? 2 : 1;
 		}
+		(void)fell_back;
 	}
 	return rc;
 }
@@ -1008,7 +1252,14 @@ extern "C" int x3h_decompress_container(x3h_ctx *const *ctxs, int ndevices, cons
 #ifndef X3_EMU
 #include <dlfcn.h>
 #include <mutex>
-#include <rccl/rccl.h>
+
+/* The six entry points of librccl this file uses, declared here (the library is dlopen'ed: building libx3hip.so needs no RCCL headers).
+ * Values as in rccl.h: ncclSuccess == 0, ncclUint8 == 1. */
+typedef struct ncclComm *ncclComm_t;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+static const ncclResult_t ncclSuccess = 0;
+static const ncclDataType_t ncclUint8 = 1;
 
 namespace {
 struct RcclApi {
@@ -1078,15 +1329,18 @@ extern "C" int x3h_compress_container_rccl(x3h_ctx *const *ctxs, int ndevices, c
 	const size_t head = x3h_container_header_bytes(nch);
 	if (cap < head + 4 * (size_t)nch) return X3H_E_OUTPUT_FULL;
 
-	std::lock_guard<std::mutex> lk(g_rccl.mu);
-	if (!rccl_load()) return X3H_E_RCCL;
-	std::vector<int> devs((size_t)nd);
-	for (int d = 0; d < nd; d++) devs[(size_t)d] = ctxs[d]->device;
-	if (g_rccl.devs != devs) {
-		rccl_drop_comms();
-		g_rccl.comms.assign((size_t)nd, nullptr);
-		if (g_rccl.CommInitAll(g_rccl.comms.data(), nd, devs.data()) != ncclSuccess) { g_rccl.comms.clear(); return X3H_E_RCCL; }
-		g_rccl.devs = devs;
+	/* the mutex covers the communicators (lookup / creation here, the exchange below): independent callers still code their chunks side by side */
+	{
+		std::lock_guard<std::mutex> lk(g_rccl.mu);
+		if (!rccl_load()) return X3H_E_RCCL;
+		std::vector<int> devs((size_t)nd);
+		for (int d = 0; d < nd; d++) devs[(size_t)d] = ctxs[d]->device;
+		if (g_rccl.devs != devs) {
+			rccl_drop_comms();
+			g_rccl.comms.assign((size_t)nd, nullptr);
+			if (g_rccl.CommInitAll(g_rccl.comms.data(), nd, devs.data()) != ncclSuccess) { g_rccl.comms.clear(); return X3H_E_RCCL; }
+			g_rccl.devs = devs;
+		}
 	}
 
 	std::vector<uint64_t> off((size_t)nch + 1), raw((size_t)nch), lens((size_t)nch, 0);
@@ -1119,7 +1373,7 @@ extern "C" int x3h_compress_container_rccl(x3h_ctx *const *ctxs, int ndevices, c
 			const uint64_t lead = d == 0 ? head : 0;
 			CHK(c->g_pack.reserve(lead + g.payload + 16));
 			CHK(c->srcoff.reserve((size_t)(k + 1) * 8));
-			HIPCHK(hipMemcpyAsync(c->srcoff.p, po.data(), (size_t)(k + 1) * 8, hipMemcpyHostToDevice, c->stream));
+			HIPCHK(hipMemcpy(c->srcoff.p, po.data(), (size_t)(k + 1) * 8, hipMemcpyHostToDevice)); /* (synchronous: `po` is a local) */
 			const uint64_t *dpo = c->srcoff.as<uint64_t>();
 			const uint32_t *src = c->g_out.as<uint32_t>();
 			uint32_t *dst = (uint32_t *)(c->g_pack.as<uint8_t>() + lead);
@@ -1147,38 +1401,55 @@ extern "C" int x3h_compress_container_rccl(x3h_ctx *const *ctxs, int ndevices, c
 	/* root: header + its own block are in place; the other blocks arrive behind them.  ndevices == 1: the block makes the round trip
 	 * through RCCL all the same (send to self), so that this leg is exercised on a one-GPU machine. */
 	x3h_ctx *root = ctxs[0];
-	HIPCHK(hipSetDevice(root->device));
 	std::vector<uint8_t> hdr(head);
 	CHK(x3h_container_write_header(hdr.data(), head, &prm, nch, raw.data(), lens.data()));
-	uint8_t *final_buf = root->g_pack.as<uint8_t>();
-	if (nd == 1) { /* self-send: the packed block moves to a second buffer behind a copy of the header */
-		CHK(root->g_final.reserve(total + 16));
-		final_buf = root->g_final.as<uint8_t>();
-	} else {
-		uint64_t need = total + 16; /* g_pack of the root was sized for its own block only */
-		if (root->g_pack.cap < need) {
-			CHK(root->g_final.reserve(need));
-			HIPCHK(hipMemcpyAsync(root->g_final.p, root->g_pack.p, head + gd[0].payload, hipMemcpyDeviceToDevice, root->stream));
+	/* the exchange and what follows: whatever fails in here, no stream of any device is left with work in flight when this function returns
+	 * (the header travels by a synchronous copy: its source is a local) */
+	auto exchange = [&]() -> int {
+		HIPCHK(hipSetDevice(root->device));
+		uint8_t *final_buf = root->g_pack.as<uint8_t>();
+		if (nd == 1) { /* self-send: the packed block moves to a second buffer behind a copy of the header */
+			CHK(root->g_final.reserve(total + 16));
 			final_buf = root->g_final.as<uint8_t>();
+		} else {
+			uint64_t need = total + 16; /* g_pack of the root was sized for its own block only */
+			if (root->g_pack.cap < need) {
+				CHK(root->g_final.reserve(need));
+				HIPCHK(hipMemcpyAsync(root->g_final.p, root->g_pack.p, head + gd[0].payload, hipMemcpyDeviceToDevice, root->stream));
+				HIPCHK(hipStreamSynchronize(root->stream));
+				final_buf = root->g_final.as<uint8_t>();
+			}
 		}
-	}
-	HIPCHK(hipMemcpyAsync(final_buf, hdr.data(), head, hipMemcpyHostToDevice, root->stream));
-	bool ok = g_rccl.GroupStart() == ncclSuccess;
-	uint64_t at = head + (nd == 1 ? 0 : gd[0].payload);
-	for (int d = (nd == 1 ? 0 : 1); d < nd && ok; d++) {
-		const GatherDev &g = gd[(size_t)d];
-		if (g.payload) {
-			ok = ok && g_rccl.Send(g.packed, (size_t)g.payload, ncclUint8, 0, g_rccl.comms[(size_t)d], ctxs[d]->stream) == ncclSuccess;
-			ok = ok && g_rccl.Recv(final_buf + at, (size_t)g.payload, ncclUint8, d, g_rccl.comms[0], root->stream) == ncclSuccess;
+		HIPCHK(hipMemcpy(final_buf, hdr.data(), head, hipMemcpyHostToDevice));
+		std::lock_guard<std::mutex> lk(g_rccl.mu);
+		std::vector<int> devs((size_t)nd);
+		for (int d = 0; d < nd; d++) devs[(size_t)d] = ctxs[d]->device;
+		if (g_rccl.devs != devs || g_rccl.comms.size() != (size_t)nd) return X3H_E_RCCL; /* another caller replaced the communicators meanwhile */
+		bool ok = g_rccl.GroupStart() == ncclSuccess;
+		uint64_t at = head + (nd == 1 ? 0 : gd[0].payload);
+		for (int d = (nd == 1 ? 0 : 1); d < nd && ok; d++) {
+			const GatherDev &g = gd[(size_t)d];
+			if (g.payload) {
+				ok = ok && g_rccl.Send(g.packed, (size_t)g.payload, ncclUint8, 0, g_rccl.comms[(size_t)d], ctxs[d]->stream) == ncclSuccess;
+				ok = ok && g_rccl.Recv(final_buf + at, (size_t)g.payload, ncclUint8, d, g_rccl.comms[0], root->stream) == ncclSuccess;
+			}
+			at += g.payload;
 		}
-		at += g.payload;
+		ok = (g_rccl.GroupEnd() == ncclSuccess) && ok;
+		if (!ok) { rccl_drop_comms(); return X3H_E_RCCL; }
+		for (int d = 1; d < nd; d++) { HIPCHK(hipSetDevice(ctxs[d]->device)); HIPCHK(hipStreamSynchronize(ctxs[d]->stream)); }
+		HIPCHK(hipSetDevice(root->device));
+		HIPCHK(hipMemcpyAsync(out, final_buf, (size_t)total, hipMemcpyDeviceToHost, root->stream)); /* the ONE transfer of the container over PCIe */
+		HIPCHK(hipStreamSynchronize(root->stream));
+		return X3H_OK;
+	};
+	const int xrc = exchange();
+	if (xrc != X3H_OK) { /* drain every stream before the caller (or a fallback path) touches these handles again */
+		const int keep = x3_last_hip;
+		for (int d = 0; d < nd; d++) { (void)hipSetDevice(ctxs[d]->device); (void)hipStreamSynchronize(ctxs[d]->stream); }
+		x3_last_hip = keep;
+		return xrc;
 	}
-	ok = (g_rccl.GroupEnd() == ncclSuccess) && ok;
-	if (!ok) { rccl_drop_comms(); return X3H_E_RCCL; }
-	for (int d = 1; d < nd; d++) { HIPCHK(hipSetDevice(ctxs[d]->device)); HIPCHK(hipStreamSynchronize(ctxs[d]->stream)); }
-	HIPCHK(hipSetDevice(root->device));
-	HIPCHK(hipMemcpyAsync(out, final_buf, (size_t)total, hipMemcpyDeviceToHost, root->stream)); /* the ONE transfer of the container over PCIe */
-	HIPCHK(hipStreamSynchronize(root->stream));
 	*out_len = (size_t)total;
 	return X3H_OK;
 }

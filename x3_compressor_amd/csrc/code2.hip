@@ -23,9 +23,8 @@
  * x3_code_v2_run also serves the pipelined schedule of api.hip: called on growing prefixes (X3CodeSeg), it queues the recurrence of
  * the new symbols on a separate HIP stream.
  */
-#include "x3_host.h"
+#include "k3_sym.h"
 
-#include <math.h>
 #include <vector>
 
 #define NONE32 0xFFFFFFFFu
@@ -192,35 +191,7 @@ __device__ static __forceinline__ uint32_t wave_count_less_u32(uint32_t v, uint3
 	return cnt;
 }
 
-struct X3ModesArgs {
-	const X3ParseResult *parsed;
-	const uint32_t *ho, *dof;          /* per chunk: first hit, first tag */
-	const uint32_t *f0, *t0, *f1, *t1; /* per hit: freq/total in ctx0 and ctx1 (freq 0 == tag absent) */
-	uint32_t fs;                       /* stride of those four in words: 1 = plain arrays, 4 = fields of the per-hit records the context kernel stores */
-	const uint32_t *rank, *dk, *step;  /* per hit: MTF rank, dictionary size at that step, step index */
-	uint32_t *idxfreq;                 /* per tag slot (by rank), pre-set to 1: spill area for ranks >= X3_IDXF_LDS */
-	uint32_t *mode;                    /* out per hit: the chosen event (E_CTX0 / E_CTX1 / E_IDX1) */
-	/* optional (pe0 != nullptr; batches of many streams): the model state every hit is coded under, straight from the chain's counters --
-	 * otherwise x3_code_v2_run recovers it from the modes with scans, sorts and a count-smaller-before over the IDX1 hits */
-	uint32_t *pe0, *pe1;               /* out per hit: model_events freq of E_CTX0 / E_CTX1 before the hit (x3.c:176-177)            */
-	uint32_t *ilist_rank, *ilist_hit;  /* out: the IDX1-coded hits of stream c in time order, at [ho[c], ho[c] + evfinal[4c+3])          */
-	uint32_t *evfinal;                 /* out per chunk: the three model_events freqs after the last hit, and the number of IDX1 hits */
-	uint32_t *nzl, *nnoop;             /* optional (with pe0): per hit, the stream's earlier hits whose tag / index symbol is a no-op for the coder (model total 1:
-	                                    * x3_make_symbol); per chunk, how many there are -- the compacted symbol index of every step follows without a scan */
-	/* optional (state != nullptr; growing prefixes of a few long streams): the chain's state after the last hit is saved per stream
-	 * {E0, E1, E2, nidx, hits done, table entries, 0, 0, table...} (stride X3_MODES_STATE_STRIDE words), and a later call on a longer prefix
-	 * resumes behind the hits already decided instead of starting over (their modes are in `mode` already) */
-	uint32_t *state;
-	uint32_t resume;                   /* 1: continue from the saved state where it is valid (hits done <= this prefix's hits) */
-};
-#define X3_MODES_STATE_STRIDE (X3_IDXF_LDS + 8u)
 
-#ifndef X3_IDXF_LDS
-#define X3_IDXF_LDS 32768u /* ranks whose model_index1 frequency lives in LDS (128 KiB); beyond that: global memory */
-#endif
-#ifndef X3_IDXF_LDS_SMALL
-#define X3_IDXF_LDS_SMALL 2048u /* ... in batches of many streams: 8 KiB per stream, so the whole batch is resident instead of one stream per CU */
-#endif
 
 /* The mode choice of x3.c:152-172 feeds back through model_events (three counters) and model_index1 (one frequency per
  * rank), so in the reference it is a strictly serial chain.  A lone wavefront executes such a chain at ~5 cycles per
@@ -236,11 +207,12 @@ struct X3ModesArgs {
  * Typically only a few percent of the hits need the serial path.  ALL_LDS: every rank fits the LDS table. */
 template <bool ALL_LDS, uint32_t NIDX, bool EMIT>
 __device__ static __forceinline__ void x3_modes_loop(const X3ModesArgs &a, uint32_t *sidx, uint32_t *spre, uint32_t *scr, uint32_t *idxf, uint32_t H, uint32_t h0, uint32_t lane, uint32_t Dc,
-                                                     uint32_t first = 0, const uint32_t *st0 = nullptr, uint32_t *st1 = nullptr)
+                                                     uint32_t first = 0, const uint32_t *st0 = nullptr, uint32_t *st1 = nullptr, uint32_t nnoop0 = 0, bool sliced = false)
 {
 	uint32_t E0 = 1024, E1 = 1024, E2 = 1, nidx = 0; /* model_events freqs (x3.c:239-241), IDX1 uses so far */
-	uint32_t nnoop = 0;                              /* hits so far whose symbol is coded under a model total of 1 */
-	if (st0) { E0 = st0[0]; E1 = st0[1]; E2 = st0[2]; nidx = st0[3]; } /* resumed behind `first` hits */
+	uint32_t nnoop = nnoop0;                         /* hits so far whose symbol is coded under a model total of 1 */
+	if (st0) { E0 = st0[0]; E1 = st0[1]; E2 = st0[2]; nidx = st0[3]; } /* resumed behind `first` hits (or: behind the earlier slices) */
+	const uint32_t nidx_start = sliced ? nidx : 0u;  /* a slice's list of IDX1-coded hits starts at its own first entry */
 	const uint64_t below = ((uint64_t)1 << lane) - 1;
 	/* features of the next block are fetched while this block is decided (a lone wave cannot hide the load latency otherwise) */
 	uint32_t nf0, nt0, nf1, nt1, nr, nd, ns;
@@ -326,7 +298,7 @@ __device__ static __forceinline__ void x3_modes_loop(const X3ModesArgs &a, uint3
 			/* what x3_code_v2_run would otherwise recover from the modes with scans: the model_events freqs before the hit (x3.c:176-177), and
 			 * the stream's IDX1-coded hits as a list (rank, hit) in time order for x3_idxstat_kernel */
 			if (in) { a.pe0[g] = E0 + (uint32_t)x3_popc64(m0 & below); a.pe1[g] = E1 + (uint32_t)x3_popc64(m1 & below); }
-			if (in && fin == X3_E_IDX1) { const uint32_t j = h0 + nidx + (uint32_t)x3_popc64(m2 & below); a.ilist_rank[j] = vr; a.ilist_hit[j] = g; }
+			if (in && fin == X3_E_IDX1) { const uint32_t j = h0 + (nidx - nidx_start) + (uint32_t)x3_popc64(m2 & below); a.ilist_rank[j] = vr; a.ilist_hit[j] = g; }
 			if (a.nzl) { /* total of the model the hit's symbol is coded under: the context's, or model_index1's = elements + earlier IDX1 uses */
 				const uint32_t tsel = fin == X3_E_CTX0 ? vt0 : fin == X3_E_CTX1 ? vt1 : vd + nidx + (uint32_t)x3_popc64(m2 & below);
 				const uint64_t NZ = x3_ballot(in && tsel <= 1u);
@@ -371,6 +343,27 @@ __device__ static void x3_modes_body(const X3ModesArgs &a)
 	else if (a.state && lane == 0) a.state[(size_t)c * X3_MODES_STATE_STRIDE + 4] = 0; /* nothing to resume from */
 }
 
+/* The mode chain of one SLICE of every stream (K3 in slices, code4.hip): the same loop on the slice's hits, continued from the state the earlier
+ * slices left in evfinal[4c ..] = {E0, E1, E2, IDX1 uses}, nnoop[c] and the per-rank frequencies idxfreq[elem_off + rank] (model_index1, x3.c:188,419:
+ * a new element's symbol starts at 1), and leaving it there for the next slice. */
+template <uint32_t NIDX>
+__device__ static void x3s_modes_body(const X3ModesArgs &a)
+{
+	X3_LDS uint32_t sidx[NIDX];
+	X3_LDS uint32_t scr[256];
+	const uint32_t c = blockIdx.x, lane = x3_lane();
+	const X3Slice sl = a.slice[c];
+	const uint32_t H = sl.h1 - sl.h0, Dc = sl.d1;
+	uint32_t *gidx = a.idxfreq + a.chunks[c].elem_off;
+	for (uint32_t i = lane; i < Dc && i < NIDX; i += X3_WAVE) sidx[i] = i < sl.d0 ? gidx[i] : 1u;
+	x3_wave_sync();
+	uint32_t *ef = a.evfinal + 4 * c;
+	const uint32_t st0[4] = { ef[0], ef[1], ef[2], ef[3] };
+	x3_modes_loop<true, NIDX, true>(a, sidx, nullptr, scr, gidx, H, sl.sh, lane, Dc, 0, st0, nullptr, a.nnoop[c], true);
+	x3_wave_sync();
+	for (uint32_t i = lane; i < Dc && i < NIDX; i += X3_WAVE) gidx[i] = sidx[i];
+}
+
 /* ============================================================================================================
  * serial pass 2: the arithmetic-coder interval recurrence ALONE (ac.c:77-85 + the renormalisation of ac.c:46-75).
  *
@@ -393,24 +386,6 @@ struct X3Ac2Args {
 	uint32_t compact;                     /* 1: the state of group g of stream c goes to slot (first symbol >> 3) + c + g (consecutive 8-byte stores that fill whole
 	                                         lines) instead of the slot of the group's first symbol (one 8-byte store per 64 bytes) -- whole-stream form only */
 };
-
-/* range / total as a multiply-shift (Granlund-Montgomery, N = 31): L = ceil(log2 total) >= 1, m = ceil(2^(31+L)/total) in [2^31, 2^32),
- * floor(range*m / 2^(31+L)) == floor(range/total) for every range <= 2^31 because m*total - 2^(31+L) < total <= 2^L.  The chain takes the
- * high product word (s_mul_hi_u32) and shifts it by L-1: two instructions.  total == 1 (a context or index model with a single symbol of
- * frequency 1) would need m = 2^32 -- but such a symbol is a NO-OP for the coder (step = range, the interval does not change, nothing is
- * renormalised): it is marked (w = X3_SYM_NOOP) and dropped from the chain's input by the compaction pass of x3_code_v2_run.
- * Computed per symbol by the parallel assembly kernels, off the serial chain. */
-#define X3_SYM_NOOP 0xFFFFFFFFu
-__device__ static __forceinline__ uint4 x3_make_symbol(uint32_t cum, uint32_t freq, uint32_t total)
-{
-	uint4 q;
-	q.x = cum; q.y = freq;
-	if (total <= 1) { q.z = 0; q.w = X3_SYM_NOOP; return q; }
-	const uint32_t L = 32u - (uint32_t)x3_clz32(total - 1);
-	q.z = (uint32_t)((((uint64_t)1 << (31 + L)) + total - 1) / total);
-	q.w = L - 1;
-	return q;
-}
 
 /* The serial chain, state (lo, R = range):  step = R / total;  nlo = lo + step*cum;  sf = step*freq;  nhi = nlo + sf - 1;  then the
  * renormalisation of ac.c:46-75.  E1/E2 zoom into the lower/upper half and E3 into the middle half of the current window, so after s
@@ -467,8 +442,6 @@ __device__ static __forceinline__ uint2 x3_ac2_sym(uint32_t &lo, uint32_t &R, ui
 	return iv;
 }
 
-#define X3_AC2_G 8u   /* symbols per stored chain state */
-#define X3_SYM_PAD 72 /* readable operand entries behind the last symbol (the chain fetches one group of 8 ahead) */
 #ifndef X3_EMU
 /* Everything on the chain lives in SGPRs.  Operands arrive by s_load_dwordx16 (4 symbols per load, 8 symbols = one "group" per
  * ping-pong register set, fetched one group ahead of their use), the state leaves by one s_store_dwordx2 per group through the scalar
@@ -609,6 +582,15 @@ __global__ void __launch_bounds__(4 * X3_WAVE) x3_ac2_wide_compact_kernel(X3Ac2A
 	const uint32_t c = x3_uniform(blockIdx.x * 4u + (threadIdx.x >> 6));
 	if (c < a.nstreams) x3_ac2_body<true>(a, c);
 }
+__global__ void __launch_bounds__(X3_WAVE) x3s_modes_kernel_s(X3ModesArgs a) { x3s_modes_body<2048>(a); }
+__global__ void __launch_bounds__(X3_WAVE) x3s_modes_kernel_l(X3ModesArgs a) { x3s_modes_body<X3_STREAM_DMAX>(a); }
+int x3s_modes_launch(const X3ModesArgs &a, uint32_t nc, uint64_t max_dict, hipStream_t st)
+{
+	if (max_dict <= 2048) hipLaunchKernelGGL(x3s_modes_kernel_s, dim3(nc), dim3(X3_WAVE), 0, st, a);
+	else hipLaunchKernelGGL(x3s_modes_kernel_l, dim3(nc), dim3(X3_WAVE), 0, st, a);
+	HIPCHK(hipGetLastError());
+	return X3H_OK;
+}
 static void launch_modes(const X3ModesArgs &a, uint32_t nchunks, hipStream_t st, uint64_t max_dict)
 {
 	if (a.pe0) { /* many streams, model state handed out by the kernel: a table (and its running sums) that holds every rank */
@@ -638,6 +620,8 @@ static void launch_ac2(X3Ac2Args a, uint32_t nchunks, hipStream_t st)
 }
 __device__ static __forceinline__ uint32_t x3_brev32(uint32_t v) { return __brev(v); }
 #else
+static void smodes_tramp(void *p) { x3s_modes_body<X3_STREAM_DMAX>(*(const X3ModesArgs *)p); }
+int x3s_modes_launch(const X3ModesArgs &a, uint32_t nc, uint64_t, hipStream_t) { x3emu_launch(smodes_tramp, (void *)&a, dim3(nc), dim3(X3_WAVE)); return X3H_OK; }
 static void modes_tramp(void *p) { x3_modes_body<X3_IDXF_LDS, false>(*(const X3ModesArgs *)p); }
 static void modes_stream_tramp(void *p) { x3_modes_body<X3_STREAM_DMAX, true>(*(const X3ModesArgs *)p); }
 static void ac2_tramp(void *p) { const X3Ac2Args &a = *(const X3Ac2Args *)p; if (a.compact && !a.seg_off) x3_ac2_body<true>(a, blockIdx.x); else x3_ac2_body<false>(a, blockIdx.x); }
@@ -731,23 +715,6 @@ __device__ static __forceinline__ void x3_or_run(uint32_t *out32, uint32_t capw,
 #ifndef X3_EMIT_LDSW
 #define X3_EMIT_LDSW 4096u
 #endif                      /* words of a tile's output assembled in LDS: 16 bits per symbol of a tile of 8192 (text emits ~1.4); a tile with more ORs straight into memory */
-struct X3EmitArgs {
-	const uint32_t *yoc;        /* nc+1: symbol ranges (no-op symbols already dropped) */
-	const uint4 *sym;           /* per symbol: {cum, freq, magic, shift}               */
-	const uint32_t *state;      /* per symbol slot: {lo, R} at the first symbol of every group of X3_AC2_G */
-	const uint32_t *final_lo;   /* per stream: lo after the last symbol                */
-	const X3Chunk *chunks;      /* out_off / out_cap                                   */
-	const X3ParseResult *parsed;
-	const uint32_t *npairs, *evfinal;
-	uint8_t *out;               /* streams are assembled with ORs into pre-zeroed slots */
-	X3CodeResult *result;
-	/* segment form (pipelined schedule of a few long streams): the symbols of stream c are [seg_off[c], seg_off[c] + seg_len[c]) of the operand /
-	 * state rings, the pending-bit count and the bit position come from and go back to carry[4c ..], flush + result only when last */
-	const uint32_t *seg_off, *seg_len;
-	uint32_t *carry;
-	uint32_t last;
-	uint32_t compact;           /* the states lie in compact slots (X3Ac2Args::compact) */
-};
 
 __device__ static __forceinline__ uint32_t x3_wave_incl_maxscan_u32(uint32_t v)
 {
@@ -898,7 +865,7 @@ __device__ static void x3_emit_body(const X3EmitArgs &a)
 		X3CodeResult r;
 		r.out_len = (uint32_t)(words * 4); r.status = words > capw ? X3_ST_OUT_FULL : X3_ST_OK; r.pairs = a.npairs[c]; r._r = 0;
 		r.events[0] = a.evfinal[4 * c] - 1024; r.events[1] = a.evfinal[4 * c + 1] - 1024; r.events[2] = a.evfinal[4 * c + 2] - 1;
-		r.events[3] = a.parsed[c].ntok - a.parsed[c].hits;
+		r.events[3] = a.ntok ? a.ntok[c] - a.nhits[c] : a.parsed[c].ntok - a.parsed[c].hits;
 		r.events[4] = r.events[5] = r.events[6] = r.events[7] = 0;
 		a.result[c] = r;
 	}
@@ -1058,16 +1025,18 @@ static int modes_fixed_point(X3Code2Bufs &B, hipStream_t st, size_t nH, uint32_t
  * assembly pass (x3_est_term: the same float expression as the mode choice, -log2 in double rounded to single); here one wavefront per
  * stream replays the four accumulators: 64 terms are loaded at once, then taken lane by lane in order.
  * ============================================================================================================ */
-#define X3_EST_NONE 0xFFu
-__device__ static __forceinline__ float x3_est_term(float prob) { return (float)(-log2((double)prob)); }
 
-struct X3EstArgs { const uint32_t *range; const float *val; const uint8_t *cls; float *out; };
 
 __device__ static void x3_est_body(const X3EstArgs &a)
 {
 	const uint32_t c = blockIdx.x, lane = x3_lane();
-	const uint32_t y0 = a.range[c], y1 = a.range[c + 1];
+	uint32_t y0, y1;
 	float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+	if (a.seg_first) { /* a slice: the sums continue where the earlier slices left them */
+		y0 = a.seg_first[c]; y1 = y0 + a.seg_count[c];
+		const float *o = a.out + 4 * (size_t)c;
+		acc0 = o[0]; acc1 = o[1]; acc2 = o[2]; acc3 = o[3];
+	} else { y0 = a.range[c]; y1 = a.range[c + 1]; }
 	for (uint32_t base = y0; base < y1; base += X3_WAVE) {
 		const uint32_t y = base + lane;
 		const uint32_t k = y < y1 ? a.cls[y] : X3_EST_NONE;
@@ -1090,6 +1059,17 @@ static void launch_est(const X3EstArgs &a, uint32_t nchunks, hipStream_t st) { h
 static void est_tramp(void *p) { x3_est_body(*(const X3EstArgs *)p); }
 static void launch_est(const X3EstArgs &a, uint32_t nchunks, hipStream_t) { x3emu_launch(est_tramp, (void *)&a, dim3(nchunks), dim3(X3_WAVE)); }
 #endif
+
+int x3s_est_launch(const X3EstArgs &a, uint32_t nc, hipStream_t st) { launch_est(a, nc, st); HIPCHK(hipGetLastError()); return X3H_OK; }
+int x3s_emit_launch(const X3EmitArgs &a, uint32_t nc, hipStream_t st) { launch_emit(a, nc, st, true); HIPCHK(hipGetLastError()); return X3H_OK; }
+int x3s_ac2_launch(const uint4 *sym, uint32_t *states, uint32_t *final_lo, const uint32_t *seg_off, const uint32_t *seg_len, uint32_t *seg_state, uint32_t nc, hipStream_t st)
+{
+	X3Ac2Args aa;
+	aa.yo = nullptr; aa.sym = sym; aa.rec_nk = states; aa.final_lo = final_lo; aa.seg_off = seg_off; aa.seg_len = seg_len; aa.seg_state = seg_state; aa.compact = 0;
+	launch_ac2(aa, nc, st);
+	HIPCHK(hipGetLastError());
+	return X3H_OK;
+}
 
 /* ============================================================================================================
  * K2 post-pass: the parse walker only emits one word per step (tag or fragment length); positions and the running
@@ -1159,6 +1139,8 @@ static int zero_output_slots(hipStream_t st, uint32_t nc, const X3Chunk *h_chunk
 	HIPCHK(hipGetLastError());
 	return X3H_OK;
 }
+
+int x3_zero_output_slots(hipStream_t st, uint32_t nc, const X3Chunk *h_chunks, const X3Chunk *d_chunks, uint8_t *d_out) { return zero_output_slots(st, nc, h_chunks, d_chunks, d_out); }
 
 /* ============================================================================================================ */
 int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h_chunks, const X3Chunk *d_chunks,
@@ -1444,7 +1426,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 			}
 			ma.idxfreq = idxf; ma.mode = mode;
 			ma.pe0 = ma.pe1 = ma.ilist_rank = ma.ilist_hit = ma.evfinal = nullptr; ma.nzl = ma.nnoop = nullptr;
-			ma.state = nullptr; ma.resume = 0;
+			ma.state = nullptr; ma.resume = 0; ma.slice = nullptr; ma.chunks = nullptr;
 			if (seg) {
 				/* growing prefixes: the serial chain continues where the previous call stopped.  The hit arrays are laid out by the CURRENT
 				 * per-stream counts, so the modes decided earlier are moved to their new places first. */
@@ -1674,7 +1656,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	B.est_pending = false;
 	if (est) { /* the four float accumulators of every stream, on their own HIP stream beside the coder; api.hip joins it (est_pending) */
 		X3EstArgs ea;
-		ea.range = direct ? d_yoc : d_yo; ea.val = est_val; ea.cls = est_cls; ea.out = B.est_out.as<float>();
+		ea.range = direct ? d_yoc : d_yo; ea.val = est_val; ea.cls = est_cls; ea.out = B.est_out.as<float>(); ea.seg_first = ea.seg_count = nullptr;
 		HIPCHK(hipEventRecord(B.ev_est_fork, st));
 		HIPCHK(hipStreamWaitEvent(B.est_stream, B.ev_est_fork, 0));
 		launch_est(ea, nc, B.est_stream);
@@ -1760,7 +1742,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 			X3EmitArgs ea;
 			ea.yoc = nullptr; ea.sym = sy; ea.state = rec_nk; ea.final_lo = m_finallo; ea.chunks = d_chunks; ea.parsed = d_parsed;
 			ea.npairs = m_npairs; ea.evfinal = m_evfinal; ea.out = d_out; ea.result = d_result;
-			ea.seg_off = d_off; ea.seg_len = d_len; ea.carry = seg->emit_state.as<uint32_t>(); ea.last = final ? 1u : 0u; ea.compact = 0;
+			ea.seg_off = d_off; ea.seg_len = d_len; ea.carry = seg->emit_state.as<uint32_t>(); ea.last = final ? 1u : 0u; ea.compact = 0; ea.ntok = ea.nhits = nullptr;
 			launch_emit(ea, nc, seg->emit_stream, true);
 			HIPCHK(hipGetLastError());
 			if (!final) return X3H_OK;
@@ -1798,7 +1780,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 		X3EmitArgs ea;
 		ea.yoc = d_yoc; ea.sym = sy; ea.state = rec_nk; ea.final_lo = m_finallo; ea.chunks = d_chunks; ea.parsed = d_parsed;
 		ea.npairs = m_npairs; ea.evfinal = m_evfinal; ea.out = d_out; ea.result = d_result;
-		ea.seg_off = ea.seg_len = nullptr; ea.carry = nullptr; ea.last = 1; ea.compact = seg ? 0u : 1u;
+		ea.seg_off = ea.seg_len = nullptr; ea.carry = nullptr; ea.last = 1; ea.compact = seg ? 0u : 1u; ea.ntok = ea.nhits = nullptr;
 		launch_emit(ea, nc, st);
 		HIPCHK(hipGetLastError());
 	} else {

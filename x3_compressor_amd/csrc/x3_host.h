@@ -165,6 +165,111 @@ struct X3CodeSeg {
 	size_t res_steps = 0, res_hits = 0, res_elems = 0, res_mbytes = 0, res_bytes = 0; /* sizing estimates for the whole batch: nothing is reallocated while other streams run */
 };
 
+
+/* ---- K3 in slices (code4.hip) ------------------------------------------------------------------------------ */
+/* One stream's part of one slice: the parse steps [t0, t1) between two checkpoints of the running parse (X3ParseCkpt), with the running counts at
+ * both ends -- all known to the host from the checkpoint records, so every launch of a slice is sized without a device round trip.  The per-hit /
+ * per-step work arrays of a slice are DENSE over the slice (stream c's entries start at sh / se / sm / sb / ss): they are temporaries of the slice,
+ * what persists from slice to slice is the adaptive state (recency order, context lists, model counters, coder interval). */
+struct X3Slice {
+	uint32_t t0, t1;           /* steps                                             */
+	uint32_t h0, h1;           /* hits before t0 / t1                               */
+	uint32_t d0, d1;           /* dictionary elements before t0 / t1                */
+	uint32_t mb0, mb1;         /* new-fragment bytes before t0 / t1                 */
+	uint32_t p0;               /* input position of step t0                         */
+	uint32_t sh, se, sm, sb, ss, sy; /* first slice-local hit / touch event / new fragment / fragment byte / step / (raw) symbol of this stream */
+	uint32_t last;             /* 1: the stream ends with this slice                */
+};
+
+#define X3S_DMAX 2048u          /* largest dictionary of a stream the sliced kernels hold in their LDS tables (api.hip falls back to the other schedules beyond) */
+#define X3S_MAX_SLICES 24u
+#define X3S_NARR 28
+/* per-stream carried scalars, one array of nc (x multiplicity) words each inside X3SliceRun::small, in this order */
+enum { X3S_EVFINAL = 0 /* x4: model_events freqs of E_CTX0 / E_CTX1 / E_IDX1, IDX1 uses */, X3S_NNOOP = 4, X3S_NPAIRS = 5, X3S_ORD00 = 6, X3S_LASTORD = 7, X3S_YCNT = 8, X3S_YDONE = 9,
+       X3S_TOP1 = 10, X3S_TOP0 = 11, X3S_STATUS = 12, X3S_FIRST00 = 13, X3S_NIDX0 = 14, X3S_SEGOFF = 15, X3S_SEGLEN = 16, X3S_NTOK = 17, X3S_NHITS = 18, X3S_ESTFIRST = 19,
+       X3S_ESTCNT = 20, X3S_CODER = 21 /* x2: {lo, R} */, X3S_EMITCARRY = 23 /* x4 */, X3S_FINALLO = 27, X3S_EST = 28 /* x4 floats */, X3S_O0HIST = 32 /* x288: model_match_size + model_chars counters */,
+       X3S_SMALL_WORDS = 32 + 288 };
+struct X3SliceRun {
+	uint32_t nc = 0;
+	uint64_t elems = 0;
+	/* carried state (per stream at elem_off / 4 * elem_off / 3 * elem_off) */
+	DevBuf lt, idxfreq, idxhist, hdr1, hdr0, pool1, pord1, pool0, sym, states, small;
+	/* temporaries of a slice */
+	DevBuf a[X3S_NARR], b[3], stat1, stat0, est_val, est_cls, tmp, tables;
+	std::vector<std::vector<X3Slice>> slices; /* host copies of the slice tables, kept until the run ends (their H2D copies are asynchronous) */
+	void release()
+	{
+		DevBuf *all[] = { &lt, &idxfreq, &idxhist, &hdr1, &hdr0, &pool1, &pord1, &pool0, &sym, &states, &small, &b[0], &b[1], &b[2], &stat1, &stat0, &est_val, &est_cls, &tmp, &tables };
+		for (DevBuf *d : all) d->release();
+		for (DevBuf &d : a) d.release();
+	}
+};
+int x3s_begin(X3SliceRun &R, hipStream_t st, uint32_t nc, const X3Chunk *h_chunks, uint64_t max_slice_steps, uint64_t max_slice_bytes);
+int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, const X3Chunk *d_chunks, const std::vector<X3Slice> &hs,
+              uint64_t max_dict, const uint8_t *d_bytes, const uint32_t *tok_info, const uint8_t *dict_len, bool last, bool want_est, uint32_t **seg_off_out, uint32_t **seg_len_out);
+int x3_zero_output_slots(hipStream_t st, uint32_t nc, const X3Chunk *h_chunks, const X3Chunk *d_chunks, uint8_t *d_out);
+
+/* argument blocks of kernels that code2.hip defines and code4.hip launches too */
+#ifndef X3_IDXF_LDS
+#define X3_IDXF_LDS 32768u /* ranks whose model_index1 frequency lives in LDS (128 KiB); beyond that: global memory */
+#endif
+#ifndef X3_IDXF_LDS_SMALL
+#define X3_IDXF_LDS_SMALL 2048u /* ... in batches of many streams: 8 KiB per stream, so the whole batch is resident instead of one stream per CU */
+#endif
+struct X3ModesArgs {
+	const X3ParseResult *parsed;
+	const uint32_t *ho, *dof;          /* per chunk: first hit, first tag */
+	const uint32_t *f0, *t0, *f1, *t1; /* per hit: freq/total in ctx0 and ctx1 (freq 0 == tag absent) */
+	uint32_t fs;                       /* stride of those four in words: 1 = plain arrays, 4 = fields of the per-hit records the context kernel stores */
+	const uint32_t *rank, *dk, *step;  /* per hit: MTF rank, dictionary size at that step, step index */
+	uint32_t *idxfreq;                 /* per tag slot (by rank), pre-set to 1: spill area for ranks >= X3_IDXF_LDS */
+	uint32_t *mode;                    /* out per hit: the chosen event (E_CTX0 / E_CTX1 / E_IDX1) */
+	/* optional (pe0 != nullptr; batches of many streams): the model state every hit is coded under, straight from the chain's counters --
+	 * otherwise x3_code_v2_run recovers it from the modes with scans, sorts and a count-smaller-before over the IDX1 hits */
+	uint32_t *pe0, *pe1;               /* out per hit: model_events freq of E_CTX0 / E_CTX1 before the hit (x3.c:176-177)            */
+	uint32_t *ilist_rank, *ilist_hit;  /* out: the IDX1-coded hits of stream c in time order, at [ho[c], ho[c] + evfinal[4c+3])          */
+	uint32_t *evfinal;                 /* out per chunk: the three model_events freqs after the last hit, and the number of IDX1 hits */
+	uint32_t *nzl, *nnoop;             /* optional (with pe0): per hit, the stream's earlier hits whose tag / index symbol is a no-op for the coder (model total 1:
+	                                    * x3_make_symbol); per chunk, how many there are -- the compacted symbol index of every step follows without a scan */
+	/* optional (state != nullptr; growing prefixes of a few long streams): the chain's state after the last hit is saved per stream
+	 * {E0, E1, E2, nidx, hits done, table entries, 0, 0, table...} (stride X3_MODES_STATE_STRIDE words), and a later call on a longer prefix
+	 * resumes behind the hits already decided instead of starting over (their modes are in `mode` already) */
+	uint32_t *state;
+	uint32_t resume;                   /* 1: continue from the saved state where it is valid (hits done <= this prefix's hits) */
+	/* optional (slice != nullptr; K3 in slices, code4.hip): the hits are those of ONE SLICE of every stream (slice-local arrays, stream c's start at
+	 * slice[c].sh), the chain continues from evfinal[4c ..] / nnoop[c] / the per-rank table idxfreq[chunks[c].elem_off + .] of the earlier slices and
+	 * leaves its state there; parsed / ho / dof are not read */
+	const struct X3Slice *slice;
+	const X3Chunk *chunks;
+};
+#define X3_MODES_STATE_STRIDE (X3_IDXF_LDS + 8u)
+struct X3EmitArgs {
+	const uint32_t *yoc;        /* nc+1: symbol ranges (no-op symbols already dropped) */
+	const uint4 *sym;           /* per symbol: {cum, freq, magic, shift}               */
+	const uint32_t *state;      /* per symbol slot: {lo, R} at the first symbol of every group of X3_AC2_G */
+	const uint32_t *final_lo;   /* per stream: lo after the last symbol                */
+	const X3Chunk *chunks;      /* out_off / out_cap                                   */
+	const X3ParseResult *parsed;
+	const uint32_t *npairs, *evfinal;
+	uint8_t *out;               /* streams are assembled with ORs into pre-zeroed slots */
+	X3CodeResult *result;
+	/* segment form (pipelined schedule of a few long streams): the symbols of stream c are [seg_off[c], seg_off[c] + seg_len[c]) of the operand /
+	 * state rings, the pending-bit count and the bit position come from and go back to carry[4c ..], flush + result only when last */
+	const uint32_t *seg_off, *seg_len;
+	uint32_t *carry;
+	uint32_t last;
+	uint32_t compact;           /* the states lie in compact slots (X3Ac2Args::compact) */
+	const uint32_t *ntok, *nhits; /* sliced schedule: steps / hits per stream for the result record (nullptr: parsed[c]) */
+};
+struct X3EstArgs { const uint32_t *range; const float *val; const uint8_t *cls; float *out;
+	const uint32_t *seg_first, *seg_count; /* sliced schedule (nullptr otherwise): stream c's terms are [seg_first[c], + seg_count[c]) and out[4c ..] carries the four sums from slice to slice */
+};
+
+int x3s_modes_launch(const X3ModesArgs &a, uint32_t nc, uint64_t max_dict, hipStream_t st);   /* the mode chain of one slice (a.slice != nullptr) */
+int x3s_ac2_launch(const uint4 *sym, uint32_t *states, uint32_t *final_lo, const uint32_t *seg_off, const uint32_t *seg_len, uint32_t *seg_state, uint32_t nc, hipStream_t st);
+int x3s_emit_launch(const X3EmitArgs &a, uint32_t nc, hipStream_t st);
+int x3s_est_launch(const X3EstArgs &a, uint32_t nc, hipStream_t st);
+
 int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h_chunks, const X3Chunk *d_chunks,
                    const X3ParseResult *h_parsed, const X3ParseResult *d_parsed,
                    const uint8_t *d_bytes, const uint32_t *tok_pos, const uint32_t *tok_info, const uint32_t *tok_hb,

@@ -68,7 +68,7 @@ struct X3ScanArgs {
  * marks, the kernel makes every token of that chunk written so far visible device-wide and publishes the chunk's counters to
  * host-mapped memory; the host starts the coding stage of the prefixes while the parse continues.  seq is written last (mark + 1).
  * Slot X3_MAX_CKPT of a chunk is its "done" record (the final counters). */
-#define X3_MAX_CKPT 8
+#define X3_MAX_CKPT 16
 #define X3_CKPT_SLOTS (X3_MAX_CKPT + 1)
 struct X3ParseCkpt { volatile uint32_t seq, p, ntok, hits, dict_elems, miss_bytes, _r0, _r1; };
 
