@@ -438,3 +438,63 @@ def test_emulated_size_estimates_match_oracle(oracle, monkeypatch, env):
             _, ost = oracle.compress(p, oracle_lib.params(w_kib=1, t=3), want_stats=True)
             want = [a + float(b) for a, b in zip(want, ost.sizes)]
         assert all(abs(g - w) <= 1e-6 * max(abs(w), 1.0) for g, w in zip(got, want)), (got, want)
+
+
+# ---- K3 in slices (code4.hip; api.hip run_sliced) ---------------------------------------------------------------------------------
+SLICED_CASES = [
+    ("abra_two_slices", b"abracadabra" * 30, dict(w_kib=1, t=2), "100", None),            # the first slice only inserts elements (no hit): recency order and index model still move
+    ("english_eleven_slices", synth.english_like(6000, seed=8).tobytes(), dict(w_kib=2, t=1), "200", "3"),
+    ("zipf_many_pairs", synth.zipf_bytes(5000).tobytes(), dict(w_kib=1, t=2), "150", "2"),
+    ("zeros", bytes(3000), dict(w_kib=1, t=15), "100", None),
+    ("mr_like", synth.mr_like(3000).tobytes(), dict(w_kib=1, t=3), "100", "7"),
+    ("one_byte", b"a", dict(), "100", None),
+]
+
+
+@pytest.mark.parametrize("name,data,kw,gap,sub", SLICED_CASES, ids=[c[0] for c in SLICED_CASES])
+def test_emulated_sliced_schedule_matches_oracle(oracle, monkeypatch, name, data, kw, gap, sub):
+    """K3 in slices forced on small inputs: the parse's checkpoints cut a stream into up to eleven slices (X3H_SLICE_GAP = smallest distance of two marks),
+    each slice goes through the per-stream feature kernels with the state of the earlier slices carried (last touches, context item lists in their pools,
+    pair ordinals, model counters, order-0 models, coder interval, pending bits) -- stream, statistics and size estimates == the oracle's"""
+    subprocess.run(["make", "-C", os.path.join(HERE, "emu")], check=True, capture_output=True)
+    monkeypatch.setenv("X3H_SLICED_MIN", "1")
+    monkeypatch.setenv("X3H_SLICE_GAP", gap)
+    if sub:
+        monkeypatch.setenv("X3H_SLICE_SUB", sub)
+    with _lib.X3Context(0, library=EMU_SO) as ctx:
+        ctx.set_estimates(True)
+        want, ost = oracle.compress(data, oracle_lib.params(**kw), want_stats=True)
+        assert ctx.compress(data, _lib.make_params(**kw)) == want
+        st = ctx.last_stats
+        assert st.pipelined == 2
+        assert list(st.events)[:4] == list(ost.events)[:4] and st.ctx0_entries == ost.ctx0_entries and st.dict_elems == ost.dict_elems and st.steps == ost.steps
+        assert all(abs(g - w) <= 1e-6 * max(abs(w), 1.0) for g, w in zip(st.est_bits, ost.sizes))
+
+
+def test_emulated_sliced_ragged_batch(oracle, monkeypatch):
+    """streams of different lengths end in different slices (an ended stream keeps its E_EOF symbol and codes nothing more), an empty and a one-byte
+    stream in between; every stream == the oracle's stream of that chunk alone"""
+    subprocess.run(["make", "-C", os.path.join(HERE, "emu")], check=True, capture_output=True)
+    monkeypatch.setenv("X3H_SLICED_MIN", "1")
+    monkeypatch.setenv("X3H_SLICE_GAP", "100")
+    parts = [synth.english_like(4000, seed=2).tobytes(), b"", b"x", synth.zipf_bytes(2500, offset=99).tobytes(), synth.english_like(6000, seed=9).tobytes(), bytes(1500)]
+    off = np.cumsum([0] + [len(p) for p in parts]).astype(np.uint64)
+    kw = dict(w_kib=1, t=3)
+    with _lib.X3Context(0, library=EMU_SO) as ctx:
+        got = ctx.compress_chunks(np.frombuffer(b"".join(parts), np.uint8), off, _lib.make_params(**kw))
+        assert ctx.last_stats.pipelined == 2
+    for g, p in zip(got, parts):
+        assert g == oracle.compress(p, oracle_lib.params(**kw))
+
+
+def test_emulated_sliced_falls_back_on_a_large_dictionary(oracle, monkeypatch):
+    """a dictionary beyond the sliced kernels' LDS tables (X3S_DMAX): run_sliced gives up after the parse and the batch is coded stage after stage"""
+    subprocess.run(["make", "-C", os.path.join(HERE, "emu")], check=True, capture_output=True)
+    monkeypatch.setenv("X3H_SLICED_MIN", "1")
+    monkeypatch.setenv("X3H_SLICE_GAP", "500")
+    rng = np.random.default_rng(7)
+    data = rng.integers(0, 256, size=9000, dtype=np.uint8).tobytes() + rng.integers(0, 256, size=(1200, 3), dtype=np.uint8).repeat(2, axis=0).tobytes()
+    kw = dict(w_kib=1, t=0)   # t = 0: every step is a one-byte fragment or a hit on one; 3-byte records repeated -> many elements
+    with _lib.X3Context(0, library=EMU_SO) as ctx:
+        want, ost = oracle.compress(data, oracle_lib.params(**kw), want_stats=True)
+        assert ctx.compress(data, _lib.make_params(**kw)) == want

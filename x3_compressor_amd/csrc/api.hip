@@ -577,6 +577,7 @@ static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, 
 			s.sh = sh; s.se = se; s.sm = smi; s.sb = sb; s.ss = ss; s.sy = sy;
 			s.last = (avail[i] == X3_MAX_CKPT && !ended[i]) ? 1u : 0u;
 			if (s.last) ended[i] = 1;
+			s.ended = ended[i];
 			sh += s.h1 - s.h0; se += (s.h1 - s.h0) + (s.d1 - s.d0); smi += (s.t1 - s.t0) - (s.h1 - s.h0); sb += s.mb1 - s.mb0; ss += s.t1 - s.t0;
 			sy += 2 * (s.t1 - s.t0) + (s.mb1 - s.mb0) + s.last;
 		}

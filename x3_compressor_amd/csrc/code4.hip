@@ -793,9 +793,12 @@ int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_for
 		const X3Slice sl = d_sl[c];
 		const uint64_t base = d_chunks[c].elem_off;
 		uint32_t ycnt = 2 * sl.t1 + sl.mb1 - m_nnoop[c];
-		if (sl.last) { const uint32_t evtotal = 2051u + sl.t1; sy[3 * base + ycnt] = x3_make_symbol(evtotal - 1, 1, evtotal); ycnt++; }
-		const uint32_t done = m_ydone[c], avail = ycnt - done;
-		const uint32_t len = sl.last ? avail : avail - avail % X3_AC2_G;
+		if (sl.last) { const uint32_t evtotal = 2051u + sl.t1; sy[3 * base + ycnt] = x3_make_symbol(evtotal - 1, 1, evtotal); }
+		ycnt += sl.ended;
+		const uint32_t done = m_ydone[c];
+		uint32_t avail = ycnt - done;
+		if (ycnt < done || avail > 3u * (d_chunks[c].len + 16u)) { m_status[c] = X3_ST_POOL_FULL; avail = 0; } /* (a bookkeeping bug must not become a runaway coder chain) */
+		const uint32_t len = sl.ended ? avail : avail - avail % X3_AC2_G;
 		m_ycnt[c] = ycnt; m_segoff[c] = (uint32_t)(3 * base) + done; m_seglen[c] = len; m_ydone[c] = done + len;
 		m_ntok[c] = sl.t1; m_nhits[c] = sl.h1;
 		m_estfirst[c] = sl.sy; m_estcnt[c] = 2 * (sl.t1 - sl.t0) + (sl.mb1 - sl.mb0);

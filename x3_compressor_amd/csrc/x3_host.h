@@ -179,6 +179,7 @@ struct X3Slice {
 	uint32_t p0;               /* input position of step t0                         */
 	uint32_t sh, se, sm, sb, ss, sy; /* first slice-local hit / touch event / new fragment / fragment byte / step / (raw) symbol of this stream */
 	uint32_t last;             /* 1: the stream ends with this slice                */
+	uint32_t ended;            /* 1: the stream has ended, with this slice or an earlier one (its E_EOF symbol exists) */
 };
 
 #define X3S_DMAX 2048u          /* largest dictionary of a stream the sliced kernels hold in their LDS tables (api.hip falls back to the other schedules beyond) */
