@@ -492,9 +492,12 @@ def test_emulated_sliced_falls_back_on_a_large_dictionary(oracle, monkeypatch):
     subprocess.run(["make", "-C", os.path.join(HERE, "emu")], check=True, capture_output=True)
     monkeypatch.setenv("X3H_SLICED_MIN", "1")
     monkeypatch.setenv("X3H_SLICE_GAP", "500")
-    rng = np.random.default_rng(7)
-    data = rng.integers(0, 256, size=9000, dtype=np.uint8).tobytes() + rng.integers(0, 256, size=(1200, 3), dtype=np.uint8).repeat(2, axis=0).tobytes()
-    kw = dict(w_kib=1, t=0)   # t = 0: every step is a one-byte fragment or a hit on one; 3-byte records repeated -> many elements
+    # 2300 distinct three-byte records, each written three times in a row: at -t 1 every record becomes a dictionary element of its own
+    recs = [bytes([i % 251, (i // 251) % 241 + 1, (i * 7) % 239 + 3]) for i in range(2300)]
+    data = b"".join(r * 3 for r in recs)
+    kw = dict(w_kib=1, t=1)
     with _lib.X3Context(0, library=EMU_SO) as ctx:
         want, ost = oracle.compress(data, oracle_lib.params(**kw), want_stats=True)
+        assert ost.dict_elems > 2048
         assert ctx.compress(data, _lib.make_params(**kw)) == want
+        assert ctx.last_stats.pipelined == 0 and ctx.last_stats.dict_elems == ost.dict_elems

@@ -10,6 +10,7 @@ import json
 import os
 
 import pytest
+import torch  # before libx3hip.so is loaded: torch brings its own HIP runtime, and the process must end up with one (the first one loaded)
 
 import golden_util
 from x3_compressor_amd import _lib, synth
@@ -108,7 +109,6 @@ def test_config4_share_in_the_form_that_is_timed():
     parse | feature stages | coder | bit emission of a stream's slices overlap on four HIP streams).  The pinned chunks 0, 1, 15 must equal the real reference's
     `x3 -z -w 64 -t 256` of that chunk alone (x3.c:372-434,593-611)."""
     import numpy as np
-    import torch
     per = 16
     data = synth.zipf_bytes(per * CHUNK4)
     prm = _lib.make_params(w_kib=64, t=256)

@@ -58,8 +58,7 @@ struct x3h_ctx {
 	double slice_marks[X3_MAX_CKPT] = { 0.02, 0.05, 0.10, 0.17, 0.26, 0.36, 0.47, 0.59, 0.72, 0.86 }; /* X3H_SLICE_MARKS: small slices first (the coder starts early), then ~12 % each */
 	uint32_t slice_nmarks = 10;
 	X3SliceRun sr;
-	hipEvent_t ev_sf[X3S_MAX_SLICES + 2] = {}, ev_sb[X3S_MAX_SLICES + 2] = {}, ev_se[X3S_MAX_SLICES + 2] = {}, ev_s0 = nullptr;
-	hipStream_t s_side = nullptr;
+	hipEvent_t ev_sf[X3S_MAX_SLICES + 2] = {}, ev_sb[X3S_MAX_SLICES + 2] = {}, ev_se[X3S_MAX_SLICES + 2] = {}, ev_sc[X3S_MAX_SLICES + 2] = {}, ev_s0 = nullptr;
 	hipEvent_t ev_sfork = nullptr, ev_sjoin = nullptr;
 	X3ParseCkpt *ckpt = nullptr; /* host-mapped, X3_CKPT_SLOTS per stream */
 	uint32_t ckpt_cap = 0;
@@ -199,9 +198,8 @@ extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 	c->coder_state.release(); c->prefix_result.release(); c->srcoff.release(); c->ckpt_pos.release(); c->seg.meta.release(); c->seg.modes_state.release(); c->seg.mode_prev.release();
 	c->c2.yfin.release(); c->c2.yfinrec.release();
 	c->sr.release();
-	for (uint32_t i = 0; i < X3S_MAX_SLICES + 2; i++) { if (c->ev_sf[i]) (void)hipEventDestroy(c->ev_sf[i]); if (c->ev_sb[i]) (void)hipEventDestroy(c->ev_sb[i]); if (c->ev_se[i]) (void)hipEventDestroy(c->ev_se[i]); }
-	if (c->ev_s0) (void)hipEventDestroy(c->ev_s0);
-	if (c->s_side) { (void)hipStreamDestroy(c->s_side); (void)hipEventDestroy(c->ev_sfork); (void)hipEventDestroy(c->ev_sjoin); }
+	for (uint32_t i = 0; i < X3S_MAX_SLICES + 2; i++) { if (c->ev_sf[i]) (void)hipEventDestroy(c->ev_sf[i]); if (c->ev_sb[i]) (void)hipEventDestroy(c->ev_sb[i]); if (c->ev_se[i]) (void)hipEventDestroy(c->ev_se[i]); if (c->ev_sc[i]) (void)hipEventDestroy(c->ev_sc[i]); }
+	if (c->ev_s0) { (void)hipEventDestroy(c->ev_s0); (void)hipEventDestroy(c->ev_sfork); (void)hipEventDestroy(c->ev_sjoin); }
 	c->c2.est_val.release(); c->c2.est_cls.release(); c->c2.est_out.release();
 	if (c->c2.est_stream) { (void)hipStreamSynchronize(c->c2.est_stream); (void)hipStreamDestroy(c->c2.est_stream); (void)hipEventDestroy(c->c2.ev_est_fork); (void)hipEventDestroy(c->c2.ev_est_done); }
 	if (c->ckpt) (void)hipHostFree((void *)c->ckpt);
@@ -318,12 +316,12 @@ struct PipeStats { double ms_parse = 0, ms_features = 0, ms_modes = 0, ms_coder 
 
 static int pipe_setup(x3h_ctx *c)
 {
-	if (c->s_parse) return X3H_OK;
-	HIPCHK(hipStreamCreate(&c->s_parse));
-	HIPCHK(hipStreamCreate(&c->s_coder));
+	if (c->s_emit) return X3H_OK;
+	if (!c->s_parse) HIPCHK(hipStreamCreate(&c->s_parse));
+	if (!c->s_coder) HIPCHK(hipStreamCreate(&c->s_coder));
 	HIPCHK(hipStreamCreate(&c->s_emit));
-	HIPCHK(hipEventCreate(&c->ev_emit));
-	HIPCHK(hipEventCreate(&c->ev_p0)); HIPCHK(hipEventCreate(&c->ev_p1)); HIPCHK(hipEventCreate(&c->ev_ready));
+	if (!c->ev_emit) HIPCHK(hipEventCreate(&c->ev_emit));
+	if (!c->ev_p0) { HIPCHK(hipEventCreate(&c->ev_p0)); HIPCHK(hipEventCreate(&c->ev_p1)); HIPCHK(hipEventCreate(&c->ev_ready)); }
 	for (int i = 0; i <= X3_MAX_CKPT; i++) { HIPCHK(hipEventCreate(&c->ev_cb[i])); HIPCHK(hipEventCreate(&c->ev_ce[i])); }
 	return X3H_OK;
 }
@@ -478,13 +476,21 @@ static int run_pipelined_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_byte
  * ------------------------------------------------------------------------------------------------------------ */
 #define X3S_FALLBACK 1000
 
+/* HIP streams of the sliced schedule: the handle's main stream (feature stages), a parse stream and a coder stream -- THREE, on purpose.  The ROCm
+ * runtime multiplexes a process's streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default), and two streams that share a queue run one
+ * after the other: with five streams the feature stages of slice 0 sat behind the 90 ms parse kernel (profiles/r04_stream_queue_aliasing.txt).  The bit
+ * emission of a slice needs its own queue least (it only has to be done by the end), so it is queued on the parse stream: behind the parse kernel its
+ * launches run as their coder segments complete.  The move-to-front ranks run on the feature stream. */
 static int sliced_setup(x3h_ctx *c)
 {
-	CHK(pipe_setup(c));
-	if (c->s_side) return X3H_OK;
-	HIPCHK(hipStreamCreate(&c->s_side));
-	HIPCHK(hipEventCreate(&c->ev_sfork)); HIPCHK(hipEventCreate(&c->ev_sjoin)); HIPCHK(hipEventCreate(&c->ev_s0));
-	for (uint32_t i = 0; i < X3S_MAX_SLICES + 2; i++) { HIPCHK(hipEventCreate(&c->ev_sf[i])); HIPCHK(hipEventCreate(&c->ev_sb[i])); HIPCHK(hipEventCreate(&c->ev_se[i])); }
+	if (c->ev_s0) return X3H_OK;
+	if (!c->s_parse) HIPCHK(hipStreamCreate(&c->s_parse));
+	if (!c->s_coder) HIPCHK(hipStreamCreate(&c->s_coder));
+	if (!c->ev_emit) HIPCHK(hipEventCreate(&c->ev_emit));
+	if (!c->ev_p0) { HIPCHK(hipEventCreate(&c->ev_p0)); HIPCHK(hipEventCreate(&c->ev_p1)); HIPCHK(hipEventCreate(&c->ev_ready)); }
+	HIPCHK(hipEventCreate(&c->ev_sfork)); HIPCHK(hipEventCreate(&c->ev_sjoin));
+	for (uint32_t i = 0; i < X3S_MAX_SLICES + 2; i++) { HIPCHK(hipEventCreate(&c->ev_sf[i])); HIPCHK(hipEventCreate(&c->ev_sb[i])); HIPCHK(hipEventCreate(&c->ev_se[i])); HIPCHK(hipEventCreate(&c->ev_sc[i])); }
+	HIPCHK(hipEventCreate(&c->ev_s0));
 	return X3H_OK;
 }
 
@@ -526,11 +532,11 @@ static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, 
 	HIPCHK(hipEventRecord(c->ev_ready, c->stream));
 	HIPCHK(hipStreamWaitEvent(c->s_parse, c->ev_ready, 0));
 	HIPCHK(hipStreamWaitEvent(c->s_coder, c->ev_ready, 0));
-	HIPCHK(hipStreamWaitEvent(c->s_emit, c->ev_ready, 0));
 	HIPCHK(hipEventRecord(c->ev_p0, c->s_parse));
 	x3k_launch_parse(&pa, nc, c->s_parse);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(c->ev_p1, c->s_parse));
+	hipStream_t s_emit = c->s_parse; /* see sliced_setup */
 
 	X3SliceRun &R = c->sr;
 	uint32_t *sm = R.small.as<uint32_t>();
@@ -585,7 +591,7 @@ static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, 
 		if (nslice >= (int)X3S_MAX_SLICES + 1) return X3H_E_INTERNAL;
 		uint32_t *d_segoff = nullptr, *d_seglen = nullptr;
 		HIPCHK(hipEventRecord(c->ev_sb[nslice], c->stream));
-		CHK(x3s_slice(R, c->stream, c->s_side, c->ev_sfork, c->ev_sjoin, c->chunks.as<X3Chunk>(), hs, max_dict, d_bytes, pa.tok_info, pa.dict_len, final,
+		CHK(x3s_slice(R, c->stream, c->stream, c->ev_sfork, c->ev_sjoin, c->chunks.as<X3Chunk>(), hs, max_dict, d_bytes, pa.tok_info, pa.dict_len, final,
 		              c->c2.want_est, &d_segoff, &d_seglen));
 		if (c->c2.want_est) { /* the reference's float accumulators (x3.c:43), continued in coding order: one more chain per stream, on the feature stream */
 			X3EstArgs ea;
@@ -596,26 +602,25 @@ static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, 
 		HIPCHK(hipEventRecord(c->ev_sf[nslice], c->stream));
 		/* coder recurrence of the slice's symbols, then their bits (both carry their state per stream from launch to launch) */
 		HIPCHK(hipStreamWaitEvent(c->s_coder, c->ev_sf[nslice], 0));
-		HIPCHK(hipEventRecord(c->ev_cb[nslice % (X3_MAX_CKPT + 1)], c->s_coder));
+		HIPCHK(hipEventRecord(c->ev_sc[nslice], c->s_coder));
 		CHK(x3s_ac2_launch(R.sym.as<uint4>(), R.states.as<uint32_t>(), sm + X3S_FINALLO * nc, d_segoff, d_seglen, sm + X3S_CODER * nc, nc, c->s_coder));
 		HIPCHK(hipEventRecord(c->ev_se[nslice], c->s_coder));
-		HIPCHK(hipStreamWaitEvent(c->s_emit, c->ev_se[nslice], 0));
+		HIPCHK(hipStreamWaitEvent(s_emit, c->ev_se[nslice], 0));
 		X3EmitArgs ea;
 		ea.yoc = nullptr; ea.sym = R.sym.as<uint4>(); ea.state = R.states.as<uint32_t>(); ea.final_lo = sm + X3S_FINALLO * nc; ea.chunks = c->chunks.as<X3Chunk>(); ea.parsed = nullptr;
 		ea.npairs = sm + X3S_NPAIRS * nc; ea.evfinal = sm + X3S_EVFINAL * nc; ea.out = d_out; ea.result = c->cresult.as<X3CodeResult>();
 		ea.seg_off = d_segoff; ea.seg_len = d_seglen; ea.carry = sm + X3S_EMITCARRY * nc; ea.last = final ? 1u : 0u; ea.compact = 0;
 		ea.ntok = sm + X3S_NTOK * nc; ea.nhits = sm + X3S_NHITS * nc;
-		CHK(x3s_emit_launch(ea, nc, c->s_emit));
+		CHK(x3s_emit_launch(ea, nc, s_emit));
 		prev = cur;
 		nslice++;
 		if (final) break;
 	}
 	if (fallback) { /* nothing of the slices is kept: wait for everything in flight, the caller codes the batch stage after stage */
-		HIPCHK(hipStreamSynchronize(c->s_parse)); HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipStreamSynchronize(c->s_side));
-		HIPCHK(hipStreamSynchronize(c->s_coder)); HIPCHK(hipStreamSynchronize(c->s_emit));
+		HIPCHK(hipStreamSynchronize(c->s_parse)); HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipStreamSynchronize(c->s_coder));
 		return X3S_FALLBACK;
 	}
-	HIPCHK(hipEventRecord(c->ev_emit, c->s_emit));
+	HIPCHK(hipEventRecord(c->ev_emit, s_emit));
 	HIPCHK(hipStreamWaitEvent(c->stream, c->ev_emit, 0));
 	/* results: what the parse counted (its own records) and, if asked for, the size estimates */
 	c->hparse.resize(nc);
@@ -634,7 +639,7 @@ static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, 
 	}
 	{ /* coder: first segment's begin to last segment's end minus nothing -- the segments of a stream follow each other without a gap when the pipeline is fed */
 		float tot = 0;
-		for (int i = 0; i < nslice && i <= X3_MAX_CKPT; i++) { (void)hipEventElapsedTime(&ms, c->ev_cb[i % (X3_MAX_CKPT + 1)], c->ev_se[i]); tot += ms; }
+		for (int i = 0; i < nslice; i++) { (void)hipEventElapsedTime(&ms, c->ev_sc[i], c->ev_se[i]); tot += ms; }
 		ps->ms_coder = tot;
 	}
 	ps->mode_iters = 0;
@@ -648,8 +653,8 @@ static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, 
 	}
 	if (getenv("X3H_DEBUG")) {
 		fprintf(stderr, "[x3h] sliced: %d slices, parse %.1f ms;", nslice, ps->ms_parse);
-		for (int i = 0; i < nslice && i <= X3_MAX_CKPT; i++) { float f0 = 0, f1 = 0, b = 0, e = 0; (void)hipEventElapsedTime(&f0, c->ev_p0, c->ev_sb[i]); (void)hipEventElapsedTime(&f1, c->ev_p0, c->ev_sf[i]);
-			(void)hipEventElapsedTime(&b, c->ev_p0, c->ev_cb[i % (X3_MAX_CKPT + 1)]); (void)hipEventElapsedTime(&e, c->ev_p0, c->ev_se[i]); fprintf(stderr, " [%d] features %.2f..%.2f coder %.2f..%.2f;", i, f0, f1, b, e); }
+		for (int i = 0; i < nslice; i++) { float f0 = 0, f1 = 0, b = 0, e = 0; (void)hipEventElapsedTime(&f0, c->ev_p0, c->ev_sb[i]); (void)hipEventElapsedTime(&f1, c->ev_p0, c->ev_sf[i]);
+			(void)hipEventElapsedTime(&b, c->ev_p0, c->ev_sc[i]); (void)hipEventElapsedTime(&e, c->ev_p0, c->ev_se[i]); fprintf(stderr, " [%d] features %.2f..%.2f coder %.2f..%.2f;", i, f0, f1, b, e); }
 		{ float e = 0; (void)hipEventElapsedTime(&e, c->ev_p0, c->ev_emit); fprintf(stderr, " last bits written %.2f\n", e); }
 	}
 	return X3H_OK;
@@ -660,7 +665,7 @@ static int run_sliced(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, uint8
 	CHK(sliced_setup(c));
 	const int rc = run_sliced_body(c, pa, d_bytes, d_out, ps, est);
 	if (rc != X3H_OK && rc != X3S_FALLBACK) { /* never return with work in flight on the side streams */
-		(void)hipStreamSynchronize(c->s_parse); (void)hipStreamSynchronize(c->s_coder); (void)hipStreamSynchronize(c->s_emit); (void)hipStreamSynchronize(c->s_side); (void)hipStreamSynchronize(c->stream);
+		(void)hipStreamSynchronize(c->s_parse); (void)hipStreamSynchronize(c->s_coder); (void)hipStreamSynchronize(c->stream);
 	}
 	return rc;
 }
