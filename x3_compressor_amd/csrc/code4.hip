@@ -44,6 +44,17 @@ __device__ static __forceinline__ uint32_t s_find(const X3Slice *sl, uint32_t n,
 	return lo;
 }
 
+/* ... by slice-local hit */
+__device__ static __forceinline__ uint32_t s_find_hit(const X3Slice *sl, uint32_t n, uint32_t idx)
+{
+	uint32_t lo = 0, hi = n;
+	while (hi - lo > 1) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (sl[mid].sh <= idx) lo = mid; else hi = mid;
+	}
+	return lo;
+}
+
 /* ============================================================================================================
  * Token walk of a slice (x3.c:379-429 read back from K2's one word per step): running counts, per-hit / per-touch records, the values of the
  * new fragments.  One workgroup per stream; the counts at the slice's first step come from the checkpoint (X3Slice).
@@ -205,7 +216,7 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 	X3_LDS uint16_t tpos[DMAX];      /* tag -> list position, NONE16: absent */
 	X3_LDS uint16_t ltag[DMAX];      /* position -> tag                      */
 	X3_LDS uint32_t lfreq[DMAX];     /* position -> freq                     */
-	X3_LDS uint32_t lpre[DMAX];      /* position -> cum_freq as of the tile's start */
+	X3_LDS uint32_t lpre[DMAX];      /* position -> cum_freq (valid when !stale) */
 	X3_LDS uint32_t lord[ORD ? DMAX : 1]; /* position -> pair ordinal, or 0x80000000 | making hit */
 	const uint32_t lane = x3_lane();
 	const uint32_t c = blockIdx.x / a.nsub, sub = blockIdx.x % a.nsub;
@@ -239,107 +250,145 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 		}
 		h0 = cut[0]; h1 = cut[1];
 	}
+	if (h0 >= h1) return;
 	for (uint32_t i = lane; i < DMAX; i += X3_WAVE) tpos[i] = NONE16;
 	x3_wave_sync();
-	uint32_t gi = h0;
-	while (gi < h1) {
-		const uint32_t key = x3_uniform(a.kA[gi]);
-		const uint32_t ctx = key & a.kmask;
-		uint32_t ge = gi; /* one past the context's last hit */
-		for (;;) {
-			const uint32_t i = ge + lane;
-			const uint64_t bm = x3_ballot(i < h1 && a.kA[i] != key);
-			if (bm) { ge += (uint32_t)x3_ctz64(bm); break; }
-			ge += X3_WAVE;
-			if (ge >= h1) { ge = h1; break; }
-		}
-		/* ---- load ---- */
-		const X3CtxHdr hd = hdrs[ctx];
-		const uint32_t k0 = x3_uniform(hd.items), off0 = x3_uniform(hd.off), cap0 = x3_uniform(hd.cap);
-		uint32_t total = x3_uniform(hd.total), k = k0;
+	/* the OPEN context: its list is in the LDS tables (wave-uniform bookkeeping) */
+	bool open = false, stale = false;
+	uint32_t okey = 0, ok0 = 0, ooff = 0, ocap = 0, ok = 0, ototal = 0;
+	/* records of the range in tiles of 64, fetched ahead: keys and hits one tile, the gathered tags one tile (their hits two tiles), and every lane the
+	 * header of ITS key's context -- up to 64 headers in flight at once instead of one dependent load per context */
+	uint32_t nk_ = 0, nj_ = 0, nt_ = 0, nj2_ = 0;
+	X3CtxHdr nhd_; nhd_.off = nhd_.items = nhd_.cap = nhd_.total = 0;
+	if (h0 + lane < h1) { nk_ = a.kA[h0 + lane]; nj_ = a.vA[h0 + lane]; }
+	if (h0 + X3_WAVE + lane < h1) nj2_ = a.vA[h0 + X3_WAVE + lane];
+	if (h0 + lane < h1) { nt_ = a.h_tag[nj_]; nhd_ = hdrs[nk_ & a.kmask]; }
+	for (uint32_t base = h0; base < h1; base += X3_WAVE) {
+		const bool valid = base + lane < h1;
+		const uint32_t key = nk_, j = nj_, t = valid ? nt_ : 0u;
+		const X3CtxHdr hd = nhd_;
 		{
-			uint32_t carry = 0;
-			for (uint32_t pb = 0; pb < k0; pb += X3_WAVE) {
-				const uint32_t p = pb + lane;
-				const uint64_t it = p < k0 ? pool[(uint64_t)off0 + p] : 0;
-				const uint32_t fq = (uint32_t)it, tg = (uint32_t)(it >> 32);
-				const uint32_t incl = x3_wave_incl_scan_u32(fq) + carry;
-				if (p < k0) { ltag[p] = (uint16_t)tg; lfreq[p] = fq; lpre[p] = incl - fq; tpos[tg] = (uint16_t)p; if (ORD) lord[p] = pord[(uint64_t)off0 + p]; }
-				carry = x3_readlane_u32(incl, X3_WAVE - 1);
-			}
+			const uint32_t nx = base + X3_WAVE + lane;
+			if (nx < h1) { nk_ = a.kA[nx]; nj_ = nj2_; nt_ = a.h_tag[nj2_]; nhd_ = hdrs[nk_ & a.kmask]; }
+			if (nx + X3_WAVE < h1) nj2_ = a.vA[nx + X3_WAVE];
 		}
-		x3_wave_sync();
-		/* ---- sweep ---- */
-		for (uint32_t base = gi; base < ge; base += X3_WAVE) {
-			const bool valid = base + lane < ge;
-			const uint32_t j = valid ? a.vA[base + lane] : 0u;
-			const uint32_t t = valid ? a.h_tag[j] : 0u;
-			const uint64_t V = x3_ballot(valid);
-			const uint32_t nvalid = (uint32_t)x3_popc64(V);
-			const uint64_t M = wave_same_mask(t, tbits, V, valid);
+		const uint64_t V = x3_ballot(valid);
+		const uint32_t nvalid = (uint32_t)x3_popc64(V);
+		const uint32_t kprev = wave_prev_u32(key);
+		uint64_t S = x3_ballot(valid && (lane == 0 || key != kprev)); /* first lanes of the tile's contexts */
+		while (S) {
+			const uint32_t s = (uint32_t)x3_ctz64(S);
+			S &= S - 1;
+			const uint32_t e = S ? (uint32_t)x3_ctz64(S) : nvalid;
+			const uint64_t seg = (e >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << e) - 1)) & ~(((uint64_t)1 << s) - 1);
+			const uint32_t key_s = x3_readlane_u32(key, s);
+			if (!(open && key_s == okey)) {
+				if (open) { /* ---- store the context that ended ---- */
+					uint32_t off = ooff, cap = ocap;
+					if (ok > ocap) { /* ctx_enlarge: a new block (the old one is abandoned, like a realloc that moved) */
+						cap = ocap ? ocap : 2u;
+						while (cap < ok) cap <<= 1;
+						uint32_t got = 0;
+						if (lane == 0) got = atomicAdd(&a.top[c], cap);
+						off = x3_uniform(x3_bcast_u32(got, 0));
+						if ((uint64_t)off + cap > pool_cap) { if (lane == 0) a.status[c] = X3_ST_POOL_FULL; off = 0; cap = 0; ok = 0; } /* (cannot happen: 4 x hits bounds the blocks of a stream) */
+					}
+					for (uint32_t p = lane; p < ok; p += X3_WAVE) {
+						const uint32_t tg = ltag[p];
+						pool[(uint64_t)off + p] = ((uint64_t)tg << 32) | lfreq[p];
+						if (ORD) {
+							const uint32_t o = lord[p];
+							pord[(uint64_t)off + p] = o;
+							if (o & 0x80000000u) a.newaddr[o & 0x7FFFFFFFu] = off + p; /* made in this slice: x3s_pairs_kernel writes its ordinal there */
+						}
+						tpos[tg] = NONE16;
+					}
+					if (lane == 0) { X3CtxHdr nh; nh.off = off; nh.items = ok; nh.cap = cap; nh.total = ototal; hdrs[okey & a.kmask] = nh; }
+					x3_wave_sync();
+				}
+				/* ---- load the context that starts (its header came with the tile) ---- */
+				okey = key_s; open = true;
+				ok0 = x3_readlane_u32(hd.items, s); ooff = x3_readlane_u32(hd.off, s); ocap = x3_readlane_u32(hd.cap, s); ototal = x3_readlane_u32(hd.total, s);
+				ok = ok0;
+				uint32_t carry = 0;
+				for (uint32_t pb = 0; pb < ok0; pb += X3_WAVE) {
+					const uint32_t p = pb + lane;
+					const uint64_t it = p < ok0 ? pool[(uint64_t)ooff + p] : 0;
+					const uint32_t fq = (uint32_t)it, tg = (uint32_t)(it >> 32);
+					const uint32_t incl = x3_wave_incl_scan_u32(fq) + carry;
+					if (p < ok0) { ltag[p] = (uint16_t)tg; lfreq[p] = fq; lpre[p] = incl - fq; tpos[tg] = (uint16_t)p; if (ORD) lord[p] = pord[(uint64_t)ooff + p]; }
+					carry = x3_readlane_u32(incl, X3_WAVE - 1);
+				}
+				stale = false;
+				x3_wave_sync();
+			} else if (stale) { /* the open context goes on in this tile: cum_freqs of its list as this tile sees them */
+				uint32_t carry = 0;
+				for (uint32_t pb = 0; pb < ok; pb += X3_WAVE) {
+					const uint32_t p = pb + lane;
+					const uint32_t v = p < ok ? lfreq[p] : 0u;
+					const uint32_t incl = x3_wave_incl_scan_u32(v) + carry;
+					if (p < ok) lpre[p] = incl - v;
+					carry = x3_readlane_u32(incl, X3_WAVE - 1);
+				}
+				stale = false;
+				x3_wave_sync();
+			}
+			/* ---- the context's hits of this tile: lanes [s, e) ---- */
+			const bool in = (seg >> lane) & 1u;
+			const uint64_t B = seg & below;
+			const uint64_t M = wave_same_mask(t, tbits, seg, in);
 			const uint64_t E = M & below;
-			const uint32_t fl = E ? (uint32_t)x3_ctz64(E) : lane;    /* first lane of my tag in the tile */
-			const uint32_t cp = valid ? (uint32_t)tpos[t] : (uint32_t)NONE16;
+			const uint32_t fl = E ? (uint32_t)x3_ctz64(E) : lane;    /* first lane of my tag in the segment */
+			const uint32_t cp = in ? (uint32_t)tpos[t] : (uint32_t)NONE16;
 			const bool known = cp != NONE16;
-			const bool isnew = valid && fl == lane && !known;        /* this hit adds the tag to the context */
+			const bool isnew = in && fl == lane && !known;           /* this hit adds the tag to the context */
 			const uint64_t N = x3_ballot(isnew);
-			uint32_t pos = known ? cp : k + (uint32_t)x3_popc64(N & below);
+			uint32_t pos = known ? cp : ok + (uint32_t)x3_popc64(N & below);
 			const uint32_t pos_fl = x3_bcast_u32(pos, (int)fl);
-			if (!known && fl != lane) pos = pos_fl;
+			if (in && !known && fl != lane) pos = pos_fl;
 			const uint32_t freq = (known ? lfreq[cp] : 0u) + (uint32_t)x3_popc64(E);
-			const uint32_t cbase = known ? lpre[cp] : total; /* a new item stands behind every carried one */
-			const uint32_t cum = cbase + wave_count_less(pos, pos, tbits, below & V);
+			const uint32_t cbase = known ? lpre[cp] : ototal; /* a new item stands behind every carried one */
+			const uint32_t cum = cbase + wave_count_less(pos, pos, tbits, B);
 			const uint32_t j_fl = x3_bcast_u32(j, (int)fl);
-			if (valid) {
+			if (in) {
 				uint4 r;
-				r.x = freq; r.y = total + lane; r.z = cum;
+				r.x = freq; r.y = ototal + (lane - s); r.z = cum;
 				r.w = ORD ? (known ? lord[cp] : (0x80000000u | j_fl)) : 0u;
 				a.stat[j] = r;
-				if (ORD && isnew && t == 0u && ctx == 0u) a.first00[c] = j; /* x3.c:424-425: both contexts after a new fragment */
+				if (ORD && isnew && t == 0u && (key_s & a.kmask) == 0u) a.first00[c] = j; /* x3.c:424-425: both contexts after a new fragment */
 			}
 			x3_wave_sync();
 			if (isnew) { tpos[t] = (uint16_t)pos; ltag[pos] = (uint16_t)t; lfreq[pos] = 0; if (ORD) lord[pos] = 0x80000000u | j; }
 			x3_wave_sync();
-			if (valid) atomicAdd(&lfreq[pos], 1u);
-			k += (uint32_t)x3_popc64(N);
-			total += nvalid;
+			if (in) atomicAdd(&lfreq[pos], 1u);
+			ok += (uint32_t)x3_popc64(N);
+			ototal += e - s;
+			stale = true;
 			x3_wave_sync();
-			if (base + X3_WAVE < ge) { /* cum_freqs of the list as the next tile will see them */
-				uint32_t carry = 0;
-				for (uint32_t pb = 0; pb < k; pb += X3_WAVE) {
-					const uint32_t p = pb + lane;
-					const uint32_t v = p < k ? lfreq[p] : 0u;
-					const uint32_t incl = x3_wave_incl_scan_u32(v) + carry;
-					if (p < k) lpre[p] = incl - v;
-					carry = x3_readlane_u32(incl, X3_WAVE - 1);
-				}
-				x3_wave_sync();
-			}
 		}
-		/* ---- store ---- */
-		uint32_t off = off0, cap = cap0;
-		if (k > cap0) { /* ctx_enlarge: a new block (the old one is abandoned, like a realloc that moved) */
-			cap = cap0 ? cap0 : 2u;
-			while (cap < k) cap <<= 1;
+	}
+	if (open) { /* the last context of the range */
+		uint32_t off = ooff, cap = ocap;
+		if (ok > ocap) {
+			cap = ocap ? ocap : 2u;
+			while (cap < ok) cap <<= 1;
 			uint32_t got = 0;
 			if (lane == 0) got = atomicAdd(&a.top[c], cap);
 			off = x3_uniform(x3_bcast_u32(got, 0));
-			if ((uint64_t)off + cap > pool_cap) { if (lane == 0) a.status[c] = X3_ST_POOL_FULL; off = 0; cap = 0; k = 0; } /* (cannot happen: 4 x hits bounds the blocks of a stream) */
+			if ((uint64_t)off + cap > pool_cap) { if (lane == 0) a.status[c] = X3_ST_POOL_FULL; off = 0; cap = 0; ok = 0; }
 		}
-		for (uint32_t p = lane; p < k; p += X3_WAVE) {
+		for (uint32_t p = lane; p < ok; p += X3_WAVE) {
 			const uint32_t tg = ltag[p];
 			pool[(uint64_t)off + p] = ((uint64_t)tg << 32) | lfreq[p];
 			if (ORD) {
 				const uint32_t o = lord[p];
 				pord[(uint64_t)off + p] = o;
-				if (o & 0x80000000u) a.newaddr[o & 0x7FFFFFFFu] = off + p; /* made in this slice: x3s_pairs_kernel writes its ordinal there */
+				if (o & 0x80000000u) a.newaddr[o & 0x7FFFFFFFu] = off + p;
 			}
-			tpos[tg] = NONE16; /* ready for the next context */
 		}
-		if (lane == 0) { X3CtxHdr nh; nh.off = off; nh.items = k; nh.cap = cap; nh.total = total; hdrs[ctx] = nh; }
-		x3_wave_sync();
-		gi = ge;
+		if (lane == 0) { X3CtxHdr nh; nh.off = off; nh.items = ok; nh.cap = cap; nh.total = ototal; hdrs[okey & a.kmask] = nh; }
 	}
+	(void)ok0;
 }
 
 /* ============================================================================================================
@@ -363,6 +412,7 @@ struct X3sPairArgs {
 
 __device__ static void x3s_pairs_body(const X3sPairArgs &a)
 {
+	/* (1) one workgroup per stream: the slice's pair-registering hits numbered in time order (a running count carried from tile to tile) */
 	X3_LDS uint32_t s_w[X3S_PAIR_THREADS / X3_WAVE];
 	const uint32_t NW = X3S_PAIR_THREADS / X3_WAVE;
 	const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = x3_lane(), wave = tid / X3_WAVE;
@@ -370,13 +420,13 @@ __device__ static void x3s_pairs_body(const X3sPairArgs &a)
 	const uint32_t j0 = sl.sh, j1 = sl.sh + (sl.h1 - sl.h0);
 	uint32_t *pord = a.pord + 4 * a.chunks[c].elem_off;
 	const uint64_t below = ((uint64_t)1 << lane) - 1;
-	const uint32_t np0 = a.npairs[c];
-	uint32_t run = np0;
-	/* (1) + the ordinals of the new items */
+	uint32_t run = a.npairs[c];
+	uint32_t nw_ = j0 + tid < j1 ? a.stat1[j0 + tid].w : 0u; /* the next tile's words are in flight while this one is counted */
 	for (uint32_t tb = j0; tb < j1; tb += X3S_PAIR_THREADS) {
 		const uint32_t j = tb + tid;
 		const bool in = j < j1;
-		const uint32_t w = in ? a.stat1[j].w : 0u;
+		const uint32_t w = nw_;
+		if (j + X3S_PAIR_THREADS < j1) nw_ = a.stat1[j + X3S_PAIR_THREADS].w;
 		const bool isnew = in && w == (0x80000000u | j);
 		const uint64_t Nm = x3_ballot(isnew);
 		if (lane == 0) s_w[wave] = (uint32_t)x3_popc64(Nm);
@@ -391,33 +441,7 @@ __device__ static void x3s_pairs_body(const X3sPairArgs &a)
 		run += tot;
 		__syncthreads();
 	}
-	__threadfence_block();
-	__syncthreads();
-	/* (2) hits that met a pair made earlier in this slice: the making hit holds the ordinal by now */
-	for (uint32_t j = j0 + tid; j < j1; j += X3S_PAIR_THREADS) {
-		const uint32_t w = a.stat1[j].w;
-		if ((w & 0x80000000u) && w != (0x80000000u | j)) a.stat1[j].w = a.stat1[w & 0x7FFFFFFFu].w;
-	}
-	__threadfence_block();
-	__syncthreads();
-	/* (3) */
-	const uint32_t f00 = a.first00[c];
-	const uint32_t o00_before = a.ord00[c];
-	const uint32_t o00_new = f00 != NONE32 ? a.stat1[f00].w : NONE32;
-	const uint32_t lastord = a.last_ord[c];
-	for (uint32_t j = j0 + tid; j < j1; j += X3S_PAIR_THREADS) {
-		uint32_t g;
-		if (a.h_pv[j]) g = j > j0 ? a.stat1[j - 1].w : lastord;
-		else if (o00_before != NONE32) g = o00_before;
-		else g = (f00 != NONE32 && f00 < j) ? o00_new : 0u;
-		a.k0[j] = (c << a.kshift) | g;
-	}
-	__syncthreads();
-	if (tid == 0) {
-		a.npairs[c] = run;
-		if (o00_before == NONE32 && f00 != NONE32) a.ord00[c] = o00_new;
-		if (j1 > j0) a.last_ord[c] = a.stat1[j1 - 1].w;
-	}
+	if (tid == 0) a.npairs[c] = run;
 }
 
 /* ============================================================================================================
@@ -538,7 +562,7 @@ __device__ static void x3s_order0_body(const X3sOrder0Args &a)
 
 #ifndef X3_EMU
 __global__ void __launch_bounds__(X3S_TOK_THREADS) x3s_tokens_kernel(X3sTokArgs a) { x3s_tokens_body(a); }
-__global__ void __launch_bounds__(8 * X3_WAVE) x3s_mtf_kernel_t(X3sMtfArgs a) { x3s_mtf_body<512, 8>(a); }
+__global__ void __launch_bounds__(16 * X3_WAVE) x3s_mtf_kernel_t(X3sMtfArgs a) { x3s_mtf_body<512, 16>(a); }
 __global__ void __launch_bounds__(8 * X3_WAVE) x3s_mtf_kernel_s(X3sMtfArgs a) { x3s_mtf_body<2048, 8>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3s_ctx1_kernel_t(X3sCtxArgs a) { x3s_ctx_body<512, true>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3s_ctx1_kernel_s(X3sCtxArgs a) { x3s_ctx_body<2048, true>(a); }
@@ -551,7 +575,7 @@ __global__ void __launch_bounds__(X3_WAVE) x3s_order0_kernel(X3sOrder0Args a) { 
 #define X3S_LAUNCH(kern, args, grid, block, st) hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, st, args)
 #else
 static void stok_tramp(void *p) { x3s_tokens_body(*(const X3sTokArgs *)p); }
-static void smtf_tramp_t(void *p) { x3s_mtf_body<512, 8>(*(const X3sMtfArgs *)p); }
+static void smtf_tramp_t(void *p) { x3s_mtf_body<512, 16>(*(const X3sMtfArgs *)p); }
 static void smtf_tramp_s(void *p) { x3s_mtf_body<2048, 8>(*(const X3sMtfArgs *)p); }
 static void sctx1_tramp_t(void *p) { x3s_ctx_body<512, true>(*(const X3sCtxArgs *)p); }
 static void sctx1_tramp_s(void *p) { x3s_ctx_body<2048, true>(*(const X3sCtxArgs *)p); }
@@ -676,7 +700,7 @@ int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_for
 		HIPCHK(hipStreamWaitEvent(side, ev_fork, 0));
 		X3sMtfArgs ma;
 		ma.chunks = d_chunks; ma.sl = d_sl; ma.e_tag = e_tag; ma.e_hit = e_hit; ma.h_rank = h_rank; ma.lt = R.lt.as<uint32_t>();
-		if (small) X3S_LAUNCH(x3s_mtf_kernel_t, ma, nc, 8 * X3_WAVE, side); else X3S_LAUNCH(x3s_mtf_kernel_s, ma, nc, 8 * X3_WAVE, side);
+		if (small) X3S_LAUNCH(x3s_mtf_kernel_t, ma, nc, 16 * X3_WAVE, side); else X3S_LAUNCH(x3s_mtf_kernel_s, ma, nc, 8 * X3_WAVE, side);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipEventRecord(ev_join, side));
 	}
@@ -700,6 +724,32 @@ int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_for
 		pa.npairs = m_npairs; pa.ord00 = m_ord00; pa.last_ord = m_lastord; pa.k0 = k0; pa.kshift = psh;
 		X3S_LAUNCH(x3s_pairs_kernel, pa, nc, X3S_PAIR_THREADS, st);
 		HIPCHK(hipGetLastError());
+		/* (2) hits that met a pair made earlier in this slice: the making hit holds the ordinal by now; (3) context0 of every hit (x3.c:139-147): the pair the
+		 * previous hit registered or met, or -- after a new fragment -- the pair (0, 0) once it exists, else ordinal 0 */
+		x3_foreach(nH, st, X3_LAMBDA(size_t j) {
+			const uint32_t w = stat1[j].w;
+			if (w & 0x80000000u) stat1[j].w = stat1[w & 0x7FFFFFFFu].w; /* (a making hit's own word has no flag any more) */
+		});
+		{
+			const uint32_t kshift0 = psh;
+			x3_foreach(nH, st, X3_LAMBDA(size_t j) {
+				const uint32_t c = s_find_hit(d_sl, nc, (uint32_t)j);
+				const uint32_t j0 = d_sl[c].sh;
+				uint32_t g;
+				if (h_pv[j]) g = j > j0 ? stat1[j - 1].w : m_lastord[c];
+				else {
+					const uint32_t ob = m_ord00[c], f00 = m_first00[c];
+					g = ob != NONE32 ? ob : (f00 != NONE32 && f00 < j) ? stat1[f00].w : 0u;
+				}
+				k0[j] = (c << kshift0) | g;
+			});
+		}
+		x3_foreach(nc, st, X3_LAMBDA(size_t c) {
+			const X3Slice sl = d_sl[c];
+			const uint32_t f00 = m_first00[c];
+			if (m_ord00[c] == NONE32 && f00 != NONE32) m_ord00[c] = stat1[f00].w;
+			if (sl.h1 > sl.h0) m_lastord[c] = stat1[sl.sh + (sl.h1 - sl.h0) - 1].w;
+		});
 		CHK(x3p_sort_pairs(R.tmp, k0, kA, iota, vA, nH, (int)psh + cb, st));
 		ca.stat = stat0; ca.hdr = R.hdr0.as<X3CtxHdr>(); ca.pool = R.pool0.as<uint64_t>(); ca.pord = nullptr; ca.newaddr = nullptr; ca.top = m_top0; ca.first00 = nullptr;
 		ca.kshift = psh; ca.kmask = (psh >= 32 ? 0xFFFFFFFFu : (1u << psh) - 1u);
