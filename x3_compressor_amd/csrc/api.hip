@@ -630,7 +630,7 @@ static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, 
 	HIPCHK(hipMemcpyAsync(hstat.data(), sm + X3S_STATUS * nc, (size_t)nc * 4, hipMemcpyDeviceToHost, c->stream));
 	if (est && c->c2.want_est) { est->resize((size_t)nc * 4); HIPCHK(hipMemcpyAsync(est->data(), sm + X3S_EST * nc, (size_t)nc * 16, hipMemcpyDeviceToHost, c->stream)); }
 	HIPCHK(hipStreamSynchronize(c->stream));
-	for (uint32_t i = 0; i < nc; i++) if (hstat[i] != X3_ST_OK) return X3H_E_INTERNAL;
+	for (uint32_t i = 0; i < nc; i++) if (hstat[i] != X3_ST_OK) return X3S_FALLBACK; /* a list pool's bound was violated (adversarial input): every stream is idle, the caller codes the batch stage after stage */
 	float ms = 0;
 	(void)hipEventElapsedTime(&ms, c->ev_p0, c->ev_p1); ps->ms_parse = ms;
 	for (int i = 0; i < nslice; i++) {

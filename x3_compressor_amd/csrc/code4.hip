@@ -196,12 +196,15 @@ __device__ static void x3s_mtf_body(const X3sMtfArgs &a)
  * over ALL contexts of the stream); until then the item holds 0x80000000 | the slice-local hit that made it, and newaddr[that hit] = its pool slot.
  * Per hit: stat = {freq (0: the tag is not in the context yet), total, cum_freq, ORD: the pair's ordinal or 0x80000000 | making hit}.
  * ============================================================================================================ */
+#define X3S_CHUNK 512u          /* entries a wavefront takes from its stream's pool at a time */
+#define X3S_POOL_PER_BYTE 6u    /* pool entries per input byte: 4 bound the lists' blocks (every block at most twice its list, every abandoned block at most half the next), */
+#define X3S_POOL_EXTRA 65536u   /* ... the rest and this much per stream is for the ends of chunks that were abandoned (a violated bound ends the sliced run, see X3_ST_POOL_FULL) */
 struct X3sCtxArgs {
 	const X3Chunk *chunks; const X3Slice *sl;
 	const uint32_t *kA, *vA, *h_tag;
 	uint4 *stat;
 	X3CtxHdr *hdr;             /* per stream at elem_off: one header per context (tag / pair ordinal) */
-	uint64_t *pool;            /* per stream at 4 * elem_off: items tag << 32 | freq */
+	uint64_t *pool;            /* per stream at X3S_POOL_PER_BYTE * elem_off + stream * X3S_POOL_EXTRA: items tag << 32 | freq */
 	uint32_t *pord;            /* ORD: same layout, the pair ordinal of the item */
 	uint32_t *newaddr;         /* ORD: per slice hit that made an item: its slot in the stream's pool */
 	uint32_t *top;             /* per stream: bump pointer of the pool */
@@ -224,9 +227,9 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 	const uint32_t c0 = sl.sh, c1 = sl.sh + (sl.h1 - sl.h0);
 	const uint64_t eoff = a.chunks[c].elem_off;
 	X3CtxHdr *hdrs = a.hdr + eoff;
-	uint64_t *pool = a.pool + 4 * eoff;
-	uint32_t *pord = ORD ? a.pord + 4 * eoff : nullptr;
-	const uint32_t pool_cap = 4u * (a.chunks[c].len + 16u);
+	uint64_t *pool = a.pool + X3S_POOL_PER_BYTE * eoff + (uint64_t)c * X3S_POOL_EXTRA;
+	uint32_t *pord = ORD ? a.pord + X3S_POOL_PER_BYTE * eoff + (uint64_t)c * X3S_POOL_EXTRA : nullptr;
+	const uint32_t pool_cap = X3S_POOL_PER_BYTE * (a.chunks[c].len + 16u) + X3S_POOL_EXTRA;
 	const uint64_t bit = (uint64_t)1 << lane, below = bit - 1;
 	const int tbits = (int)a.dbits;
 	/* my part of the stream's range: from the first context boundary at or after the nominal cut to the first one at or after the next cut */
@@ -252,10 +255,13 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 	}
 	if (h0 >= h1) return;
 	for (uint32_t i = lane; i < DMAX; i += X3_WAVE) tpos[i] = NONE16;
-	x3_wave_sync();
+	x3_wave_order();
 	/* the OPEN context: its list is in the LDS tables (wave-uniform bookkeeping) */
 	bool open = false, stale = false;
 	uint32_t okey = 0, ok0 = 0, ooff = 0, ocap = 0, ok = 0, ototal = 0;
+	/* blocks for new / outgrown lists come from a chunk this wavefront takes from the stream's pool in one go: one atomic per X3S_CHUNK entries instead of one
+	 * per list (a returning atomic on ONE address per stream serialises: 15 000 of them per slice and stream were most of this kernel's time) */
+	uint32_t chunk_at = 0, chunk_end = 0;
 	/* records of the range in tiles of 64, fetched ahead: keys and hits one tile, the gathered tags one tile (their hits two tiles), and every lane the
 	 * header of ITS key's context -- up to 64 headers in flight at once instead of one dependent load per context */
 	uint32_t nk_ = 0, nj_ = 0, nt_ = 0, nj2_ = 0;
@@ -288,10 +294,14 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 					if (ok > ocap) { /* ctx_enlarge: a new block (the old one is abandoned, like a realloc that moved) */
 						cap = ocap ? ocap : 2u;
 						while (cap < ok) cap <<= 1;
-						uint32_t got = 0;
-						if (lane == 0) got = atomicAdd(&a.top[c], cap);
-						off = x3_uniform(x3_bcast_u32(got, 0));
-						if ((uint64_t)off + cap > pool_cap) { if (lane == 0) a.status[c] = X3_ST_POOL_FULL; off = 0; cap = 0; ok = 0; } /* (cannot happen: 4 x hits bounds the blocks of a stream) */
+						if (chunk_end - chunk_at < cap) { /* (what is left of the old chunk is abandoned: < X3S_CHUNK entries) */
+							const uint32_t want = cap > X3S_CHUNK ? cap : X3S_CHUNK;
+							uint32_t got = 0;
+							if (lane == 0) got = atomicAdd(&a.top[c], want);
+							chunk_at = x3_uniform(x3_bcast_u32(got, 0)); chunk_end = chunk_at + want;
+						}
+						off = chunk_at; chunk_at += cap;
+						if ((uint64_t)off + cap > pool_cap) { if (lane == 0) a.status[c] = X3_ST_POOL_FULL; off = 0; cap = 0; ok = 0; } /* the pool bound was violated: api.hip codes the batch again, stage after stage */
 					}
 					for (uint32_t p = lane; p < ok; p += X3_WAVE) {
 						const uint32_t tg = ltag[p];
@@ -304,7 +314,7 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 						tpos[tg] = NONE16;
 					}
 					if (lane == 0) { X3CtxHdr nh; nh.off = off; nh.items = ok; nh.cap = cap; nh.total = ototal; hdrs[okey & a.kmask] = nh; }
-					x3_wave_sync();
+					x3_wave_order();
 				}
 				/* ---- load the context that starts (its header came with the tile) ---- */
 				okey = key_s; open = true;
@@ -320,7 +330,7 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 					carry = x3_readlane_u32(incl, X3_WAVE - 1);
 				}
 				stale = false;
-				x3_wave_sync();
+				x3_wave_order();
 			} else if (stale) { /* the open context goes on in this tile: cum_freqs of its list as this tile sees them */
 				uint32_t carry = 0;
 				for (uint32_t pb = 0; pb < ok; pb += X3_WAVE) {
@@ -331,7 +341,7 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 					carry = x3_readlane_u32(incl, X3_WAVE - 1);
 				}
 				stale = false;
-				x3_wave_sync();
+				x3_wave_order();
 			}
 			/* ---- the context's hits of this tile: lanes [s, e) ---- */
 			const bool in = (seg >> lane) & 1u;
@@ -357,14 +367,14 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 				a.stat[j] = r;
 				if (ORD && isnew && t == 0u && (key_s & a.kmask) == 0u) a.first00[c] = j; /* x3.c:424-425: both contexts after a new fragment */
 			}
-			x3_wave_sync();
+			x3_wave_order();
 			if (isnew) { tpos[t] = (uint16_t)pos; ltag[pos] = (uint16_t)t; lfreq[pos] = 0; if (ORD) lord[pos] = 0x80000000u | j; }
-			x3_wave_sync();
+			x3_wave_order();
 			if (in) atomicAdd(&lfreq[pos], 1u);
 			ok += (uint32_t)x3_popc64(N);
 			ototal += e - s;
 			stale = true;
-			x3_wave_sync();
+			x3_wave_order();
 		}
 	}
 	if (open) { /* the last context of the range */
@@ -372,9 +382,13 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 		if (ok > ocap) {
 			cap = ocap ? ocap : 2u;
 			while (cap < ok) cap <<= 1;
-			uint32_t got = 0;
-			if (lane == 0) got = atomicAdd(&a.top[c], cap);
-			off = x3_uniform(x3_bcast_u32(got, 0));
+			if (chunk_end - chunk_at < cap) {
+				const uint32_t want = cap > X3S_CHUNK ? cap : X3S_CHUNK;
+				uint32_t got = 0;
+				if (lane == 0) got = atomicAdd(&a.top[c], want);
+				chunk_at = x3_uniform(x3_bcast_u32(got, 0)); chunk_end = chunk_at + want;
+			}
+			off = chunk_at; chunk_at += cap;
 			if ((uint64_t)off + cap > pool_cap) { if (lane == 0) a.status[c] = X3_ST_POOL_FULL; off = 0; cap = 0; ok = 0; }
 		}
 		for (uint32_t p = lane; p < ok; p += X3_WAVE) {
@@ -418,7 +432,7 @@ __device__ static void x3s_pairs_body(const X3sPairArgs &a)
 	const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = x3_lane(), wave = tid / X3_WAVE;
 	const X3Slice sl = a.sl[c];
 	const uint32_t j0 = sl.sh, j1 = sl.sh + (sl.h1 - sl.h0);
-	uint32_t *pord = a.pord + 4 * a.chunks[c].elem_off;
+	uint32_t *pord = a.pord + X3S_POOL_PER_BYTE * a.chunks[c].elem_off + (uint64_t)c * X3S_POOL_EXTRA;
 	const uint64_t below = ((uint64_t)1 << lane) - 1;
 	uint32_t run = a.npairs[c];
 	uint32_t nw_ = j0 + tid < j1 ? a.stat1[j0 + tid].w : 0u; /* the next tile's words are in flight while this one is counted */
@@ -612,7 +626,8 @@ int x3s_begin(X3SliceRun &R, hipStream_t st, uint32_t nc, const X3Chunk *h_chunk
 	/* carried state */
 	CHK(R.lt.reserve(elems * 4)); CHK(R.idxfreq.reserve(elems * 4)); CHK(R.idxhist.reserve(elems * 4));
 	CHK(R.hdr1.reserve(elems * sizeof(X3CtxHdr))); CHK(R.hdr0.reserve(elems * sizeof(X3CtxHdr)));
-	CHK(R.pool1.reserve(4 * elems * 8)); CHK(R.pord1.reserve(4 * elems * 4)); CHK(R.pool0.reserve(4 * elems * 8));
+	const uint64_t pool_entries = X3S_POOL_PER_BYTE * elems + (uint64_t)nc * X3S_POOL_EXTRA;
+	CHK(R.pool1.reserve(pool_entries * 8)); CHK(R.pord1.reserve(pool_entries * 4)); CHK(R.pool0.reserve(pool_entries * 8));
 	CHK(R.sym.reserve((3 * elems + X3_SYM_PAD) * 16)); CHK(R.states.reserve((3 * elems + 8) * 8));
 	CHK(R.small.reserve((size_t)nc * X3S_SMALL_WORDS * 4 + 64));
 	HIPCHK(hipMemsetAsync(R.idxhist.p, 0, elems * 4, st)); /* a slice without an IDX1 hit leaves the new elements' counters untouched: they start here */

@@ -71,7 +71,9 @@ struct X3MtfArgs {
 	uint32_t *h_rank;          /* out per hit                                            */
 };
 
-/* the events [e0, e1) of one stream, 64 per trip, on the list (lst, pos0) that holds Dcur elements when the range starts */
+/* the events [e0, e1) of one stream, 64 per trip, on the list (lst, pos0) that holds Dcur elements when the range starts.  lst / pos0 are PRIVATE to the
+ * calling wavefront (every user gives each wavefront its own tables), so a compiler barrier orders its LDS accesses (x3_wave_order, simt.h): the fence
+ * of x3_wave_sync would also wait for the records in flight for the next tile and for the rank stores of this one -- two memory round trips per tile */
 __device__ static __forceinline__ void x3_mtf_tiles(const X3MtfArgs &a, uint16_t *lst, uint16_t *pos0, const uint32_t e0, const uint32_t e1, uint32_t Dcur,
                                                     const uint32_t dof, const uint32_t lane)
 {
@@ -113,9 +115,9 @@ __device__ static __forceinline__ void x3_mtf_tiles(const X3MtfArgs &a, uint16_t
 		const uint32_t p0_tag = valid && !x3_popc64(M & NEW) ? (uint32_t)pos0[t] : 0u;
 		uint32_t qmax = wave_max_u32(last_old ? p0_tag : 0u);
 		if (n_new && Dcur) qmax = Dcur - 1;
-		x3_wave_sync();
+		x3_wave_order();
 		if (last_old) pos0[t] = (uint16_t)(p0_tag | 0x8000u); /* mark: this position moves to the front */
-		x3_wave_sync();
+		x3_wave_order();
 		if (t_old || (n_new && Dcur)) {
 			uint32_t after = 0; /* touched old positions in the blocks above the current one */
 			for (int blk = (int)(qmax / X3_WAVE); blk >= 0; blk--) {
@@ -126,15 +128,15 @@ __device__ static __forceinline__ void x3_mtf_tiles(const X3MtfArgs &a, uint16_t
 				const uint64_t mm = x3_ballot(moved);
 				const uint32_t ge = after + (uint32_t)x3_popc64(mm & (above | bit)); /* touched old positions >= q */
 				const uint32_t np = nt + q - (t_old - ge);
-				x3_wave_sync(); /* the block is read before any lane writes into it */
+				x3_wave_order(); /* the block is read before any lane writes into it */
 				if (in && !moved) { lst[np] = (uint16_t)tq; pos0[tq] = (uint16_t)np; }
 				after += (uint32_t)x3_popc64(mm);
-				x3_wave_sync();
+				x3_wave_order();
 			}
 		}
 		if (last) { const uint32_t np = (uint32_t)x3_popc64(L & above); lst[np] = (uint16_t)t; pos0[t] = (uint16_t)np; }
 		Dcur += n_new;
-		x3_wave_sync();
+		x3_wave_order();
 	}
 }
 
