@@ -129,57 +129,85 @@ __device__ static void x3s_tokens_body(const X3sTokArgs &a)
  * into WAVES time ranges, one wavefront each.  The list at the start of a range is the elements that exist by then in order of their last touch --
  * and the last touches BEFORE the slice are the carried state: lt[tag] = 1 + (stream-absolute index of the element's last touch event), per stream.
  * ============================================================================================================ */
-struct X3sMtfArgs { const X3Chunk *chunks; const X3Slice *sl; const uint32_t *e_tag, *e_hit; uint32_t *h_rank; uint32_t *lt; };
+struct X3sMtfArgs {
+	const X3Chunk *chunks; const X3Slice *sl; const uint32_t *e_tag, *e_hit; uint32_t *h_rank;
+	uint32_t *lt;       /* carried per stream (at elem_off): per tag, last touch + 1 (stream-absolute index of the touch event), 0: never */
+	uint32_t *scratch;  /* [stream][range][X3S_DMAX + 1]: last touch + 1 of every tag INSIDE the range (0: none), and the range's insertions in the last word */
+	uint32_t nranges;   /* time ranges per stream, one wavefront (= workgroup) each */
+};
 
-template <uint32_t DMAX, uint32_t WAVES>
-__device__ static void x3s_mtf_body(const X3sMtfArgs &a)
+/* pass 1: wavefront (stream, range) records the last touch of every tag inside its range, and how many elements the range inserts */
+template <uint32_t DMAX>
+__device__ static void x3s_mtf_scan_body(const X3sMtfArgs &a)
 {
-	X3_LDS uint32_t tab[WAVES][DMAX];   /* last touch + 1 inside range w, 0: none; then: last touch + 1 before range w */
-	X3_LDS uint16_t lstw[WAVES][DMAX];
-	X3_LDS uint16_t pos0w[WAVES][DMAX];
-	X3_LDS uint32_t nnew[WAVES];
-	const uint32_t c = blockIdx.x, lane = x3_lane(), wv = threadIdx.x / X3_WAVE;
+	X3_LDS uint32_t tab[DMAX];
+	const uint32_t c = blockIdx.x / a.nranges, r = blockIdx.x % a.nranges, lane = x3_lane();
 	const X3Slice sl = a.sl[c];
-	uint32_t *lt = a.lt + a.chunks[c].elem_off;
 	const uint32_t e0 = sl.se, e1 = sl.se + (sl.h1 - sl.h0) + (sl.d1 - sl.d0);
 	const uint32_t abs0 = sl.h0 + sl.d0; /* stream-absolute index of the slice's first touch event */
-	const uint32_t per = (((e1 - e0 + WAVES - 1) / WAVES) + X3_WAVE - 1) & ~(X3_WAVE - 1);
-	const uint32_t s0 = e0 + wv * per < e1 ? e0 + wv * per : e1, s1 = s0 + per < e1 ? s0 + per : e1;
-	for (uint32_t i = lane; i < DMAX; i += X3_WAVE) tab[wv][i] = 0;
-	x3_wave_sync();
+	const uint32_t per = (((e1 - e0 + a.nranges - 1) / a.nranges) + X3_WAVE - 1) & ~(X3_WAVE - 1);
+	const uint32_t s0 = e0 + r * per < e1 ? e0 + r * per : e1, s1 = s0 + per < e1 ? s0 + per : e1;
+	uint32_t *out = a.scratch + ((size_t)c * a.nranges + r) * (X3S_DMAX + 1);
+	const uint32_t D = sl.d1;
+	for (uint32_t i = lane; i < D; i += X3_WAVE) tab[i] = 0;
+	x3_wave_order();
 	uint32_t cnt_new = 0;
+	uint32_t nt_ = 0, nh_ = 0;
+	if (s0 + lane < s1) { nt_ = a.e_tag[s0 + lane]; nh_ = a.e_hit[s0 + lane]; }
 	for (uint32_t base = s0; base < s1; base += X3_WAVE) {
 		const uint32_t i = base + lane;
 		const bool valid = i < s1;
-		const uint32_t t = valid ? a.e_tag[i] : 0u;
-		const bool isnew = valid && a.e_hit[i] == NONE32;
-		if (valid) atomicMax(&tab[wv][t], abs0 + (i - e0) + 1);
-		cnt_new += (uint32_t)x3_popc64(x3_ballot(isnew));
+		const uint32_t t = nt_, hit = nh_;
+		if (i + X3_WAVE < s1) { nt_ = a.e_tag[i + X3_WAVE]; nh_ = a.e_hit[i + X3_WAVE]; }
+		if (valid) atomicMax(&tab[t], abs0 + (i - e0) + 1);
+		cnt_new += (uint32_t)x3_popc64(x3_ballot(valid && hit == NONE32));
 	}
-	if (lane == 0) nnew[wv] = cnt_new;
-	__syncthreads();
-	for (uint32_t t = threadIdx.x; t < sl.d1; t += WAVES * X3_WAVE) { /* running maximum over the ranges, in place; the earlier slices first */
-		uint32_t run = t < sl.d0 ? lt[t] : 0u;
-		for (uint32_t w = 0; w < WAVES; w++) { const uint32_t own = tab[w][t]; tab[w][t] = run; run = own > run ? own : run; }
-		lt[t] = run;
-	}
+	x3_wave_order();
+	for (uint32_t i = lane; i < D; i += X3_WAVE) out[i] = tab[i];
+	if (lane == 0) out[X3S_DMAX] = cnt_new;
+}
+
+/* pass 2: wavefront (stream, range) builds the list as of its range's first event -- the elements that exist by then in order of their last touch, latest
+ * first: last touch before the range = the maximum over the carried table and the earlier ranges' tables; an element's position = how many elements were
+ * touched later (last touches are distinct events) -- and replays its events in tiles (x3_mtf_tiles).  The last range leaves the stream's table behind. */
+template <uint32_t DMAX>
+__device__ static void x3s_mtf_body(const X3sMtfArgs &a)
+{
+	X3_LDS uint32_t tab[DMAX];
+	X3_LDS uint16_t lst[DMAX];
+	X3_LDS uint16_t pos0[DMAX];
+	const uint32_t c = blockIdx.x / a.nranges, r = blockIdx.x % a.nranges, lane = x3_lane();
+	const X3Slice sl = a.sl[c];
+	uint32_t *lt = a.lt + a.chunks[c].elem_off;
+	const uint32_t e0 = sl.se, e1 = sl.se + (sl.h1 - sl.h0) + (sl.d1 - sl.d0);
+	const uint32_t per = (((e1 - e0 + a.nranges - 1) / a.nranges) + X3_WAVE - 1) & ~(X3_WAVE - 1);
+	const uint32_t s0 = e0 + r * per < e1 ? e0 + r * per : e1, s1 = s0 + per < e1 ? s0 + per : e1;
+	const uint32_t *rows = a.scratch + (size_t)c * a.nranges * (X3S_DMAX + 1);
+	const bool lastr = r + 1 == a.nranges;
+	if (s0 >= s1 && !lastr) return;
 	uint32_t Dcur = sl.d0;
-	for (uint32_t w = 0; w < wv; w++) Dcur += nnew[w];
-	__syncthreads();
-	uint16_t *const lst = lstw[wv], *const pos0 = pos0w[wv];
-	if (s0 < s1) {
-		for (uint32_t tb = 0; tb < Dcur; tb += X3_WAVE) { /* an element's position = how many elements were touched later (last touches are distinct events) */
-			const uint32_t t = tb + lane;
-			const uint32_t mine = t < Dcur ? tab[wv][t] : 0xFFFFFFFFu;
-			uint32_t later = 0;
-			for (uint32_t u = 0; u < Dcur; u++) later += tab[wv][u] > mine ? 1u : 0u;
-			if (t < Dcur) { lst[later] = (uint16_t)t; pos0[t] = (uint16_t)later; }
-		}
-		x3_wave_sync();
-		X3MtfArgs m;
-		m.eo = nullptr; m.dof = nullptr; m.e_tag = a.e_tag; m.e_hit = a.e_hit; m.h_rank = a.h_rank;
-		x3_mtf_tiles(m, lst, pos0, s0, s1, Dcur, 0, lane);
+	for (uint32_t w = 0; w < r; w++) Dcur += rows[(size_t)w * (X3S_DMAX + 1) + X3S_DMAX];
+	const uint32_t Dend = lastr ? sl.d1 : Dcur; /* the last range also folds its own table in, for the next slice */
+	for (uint32_t tb = 0; tb < Dend; tb += X3_WAVE) {
+		const uint32_t t = tb + lane;
+		uint32_t run = t < sl.d0 ? lt[t] : 0u;
+		if (t < Dend) for (uint32_t w = 0; w < r; w++) { const uint32_t v = rows[(size_t)w * (X3S_DMAX + 1) + t]; run = v > run ? v : run; }
+		if (t < Dcur) tab[t] = run;
+		if (lastr && t < Dend) { const uint32_t v = rows[(size_t)r * (X3S_DMAX + 1) + t]; lt[t] = v > run ? v : run; }
 	}
+	x3_wave_order();
+	if (s0 >= s1) return;
+	for (uint32_t tb = 0; tb < Dcur; tb += X3_WAVE) {
+		const uint32_t t = tb + lane;
+		const uint32_t mine = t < Dcur ? tab[t] : 0xFFFFFFFFu;
+		uint32_t later = 0;
+		for (uint32_t u = 0; u < Dcur; u++) later += tab[u] > mine ? 1u : 0u;
+		if (t < Dcur) { lst[later] = (uint16_t)t; pos0[t] = (uint16_t)later; }
+	}
+	x3_wave_order();
+	X3MtfArgs m;
+	m.eo = nullptr; m.dof = nullptr; m.e_tag = a.e_tag; m.e_hit = a.e_hit; m.h_rank = a.h_rank;
+	x3_mtf_tiles(m, lst, pos0, s0, s1, Dcur, 0, lane);
 }
 
 /* ============================================================================================================
@@ -210,8 +238,59 @@ struct X3sCtxArgs {
 	uint32_t *top;             /* per stream: bump pointer of the pool */
 	uint32_t *first00;         /* ORD: per stream, the slice-local hit that registers the pair (0, 0) in this slice (preset to NONE32 by the caller) */
 	uint32_t *status;          /* per stream: X3_ST_POOL_FULL if the pool bound was violated (a sizing bug) */
+	uint32_t *scratch;         /* [stream * nsub + wavefront][2 * sstride + 4]: per tag, the hits of the wavefront's LAST context inside its part of the range and the first of them
+	                            * (slice-local hit, NONE32: none) -- published when that context goes on in the next wavefront's part (x3s_ctx_publish_kernel) */
+	uint32_t sstride;          /* tags a row holds: the batch's largest dictionary, rounded up to 64 */
 	uint32_t kshift, kmask, dbits, nsub, nc;
 };
+
+/* first index in [lo, hi) whose key is >= key (keys ascend) */
+__device__ static __forceinline__ uint32_t s_lower_bound(const uint32_t *kA, uint32_t lo, uint32_t hi, uint32_t key)
+{
+	while (lo < hi) { const uint32_t mid = lo + ((hi - lo) >> 1); if (kA[mid] < key) lo = mid + 1; else hi = mid; }
+	return lo;
+}
+
+/* A stream's range of the arrangement is cut into `nsub` EQUAL parts, one wavefront each, wherever the cuts fall: a context that is cut goes through its parts
+ * like a stream through time ranges.  Pass 1 (this kernel): a wavefront whose last context goes on behind its part publishes what the later parts need of it:
+ * per tag the number of hits and the first hit inside the part.  Pass 2 (x3s_ctx_kernel): a wavefront that starts inside a context adds up the rows of the
+ * parts before it -- counts are additive, new tags enter the list in the order of their first hits -- and continues from there. */
+template <uint32_t DMAX>
+__device__ static void x3s_ctx_publish_body(const X3sCtxArgs &a)
+{
+	X3_LDS uint32_t cnt[DMAX];
+	X3_LDS uint32_t fst[DMAX];
+	const uint32_t lane = x3_lane();
+	const uint32_t c = blockIdx.x / a.nsub, sub = blockIdx.x % a.nsub;
+	const X3Slice sl = a.sl[c];
+	const uint32_t c0 = sl.sh, c1 = sl.sh + (sl.h1 - sl.h0);
+	const uint32_t per = (c1 - c0 + a.nsub - 1) / a.nsub;
+	const uint64_t n0 = (uint64_t)c0 + (uint64_t)sub * per, n1 = n0 + per;
+	const uint32_t h0 = n0 < c1 ? (uint32_t)n0 : c1, h1 = n1 < c1 ? (uint32_t)n1 : c1;
+	uint32_t *row = a.scratch + ((size_t)c * a.nsub + sub) * (2 * (size_t)a.sstride + 4);
+	if (h0 >= h1 || h1 >= c1) { if (lane == 0) row[2 * a.sstride] = 0; return; }
+	const uint32_t kl = a.kA[h1 - 1];
+	if (a.kA[h1] != kl) { if (lane == 0) row[2 * a.sstride] = 0; return; } /* my last context ends with my part */
+	const uint32_t ps = s_lower_bound(a.kA, h0, h1, kl); /* where it starts inside my part */
+	const uint32_t D = a.sstride < DMAX ? a.sstride : DMAX;
+	for (uint32_t i = lane; i < D; i += X3_WAVE) { cnt[i] = 0; fst[i] = NONE32; }
+	x3_wave_order();
+	uint32_t nj_ = ps + lane < h1 ? a.vA[ps + lane] : 0u, nj2_ = ps + X3_WAVE + lane < h1 ? a.vA[ps + X3_WAVE + lane] : 0u;
+	uint32_t nt_ = ps + lane < h1 ? a.h_tag[nj_] : 0u;
+	for (uint32_t base = ps; base < h1; base += X3_WAVE) {
+		const bool valid = base + lane < h1;
+		const uint32_t j = nj_, t = nt_;
+		{
+			const uint32_t nx = base + X3_WAVE + lane;
+			if (nx < h1) { nj_ = nj2_; nt_ = a.h_tag[nj2_]; }
+			if (nx + X3_WAVE < h1) nj2_ = a.vA[nx + X3_WAVE];
+		}
+		if (valid) { atomicAdd(&cnt[t], 1u); atomicMin(&fst[t], j); }
+	}
+	x3_wave_order();
+	for (uint32_t i = lane; i < D; i += X3_WAVE) { row[i] = cnt[i]; row[a.sstride + i] = fst[i]; }
+	if (lane == 0) row[2 * a.sstride] = h1 - ps;
+}
 
 template <uint32_t DMAX, bool ORD>
 __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
@@ -221,6 +300,7 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 	X3_LDS uint32_t lfreq[DMAX];     /* position -> freq                     */
 	X3_LDS uint32_t lpre[DMAX];      /* position -> cum_freq (valid when !stale) */
 	X3_LDS uint32_t lord[ORD ? DMAX : 1]; /* position -> pair ordinal, or 0x80000000 | making hit */
+	X3_LDS uint32_t fmin[DMAX];      /* (start inside a context) tag -> its first hit in the earlier parts */
 	const uint32_t lane = x3_lane();
 	const uint32_t c = blockIdx.x / a.nsub, sub = blockIdx.x % a.nsub;
 	const X3Slice sl = a.sl[c];
@@ -232,27 +312,10 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 	const uint32_t pool_cap = X3S_POOL_PER_BYTE * (a.chunks[c].len + 16u) + X3S_POOL_EXTRA;
 	const uint64_t bit = (uint64_t)1 << lane, below = bit - 1;
 	const int tbits = (int)a.dbits;
-	/* my part of the stream's range: from the first context boundary at or after the nominal cut to the first one at or after the next cut */
-	uint32_t h0 = c0, h1 = c1;
-	if (a.nsub > 1) {
-		const uint32_t per = (c1 - c0 + a.nsub - 1) / a.nsub;
-		uint32_t cut[2];
-		for (int w = 0; w < 2; w++) {
-			const uint64_t nom = (uint64_t)c0 + (uint64_t)(sub + (uint32_t)w) * per;
-			uint32_t p = nom >= c1 ? c1 : (uint32_t)nom;
-			if (p > c0 && p < c1) { /* first i >= p with kA[i] != kA[i-1] */
-				for (;;) {
-					const uint32_t i = p + lane;
-					const uint64_t bm = x3_ballot(i < c1 && a.kA[i] != a.kA[i - 1]);
-					if (bm) { p += (uint32_t)x3_ctz64(bm); break; }
-					p += X3_WAVE;
-					if (p >= c1) { p = c1; break; }
-				}
-			}
-			cut[w] = p;
-		}
-		h0 = cut[0]; h1 = cut[1];
-	}
+	/* my part of the stream's range: equal parts, wherever the cuts fall (see x3s_ctx_publish_body) */
+	const uint32_t per = (c1 - c0 + a.nsub - 1) / a.nsub;
+	const uint64_t n0 = (uint64_t)c0 + (uint64_t)sub * per, n1 = n0 + per;
+	const uint32_t h0 = n0 < c1 ? (uint32_t)n0 : c1, h1 = n1 < c1 ? (uint32_t)n1 : c1;
 	if (h0 >= h1) return;
 	for (uint32_t i = lane; i < DMAX; i += X3_WAVE) tpos[i] = NONE16;
 	x3_wave_order();
@@ -262,6 +325,51 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 	/* blocks for new / outgrown lists come from a chunk this wavefront takes from the stream's pool in one go: one atomic per X3S_CHUNK entries instead of one
 	 * per list (a returning atomic on ONE address per stream serialises: 15 000 of them per slice and stream were most of this kernel's time) */
 	uint32_t chunk_at = 0, chunk_end = 0;
+	const bool goes_on = h1 < c1 && a.kA[h1] == a.kA[h1 - 1]; /* my last context goes on in the next part: the wavefront that sees its end stores it */
+	if (h0 > c0 && a.kA[h0 - 1] == a.kA[h0]) {
+		/* ---- I start INSIDE a context: its list as of my first hit = the carried list + what the earlier parts did to it ---- */
+		const uint32_t kf = x3_uniform(a.kA[h0]);
+		const uint32_t cs = s_lower_bound(a.kA, c0, h0, kf);     /* the context's first hit of the slice */
+		const uint32_t w0 = (cs - c0) / per;                      /* ... lies in this wavefront's part    */
+		const X3CtxHdr hd0 = hdrs[kf & a.kmask];
+		okey = kf; open = true; ok0 = x3_uniform(hd0.items); ooff = x3_uniform(hd0.off); ocap = x3_uniform(hd0.cap); ototal = x3_uniform(hd0.total) + (h0 - cs);
+		for (uint32_t pb = 0; pb < ok0; pb += X3_WAVE) {
+			const uint32_t p = pb + lane;
+			if (p < ok0) {
+				const uint64_t it = pool[(uint64_t)ooff + p];
+				const uint32_t tg = (uint32_t)(it >> 32);
+				ltag[p] = (uint16_t)tg; lfreq[p] = (uint32_t)it; tpos[tg] = (uint16_t)p; if (ORD) lord[p] = pord[(uint64_t)ooff + p];
+			}
+		}
+		x3_wave_order();
+		const uint32_t D = a.sstride < DMAX ? a.sstride : DMAX;
+		const size_t rs = 2 * (size_t)a.sstride + 4;
+		const uint32_t *rows = a.scratch + (size_t)c * a.nsub * rs;
+		uint32_t nnew_total = 0;
+		for (uint32_t tb = 0; tb < D; tb += X3_WAVE) { /* per tag: hits in the earlier parts, the first of them (lpre doubles as the counter array here) */
+			const uint32_t t = tb + lane;
+			uint32_t acc = 0, fj = NONE32;
+			if (t < D) for (uint32_t w = w0; w < sub; w++) { const uint32_t *r = rows + (size_t)w * rs; acc += r[t]; const uint32_t f = r[a.sstride + t]; fj = f < fj ? f : fj; }
+			const uint32_t cp = t < D ? (uint32_t)tpos[t] : (uint32_t)NONE16;
+			if (t < D && acc && cp != NONE16) lfreq[cp] += acc;
+			const bool isn = t < D && acc && cp == NONE16;
+			if (t < D) { lpre[t] = isn ? acc : 0u; fmin[t] = isn ? fj : NONE32; }
+			nnew_total += (uint32_t)x3_popc64(x3_ballot(isn));
+		}
+		x3_wave_order();
+		if (nnew_total) { /* tags the earlier parts added: behind the carried ones, in the order of their first hits */
+			for (uint32_t tb = 0; tb < D; tb += X3_WAVE) {
+				const uint32_t t = tb + lane;
+				const uint32_t mine = t < D ? fmin[t] : NONE32;
+				uint32_t before = 0;
+				if (mine != NONE32) for (uint32_t u = 0; u < D; u++) before += fmin[u] < mine ? 1u : 0u;
+				if (mine != NONE32) { const uint32_t pos = ok0 + before; tpos[t] = (uint16_t)pos; ltag[pos] = (uint16_t)t; lfreq[pos] = lpre[t]; if (ORD) lord[pos] = 0x80000000u | mine; }
+			}
+		}
+		ok = ok0 + nnew_total;
+		stale = true; /* the first tile rescans the cum_freqs */
+		x3_wave_order();
+	}
 	/* records of the range in tiles of 64, fetched ahead: keys and hits one tile, the gathered tags one tile (their hits two tiles), and every lane the
 	 * header of ITS key's context -- up to 64 headers in flight at once instead of one dependent load per context */
 	uint32_t nk_ = 0, nj_ = 0, nt_ = 0, nj2_ = 0;
@@ -377,7 +485,7 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 			x3_wave_order();
 		}
 	}
-	if (open) { /* the last context of the range */
+	if (open && !goes_on) { /* the last context of my part ends there: its final list goes back to the pool */
 		uint32_t off = ooff, cap = ocap;
 		if (ok > ocap) {
 			cap = ocap ? ocap : 2u;
@@ -576,8 +684,12 @@ __device__ static void x3s_order0_body(const X3sOrder0Args &a)
 
 #ifndef X3_EMU
 __global__ void __launch_bounds__(X3S_TOK_THREADS) x3s_tokens_kernel(X3sTokArgs a) { x3s_tokens_body(a); }
-__global__ void __launch_bounds__(16 * X3_WAVE) x3s_mtf_kernel_t(X3sMtfArgs a) { x3s_mtf_body<512, 16>(a); }
-__global__ void __launch_bounds__(8 * X3_WAVE) x3s_mtf_kernel_s(X3sMtfArgs a) { x3s_mtf_body<2048, 8>(a); }
+__global__ void __launch_bounds__(X3_WAVE) x3s_mtf_scan_kernel_t(X3sMtfArgs a) { x3s_mtf_scan_body<512>(a); }
+__global__ void __launch_bounds__(X3_WAVE) x3s_mtf_scan_kernel_s(X3sMtfArgs a) { x3s_mtf_scan_body<2048>(a); }
+__global__ void __launch_bounds__(X3_WAVE) x3s_mtf_kernel_t(X3sMtfArgs a) { x3s_mtf_body<512>(a); }
+__global__ void __launch_bounds__(X3_WAVE) x3s_mtf_kernel_s(X3sMtfArgs a) { x3s_mtf_body<2048>(a); }
+__global__ void __launch_bounds__(X3_WAVE) x3s_ctx_publish_kernel_t(X3sCtxArgs a) { x3s_ctx_publish_body<512>(a); }
+__global__ void __launch_bounds__(X3_WAVE) x3s_ctx_publish_kernel_s(X3sCtxArgs a) { x3s_ctx_publish_body<2048>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3s_ctx1_kernel_t(X3sCtxArgs a) { x3s_ctx_body<512, true>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3s_ctx1_kernel_s(X3sCtxArgs a) { x3s_ctx_body<2048, true>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3s_ctx0_kernel_t(X3sCtxArgs a) { x3s_ctx_body<512, false>(a); }
@@ -589,8 +701,12 @@ __global__ void __launch_bounds__(X3_WAVE) x3s_order0_kernel(X3sOrder0Args a) { 
 #define X3S_LAUNCH(kern, args, grid, block, st) hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, st, args)
 #else
 static void stok_tramp(void *p) { x3s_tokens_body(*(const X3sTokArgs *)p); }
-static void smtf_tramp_t(void *p) { x3s_mtf_body<512, 16>(*(const X3sMtfArgs *)p); }
-static void smtf_tramp_s(void *p) { x3s_mtf_body<2048, 8>(*(const X3sMtfArgs *)p); }
+static void smtfscan_tramp_t(void *p) { x3s_mtf_scan_body<512>(*(const X3sMtfArgs *)p); }
+static void smtfscan_tramp_s(void *p) { x3s_mtf_scan_body<2048>(*(const X3sMtfArgs *)p); }
+static void smtf_tramp_t(void *p) { x3s_mtf_body<512>(*(const X3sMtfArgs *)p); }
+static void smtf_tramp_s(void *p) { x3s_mtf_body<2048>(*(const X3sMtfArgs *)p); }
+static void sctxpub_tramp_t(void *p) { x3s_ctx_publish_body<512>(*(const X3sCtxArgs *)p); }
+static void sctxpub_tramp_s(void *p) { x3s_ctx_publish_body<2048>(*(const X3sCtxArgs *)p); }
 static void sctx1_tramp_t(void *p) { x3s_ctx_body<512, true>(*(const X3sCtxArgs *)p); }
 static void sctx1_tramp_s(void *p) { x3s_ctx_body<2048, true>(*(const X3sCtxArgs *)p); }
 static void sctx0_tramp_t(void *p) { x3s_ctx_body<512, false>(*(const X3sCtxArgs *)p); }
@@ -600,8 +716,12 @@ static void sidx_tramp_t(void *p) { x3s_idxstat_body<512>(*(const X3sIdxArgs *)p
 static void sidx_tramp_s(void *p) { x3s_idxstat_body<2048>(*(const X3sIdxArgs *)p); }
 static void sorder0_tramp(void *p) { x3s_order0_body(*(const X3sOrder0Args *)p); }
 #define x3s_tokens_kernel stok_tramp
+#define x3s_mtf_scan_kernel_t smtfscan_tramp_t
+#define x3s_mtf_scan_kernel_s smtfscan_tramp_s
 #define x3s_mtf_kernel_t smtf_tramp_t
 #define x3s_mtf_kernel_s smtf_tramp_s
+#define x3s_ctx_publish_kernel_t sctxpub_tramp_t
+#define x3s_ctx_publish_kernel_s sctxpub_tramp_s
 #define x3s_ctx1_kernel_t sctx1_tramp_t
 #define x3s_ctx1_kernel_s sctx1_tramp_s
 #define x3s_ctx0_kernel_t sctx0_tramp_t
@@ -630,6 +750,8 @@ int x3s_begin(X3SliceRun &R, hipStream_t st, uint32_t nc, const X3Chunk *h_chunk
 	CHK(R.pool1.reserve(pool_entries * 8)); CHK(R.pord1.reserve(pool_entries * 4)); CHK(R.pool0.reserve(pool_entries * 8));
 	CHK(R.sym.reserve((3 * elems + X3_SYM_PAD) * 16)); CHK(R.states.reserve((3 * elems + 8) * 8));
 	CHK(R.small.reserve((size_t)nc * X3S_SMALL_WORDS * 4 + 64));
+	CHK(R.mtf_scratch.reserve((size_t)nc * X3S_MTF_RANGES * (X3S_DMAX + 1) * 4));
+	CHK(R.ctx_scratch.reserve(((size_t)max_slice_steps / 256 + 2 * (size_t)nc) * (2 * 512 + 4) * 4)); /* rows of x3s_ctx_publish_kernel for dictionaries up to 512 elements */
 	HIPCHK(hipMemsetAsync(R.idxhist.p, 0, elems * 4, st)); /* a slice without an IDX1 hit leaves the new elements' counters untouched: they start here */
 	{ uint32_t *f = R.idxfreq.as<uint32_t>(); x3_foreach((size_t)elems, st, X3_LAMBDA(size_t i) { f[i] = 1u; }); } /* model_enlarge: a new symbol has frequency 1 (ac.c:250-266) */
 	HIPCHK(hipMemsetAsync(R.hdr1.p, 0, elems * sizeof(X3CtxHdr), st));
@@ -714,8 +836,13 @@ int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_for
 		HIPCHK(hipEventRecord(ev_fork, st));
 		HIPCHK(hipStreamWaitEvent(side, ev_fork, 0));
 		X3sMtfArgs ma;
-		ma.chunks = d_chunks; ma.sl = d_sl; ma.e_tag = e_tag; ma.e_hit = e_hit; ma.h_rank = h_rank; ma.lt = R.lt.as<uint32_t>();
-		if (small) X3S_LAUNCH(x3s_mtf_kernel_t, ma, nc, 16 * X3_WAVE, side); else X3S_LAUNCH(x3s_mtf_kernel_s, ma, nc, 8 * X3_WAVE, side);
+		ma.chunks = d_chunks; ma.sl = d_sl; ma.e_tag = e_tag; ma.e_hit = e_hit; ma.h_rank = h_rank; ma.lt = R.lt.as<uint32_t>(); ma.scratch = R.mtf_scratch.as<uint32_t>();
+		/* time ranges of ~4096 events, one wavefront each: a range's cost is its events plus building its list (elements^2 / 64), so few elements allow many ranges */
+		uint64_t rw = (nE / nc + 4095) / 4096;
+		ma.nranges = rw < 1 ? 1u : rw > X3S_MTF_RANGES ? X3S_MTF_RANGES : (uint32_t)rw;
+		if (const char *e = getenv("X3H_SLICE_MTF_RANGES")) { const int v = atoi(e); if (v >= 1 && v <= (int)X3S_MTF_RANGES) ma.nranges = (uint32_t)v; }
+		if (small) { X3S_LAUNCH(x3s_mtf_scan_kernel_t, ma, nc * ma.nranges, X3_WAVE, side); X3S_LAUNCH(x3s_mtf_kernel_t, ma, nc * ma.nranges, X3_WAVE, side); }
+		else { X3S_LAUNCH(x3s_mtf_scan_kernel_s, ma, nc * ma.nranges, X3_WAVE, side); X3S_LAUNCH(x3s_mtf_kernel_s, ma, nc * ma.nranges, X3_WAVE, side); }
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipEventRecord(ev_join, side));
 	}
@@ -731,6 +858,13 @@ int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_for
 		uint64_t want = (nH / nc + 255) / 256;
 		ca.nsub = want < 1 ? 1u : want > 512 ? 512u : (uint32_t)want;
 		if (const char *e = getenv("X3H_SLICE_SUB")) { const int v = atoi(e); if (v >= 1 && v <= 1024) ca.nsub = (uint32_t)v; }
+		ca.sstride = (uint32_t)((max_dict + 63) & ~(uint64_t)63);
+		{
+			const size_t need = (size_t)nc * ca.nsub * (2 * (size_t)ca.sstride + 4) * 4;
+			if (R.ctx_scratch.cap < need) CHK(R.ctx_scratch.reserve(need)); /* (beyond x3s_begin's guess: a reallocation in mid-flight waits for the device, once) */
+			ca.scratch = R.ctx_scratch.as<uint32_t>();
+		}
+		if (ca.nsub > 1) { if (small) X3S_LAUNCH(x3s_ctx_publish_kernel_t, ca, nc * ca.nsub, X3_WAVE, st); else X3S_LAUNCH(x3s_ctx_publish_kernel_s, ca, nc * ca.nsub, X3_WAVE, st); }
 		if (small) X3S_LAUNCH(x3s_ctx1_kernel_t, ca, nc * ca.nsub, X3_WAVE, st); else X3S_LAUNCH(x3s_ctx1_kernel_s, ca, nc * ca.nsub, X3_WAVE, st);
 		HIPCHK(hipGetLastError());
 		/* pair ordinals, context0 */
@@ -768,6 +902,7 @@ int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_for
 		CHK(x3p_sort_pairs(R.tmp, k0, kA, iota, vA, nH, (int)psh + cb, st));
 		ca.stat = stat0; ca.hdr = R.hdr0.as<X3CtxHdr>(); ca.pool = R.pool0.as<uint64_t>(); ca.pord = nullptr; ca.newaddr = nullptr; ca.top = m_top0; ca.first00 = nullptr;
 		ca.kshift = psh; ca.kmask = (psh >= 32 ? 0xFFFFFFFFu : (1u << psh) - 1u);
+		if (ca.nsub > 1) { if (small) X3S_LAUNCH(x3s_ctx_publish_kernel_t, ca, nc * ca.nsub, X3_WAVE, st); else X3S_LAUNCH(x3s_ctx_publish_kernel_s, ca, nc * ca.nsub, X3_WAVE, st); }
 		if (small) X3S_LAUNCH(x3s_ctx0_kernel_t, ca, nc * ca.nsub, X3_WAVE, st); else X3S_LAUNCH(x3s_ctx0_kernel_s, ca, nc * ca.nsub, X3_WAVE, st);
 		HIPCHK(hipGetLastError());
 	}

@@ -132,6 +132,7 @@ static inline int x3_clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
 
 template <typename T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
 template <typename T> static inline T atomicMax(T *p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <typename T> static inline T atomicMin(T *p, T v) { T o = *p; if (v < o) *p = v; return o; }
 template <typename T> static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
 template <typename T> static inline T atomicCAS(T *p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
 static inline void __threadfence() {}

@@ -184,6 +184,7 @@ struct X3Slice {
 
 #define X3S_DMAX 2048u          /* largest dictionary of a stream the sliced kernels hold in their LDS tables (api.hip falls back to the other schedules beyond) */
 #define X3S_MAX_SLICES 24u
+#define X3S_MTF_RANGES 128u      /* most time ranges per stream and slice of the move-to-front kernel */
 #define X3S_NARR 28
 /* per-stream carried scalars, one array of nc (x multiplicity) words each inside X3SliceRun::small, in this order */
 enum { X3S_EVFINAL = 0 /* x4: model_events freqs of E_CTX0 / E_CTX1 / E_IDX1, IDX1 uses */, X3S_NNOOP = 4, X3S_NPAIRS = 5, X3S_ORD00 = 6, X3S_LASTORD = 7, X3S_YCNT = 8, X3S_YDONE = 9,
@@ -194,13 +195,13 @@ struct X3SliceRun {
 	uint32_t nc = 0;
 	uint64_t elems = 0;
 	/* carried state (per stream at elem_off / 4 * elem_off / 3 * elem_off) */
-	DevBuf lt, idxfreq, idxhist, hdr1, hdr0, pool1, pord1, pool0, sym, states, small;
+	DevBuf lt, idxfreq, idxhist, hdr1, hdr0, pool1, pord1, pool0, sym, states, small, mtf_scratch, ctx_scratch;
 	/* temporaries of a slice */
 	DevBuf a[X3S_NARR], b[3], stat1, stat0, est_val, est_cls, tmp, tables;
 	std::vector<std::vector<X3Slice>> slices; /* host copies of the slice tables, kept until the run ends (their H2D copies are asynchronous) */
 	void release()
 	{
-		DevBuf *all[] = { &lt, &idxfreq, &idxhist, &hdr1, &hdr0, &pool1, &pord1, &pool0, &sym, &states, &small, &b[0], &b[1], &b[2], &stat1, &stat0, &est_val, &est_cls, &tmp, &tables };
+		DevBuf *all[] = { &lt, &idxfreq, &idxhist, &hdr1, &hdr0, &pool1, &pord1, &pool0, &sym, &states, &small, &mtf_scratch, &ctx_scratch, &b[0], &b[1], &b[2], &stat1, &stat0, &est_val, &est_cls, &tmp, &tables };
 		for (DevBuf *d : all) d->release();
 		for (DevBuf &d : a) d.release();
 	}
