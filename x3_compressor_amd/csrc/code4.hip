@@ -131,7 +131,8 @@ __device__ static void x3s_tokens_body(const X3sTokArgs &a)
  * ============================================================================================================ */
 struct X3sMtfArgs {
 	const X3Chunk *chunks; const X3Slice *sl; const uint32_t *e_tag, *e_hit; uint32_t *h_rank;
-	uint32_t *lt;       /* carried per stream (at elem_off): per tag, last touch + 1 (stream-absolute index of the touch event), 0: never */
+	const uint32_t *lt; /* carried per stream (at elem_off): per tag, last touch + 1 (stream-absolute index of the touch event), 0: never */
+	uint32_t *lt_out;   /* ... as the NEXT slice finds it: a second array, because the ranges of this slice read `lt` whenever they get to run */
 	uint32_t *scratch;  /* [stream][range][X3S_DMAX + 1]: last touch + 1 of every tag INSIDE the range (0: none), and the range's insertions in the last word */
 	uint32_t nranges;   /* time ranges per stream, one wavefront (= workgroup) each */
 };
@@ -178,7 +179,8 @@ __device__ static void x3s_mtf_body(const X3sMtfArgs &a)
 	X3_LDS uint16_t pos0[DMAX];
 	const uint32_t c = blockIdx.x / a.nranges, r = blockIdx.x % a.nranges, lane = x3_lane();
 	const X3Slice sl = a.sl[c];
-	uint32_t *lt = a.lt + a.chunks[c].elem_off;
+	const uint32_t *lt = a.lt + a.chunks[c].elem_off;
+	uint32_t *lt_out = a.lt_out + a.chunks[c].elem_off;
 	const uint32_t e0 = sl.se, e1 = sl.se + (sl.h1 - sl.h0) + (sl.d1 - sl.d0);
 	const uint32_t per = (((e1 - e0 + a.nranges - 1) / a.nranges) + X3_WAVE - 1) & ~(X3_WAVE - 1);
 	const uint32_t s0 = e0 + r * per < e1 ? e0 + r * per : e1, s1 = s0 + per < e1 ? s0 + per : e1;
@@ -193,7 +195,7 @@ __device__ static void x3s_mtf_body(const X3sMtfArgs &a)
 		uint32_t run = t < sl.d0 ? lt[t] : 0u;
 		if (t < Dend) for (uint32_t w = 0; w < r; w++) { const uint32_t v = rows[(size_t)w * (X3S_DMAX + 1) + t]; run = v > run ? v : run; }
 		if (t < Dcur) tab[t] = run;
-		if (lastr && t < Dend) { const uint32_t v = rows[(size_t)r * (X3S_DMAX + 1) + t]; lt[t] = v > run ? v : run; }
+		if (lastr && t < Dend) { const uint32_t v = rows[(size_t)r * (X3S_DMAX + 1) + t]; lt_out[t] = v > run ? v : run; }
 	}
 	x3_wave_order();
 	if (s0 >= s1) return;
@@ -238,6 +240,9 @@ struct X3sCtxArgs {
 	uint32_t *top;             /* per stream: bump pointer of the pool */
 	uint32_t *first00;         /* ORD: per stream, the slice-local hit that registers the pair (0, 0) in this slice (preset to NONE32 by the caller) */
 	uint32_t *status;          /* per stream: X3_ST_POOL_FULL if the pool bound was violated (a sizing bug) */
+	uint4 *pending;            /* [stream * nsub + wavefront] {context, offset, items | capacity log2 << 27, total}, context == NONE32: nothing.  The wavefront that ends a context which
+	                            * was cut leaves the context's new header HERE and its list in a NEW block: the other parts of that context read the header and the old block whenever
+	                            * they get to run.  x3s_ctx_apply moves the headers into place behind the kernel. */
 	uint32_t *scratch;         /* [stream * nsub + wavefront][2 * sstride + 4]: per tag, the hits of the wavefront's LAST context inside its part of the range and the first of them
 	                            * (slice-local hit, NONE32: none) -- published when that context goes on in the next wavefront's part (x3s_ctx_publish_kernel) */
 	uint32_t sstride;          /* tags a row holds: the batch's largest dictionary, rounded up to 64 */
@@ -316,7 +321,7 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 	const uint32_t per = (c1 - c0 + a.nsub - 1) / a.nsub;
 	const uint64_t n0 = (uint64_t)c0 + (uint64_t)sub * per, n1 = n0 + per;
 	const uint32_t h0 = n0 < c1 ? (uint32_t)n0 : c1, h1 = n1 < c1 ? (uint32_t)n1 : c1;
-	if (h0 >= h1) return;
+	if (h0 >= h1) { if (lane == 0) a.pending[(size_t)c * a.nsub + sub] = make_uint4(NONE32, 0, 0, 0); return; }
 	for (uint32_t i = lane; i < DMAX; i += X3_WAVE) tpos[i] = NONE16;
 	x3_wave_order();
 	/* the OPEN context: its list is in the LDS tables (wave-uniform bookkeeping) */
@@ -326,7 +331,10 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 	 * per list (a returning atomic on ONE address per stream serialises: 15 000 of them per slice and stream were most of this kernel's time) */
 	uint32_t chunk_at = 0, chunk_end = 0;
 	const bool goes_on = h1 < c1 && a.kA[h1] == a.kA[h1 - 1]; /* my last context goes on in the next part: the wavefront that sees its end stores it */
+	bool split = false; /* the open context was cut: I am not its first part */
+	if (lane == 0) a.pending[(size_t)c * a.nsub + sub] = make_uint4(NONE32, 0, 0, 0);
 	if (h0 > c0 && a.kA[h0 - 1] == a.kA[h0]) {
+		split = true;
 		/* ---- I start INSIDE a context: its list as of my first hit = the carried list + what the earlier parts did to it ---- */
 		const uint32_t kf = x3_uniform(a.kA[h0]);
 		const uint32_t cs = s_lower_bound(a.kA, c0, h0, kf);     /* the context's first hit of the slice */
@@ -399,7 +407,7 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 			if (!(open && key_s == okey)) {
 				if (open) { /* ---- store the context that ended ---- */
 					uint32_t off = ooff, cap = ocap;
-					if (ok > ocap) { /* ctx_enlarge: a new block (the old one is abandoned, like a realloc that moved) */
+					if (ok > ocap || split) { /* ctx_enlarge: a new block (the old one is abandoned, like a realloc that moved); a context that was cut always moves */
 						cap = ocap ? ocap : 2u;
 						while (cap < ok) cap <<= 1;
 						if (chunk_end - chunk_at < cap) { /* (what is left of the old chunk is abandoned: < X3S_CHUNK entries) */
@@ -421,7 +429,12 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 						}
 						tpos[tg] = NONE16;
 					}
-					if (lane == 0) { X3CtxHdr nh; nh.off = off; nh.items = ok; nh.cap = cap; nh.total = ototal; hdrs[okey & a.kmask] = nh; }
+					if (lane == 0) {
+						X3CtxHdr nh; nh.off = off; nh.items = ok; nh.cap = cap; nh.total = ototal;
+						if (split) a.pending[(size_t)c * a.nsub + sub] = make_uint4(okey & a.kmask, off, ok | (cap ? (uint32_t)(31 - x3_clz32(cap)) << 27 : 0u), ototal);
+						else hdrs[okey & a.kmask] = nh;
+					}
+					split = false; /* (only my first context can be one that was cut before me) */
 					x3_wave_order();
 				}
 				/* ---- load the context that starts (its header came with the tile) ---- */
@@ -487,7 +500,7 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 	}
 	if (open && !goes_on) { /* the last context of my part ends there: its final list goes back to the pool */
 		uint32_t off = ooff, cap = ocap;
-		if (ok > ocap) {
+		if (ok > ocap || split) {
 			cap = ocap ? ocap : 2u;
 			while (cap < ok) cap <<= 1;
 			if (chunk_end - chunk_at < cap) {
@@ -508,7 +521,11 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 				if (o & 0x80000000u) a.newaddr[o & 0x7FFFFFFFu] = off + p;
 			}
 		}
-		if (lane == 0) { X3CtxHdr nh; nh.off = off; nh.items = ok; nh.cap = cap; nh.total = ototal; hdrs[okey & a.kmask] = nh; }
+		if (lane == 0) {
+			X3CtxHdr nh; nh.off = off; nh.items = ok; nh.cap = cap; nh.total = ototal;
+			if (split) a.pending[(size_t)c * a.nsub + sub] = make_uint4(okey & a.kmask, off, ok | (cap ? (uint32_t)(31 - x3_clz32(cap)) << 27 : 0u), ototal);
+			else hdrs[okey & a.kmask] = nh;
+		}
 	}
 	(void)ok0;
 }
@@ -736,6 +753,22 @@ static void sorder0_tramp(void *p) { x3s_order0_body(*(const X3sOrder0Args *)p);
 /* ============================================================================================================
  * Host side: the workspace of a sliced run and one slice through the feature stages.
  * ============================================================================================================ */
+/* the headers of the contexts that were cut go into place behind the kernel (X3sCtxArgs::pending) */
+static int x3s_ctx_apply(hipStream_t st, const X3sCtxArgs &ca, const X3Chunk *d_chunks)
+{
+	if (ca.nsub <= 1) return X3H_OK;
+	const uint4 *pend = ca.pending;
+	X3CtxHdr *hdr = ca.hdr;
+	const uint32_t nsub = ca.nsub;
+	x3_foreach((size_t)ca.nc * nsub, st, X3_LAMBDA(size_t i) {
+		const uint4 p = pend[i];
+		if (p.x == NONE32) return;
+		X3CtxHdr nh; nh.off = p.y; nh.items = p.z & 0x07FFFFFFu; nh.cap = (p.z >> 27) ? 1u << (p.z >> 27) : (nh.items ? 1u : 0u); nh.total = p.w;
+		hdr[d_chunks[i / nsub].elem_off + p.x] = nh;
+	});
+	HIPCHK(hipGetLastError());
+	return X3H_OK;
+}
 int x3s_begin(X3SliceRun &R, hipStream_t st, uint32_t nc, const X3Chunk *h_chunks, uint64_t max_slice_steps, uint64_t max_slice_bytes)
 {
 	R.nc = nc;
@@ -744,13 +777,14 @@ int x3s_begin(X3SliceRun &R, hipStream_t st, uint32_t nc, const X3Chunk *h_chunk
 	if (elems >= ((uint64_t)1 << 29)) return X3H_E_ARG; /* symbol slots 3 * elems stay below 2^31 */
 	R.elems = elems;
 	/* carried state */
-	CHK(R.lt.reserve(elems * 4)); CHK(R.idxfreq.reserve(elems * 4)); CHK(R.idxhist.reserve(elems * 4));
+	CHK(R.lt.reserve(elems * 4)); CHK(R.lt2.reserve(elems * 4)); R.lt_flip = false; CHK(R.idxfreq.reserve(elems * 4)); CHK(R.idxhist.reserve(elems * 4));
 	CHK(R.hdr1.reserve(elems * sizeof(X3CtxHdr))); CHK(R.hdr0.reserve(elems * sizeof(X3CtxHdr)));
 	const uint64_t pool_entries = X3S_POOL_PER_BYTE * elems + (uint64_t)nc * X3S_POOL_EXTRA;
 	CHK(R.pool1.reserve(pool_entries * 8)); CHK(R.pord1.reserve(pool_entries * 4)); CHK(R.pool0.reserve(pool_entries * 8));
 	CHK(R.sym.reserve((3 * elems + X3_SYM_PAD) * 16)); CHK(R.states.reserve((3 * elems + 8) * 8));
 	CHK(R.small.reserve((size_t)nc * X3S_SMALL_WORDS * 4 + 64));
 	CHK(R.mtf_scratch.reserve((size_t)nc * X3S_MTF_RANGES * (X3S_DMAX + 1) * 4));
+	CHK(R.ctx_pending.reserve((size_t)nc * 1024 * 16));
 	CHK(R.ctx_scratch.reserve(((size_t)max_slice_steps / 256 + 2 * (size_t)nc) * (2 * 512 + 4) * 4)); /* rows of x3s_ctx_publish_kernel for dictionaries up to 512 elements */
 	HIPCHK(hipMemsetAsync(R.idxhist.p, 0, elems * 4, st)); /* a slice without an IDX1 hit leaves the new elements' counters untouched: they start here */
 	{ uint32_t *f = R.idxfreq.as<uint32_t>(); x3_foreach((size_t)elems, st, X3_LAMBDA(size_t i) { f[i] = 1u; }); } /* model_enlarge: a new symbol has frequency 1 (ac.c:250-266) */
@@ -836,7 +870,8 @@ int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_for
 		HIPCHK(hipEventRecord(ev_fork, st));
 		HIPCHK(hipStreamWaitEvent(side, ev_fork, 0));
 		X3sMtfArgs ma;
-		ma.chunks = d_chunks; ma.sl = d_sl; ma.e_tag = e_tag; ma.e_hit = e_hit; ma.h_rank = h_rank; ma.lt = R.lt.as<uint32_t>(); ma.scratch = R.mtf_scratch.as<uint32_t>();
+		ma.chunks = d_chunks; ma.sl = d_sl; ma.e_tag = e_tag; ma.e_hit = e_hit; ma.h_rank = h_rank; ma.scratch = R.mtf_scratch.as<uint32_t>();
+		ma.lt = (R.lt_flip ? R.lt2 : R.lt).as<uint32_t>(); ma.lt_out = (R.lt_flip ? R.lt : R.lt2).as<uint32_t>(); R.lt_flip = !R.lt_flip;
 		/* time ranges of ~4096 events, one wavefront each: a range's cost is its events plus building its list (elements^2 / 64), so few elements allow many ranges */
 		uint64_t rw = (nE / nc + 4095) / 4096;
 		ma.nranges = rw < 1 ? 1u : rw > X3S_MTF_RANGES ? X3S_MTF_RANGES : (uint32_t)rw;
@@ -864,8 +899,11 @@ int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_for
 			if (R.ctx_scratch.cap < need) CHK(R.ctx_scratch.reserve(need)); /* (beyond x3s_begin's guess: a reallocation in mid-flight waits for the device, once) */
 			ca.scratch = R.ctx_scratch.as<uint32_t>();
 		}
+		if (R.ctx_pending.cap < (size_t)nc * ca.nsub * 16) return X3H_E_INTERNAL; /* (x3s_begin sized it) */
+		ca.pending = R.ctx_pending.as<uint4>();
 		if (ca.nsub > 1) { if (small) X3S_LAUNCH(x3s_ctx_publish_kernel_t, ca, nc * ca.nsub, X3_WAVE, st); else X3S_LAUNCH(x3s_ctx_publish_kernel_s, ca, nc * ca.nsub, X3_WAVE, st); }
 		if (small) X3S_LAUNCH(x3s_ctx1_kernel_t, ca, nc * ca.nsub, X3_WAVE, st); else X3S_LAUNCH(x3s_ctx1_kernel_s, ca, nc * ca.nsub, X3_WAVE, st);
+		CHK(x3s_ctx_apply(st, ca, d_chunks));
 		HIPCHK(hipGetLastError());
 		/* pair ordinals, context0 */
 		X3sPairArgs pa;
@@ -904,6 +942,7 @@ int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_for
 		ca.kshift = psh; ca.kmask = (psh >= 32 ? 0xFFFFFFFFu : (1u << psh) - 1u);
 		if (ca.nsub > 1) { if (small) X3S_LAUNCH(x3s_ctx_publish_kernel_t, ca, nc * ca.nsub, X3_WAVE, st); else X3S_LAUNCH(x3s_ctx_publish_kernel_s, ca, nc * ca.nsub, X3_WAVE, st); }
 		if (small) X3S_LAUNCH(x3s_ctx0_kernel_t, ca, nc * ca.nsub, X3_WAVE, st); else X3S_LAUNCH(x3s_ctx0_kernel_s, ca, nc * ca.nsub, X3_WAVE, st);
+		CHK(x3s_ctx_apply(st, ca, d_chunks));
 		HIPCHK(hipGetLastError());
 	}
 	if (nE) HIPCHK(hipStreamWaitEvent(st, ev_join, 0)); /* the ranks */
