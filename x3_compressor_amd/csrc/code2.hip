@@ -215,22 +215,28 @@ __device__ static __forceinline__ void x3_modes_loop(const X3ModesArgs &a, uint3
 	const uint32_t nidx_start = sliced ? nidx : 0u;  /* a slice's list of IDX1-coded hits starts at its own first entry */
 	const uint64_t below = ((uint64_t)1 << lane) - 1;
 	/* features of the next block are fetched while this block is decided (a lone wave cannot hide the load latency otherwise) */
-	uint32_t nf0, nt0, nf1, nt1, nr, nd, ns;
+	/* (TWO blocks ahead: a block is decided in ~1 100 cycles, a load comes back in 2 000-3 000 -- SQ counters of the sliced runs: the wave waited 55 % of its time) */
+	uint32_t nf0, nt0, nf1, nt1, nr, nd, ns, mf0, mt0, mf1, mt1, mr, md, ms_;
 	{
 		const bool in0 = first + lane < H;
 		const uint32_t g0 = h0 + first + lane;
 		nf0 = in0 ? a.f0[(size_t)g0 * a.fs] : 0; nt0 = in0 ? a.t0[(size_t)g0 * a.fs] : 1; nf1 = in0 ? a.f1[(size_t)g0 * a.fs] : 0; nt1 = in0 ? a.t1[(size_t)g0 * a.fs] : 1;
 		nr = in0 ? a.rank[g0] : 0; nd = in0 ? a.dk[g0] : 1; ns = in0 ? a.step[g0] : 0;
+		const bool in1 = first + X3_WAVE + lane < H;
+		const uint32_t g1 = g0 + X3_WAVE;
+		mf0 = in1 ? a.f0[(size_t)g1 * a.fs] : 0; mt0 = in1 ? a.t0[(size_t)g1 * a.fs] : 1; mf1 = in1 ? a.f1[(size_t)g1 * a.fs] : 0; mt1 = in1 ? a.t1[(size_t)g1 * a.fs] : 1;
+		mr = in1 ? a.rank[g1] : 0; md = in1 ? a.dk[g1] : 1; ms_ = in1 ? a.step[g1] : 0;
 	}
 	for (uint32_t base = first; base < H; base += X3_WAVE) {
 		const uint32_t g = h0 + base + lane;
 		const bool in = base + lane < H;
 		const uint32_t vf0 = nf0, vt0 = nt0, vf1 = nf1, vt1 = nt1, vr = nr, vd = nd, vs = ns;
+		nf0 = mf0; nt0 = mt0; nf1 = mf1; nt1 = mt1; nr = mr; nd = md; ns = ms_;
 		{
-			const bool inn = base + X3_WAVE + lane < H;
-			const uint32_t gn = g + X3_WAVE;
-			nf0 = inn ? a.f0[(size_t)gn * a.fs] : 0; nt0 = inn ? a.t0[(size_t)gn * a.fs] : 1; nf1 = inn ? a.f1[(size_t)gn * a.fs] : 0; nt1 = inn ? a.t1[(size_t)gn * a.fs] : 1;
-			nr = inn ? a.rank[gn] : 0; nd = inn ? a.dk[gn] : 1; ns = inn ? a.step[gn] : 0;
+			const bool inn = base + 2 * X3_WAVE + lane < H;
+			const uint32_t gn = g + 2 * X3_WAVE;
+			mf0 = inn ? a.f0[(size_t)gn * a.fs] : 0; mt0 = inn ? a.t0[(size_t)gn * a.fs] : 1; mf1 = inn ? a.f1[(size_t)gn * a.fs] : 0; mt1 = inn ? a.t1[(size_t)gn * a.fs] : 1;
+			mr = inn ? a.rank[gn] : 0; md = inn ? a.dk[gn] : 1; ms_ = inn ? a.step[gn] : 0;
 		}
 		const float q0 = vf0 ? (float)vf0 / (float)vt0 : 0.f; /* (float)freq / (float)total of the context item; 0 == absent */
 		const float q1 = vf1 ? (float)vf1 / (float)vt1 : 0.f;
@@ -239,10 +245,12 @@ __device__ static __forceinline__ void x3_modes_loop(const X3ModesArgs &a, uint3
 		const uint32_t rfmin = in ? (lds_r ? sidx[lds_r ? vr : 0] : idxf[vr]) : 1;
 		/* same-rank hits in this block (an upper bound is enough: hashed counters, collisions only widen the bracket) */
 		const uint32_t hs = vr & 255u;
+		/* (the work-group is ONE wavefront and scr / sidx are LDS: a compiler barrier orders them -- the fence of x3_wave_sync would wait for the feature loads that
+		 * were just issued for the blocks ahead) */
 		scr[lane] = 0; scr[lane + 64] = 0; scr[lane + 128] = 0; scr[lane + 192] = 0;
-		x3_wave_sync();
+		x3_wave_order();
 		if (in) atomicAdd(&scr[hs], 1u);
-		x3_wave_sync();
+		x3_wave_order();
 		const uint32_t srmax = in ? scr[hs] - 1 : 0;
 		const uint32_t j = lane; /* at most j earlier hits of the block */
 		const float a0lo = (float)E0 / ftot, a0hi = (float)(E0 + j) / ftot;
@@ -313,7 +321,7 @@ __device__ static __forceinline__ void x3_modes_loop(const X3ModesArgs &a, uint3
 		E0 += (uint32_t)x3_popc64(m0); E1 += (uint32_t)x3_popc64(m1); /* inc_model(&model_events, mode), x3.c:177 */
 		const uint32_t c2 = (uint32_t)x3_popc64(m2);
 		E2 += c2; nidx += c2;
-		x3_wave_sync();
+		if (ALL_LDS) x3_wave_order(); else x3_wave_sync(); /* (ranks beyond the LDS table live in global memory: their atomics are ordered by the fence) */
 	}
 	if (a.evfinal && lane == 0) { uint32_t *ef = a.evfinal + 4 * blockIdx.x; ef[0] = E0; ef[1] = E1; ef[2] = E2; ef[3] = nidx; }
 	if (EMIT && a.nnoop && lane == 0) a.nnoop[blockIdx.x] = nnoop;

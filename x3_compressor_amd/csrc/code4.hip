@@ -398,6 +398,13 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 		const uint32_t nvalid = (uint32_t)x3_popc64(V);
 		const uint32_t kprev = wave_prev_u32(key);
 		uint64_t S = x3_ballot(valid && (lane == 0 || key != kprev)); /* first lanes of the tile's contexts */
+		/* the first items of EVERY context of the tile in one go: the i-th lane of a context's hits fetches its item i (most contexts of a tile are small: a
+		 * dependent load per context was most of this kernel's time on its busiest wavefronts) */
+		const uint32_t sl_ = 63u - (uint32_t)x3_clz64(S & (below | bit)); /* first lane of my context (valid lanes) */
+		const uint32_t ii_ = lane - sl_;
+		const bool pf_ = valid && ii_ < hd.items;
+		const uint64_t pit = pf_ ? pool[(uint64_t)hd.off + ii_] : 0;
+		const uint32_t pio = ORD && pf_ ? pord[(uint64_t)hd.off + ii_] : 0u;
 		while (S) {
 			const uint32_t s = (uint32_t)x3_ctz64(S);
 			S &= S - 1;
@@ -441,14 +448,31 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 				okey = key_s; open = true;
 				ok0 = x3_readlane_u32(hd.items, s); ooff = x3_readlane_u32(hd.off, s); ocap = x3_readlane_u32(hd.cap, s); ototal = x3_readlane_u32(hd.total, s);
 				ok = ok0;
-				uint32_t carry = 0;
-				for (uint32_t pb = 0; pb < ok0; pb += X3_WAVE) {
-					const uint32_t p = pb + lane;
-					const uint64_t it = p < ok0 ? pool[(uint64_t)ooff + p] : 0;
-					const uint32_t fq = (uint32_t)it, tg = (uint32_t)(it >> 32);
-					const uint32_t incl = x3_wave_incl_scan_u32(fq) + carry;
-					if (p < ok0) { ltag[p] = (uint16_t)tg; lfreq[p] = fq; lpre[p] = incl - fq; tpos[tg] = (uint16_t)p; if (ORD) lord[p] = pord[(uint64_t)ooff + p]; }
-					carry = x3_readlane_u32(incl, X3_WAVE - 1);
+				{
+					const uint32_t npre = ok0 < e - s ? ok0 : e - s; /* items [0, npre) came with the tile, in lanes [s, s + npre) */
+					if (lane >= s && lane < s + npre) {
+						const uint32_t p = lane - s, tg = (uint32_t)(pit >> 32);
+						ltag[p] = (uint16_t)tg; lfreq[p] = (uint32_t)pit; tpos[tg] = (uint16_t)p; if (ORD) lord[p] = pio;
+					}
+					for (uint32_t pb = npre; pb < ok0; pb += X3_WAVE) { /* a long list behind few hits: the rest */
+						const uint32_t p = pb + lane;
+						if (p < ok0) {
+							const uint64_t it = pool[(uint64_t)ooff + p];
+							const uint32_t tg = (uint32_t)(it >> 32);
+							ltag[p] = (uint16_t)tg; lfreq[p] = (uint32_t)it; tpos[tg] = (uint16_t)p; if (ORD) lord[p] = pord[(uint64_t)ooff + p];
+						}
+					}
+				}
+				x3_wave_order();
+				{ /* cum_freqs of the list */
+					uint32_t carry = 0;
+					for (uint32_t pb = 0; pb < ok0; pb += X3_WAVE) {
+						const uint32_t p = pb + lane;
+						const uint32_t v = p < ok0 ? lfreq[p] : 0u;
+						const uint32_t incl = x3_wave_incl_scan_u32(v) + carry;
+						if (p < ok0) lpre[p] = incl - v;
+						carry = x3_readlane_u32(incl, X3_WAVE - 1);
+					}
 				}
 				stale = false;
 				x3_wave_order();
@@ -872,8 +896,8 @@ int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_for
 		X3sMtfArgs ma;
 		ma.chunks = d_chunks; ma.sl = d_sl; ma.e_tag = e_tag; ma.e_hit = e_hit; ma.h_rank = h_rank; ma.scratch = R.mtf_scratch.as<uint32_t>();
 		ma.lt = (R.lt_flip ? R.lt2 : R.lt).as<uint32_t>(); ma.lt_out = (R.lt_flip ? R.lt : R.lt2).as<uint32_t>(); R.lt_flip = !R.lt_flip;
-		/* time ranges of ~4096 events, one wavefront each: a range's cost is its events plus building its list (elements^2 / 64), so few elements allow many ranges */
-		uint64_t rw = (nE / nc + 4095) / 4096;
+		/* time ranges of ~1024 events, one wavefront each (a range costs its events plus building its list: elements^2 / 64 steps) */
+		uint64_t rw = (nE / nc + 1023) / 1024;
 		ma.nranges = rw < 1 ? 1u : rw > X3S_MTF_RANGES ? X3S_MTF_RANGES : (uint32_t)rw;
 		if (const char *e = getenv("X3H_SLICE_MTF_RANGES")) { const int v = atoi(e); if (v >= 1 && v <= (int)X3S_MTF_RANGES) ma.nranges = (uint32_t)v; }
 		if (small) { X3S_LAUNCH(x3s_mtf_scan_kernel_t, ma, nc * ma.nranges, X3_WAVE, side); X3S_LAUNCH(x3s_mtf_kernel_t, ma, nc * ma.nranges, X3_WAVE, side); }
