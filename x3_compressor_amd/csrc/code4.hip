@@ -29,6 +29,7 @@
 #include "k3_sym.h"
 
 #include <stdlib.h>
+#include <algorithm>
 #include <vector>
 
 static inline int bits_for64(uint64_t maxval) { int b = 1; while (b < 32 && (maxval >> b)) b++; return b; }
@@ -226,6 +227,7 @@ __device__ static void x3s_mtf_body(const X3sMtfArgs &a)
  * over ALL contexts of the stream); until then the item holds 0x80000000 | the slice-local hit that made it, and newaddr[that hit] = its pool slot.
  * Per hit: stat = {freq (0: the tag is not in the context yet), total, cum_freq, ORD: the pair's ordinal or 0x80000000 | making hit}.
  * ============================================================================================================ */
+#define X3S_SMALL_K 8u          /* a context with at most this many hits in a tile and items in its list (afterwards) is walked by one lane */
 #define X3S_CHUNK 512u          /* entries a wavefront takes from its stream's pool at a time */
 #define X3S_POOL_PER_BYTE 6u    /* pool entries per input byte: 4 bound the lists' blocks (every block at most twice its list, every abandoned block at most half the next), */
 #define X3S_POOL_EXTRA 65536u   /* ... the rest and this much per stream is for the ends of chunks that were abandoned (a violated bound ends the sliced run, see X3_ST_POOL_FULL) */
@@ -246,6 +248,7 @@ struct X3sCtxArgs {
 	uint32_t *scratch;         /* [stream * nsub + wavefront][2 * sstride + 4]: per tag, the hits of the wavefront's LAST context inside its part of the range and the first of them
 	                            * (slice-local hit, NONE32: none) -- published when that context goes on in the next wavefront's part (x3s_ctx_publish_kernel) */
 	uint32_t sstride;          /* tags a row holds: the batch's largest dictionary, rounded up to 64 */
+	uint32_t *dbg;             /* (experiments, X3H_CTX_DEBUG) per wavefront {kcycles in all, kcycles building the start state, contexts, tiles}; nullptr otherwise */
 	uint32_t kshift, kmask, dbits, nsub, nc;
 };
 
@@ -306,6 +309,8 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 	X3_LDS uint32_t lpre[DMAX];      /* position -> cum_freq (valid when !stale) */
 	X3_LDS uint32_t lord[ORD ? DMAX : 1]; /* position -> pair ordinal, or 0x80000000 | making hit */
 	X3_LDS uint32_t fmin[DMAX];      /* (start inside a context) tag -> its first hit in the earlier parts */
+	X3_LDS uint32_t s_t[ORD ? 1 : X3_WAVE], s_j[ORD ? 1 : X3_WAVE];   /* (small contexts) the tile's tags and hits */
+	X3_LDS uint32_t s_small[ORD ? 1 : X3_WAVE * 2 * X3S_SMALL_K];     /* (small contexts) per lane: a list of up to X3S_SMALL_K items {tag, freq} */
 	const uint32_t lane = x3_lane();
 	const uint32_t c = blockIdx.x / a.nsub, sub = blockIdx.x % a.nsub;
 	const X3Slice sl = a.sl[c];
@@ -322,6 +327,10 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 	const uint64_t n0 = (uint64_t)c0 + (uint64_t)sub * per, n1 = n0 + per;
 	const uint32_t h0 = n0 < c1 ? (uint32_t)n0 : c1, h1 = n1 < c1 ? (uint32_t)n1 : c1;
 	if (h0 >= h1) { if (lane == 0) a.pending[(size_t)c * a.nsub + sub] = make_uint4(NONE32, 0, 0, 0); return; }
+	const uint64_t dbg_t0 = x3_clock();
+	uint64_t dbg_t1 = dbg_t0;
+	uint32_t dbg_nseg = 0, dbg_ntile = 0;
+	uint64_t dbg_store = 0, dbg_load = 0, dbg_body = 0;
 	for (uint32_t i = lane; i < DMAX; i += X3_WAVE) tpos[i] = NONE16;
 	x3_wave_order();
 	/* the OPEN context: its list is in the LDS tables (wave-uniform bookkeeping) */
@@ -377,6 +386,7 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 		ok = ok0 + nnew_total;
 		stale = true; /* the first tile rescans the cum_freqs */
 		x3_wave_order();
+		dbg_t1 = x3_clock();
 	}
 	/* records of the range in tiles of 64, fetched ahead: keys and hits one tile, the gathered tags one tile (their hits two tiles), and every lane the
 	 * header of ITS key's context -- up to 64 headers in flight at once instead of one dependent load per context */
@@ -398,6 +408,7 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 		const uint32_t nvalid = (uint32_t)x3_popc64(V);
 		const uint32_t kprev = wave_prev_u32(key);
 		uint64_t S = x3_ballot(valid && (lane == 0 || key != kprev)); /* first lanes of the tile's contexts */
+		const uint64_t Sall = S;
 		/* the first items of EVERY context of the tile in one go: the i-th lane of a context's hits fetches its item i (most contexts of a tile are small: a
 		 * dependent load per context was most of this kernel's time on its busiest wavefronts) */
 		const uint32_t sl_ = 63u - (uint32_t)x3_clz64(S & (below | bit)); /* first lane of my context (valid lanes) */
@@ -405,12 +416,70 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 		const bool pf_ = valid && ii_ < hd.items;
 		const uint64_t pit = pf_ ? pool[(uint64_t)hd.off + ii_] : 0;
 		const uint32_t pio = ORD && pf_ ? pord[(uint64_t)hd.off + ii_] : 0u;
+		if (!ORD) {
+			/* ---- SMALL contexts, all of the tile at once: a context with a few hits in this tile and a short list is walked by ONE LANE -- the first lane of its hits --
+			 * in plain serial code (list in the lane's LDS slot, <= X3S_SMALL_K items, <= X3S_SMALL_K hits), every such context of the tile side by side.  The tail of
+			 * the context0 arrangement is thousands of pairs with a hit or two each: through the wavefront-wide path below (about a thousand instructions per context,
+			 * whatever its size) they made the busiest wavefronts of this kernel 40 times slower than the average one.  The tile's first and last context keep to
+			 * that path (they may be the open one / go on in the next tile). ---- */
+			const uint64_t Sab = S & ~(below | bit);
+			const uint32_t e_ = Sab ? (uint32_t)x3_ctz64(Sab) : nvalid;
+			const uint32_t seglen = e_ - sl_, lastseg = 63u - (uint32_t)x3_clz64(S);
+			const bool fast = valid && lane == sl_ && sl_ != 0u && sl_ != lastseg && seglen <= X3S_SMALL_K && hd.items + seglen <= X3S_SMALL_K;
+			const uint64_t F = x3_ballot(fast);
+			if (F) {
+				s_t[lane] = t; s_j[lane] = j;
+				x3_wave_order();
+				uint32_t k = hd.items, total = hd.total, off = hd.off, cap = hd.cap, need = 0;
+				uint32_t *my = s_small + lane * 2u * X3S_SMALL_K;
+				if (fast) {
+					for (uint32_t p = 0; p < k; p++) { const uint64_t it = p == 0 ? pit : pool[(uint64_t)off + p]; my[2 * p] = (uint32_t)(it >> 32); my[2 * p + 1] = (uint32_t)it; }
+					for (uint32_t h = 0; h < seglen; h++) {
+						const uint32_t tt = s_t[sl_ + h];
+						const uint32_t jj = s_j[sl_ + h];
+						uint32_t pos = NONE32, cum = 0, fq = 0;
+						for (uint32_t p = 0; p < k; p++) { if (my[2 * p] == tt) { pos = p; fq = my[2 * p + 1]; break; } cum += my[2 * p + 1]; }
+						if (pos == NONE32) { cum = total; pos = k; my[2 * k] = tt; my[2 * k + 1] = 0; k++; } /* a new item stands behind every other one */
+						uint4 r; r.x = fq; r.y = total; r.z = cum; r.w = 0u;
+						a.stat[jj] = r;
+						my[2 * pos + 1]++; total++;
+					}
+					if (k > cap) { need = cap ? cap : 2u; while (need < k) need <<= 1; }
+				}
+				/* blocks for the lists that outgrew theirs: one bump of the wavefront's chunk for the whole tile */
+				const uint32_t incl = x3_wave_incl_scan_u32(need);
+				const uint32_t tot_need = x3_readlane_u32(incl, X3_WAVE - 1);
+				if (tot_need) {
+					if (chunk_end - chunk_at < tot_need) {
+						const uint32_t want = tot_need > X3S_CHUNK ? tot_need : X3S_CHUNK;
+						uint32_t got = 0;
+						if (lane == 0) got = atomicAdd(&a.top[c], want);
+						chunk_at = x3_uniform(x3_bcast_u32(got, 0)); chunk_end = chunk_at + want;
+					}
+					if ((uint64_t)chunk_at + tot_need > pool_cap) { if (lane == 0) a.status[c] = X3_ST_POOL_FULL; }
+					else if (need) { off = chunk_at + incl - need; cap = need; }
+					chunk_at += tot_need;
+				}
+				if (fast && k <= cap) {
+					for (uint32_t p = 0; p < k; p++) pool[(uint64_t)off + p] = ((uint64_t)my[2 * p] << 32) | my[2 * p + 1];
+					X3CtxHdr nh; nh.off = off; nh.items = k; nh.cap = cap; nh.total = total;
+					hdrs[key & a.kmask] = nh;
+				}
+				S &= ~F;
+				x3_wave_order();
+			}
+		}
+		dbg_ntile++;
 		while (S) {
+			dbg_nseg++;
 			const uint32_t s = (uint32_t)x3_ctz64(S);
 			S &= S - 1;
-			const uint32_t e = S ? (uint32_t)x3_ctz64(S) : nvalid;
+			const uint64_t Snext = Sall & ~((((uint64_t)1 << s) - 1) | ((uint64_t)1 << s)); /* (contexts that took the small path are not in S any more, but they still end this one) */
+			const uint32_t e = Snext ? (uint32_t)x3_ctz64(Snext) : nvalid;
 			const uint64_t seg = (e >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << e) - 1)) & ~(((uint64_t)1 << s) - 1);
 			const uint32_t key_s = x3_readlane_u32(key, s);
+			const uint64_t dq0 = a.dbg ? x3_clock() : 0;
+			uint64_t dq1 = dq0;
 			if (!(open && key_s == okey)) {
 				if (open) { /* ---- store the context that ended ---- */
 					uint32_t off = ooff, cap = ocap;
@@ -444,6 +513,7 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 					split = false; /* (only my first context can be one that was cut before me) */
 					x3_wave_order();
 				}
+				if (a.dbg) dq1 = x3_clock();
 				/* ---- load the context that starts (its header came with the tile) ---- */
 				okey = key_s; open = true;
 				ok0 = x3_readlane_u32(hd.items, s); ooff = x3_readlane_u32(hd.off, s); ocap = x3_readlane_u32(hd.cap, s); ototal = x3_readlane_u32(hd.total, s);
@@ -488,6 +558,7 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 				stale = false;
 				x3_wave_order();
 			}
+			const uint64_t dq2 = a.dbg ? x3_clock() : 0;
 			/* ---- the context's hits of this tile: lanes [s, e) ---- */
 			const bool in = (seg >> lane) & 1u;
 			const uint64_t B = seg & below;
@@ -520,6 +591,7 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 			ototal += e - s;
 			stale = true;
 			x3_wave_order();
+			if (a.dbg) { const uint64_t dq3 = x3_clock(); dbg_store += dq1 - dq0; dbg_load += dq2 - dq1; dbg_body += dq3 - dq2; }
 		}
 	}
 	if (open && !goes_on) { /* the last context of my part ends there: its final list goes back to the pool */
@@ -552,6 +624,7 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 		}
 	}
 	(void)ok0;
+	if (a.dbg && lane == 0) { uint32_t *d = a.dbg + 4 * ((size_t)c * a.nsub + sub); d[0] = (uint32_t)((x3_clock() - dbg_t0) >> 10); d[1] = (uint32_t)(dbg_store >> 10) | (uint32_t)(dbg_load >> 10) << 16; d[2] = dbg_nseg; d[3] = (uint32_t)(dbg_body >> 10); }
 }
 
 /* ============================================================================================================
@@ -918,6 +991,9 @@ int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_for
 		ca.nsub = want < 1 ? 1u : want > 512 ? 512u : (uint32_t)want;
 		if (const char *e = getenv("X3H_SLICE_SUB")) { const int v = atoi(e); if (v >= 1 && v <= 1024) ca.nsub = (uint32_t)v; }
 		ca.sstride = (uint32_t)((max_dict + 63) & ~(uint64_t)63);
+		ca.dbg = nullptr;
+		const bool ctx_debug = getenv("X3H_CTX_DEBUG") != nullptr;
+		if (ctx_debug) { CHK(R.ctx_dbg.reserve((size_t)nc * 1024 * 16)); ca.dbg = R.ctx_dbg.as<uint32_t>(); HIPCHK(hipMemsetAsync(ca.dbg, 0, (size_t)nc * ca.nsub * 16, st)); }
 		{
 			const size_t need = (size_t)nc * ca.nsub * (2 * (size_t)ca.sstride + 4) * 4;
 			if (R.ctx_scratch.cap < need) CHK(R.ctx_scratch.reserve(need)); /* (beyond x3s_begin's guess: a reallocation in mid-flight waits for the device, once) */
@@ -929,6 +1005,18 @@ int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_for
 		if (small) X3S_LAUNCH(x3s_ctx1_kernel_t, ca, nc * ca.nsub, X3_WAVE, st); else X3S_LAUNCH(x3s_ctx1_kernel_s, ca, nc * ca.nsub, X3_WAVE, st);
 		CHK(x3s_ctx_apply(st, ca, d_chunks));
 		HIPCHK(hipGetLastError());
+		if (ctx_debug) { /* (experiments) the slowest wavefronts of the context0 launch */
+			std::vector<uint32_t> d((size_t)nc * ca.nsub * 4);
+			HIPCHK(hipMemcpyAsync(d.data(), ca.dbg, d.size() * 4, hipMemcpyDeviceToHost, st));
+			HIPCHK(hipStreamSynchronize(st));
+			std::vector<size_t> idx((size_t)nc * ca.nsub);
+			for (size_t i = 0; i < idx.size(); i++) idx[i] = i;
+			std::sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return d[4 * x] > d[4 * y]; });
+			uint64_t sum = 0; for (size_t i = 0; i < idx.size(); i++) sum += d[4 * i];
+			fprintf(stderr, "[x3h] ctx0 slice %zu: %zu wavefronts (nsub %u), mean %.0f kcycles; slowest:", k, idx.size(), ca.nsub, (double)sum / idx.size());
+			for (size_t i = 0; i < 6 && i < idx.size(); i++) fprintf(stderr, " [stream %zu part %zu: %u kcyc = store %u + load %u + body %u + rest, contexts %u]", idx[i] / ca.nsub, idx[i] % ca.nsub, d[4 * idx[i]], d[4 * idx[i] + 1] & 0xFFFFu, d[4 * idx[i] + 1] >> 16, d[4 * idx[i] + 3], d[4 * idx[i] + 2]);
+			fprintf(stderr, "\n");
+		}
 		/* pair ordinals, context0 */
 		X3sPairArgs pa;
 		pa.chunks = d_chunks; pa.sl = d_sl; pa.stat1 = stat1; pa.newaddr = newaddr; pa.h_pv = h_pv; pa.pord = R.pord1.as<uint32_t>(); pa.first00 = m_first00;
@@ -968,6 +1056,18 @@ int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_for
 		if (small) X3S_LAUNCH(x3s_ctx0_kernel_t, ca, nc * ca.nsub, X3_WAVE, st); else X3S_LAUNCH(x3s_ctx0_kernel_s, ca, nc * ca.nsub, X3_WAVE, st);
 		CHK(x3s_ctx_apply(st, ca, d_chunks));
 		HIPCHK(hipGetLastError());
+		if (ctx_debug) { /* (experiments) the slowest wavefronts of the context0 launch */
+			std::vector<uint32_t> d((size_t)nc * ca.nsub * 4);
+			HIPCHK(hipMemcpyAsync(d.data(), ca.dbg, d.size() * 4, hipMemcpyDeviceToHost, st));
+			HIPCHK(hipStreamSynchronize(st));
+			std::vector<size_t> idx((size_t)nc * ca.nsub);
+			for (size_t i = 0; i < idx.size(); i++) idx[i] = i;
+			std::sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return d[4 * x] > d[4 * y]; });
+			uint64_t sum = 0; for (size_t i = 0; i < idx.size(); i++) sum += d[4 * i];
+			fprintf(stderr, "[x3h] ctx0 slice %zu: %zu wavefronts (nsub %u), mean %.0f kcycles; slowest:", k, idx.size(), ca.nsub, (double)sum / idx.size());
+			for (size_t i = 0; i < 6 && i < idx.size(); i++) fprintf(stderr, " [stream %zu part %zu: %u kcyc = store %u + load %u + body %u + rest, contexts %u]", idx[i] / ca.nsub, idx[i] % ca.nsub, d[4 * idx[i]], d[4 * idx[i] + 1] & 0xFFFFu, d[4 * idx[i] + 1] >> 16, d[4 * idx[i] + 3], d[4 * idx[i] + 2]);
+			fprintf(stderr, "\n");
+		}
 	}
 	if (nE) HIPCHK(hipStreamWaitEvent(st, ev_join, 0)); /* the ranks */
 	/* mode chain: continues from the earlier slices' state (also for streams without a hit in this slice: nothing happens) */

@@ -195,14 +195,14 @@ struct X3SliceRun {
 	uint32_t nc = 0;
 	uint64_t elems = 0;
 	/* carried state (per stream at elem_off / 4 * elem_off / 3 * elem_off) */
-	DevBuf lt, idxfreq, idxhist, hdr1, hdr0, pool1, pord1, pool0, sym, states, small, mtf_scratch, ctx_scratch, ctx_pending, lt2;
+	DevBuf lt, idxfreq, idxhist, hdr1, hdr0, pool1, pord1, pool0, sym, states, small, mtf_scratch, ctx_scratch, ctx_pending, ctx_dbg, lt2;
 	bool lt_flip = false;
 	/* temporaries of a slice */
 	DevBuf a[X3S_NARR], b[3], stat1, stat0, est_val, est_cls, tmp, tables;
 	std::vector<std::vector<X3Slice>> slices; /* host copies of the slice tables, kept until the run ends (their H2D copies are asynchronous) */
 	void release()
 	{
-		DevBuf *all[] = { &lt, &idxfreq, &idxhist, &hdr1, &hdr0, &pool1, &pord1, &pool0, &sym, &states, &small, &mtf_scratch, &ctx_scratch, &ctx_pending, &lt2, &b[0], &b[1], &b[2], &stat1, &stat0, &est_val, &est_cls, &tmp, &tables };
+		DevBuf *all[] = { &lt, &idxfreq, &idxhist, &hdr1, &hdr0, &pool1, &pord1, &pool0, &sym, &states, &small, &mtf_scratch, &ctx_scratch, &ctx_pending, &ctx_dbg, &lt2, &b[0], &b[1], &b[2], &stat1, &stat0, &est_val, &est_cls, &tmp, &tables };
 		for (DevBuf *d : all) d->release();
 		for (DevBuf &d : a) d.release();
 	}
