@@ -215,28 +215,26 @@ __device__ static __forceinline__ void x3_modes_loop(const X3ModesArgs &a, uint3
 	const uint32_t nidx_start = sliced ? nidx : 0u;  /* a slice's list of IDX1-coded hits starts at its own first entry */
 	const uint64_t below = ((uint64_t)1 << lane) - 1;
 	/* features of the next block are fetched while this block is decided (a lone wave cannot hide the load latency otherwise) */
-	/* (TWO blocks ahead: a block is decided in ~1 100 cycles, a load comes back in 2 000-3 000 -- SQ counters of the sliced runs: the wave waited 55 % of its time) */
+	/* features of the blocks ahead are fetched while this block is decided (a lone wave cannot hide the load latency otherwise): TWO blocks ahead -- a block is
+	 * decided in ~1 100 cycles, a load comes back in 2 000-5 000 -- and by UNCONDITIONAL loads from clamped indices: around a load that sits behind a branch the
+	 * compiler can only wait with vmcnt(0) (it must assume the branch was not taken: no younger load to count on), which waits for the loads just issued */
 	uint32_t nf0, nt0, nf1, nt1, nr, nd, ns, mf0, mt0, mf1, mt1, mr, md, ms_;
+	const uint32_t hlast = H ? H - 1 : 0;
 	{
-		const bool in0 = first + lane < H;
-		const uint32_t g0 = h0 + first + lane;
-		nf0 = in0 ? a.f0[(size_t)g0 * a.fs] : 0; nt0 = in0 ? a.t0[(size_t)g0 * a.fs] : 1; nf1 = in0 ? a.f1[(size_t)g0 * a.fs] : 0; nt1 = in0 ? a.t1[(size_t)g0 * a.fs] : 1;
-		nr = in0 ? a.rank[g0] : 0; nd = in0 ? a.dk[g0] : 1; ns = in0 ? a.step[g0] : 0;
-		const bool in1 = first + X3_WAVE + lane < H;
-		const uint32_t g1 = g0 + X3_WAVE;
-		mf0 = in1 ? a.f0[(size_t)g1 * a.fs] : 0; mt0 = in1 ? a.t0[(size_t)g1 * a.fs] : 1; mf1 = in1 ? a.f1[(size_t)g1 * a.fs] : 0; mt1 = in1 ? a.t1[(size_t)g1 * a.fs] : 1;
-		mr = in1 ? a.rank[g1] : 0; md = in1 ? a.dk[g1] : 1; ms_ = in1 ? a.step[g1] : 0;
+		const uint32_t i0 = first + lane < H ? first + lane : hlast, i1 = first + X3_WAVE + lane < H ? first + X3_WAVE + lane : hlast;
+		const uint32_t g0 = h0 + i0, g1 = h0 + i1;
+		nf0 = a.f0[(size_t)g0 * a.fs]; nt0 = a.t0[(size_t)g0 * a.fs]; nf1 = a.f1[(size_t)g0 * a.fs]; nt1 = a.t1[(size_t)g0 * a.fs]; nr = a.rank[g0]; nd = a.dk[g0]; ns = a.step[g0];
+		mf0 = a.f0[(size_t)g1 * a.fs]; mt0 = a.t0[(size_t)g1 * a.fs]; mf1 = a.f1[(size_t)g1 * a.fs]; mt1 = a.t1[(size_t)g1 * a.fs]; mr = a.rank[g1]; md = a.dk[g1]; ms_ = a.step[g1];
 	}
 	for (uint32_t base = first; base < H; base += X3_WAVE) {
 		const uint32_t g = h0 + base + lane;
 		const bool in = base + lane < H;
-		const uint32_t vf0 = nf0, vt0 = nt0, vf1 = nf1, vt1 = nt1, vr = nr, vd = nd, vs = ns;
+		const uint32_t vf0 = in ? nf0 : 0u, vt0 = in ? nt0 : 1u, vf1 = in ? nf1 : 0u, vt1 = in ? nt1 : 1u, vr = in ? nr : 0u, vd = in ? nd : 1u, vs = in ? ns : 0u;
 		nf0 = mf0; nt0 = mt0; nf1 = mf1; nt1 = mt1; nr = mr; nd = md; ns = ms_;
 		{
-			const bool inn = base + 2 * X3_WAVE + lane < H;
-			const uint32_t gn = g + 2 * X3_WAVE;
-			mf0 = inn ? a.f0[(size_t)gn * a.fs] : 0; mt0 = inn ? a.t0[(size_t)gn * a.fs] : 1; mf1 = inn ? a.f1[(size_t)gn * a.fs] : 0; mt1 = inn ? a.t1[(size_t)gn * a.fs] : 1;
-			mr = inn ? a.rank[gn] : 0; md = inn ? a.dk[gn] : 1; ms_ = inn ? a.step[gn] : 0;
+			const uint32_t i2 = base + 2 * X3_WAVE + lane < H ? base + 2 * X3_WAVE + lane : hlast;
+			const uint32_t gn = h0 + i2;
+			mf0 = a.f0[(size_t)gn * a.fs]; mt0 = a.t0[(size_t)gn * a.fs]; mf1 = a.f1[(size_t)gn * a.fs]; mt1 = a.t1[(size_t)gn * a.fs]; mr = a.rank[gn]; md = a.dk[gn]; ms_ = a.step[gn];
 		}
 		const float q0 = vf0 ? (float)vf0 / (float)vt0 : 0.f; /* (float)freq / (float)total of the context item; 0 == absent */
 		const float q1 = vf1 ? (float)vf1 / (float)vt1 : 0.f;

@@ -81,10 +81,12 @@ __device__ static void x3s_tokens_body(const X3sTokArgs &a)
 	const uint8_t *bytes = a.bytes + a.chunks[c].byte_off;
 	const uint64_t below = ((uint64_t)1 << lane) - 1;
 	uint32_t chb = sl.h0, cnb = sl.d0, cmb = sl.mb0, cpos = sl.p0; /* counts before the tile */
+	uint32_t ninfo_ = sl.t0 < sl.t1 ? a.tok_info[base + (sl.t0 + tid < sl.t1 ? sl.t0 + tid : sl.t1 - 1)] : 0u; /* (one tile ahead, unconditional loads from clamped indices) */
 	for (uint32_t tb = sl.t0; tb < sl.t1; tb += X3S_TOK_THREADS) {
 		const uint32_t k = tb + tid;
 		const bool in = k < sl.t1;
-		const uint32_t info = in ? a.tok_info[base + k] : X3_TOK_MISS;
+		const uint32_t info = in ? ninfo_ : X3_TOK_MISS;
+		ninfo_ = a.tok_info[base + (k + X3S_TOK_THREADS < sl.t1 ? k + X3S_TOK_THREADS : sl.t1 - 1)];
 		const bool hit = in && !(info & X3_TOK_MISS), nw = in && (info & X3_TOK_MISS) && !(info & X3_TOK_DUP), miss = in && (info & X3_TOK_MISS);
 		const uint32_t mb = miss ? (info & 0x3Fu) : 0u;
 		const uint32_t ln = hit ? (uint32_t)a.dict_len[base + info] : mb;
@@ -155,12 +157,12 @@ __device__ static void x3s_mtf_scan_body(const X3sMtfArgs &a)
 	x3_wave_order();
 	uint32_t cnt_new = 0;
 	uint32_t nt_ = 0, nh_ = 0;
-	if (s0 + lane < s1) { nt_ = a.e_tag[s0 + lane]; nh_ = a.e_hit[s0 + lane]; }
+	if (s0 < s1) { const uint32_t i0 = s0 + lane < s1 ? s0 + lane : s1 - 1; nt_ = a.e_tag[i0]; nh_ = a.e_hit[i0]; }
 	for (uint32_t base = s0; base < s1; base += X3_WAVE) {
 		const uint32_t i = base + lane;
 		const bool valid = i < s1;
 		const uint32_t t = nt_, hit = nh_;
-		if (i + X3_WAVE < s1) { nt_ = a.e_tag[i + X3_WAVE]; nh_ = a.e_hit[i + X3_WAVE]; }
+		{ const uint32_t nx = i + X3_WAVE < s1 ? i + X3_WAVE : s1 - 1; nt_ = a.e_tag[nx]; nh_ = a.e_hit[nx]; }
 		if (valid) atomicMax(&tab[t], abs0 + (i - e0) + 1);
 		cnt_new += (uint32_t)x3_popc64(x3_ballot(valid && hit == NONE32));
 	}
@@ -283,15 +285,15 @@ __device__ static void x3s_ctx_publish_body(const X3sCtxArgs &a)
 	const uint32_t D = a.sstride < DMAX ? a.sstride : DMAX;
 	for (uint32_t i = lane; i < D; i += X3_WAVE) { cnt[i] = 0; fst[i] = NONE32; }
 	x3_wave_order();
-	uint32_t nj_ = ps + lane < h1 ? a.vA[ps + lane] : 0u, nj2_ = ps + X3_WAVE + lane < h1 ? a.vA[ps + X3_WAVE + lane] : 0u;
-	uint32_t nt_ = ps + lane < h1 ? a.h_tag[nj_] : 0u;
+	uint32_t nj_ = a.vA[ps + lane < h1 ? ps + lane : h1 - 1], nj2_ = a.vA[ps + X3_WAVE + lane < h1 ? ps + X3_WAVE + lane : h1 - 1];
+	uint32_t nt_ = a.h_tag[nj_];
 	for (uint32_t base = ps; base < h1; base += X3_WAVE) {
 		const bool valid = base + lane < h1;
 		const uint32_t j = nj_, t = nt_;
 		{
-			const uint32_t nx = base + X3_WAVE + lane;
-			if (nx < h1) { nj_ = nj2_; nt_ = a.h_tag[nj2_]; }
-			if (nx + X3_WAVE < h1) nj2_ = a.vA[nx + X3_WAVE];
+			const uint32_t nx2 = base + 2 * X3_WAVE + lane < h1 ? base + 2 * X3_WAVE + lane : h1 - 1;
+			nj_ = nj2_; nt_ = a.h_tag[nj2_];
+			nj2_ = a.vA[nx2];
 		}
 		if (valid) { atomicAdd(&cnt[t], 1u); atomicMin(&fst[t], j); }
 	}
@@ -392,17 +394,20 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 	 * header of ITS key's context -- up to 64 headers in flight at once instead of one dependent load per context */
 	uint32_t nk_ = 0, nj_ = 0, nt_ = 0, nj2_ = 0;
 	X3CtxHdr nhd_; nhd_.off = nhd_.items = nhd_.cap = nhd_.total = 0;
-	if (h0 + lane < h1) { nk_ = a.kA[h0 + lane]; nj_ = a.vA[h0 + lane]; }
-	if (h0 + X3_WAVE + lane < h1) nj2_ = a.vA[h0 + X3_WAVE + lane];
-	if (h0 + lane < h1) { nt_ = a.h_tag[nj_]; nhd_ = hdrs[nk_ & a.kmask]; }
+	/* (unconditional loads from clamped indices: behind a branch the compiler could only wait for them with vmcnt(0), i.e. for the loads just issued as well) */
+	{
+		const uint32_t i0 = h0 + lane < h1 ? h0 + lane : h1 - 1, i1 = h0 + X3_WAVE + lane < h1 ? h0 + X3_WAVE + lane : h1 - 1;
+		nk_ = a.kA[i0]; nj_ = a.vA[i0]; nj2_ = a.vA[i1];
+		nt_ = a.h_tag[nj_]; nhd_ = hdrs[nk_ & a.kmask];
+	}
 	for (uint32_t base = h0; base < h1; base += X3_WAVE) {
 		const bool valid = base + lane < h1;
 		const uint32_t key = nk_, j = nj_, t = valid ? nt_ : 0u;
 		const X3CtxHdr hd = nhd_;
 		{
-			const uint32_t nx = base + X3_WAVE + lane;
-			if (nx < h1) { nk_ = a.kA[nx]; nj_ = nj2_; nt_ = a.h_tag[nj2_]; nhd_ = hdrs[nk_ & a.kmask]; }
-			if (nx + X3_WAVE < h1) nj2_ = a.vA[nx + X3_WAVE];
+			const uint32_t nx = base + X3_WAVE + lane < h1 ? base + X3_WAVE + lane : h1 - 1, nx2 = base + 2 * X3_WAVE + lane < h1 ? base + 2 * X3_WAVE + lane : h1 - 1;
+			nk_ = a.kA[nx]; nj_ = nj2_; nt_ = a.h_tag[nj2_]; nhd_ = hdrs[nk_ & a.kmask];
+			nj2_ = a.vA[nx2];
 		}
 		const uint64_t V = x3_ballot(valid);
 		const uint32_t nvalid = (uint32_t)x3_popc64(V);
@@ -413,9 +418,9 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 		 * dependent load per context was most of this kernel's time on its busiest wavefronts) */
 		const uint32_t sl_ = 63u - (uint32_t)x3_clz64(S & (below | bit)); /* first lane of my context (valid lanes) */
 		const uint32_t ii_ = lane - sl_;
-		const bool pf_ = valid && ii_ < hd.items;
-		const uint64_t pit = pf_ ? pool[(uint64_t)hd.off + ii_] : 0;
-		const uint32_t pio = ORD && pf_ ? pord[(uint64_t)hd.off + ii_] : 0u;
+		const uint32_t pix = hd.items ? (ii_ < hd.items ? ii_ : hd.items - 1u) : 0u; /* (always a slot of the pool: see above) */
+		const uint64_t pit = pool[(uint64_t)hd.off + pix];
+		const uint32_t pio = ORD ? pord[(uint64_t)hd.off + pix] : 0u;
 		if (!ORD) {
 			/* ---- SMALL contexts, all of the tile at once: a context with a few hits in this tile and a short list is walked by ONE LANE -- the first lane of its hits --
 			 * in plain serial code (list in the lane's LDS slot, <= X3S_SMALL_K items, <= X3S_SMALL_K hits), every such context of the tile side by side.  The tail of
@@ -657,12 +662,12 @@ __device__ static void x3s_pairs_body(const X3sPairArgs &a)
 	uint32_t *pord = a.pord + X3S_POOL_PER_BYTE * a.chunks[c].elem_off + (uint64_t)c * X3S_POOL_EXTRA;
 	const uint64_t below = ((uint64_t)1 << lane) - 1;
 	uint32_t run = a.npairs[c];
-	uint32_t nw_ = j0 + tid < j1 ? a.stat1[j0 + tid].w : 0u; /* the next tile's words are in flight while this one is counted */
+	uint32_t nw_ = j0 < j1 ? a.stat1[j0 + tid < j1 ? j0 + tid : j1 - 1].w : 0u; /* the next tile's words are in flight while this one is counted */
 	for (uint32_t tb = j0; tb < j1; tb += X3S_PAIR_THREADS) {
 		const uint32_t j = tb + tid;
 		const bool in = j < j1;
 		const uint32_t w = nw_;
-		if (j + X3S_PAIR_THREADS < j1) nw_ = a.stat1[j + X3S_PAIR_THREADS].w;
+		nw_ = a.stat1[j + X3S_PAIR_THREADS < j1 ? j + X3S_PAIR_THREADS : j1 - 1].w;
 		const bool isnew = in && w == (0x80000000u | j);
 		const uint64_t Nm = x3_ballot(isnew);
 		if (lane == 0) s_w[wave] = (uint32_t)x3_popc64(Nm);

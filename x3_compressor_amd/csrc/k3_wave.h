@@ -79,13 +79,13 @@ __device__ static __forceinline__ void x3_mtf_tiles(const X3MtfArgs &a, uint16_t
 {
 	const uint64_t bit = (uint64_t)1 << lane, below = bit - 1, above = ~(below | bit);
 	uint32_t nt_ = 0, nh_ = 0;
-	if (e0 + lane < e1) { nt_ = a.e_tag[e0 + lane] - dof; nh_ = a.e_hit[e0 + lane]; }
+	if (e0 < e1) { const uint32_t i0 = e0 + lane < e1 ? e0 + lane : e1 - 1; nt_ = a.e_tag[i0] - dof; nh_ = a.e_hit[i0]; } /* (unconditional loads from clamped indices: see below) */
 	for (uint32_t base = e0; base < e1; base += X3_WAVE) {
 		const bool valid = base + lane < e1;
 		const uint32_t t = nt_, hit = nh_;
-		{ /* next tile's records are in flight while this one is resolved */
-			const uint32_t nx = base + X3_WAVE + lane;
-			if (nx < e1) { nt_ = a.e_tag[nx] - dof; nh_ = a.e_hit[nx]; }
+		{ /* next tile's records are in flight while this one is resolved (no branch around the loads: behind one the compiler waits for them with vmcnt(0) at once) */
+			const uint32_t nx = base + X3_WAVE + lane < e1 ? base + X3_WAVE + lane : e1 - 1;
+			nt_ = a.e_tag[nx] - dof; nh_ = a.e_hit[nx];
 		}
 		const uint64_t V = x3_ballot(valid);
 		const bool isnew = valid && hit == NONE32;
