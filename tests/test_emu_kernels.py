@@ -441,6 +441,7 @@ def test_emulated_size_estimates_match_oracle(oracle, monkeypatch, env):
 
 
 # ---- K3 in slices (code4.hip; api.hip run_sliced) ---------------------------------------------------------------------------------
+ALL_MARKS = "0.02,0.05,0.10,0.17,0.26,0.36,0.47,0.59,0.72,0.86"
 SLICED_CASES = [
     ("abra_two_slices", b"abracadabra" * 30, dict(w_kib=1, t=2), "100", None),            # the first slice only inserts elements (no hit): recency order and index model still move
     ("english_eleven_slices", synth.english_like(6000, seed=8).tobytes(), dict(w_kib=2, t=1), "200", "3"),
@@ -458,6 +459,7 @@ def test_emulated_sliced_schedule_matches_oracle(oracle, monkeypatch, name, data
     pair ordinals, model counters, order-0 models, coder interval, pending bits) -- stream, statistics and size estimates == the oracle's"""
     subprocess.run(["make", "-C", os.path.join(HERE, "emu")], check=True, capture_output=True)
     monkeypatch.setenv("X3H_SLICED_MIN", "1")
+    monkeypatch.setenv("X3H_SLICE_MARKS", ALL_MARKS)   # (a short stream gets one mark by default: a slice has a fixed cost)
     monkeypatch.setenv("X3H_SLICE_GAP", gap)
     if sub:
         monkeypatch.setenv("X3H_SLICE_SUB", sub)
@@ -476,6 +478,7 @@ def test_emulated_sliced_ragged_batch(oracle, monkeypatch):
     stream in between; every stream == the oracle's stream of that chunk alone"""
     subprocess.run(["make", "-C", os.path.join(HERE, "emu")], check=True, capture_output=True)
     monkeypatch.setenv("X3H_SLICED_MIN", "1")
+    monkeypatch.setenv("X3H_SLICE_MARKS", ALL_MARKS)
     monkeypatch.setenv("X3H_SLICE_GAP", "100")
     parts = [synth.english_like(4000, seed=2).tobytes(), b"", b"x", synth.zipf_bytes(2500, offset=99).tobytes(), synth.english_like(6000, seed=9).tobytes(), bytes(1500)]
     off = np.cumsum([0] + [len(p) for p in parts]).astype(np.uint64)

@@ -321,7 +321,7 @@ def test_pipelined_stream_equals_reference_golden(gpu_env, golden, name):
 def test_sliced_schedule_equals_reference_golden(gpu_env, golden, name, gap, sub):
     """every golden stream through K3 in slices (code4.hip; api.hip run_sliced) forced on small inputs: X3H_SLICE_GAP=256 cuts them into up to eleven slices
     (carried recency order, context lists, pair ordinals, model counters, coder state), X3H_SLICE_SUB=3 spreads a stream's contexts over three wavefronts"""
-    env = dict(X3H_SLICED_MIN="1", X3H_SLICE_GAP=gap)
+    env = dict(X3H_SLICED_MIN="1", X3H_SLICE_GAP=gap, X3H_SLICE_MARKS="0.02,0.05,0.10,0.17,0.26,0.36,0.47,0.59,0.72,0.86")   # (a short stream gets one mark by default)
     if sub:
         env["X3H_SLICE_SUB"] = sub
     ctx = gpu_env(**env)

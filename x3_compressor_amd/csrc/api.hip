@@ -57,6 +57,7 @@ struct x3h_ctx {
 	int sliced_max_streams = 192;                 /* X3H_SLICED_STREAMS: beyond, every CU has a stream of every stage anyway (stage after stage) */
 	double slice_marks[X3_MAX_CKPT] = { 0.02, 0.05, 0.10, 0.17, 0.26, 0.36, 0.47, 0.59, 0.72, 0.86 }; /* X3H_SLICE_MARKS: small slices first (the coder starts early), then ~12 % each */
 	uint32_t slice_nmarks = 10;
+	bool slice_marks_fixed = false;
 	X3SliceRun sr;
 	hipEvent_t ev_sf[X3S_MAX_SLICES + 2] = {}, ev_sb[X3S_MAX_SLICES + 2] = {}, ev_se[X3S_MAX_SLICES + 2] = {}, ev_sc[X3S_MAX_SLICES + 2] = {}, ev_s0 = nullptr;
 	hipEvent_t ev_sfork = nullptr, ev_sjoin = nullptr;
@@ -154,7 +155,7 @@ extern "C" int x3h_ctx_create(x3h_ctx **out, int device)
 	  if (e && *e) {
 		double m[X3_MAX_CKPT]; uint32_t k = 0; const char *q = e; bool ok = true;
 		while (*q && k < X3_MAX_CKPT) { char *end = nullptr; const double v = strtod(q, &end); if (end == q || v <= (k ? m[k - 1] : 0.0) || v >= 1.0) { ok = false; break; } m[k++] = v; q = end; if (*q == ',') q++; }
-		if (ok && k && !*q) { for (uint32_t i = 0; i < k; i++) c->slice_marks[i] = m[i]; c->slice_nmarks = k; }
+		if (ok && k && !*q) { for (uint32_t i = 0; i < k; i++) c->slice_marks[i] = m[i]; c->slice_nmarks = k; c->slice_marks_fixed = true; }
 	  } }
 	{ const char *e = getenv("X3H_SEG_EMIT"); if (e && *e) c->seg_emit = *e != '0' ? 1 : 0; }
 	const double t_c2 = x3_now_ms();
@@ -497,7 +498,20 @@ static int sliced_setup(x3h_ctx *c)
 static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, uint8_t *d_out, PipeStats *ps, std::vector<float> *est)
 {
 	const uint32_t nc = (uint32_t)c->hchunks.size();
-	const uint32_t nmarks = c->slice_nmarks;
+	/* how many slices: a slice costs a few hundred microseconds of launches and of latency-bound per-stream kernels whatever its size, so the longest stream is cut
+	 * about every 150 KB, into at most the full set of marks (small slices first: the coder starts early); X3H_SLICE_MARKS fixes the set */
+	uint32_t nmarks = c->slice_nmarks;
+	double marks[X3_MAX_CKPT];
+	for (uint32_t k = 0; k < nmarks; k++) marks[k] = c->slice_marks[k];
+	if (!c->slice_marks_fixed) {
+		uint64_t longest = 0;
+		for (uint32_t i = 0; i < nc; i++) if (c->hchunks[i].len > longest) longest = c->hchunks[i].len;
+		const uint64_t want = longest / (150u << 10);
+		if (want < nmarks + 1) {
+			nmarks = want >= 2 ? (uint32_t)want - 1 : 1u;
+			for (uint32_t k = 0; k < nmarks; k++) marks[k] = (double)(k + 1) / (double)(nmarks + 1);
+		}
+	}
 	if (c->ckpt_cap < nc) {
 		if (c->ckpt) (void)hipHostFree((void *)c->ckpt);
 		c->ckpt = nullptr; c->ckpt_cap = 0;
@@ -516,7 +530,7 @@ static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, 
 		const uint32_t n = c->hchunks[i].len;
 		uint32_t prev = 0, gap = 0, used = 0; /* the marks a stream keeps are its marks 0, 1, ...: the parse waits for them in that order */
 		for (uint32_t k = 0; k < nmarks; k++) {
-			const uint32_t q = (uint32_t)((double)n * c->slice_marks[k]);
+			const uint32_t q = (uint32_t)((double)n * marks[k]);
 			if (q >= prev + min_gap && (uint64_t)q + min_gap <= n) { pos[(size_t)i * X3_MAX_CKPT + used++] = q; if (q - prev > gap) gap = q - prev; prev = q; }
 		}
 		if (n - prev > gap) gap = n - prev;
