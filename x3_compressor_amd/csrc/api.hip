@@ -55,8 +55,11 @@ struct x3h_ctx {
 	int sliced = 1;                               /* X3H_SLICED=0: never */
 	uint64_t sliced_min = (uint64_t)96 << 10;     /* X3H_SLICED_MIN: longest stream of the batch at least this long */
 	int sliced_max_streams = 192;                 /* X3H_SLICED_STREAMS: beyond, every CU has a stream of every stage anyway (stage after stage) */
-	double slice_marks[X3_MAX_CKPT] = { 0.02, 0.05, 0.10, 0.17, 0.26, 0.36, 0.47, 0.59, 0.72, 0.86 }; /* X3H_SLICE_MARKS: small slices first (the coder starts early), then ~12 % each */
-	uint32_t slice_nmarks = 10;
+	/* X3H_SLICE_MARKS: small slices first (the coder starts after 2 % of the input), then each about 1.7 times the one before: the feature stages of a slice take
+	 * 0.35-0.6 of its coder time and the parse has to get there first, so the coder never runs dry -- and FEW slices: every slice is one coder launch for all
+	 * streams, which ends with its longest segment (eleven equal slices cost config 3, whose streams differ in symbols per byte, 19 % of coder time) */
+	double slice_marks[X3_MAX_CKPT] = { 0.02, 0.05, 0.11, 0.20, 0.35, 0.60 };
+	uint32_t slice_nmarks = 6;
 	bool slice_marks_fixed = false;
 	X3SliceRun sr;
 	hipEvent_t ev_sf[X3S_MAX_SLICES + 2] = {}, ev_sb[X3S_MAX_SLICES + 2] = {}, ev_se[X3S_MAX_SLICES + 2] = {}, ev_sc[X3S_MAX_SLICES + 2] = {}, ev_s0 = nullptr;
@@ -504,6 +507,11 @@ static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, 
 	double marks[X3_MAX_CKPT];
 	for (uint32_t k = 0; k < nmarks; k++) marks[k] = c->slice_marks[k];
 	if (!c->slice_marks_fixed) {
+		if (nc <= 2) { /* one or two streams: no other stream's segment to wait for in a coder launch, so more and smaller slices (297 against 299 ms on the dickens-sized stream) */
+			static const double fine[10] = { 0.02, 0.05, 0.10, 0.17, 0.26, 0.36, 0.47, 0.59, 0.72, 0.86 };
+			nmarks = 10;
+			for (uint32_t k = 0; k < nmarks; k++) marks[k] = fine[k];
+		}
 		uint64_t longest = 0;
 		for (uint32_t i = 0; i < nc; i++) if (c->hchunks[i].len > longest) longest = c->hchunks[i].len;
 		const uint64_t want = longest / (150u << 10);

@@ -177,7 +177,7 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 	}
 	uint64_t max_len = 0;
 	for (uint32_t c = 0; c < nc; c++) if (h_chunks[c].len > max_len) max_len = h_chunks[c].len;
-	const int seg_form = x3_scan_seg_applies(nc, max_len); /* many chunks: one workgroup per chunk sorts and tests its own positions (scan3.hip) */
+	const int seg_form = x3_scan_seg_applies(nc, max_len, total); /* many chunks: one workgroup per chunk sorts and tests its own positions (scan3.hip) */
 	const bool seg = seg_form != 0;
 	for (int i = 0; i < 8; i++) CHK(B.a[i].reserve((P + 8) * (seg && i < 2 ? 8 : 4)));
 	CHK(B.a[9].reserve(((size_t)P / 32 + 2) * 4 + 64)); /* padding bitmap */

@@ -710,10 +710,19 @@ int x3_scan_seg_launch(const X3SegArgs &a, uint32_t nchunks, hipStream_t)
 /* One workgroup per chunk pays off once there are enough chunks to fill the chip.  -> 0: no (the chip-wide sort of scan2.hip), 1: yes, the
  * chunk's level counters fit LDS, 2: yes, with the counters in global memory (chunks up to X3_SEG_MAXLEN_BIG; needs enough of them that a
  * quarter of the CUs are busy with one chunk each for the whole scan).  X3H_SEG_MIN=n moves the first threshold (tests), 0 turns it off. */
-int x3_scan_seg_applies(uint32_t nchunks, uint64_t max_len)
+int x3_scan_seg_applies(uint32_t nchunks, uint64_t max_len, uint64_t padded_total)
 {
 	uint32_t min_streams = X3_SEG_MIN_STREAMS, min_big = X3_SEG_MIN_STREAMS_BIG;
-	if (const char *e = getenv("X3H_SEG_MIN")) { const int v = atoi(e); if (v >= 1) min_streams = min_big = (uint32_t)v; else if (v == 0 && *e == '0') return 0; }
+	bool forced = false;
+	if (const char *e = getenv("X3H_SEG_MIN")) { const int v = atoi(e); if (v >= 1) { min_streams = min_big = (uint32_t)v; forced = true; } else if (v == 0 && *e == '0') return 0; }
+	/* between 48 and ~100 chunks the chip-wide sort can be the faster one: a workgroup per chunk is a chain whose length is the CHUNK (0.45 ms + 9.3 ns per byte,
+	 * in rounds of 256 chunks), the chip-wide form streams the padded layout of the BATCH (0.9 ms + 45 ns per KB): 64 chunks of 159 KB take 1.93 against 1.45 ms
+	 * (round 4: the dickens-sized bytes as 48 / 64 / 96 chunks, gpurun_out r04a) */
+	if (!forced && padded_total && nchunks >= min_streams && max_len <= X3_SEG_MAXLEN) {
+		const double seg_ms = (0.45 + 9.3e-6 * (double)max_len) * (double)((nchunks + 255) / 256);
+		const double chip_ms = 0.9 + 4.5e-8 * (double)padded_total;
+		if (chip_ms < seg_ms) return 0;
+	}
 	uint64_t small_max = X3_SEG_MAXLEN;
 	if (const char *e = getenv("X3H_SEG_SMALL_MAX")) { const long long v = atoll(e); if (v >= 0) small_max = (uint64_t)v < X3_SEG_MAXLEN ? (uint64_t)v : X3_SEG_MAXLEN; } /* (tests: force the global-memory form) */
 	if (nchunks >= min_streams && max_len <= small_max) return 1;

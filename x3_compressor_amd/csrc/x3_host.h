@@ -105,7 +105,7 @@ struct X3SegArgs {
 	uint32_t window, ncand, Tu, dense_at;
 	uint64_t *prof;              /* nullptr, or 16 cycle counters: phase 0, passes 1-4, levels 1-4 (X3H_SEG_PROF, debugging) */
 };
-int x3_scan_seg_applies(uint32_t nchunks, uint64_t max_len); /* 0: no, 1: counters in LDS, 2: counters in global memory */
+int x3_scan_seg_applies(uint32_t nchunks, uint64_t max_len, uint64_t padded_total = 0); /* 0: no, 1: counters in LDS, 2: counters in global memory */
 int x3_scan_seg_launch(const X3SegArgs &a, uint32_t nchunks, hipStream_t st);
 int x3_scan_seg_refine_launch(const X3SegArgs &a, uint32_t nchunks, hipStream_t st); /* dense classes of every marked chunk, by the chunk's own workgroup */
 
