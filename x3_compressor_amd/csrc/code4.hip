@@ -985,8 +985,21 @@ int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_for
 	}
 	if (nH) {
 		/* context1: arrangement, statistics with carried lists */
-		x3_foreach(nH, st, X3_LAMBDA(size_t i) { iota[i] = (uint32_t)i; });
-		CHK(x3p_sort_pairs(R.tmp, k1, kA, iota, vA, nH, (int)dsh + cb, st));
+		/* arrangement by (context1, time).  Small slices: one workgroup per stream, a counting sort on the stream-local key in LDS (x3_arrange_kernel, code3.hip: one
+		 * launch per 11 key bits; a slice's arrays are L2-resident, so its scattered stores cost nothing -- on whole streams they made this kernel lose against
+		 * the library sort).  Large slices: the chip-wide radix sort (a workgroup of four wavefronts per stream would be the bottleneck). */
+		bool arrange = nH / nc <= 32768;
+		if (const char *e = getenv("X3H_SLICE_ARRANGE")) arrange = e[0] == '1';
+		uint32_t *d_aho = A[30], *d_akb = A[31]; /* (nc + 1 <= steps + 8 entries each) */
+		if ((uint64_t)nc + 1 > nS + 8) arrange = false;
+		if (arrange) {
+			const uint32_t nHs = (uint32_t)nH, ksh = dsh;
+			x3_foreach((size_t)nc + 1, st, X3_LAMBDA(size_t c) { d_aho[c] = c < nc ? d_sl[c].sh : nHs; d_akb[c] = (uint32_t)c << ksh; });
+			CHK(x3_arrange_run(st, nc, d_aho, d_akb, max_dict ? max_dict - 1 : 0, k1, nullptr, kA, vA, nullptr, A[28], A[29]));
+		} else {
+			x3_foreach(nH, st, X3_LAMBDA(size_t i) { iota[i] = (uint32_t)i; });
+			CHK(x3p_sort_pairs(R.tmp, k1, kA, iota, vA, nH, (int)dsh + cb, st));
+		}
 		HIPCHK(hipMemsetAsync(m_first00, 0xFF, (size_t)nc * 4, st));
 		X3sCtxArgs ca;
 		ca.chunks = d_chunks; ca.sl = d_sl; ca.kA = kA; ca.vA = vA; ca.h_tag = h_tag; ca.stat = stat1; ca.hdr = R.hdr1.as<X3CtxHdr>(); ca.pool = R.pool1.as<uint64_t>();
@@ -1054,7 +1067,14 @@ int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_for
 			if (m_ord00[c] == NONE32 && f00 != NONE32) m_ord00[c] = stat1[f00].w;
 			if (sl.h1 > sl.h0) m_lastord[c] = stat1[sl.sh + (sl.h1 - sl.h0) - 1].w;
 		});
-		CHK(x3p_sort_pairs(R.tmp, k0, kA, iota, vA, nH, (int)psh + cb, st));
+		if (arrange && maxH <= X3_ARRANGE_MAX_LOCAL) {
+			const uint32_t ksh = psh;
+			x3_foreach((size_t)nc, st, X3_LAMBDA(size_t c) { d_akb[c] = (uint32_t)c << ksh; });
+			CHK(x3_arrange_run(st, nc, d_aho, d_akb, maxH, k0, nullptr, kA, vA, nullptr, A[28], A[29]));
+		} else {
+			if (arrange) x3_foreach(nH, st, X3_LAMBDA(size_t i) { iota[i] = (uint32_t)i; });
+			CHK(x3p_sort_pairs(R.tmp, k0, kA, iota, vA, nH, (int)psh + cb, st));
+		}
 		ca.stat = stat0; ca.hdr = R.hdr0.as<X3CtxHdr>(); ca.pool = R.pool0.as<uint64_t>(); ca.pord = nullptr; ca.newaddr = nullptr; ca.top = m_top0; ca.first00 = nullptr;
 		ca.kshift = psh; ca.kmask = (psh >= 32 ? 0xFFFFFFFFu : (1u << psh) - 1u);
 		if (ca.nsub > 1) { if (small) X3S_LAUNCH(x3s_ctx_publish_kernel_t, ca, nc * ca.nsub, X3_WAVE, st); else X3S_LAUNCH(x3s_ctx_publish_kernel_s, ca, nc * ca.nsub, X3_WAVE, st); }

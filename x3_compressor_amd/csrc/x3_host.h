@@ -185,7 +185,7 @@ struct X3Slice {
 #define X3S_DMAX 2048u          /* largest dictionary of a stream the sliced kernels hold in their LDS tables (api.hip falls back to the other schedules beyond) */
 #define X3S_MAX_SLICES 24u
 #define X3S_MTF_RANGES 128u      /* most time ranges per stream and slice of the move-to-front kernel */
-#define X3S_NARR 28
+#define X3S_NARR 32
 /* per-stream carried scalars, one array of nc (x multiplicity) words each inside X3SliceRun::small, in this order */
 enum { X3S_EVFINAL = 0 /* x4: model_events freqs of E_CTX0 / E_CTX1 / E_IDX1, IDX1 uses */, X3S_NNOOP = 4, X3S_NPAIRS = 5, X3S_ORD00 = 6, X3S_LASTORD = 7, X3S_YCNT = 8, X3S_YDONE = 9,
        X3S_TOP1 = 10, X3S_TOP0 = 11, X3S_STATUS = 12, X3S_FIRST00 = 13, X3S_NIDX0 = 14, X3S_SEGOFF = 15, X3S_SEGLEN = 16, X3S_NTOK = 17, X3S_NHITS = 18, X3S_ESTFIRST = 19,
