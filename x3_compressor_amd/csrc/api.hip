@@ -62,7 +62,8 @@ struct x3h_ctx {
 	uint32_t slice_nmarks = 6;
 	bool slice_marks_fixed = false;
 	X3SliceRun sr;
-	hipEvent_t ev_sf[X3S_MAX_SLICES + 2] = {}, ev_sb[X3S_MAX_SLICES + 2] = {}, ev_se[X3S_MAX_SLICES + 2] = {}, ev_sc[X3S_MAX_SLICES + 2] = {}, ev_s0 = nullptr;
+	hipEvent_t ev_sf[X3S_MAX_SLICES + 2] = {}, ev_sb[X3S_MAX_SLICES + 2] = {}, ev_se[X3S_MAX_SLICES + 2] = {}, ev_sc[X3S_MAX_SLICES + 2] = {}, ev_sa[X3S_MAX_SLICES + 2] = {}, ev_s0 = nullptr;
+	int slice_bstream = 1;                        /* X3H_SLICE_BSTREAM=0: stage B always behind stage A on the handle's stream */
 	hipEvent_t ev_sfork = nullptr, ev_sjoin = nullptr;
 	X3ParseCkpt *ckpt = nullptr; /* host-mapped, X3_CKPT_SLOTS per stream */
 	uint32_t ckpt_cap = 0;
@@ -153,6 +154,7 @@ extern "C" int x3h_ctx_create(x3h_ctx **out, int device)
 	{ const char *e = getenv("X3H_PIPE_STREAMS"); if (e && *e) c->pipe_max_streams = atoi(e); }
 	{ const char *e = getenv("X3H_SLICED"); if (e && *e) c->sliced = *e != '0'; }
 	{ const char *e = getenv("X3H_SLICED_MIN"); if (e && *e) c->sliced_min = (uint64_t)atoll(e); }
+	{ const char *e = getenv("X3H_SLICE_BSTREAM"); if (e && *e) c->slice_bstream = *e != '0'; }
 	{ const char *e = getenv("X3H_SLICED_STREAMS"); if (e && *e) c->sliced_max_streams = atoi(e); }
 	{ const char *e = getenv("X3H_SLICE_MARKS");
 	  if (e && *e) {
@@ -202,7 +204,7 @@ extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 	c->coder_state.release(); c->prefix_result.release(); c->srcoff.release(); c->ckpt_pos.release(); c->seg.meta.release(); c->seg.modes_state.release(); c->seg.mode_prev.release();
 	c->c2.yfin.release(); c->c2.yfinrec.release();
 	c->sr.release();
-	for (uint32_t i = 0; i < X3S_MAX_SLICES + 2; i++) { if (c->ev_sf[i]) (void)hipEventDestroy(c->ev_sf[i]); if (c->ev_sb[i]) (void)hipEventDestroy(c->ev_sb[i]); if (c->ev_se[i]) (void)hipEventDestroy(c->ev_se[i]); if (c->ev_sc[i]) (void)hipEventDestroy(c->ev_sc[i]); }
+	for (uint32_t i = 0; i < X3S_MAX_SLICES + 2; i++) { if (c->ev_sf[i]) (void)hipEventDestroy(c->ev_sf[i]); if (c->ev_sb[i]) (void)hipEventDestroy(c->ev_sb[i]); if (c->ev_se[i]) (void)hipEventDestroy(c->ev_se[i]); if (c->ev_sc[i]) (void)hipEventDestroy(c->ev_sc[i]); if (c->ev_sa[i]) (void)hipEventDestroy(c->ev_sa[i]); }
 	if (c->ev_s0) { (void)hipEventDestroy(c->ev_s0); (void)hipEventDestroy(c->ev_sfork); (void)hipEventDestroy(c->ev_sjoin); }
 	c->c2.est_val.release(); c->c2.est_cls.release(); c->c2.est_out.release();
 	if (c->c2.est_stream) { (void)hipStreamSynchronize(c->c2.est_stream); (void)hipStreamDestroy(c->c2.est_stream); (void)hipEventDestroy(c->c2.ev_est_fork); (void)hipEventDestroy(c->c2.ev_est_done); }
@@ -493,7 +495,7 @@ static int sliced_setup(x3h_ctx *c)
 	if (!c->ev_emit) HIPCHK(hipEventCreate(&c->ev_emit));
 	if (!c->ev_p0) { HIPCHK(hipEventCreate(&c->ev_p0)); HIPCHK(hipEventCreate(&c->ev_p1)); HIPCHK(hipEventCreate(&c->ev_ready)); }
 	HIPCHK(hipEventCreate(&c->ev_sfork)); HIPCHK(hipEventCreate(&c->ev_sjoin));
-	for (uint32_t i = 0; i < X3S_MAX_SLICES + 2; i++) { HIPCHK(hipEventCreate(&c->ev_sf[i])); HIPCHK(hipEventCreate(&c->ev_sb[i])); HIPCHK(hipEventCreate(&c->ev_se[i])); HIPCHK(hipEventCreate(&c->ev_sc[i])); }
+	for (uint32_t i = 0; i < X3S_MAX_SLICES + 2; i++) { HIPCHK(hipEventCreate(&c->ev_sf[i])); HIPCHK(hipEventCreate(&c->ev_sb[i])); HIPCHK(hipEventCreate(&c->ev_se[i])); HIPCHK(hipEventCreate(&c->ev_sc[i])); HIPCHK(hipEventCreate(&c->ev_sa[i])); }
 	HIPCHK(hipEventCreate(&c->ev_s0));
 	return X3H_OK;
 }
@@ -570,6 +572,16 @@ static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, 
 	int next = 0, nslice = 0;
 	bool parse_done = false, fallback = false;
 	uint64_t max_dict = 1;
+	uint32_t *emit_off[X3S_MAX_SLICES + 2] = {}, *emit_len[X3S_MAX_SLICES + 2] = {};
+	auto queue_emit = [&](int k, bool last) -> int {
+		HIPCHK(hipStreamWaitEvent(s_emit, c->ev_se[k], 0));
+		X3EmitArgs ea;
+		ea.yoc = nullptr; ea.sym = R.sym.as<uint4>(); ea.state = R.states.as<uint32_t>(); ea.final_lo = sm + X3S_FINALLO * nc; ea.chunks = c->chunks.as<X3Chunk>(); ea.parsed = nullptr;
+		ea.npairs = sm + X3S_NPAIRS * nc; ea.evfinal = sm + X3S_EVFINAL * nc; ea.out = d_out; ea.result = c->cresult.as<X3CodeResult>();
+		ea.seg_off = emit_off[k]; ea.seg_len = emit_len[k]; ea.carry = sm + X3S_EMITCARRY * nc; ea.last = last ? 1u : 0u; ea.compact = 0;
+		ea.ntok = sm + X3S_NTOK * nc; ea.nhits = sm + X3S_NHITS * nc;
+		return x3s_emit_launch(ea, nc, s_emit);
+	};
 	for (;;) {
 		int lowest = X3_MAX_CKPT;
 		for (uint32_t i = 0; i < nc; i++) {
@@ -612,28 +624,39 @@ static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, 
 		if (max_dict > X3S_DMAX || ss > slice_bytes) { fallback = true; break; } /* (the second: cannot happen, see the marks above) */
 		if (nslice >= (int)X3S_MAX_SLICES + 1) return X3H_E_INTERNAL;
 		uint32_t *d_segoff = nullptr, *d_seglen = nullptr;
+		/* stage A (records, ranks, context statistics) on the handle's stream; its slice temporaries are one of two sets, the one stage B of slice k - 2 has read */
+		if (nslice >= 2) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_sf[nslice - 2], 0));
 		HIPCHK(hipEventRecord(c->ev_sb[nslice], c->stream));
 		CHK(x3s_slice(R, c->stream, c->stream, c->ev_sfork, c->ev_sjoin, c->chunks.as<X3Chunk>(), hs, max_dict, d_bytes, pa.tok_info, pa.dict_len, final,
-		              c->c2.want_est, &d_segoff, &d_seglen));
-		if (c->c2.want_est) { /* the reference's float accumulators (x3.c:43), continued in coding order: one more chain per stream, on the feature stream */
+		              c->c2.want_est, &d_segoff, &d_seglen, 1));
+		HIPCHK(hipEventRecord(c->ev_sa[nslice], c->stream));
+		/* stage B (mode chain, index / order-0 models, symbol assembly): once the parse kernel has finished its HIP stream is free, and stage B of this slice runs
+		 * there beside stage A of the next one; while the parse is still running (long streams) it stays behind stage A on this stream */
+		if (!parse_done) { const hipError_t q = hipEventQuery(c->ev_p1); if (q == hipSuccess) parse_done = true; }
+		hipStream_t sB = parse_done && c->slice_bstream ? c->s_parse : c->stream;
+		if (sB != c->stream) {
+			HIPCHK(hipStreamWaitEvent(sB, c->ev_sa[nslice], 0));
+			if (nslice >= 1) HIPCHK(hipStreamWaitEvent(sB, c->ev_sf[nslice - 1], 0));
+		} else if (nslice >= 1) HIPCHK(hipStreamWaitEvent(sB, c->ev_sf[nslice - 1], 0)); /* (stage B of the slice before may have run on the other stream) */
+		CHK(x3s_slice(R, sB, sB, c->ev_sfork, c->ev_sjoin, c->chunks.as<X3Chunk>(), hs, max_dict, d_bytes, pa.tok_info, pa.dict_len, final,
+		              c->c2.want_est, &d_segoff, &d_seglen, 2));
+		if (c->c2.want_est) { /* the reference's float accumulators (x3.c:43), continued in coding order: one more chain per stream, behind stage B */
 			X3EstArgs ea;
 			ea.range = nullptr; ea.val = R.est_val.as<float>(); ea.cls = R.est_cls.as<uint8_t>(); ea.out = (float *)(sm + X3S_EST * nc);
 			ea.seg_first = sm + X3S_ESTFIRST * nc; ea.seg_count = sm + X3S_ESTCNT * nc;
-			CHK(x3s_est_launch(ea, nc, c->stream));
+			CHK(x3s_est_launch(ea, nc, sB));
 		}
-		HIPCHK(hipEventRecord(c->ev_sf[nslice], c->stream));
+		HIPCHK(hipEventRecord(c->ev_sf[nslice], sB));
 		/* coder recurrence of the slice's symbols, then their bits (both carry their state per stream from launch to launch) */
 		HIPCHK(hipStreamWaitEvent(c->s_coder, c->ev_sf[nslice], 0));
 		HIPCHK(hipEventRecord(c->ev_sc[nslice], c->s_coder));
 		CHK(x3s_ac2_launch(R.sym.as<uint4>(), R.states.as<uint32_t>(), sm + X3S_FINALLO * nc, d_segoff, d_seglen, sm + X3S_CODER * nc, nc, c->s_coder));
 		HIPCHK(hipEventRecord(c->ev_se[nslice], c->s_coder));
-		HIPCHK(hipStreamWaitEvent(s_emit, c->ev_se[nslice], 0));
-		X3EmitArgs ea;
-		ea.yoc = nullptr; ea.sym = R.sym.as<uint4>(); ea.state = R.states.as<uint32_t>(); ea.final_lo = sm + X3S_FINALLO * nc; ea.chunks = c->chunks.as<X3Chunk>(); ea.parsed = nullptr;
-		ea.npairs = sm + X3S_NPAIRS * nc; ea.evfinal = sm + X3S_EVFINAL * nc; ea.out = d_out; ea.result = c->cresult.as<X3CodeResult>();
-		ea.seg_off = d_segoff; ea.seg_len = d_seglen; ea.carry = sm + X3S_EMITCARRY * nc; ea.last = final ? 1u : 0u; ea.compact = 0;
-		ea.ntok = sm + X3S_NTOK * nc; ea.nhits = sm + X3S_NHITS * nc;
-		CHK(x3s_emit_launch(ea, nc, s_emit));
+		/* the bit emission of a slice is queued on the parse stream ONE SLICE LATE (and the last ones behind the loop): it waits for its coder segment, and
+		 * whatever is queued behind it on that stream -- stage B of a later slice -- must not wait that long */
+		emit_off[nslice] = d_segoff; emit_len[nslice] = d_seglen;
+		if (nslice >= 1) CHK(queue_emit(nslice - 1, false));
+		if (final) CHK(queue_emit(nslice, true));
 		prev = cur;
 		nslice++;
 		if (final) break;
@@ -656,7 +679,8 @@ static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, 
 	float ms = 0;
 	(void)hipEventElapsedTime(&ms, c->ev_p0, c->ev_p1); ps->ms_parse = ms;
 	for (int i = 0; i < nslice; i++) {
-		(void)hipEventElapsedTime(&ms, c->ev_sb[i], c->ev_sf[i]); ps->ms_features += ms;
+		(void)hipEventElapsedTime(&ms, c->ev_sb[i], c->ev_sa[i]); ps->ms_features += ms; /* stage A */
+		(void)hipEventElapsedTime(&ms, c->ev_sa[i], c->ev_sf[i]); ps->ms_modes += ms;    /* stage B (mode chain, models, assembly; its wait for the stream it runs on included) */
 		(void)hipEventElapsedTime(&ms, c->ev_sf[i], c->ev_se[i]); /* (includes the wait of a segment for its predecessor) */
 	}
 	{ /* coder: first segment's begin to last segment's end minus nothing -- the segments of a stream follow each other without a gap when the pipeline is fed */

@@ -905,9 +905,11 @@ int x3s_begin(X3SliceRun &R, hipStream_t st, uint32_t nc, const X3Chunk *h_chunk
 	}
 	/* temporaries of a slice: dense over the slice's steps */
 	const size_t ns = (size_t)max_slice_steps + 64, nb = (size_t)max_slice_bytes + 64;
-	for (int i = 0; i < X3S_NARR; i++) CHK(R.a[i].reserve(ns * 4));
-	CHK(R.stat1.reserve(ns * 16)); CHK(R.stat0.reserve(ns * 16));
-	for (int i = 0; i < 3; i++) CHK(R.b[i].reserve(nb * 4));
+	for (int q = 0; q < 2; q++) {
+		for (int i = 0; i < X3S_NARR; i++) CHK(R.a[q][i].reserve(ns * 4));
+		CHK(R.stat1[q].reserve(ns * 16)); CHK(R.stat0[q].reserve(ns * 16));
+		for (int i = 0; i < 3; i++) CHK(R.b[q][i].reserve(nb * 4));
+	}
 	CHK(R.est_val.reserve((3 * nb + 8) * 4)); CHK(R.est_cls.reserve(3 * nb + 8));
 	CHK(R.tmp.reserve(ns * 16 + ((size_t)4 << 20)));
 	CHK(R.tables.reserve((size_t)(X3S_MAX_SLICES + 2) * nc * (sizeof(X3Slice) + 8) + 64));
@@ -918,13 +920,17 @@ int x3s_begin(X3SliceRun &R, hipStream_t st, uint32_t nc, const X3Chunk *h_chunk
 /* the feature stages of one slice, queued on `st` (the move-to-front ranks on `side`); on return the slice's new symbols are in the operand array and
  * R's per-stream {first, count} of the coder segment are set on the device: the caller queues the coder and the bit emission behind `st` */
 int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, const X3Chunk *d_chunks, const std::vector<X3Slice> &hs,
-              uint64_t max_dict, const uint8_t *d_bytes, const uint32_t *tok_info, const uint8_t *dict_len, bool last, bool want_est, uint32_t **seg_off_out, uint32_t **seg_len_out)
+              uint64_t max_dict, const uint8_t *d_bytes, const uint32_t *tok_info, const uint8_t *dict_len, bool last, bool want_est, uint32_t **seg_off_out, uint32_t **seg_len_out, int phase)
 {
+	/* phase 1 = stage A (records, ranks, context statistics), phase 2 = stage B (mode chain, index / order-0 models, symbol assembly), 3 = both.  The two stages of a
+	 * slice use one of TWO sets of slice temporaries (slice number & 1), so that stage A of slice k + 1 may run while stage B of slice k still reads its own set. */
 	const uint32_t nc = R.nc;
 	if (hs.size() != nc || max_dict > X3S_DMAX) return X3H_E_INTERNAL;
-	R.slices.push_back(hs);                           /* (kept alive: the copy below is asynchronous) */
+	if (phase & 1) R.slices.push_back(hs);            /* (kept alive: the copy below is asynchronous) */
+	if (R.slices.empty()) return X3H_E_INTERNAL;
 	const std::vector<X3Slice> &keep = R.slices.back();
 	const size_t k = R.slices.size() - 1;
+	const int set = (int)(k & 1);
 	if (k >= X3S_MAX_SLICES + 2) return X3H_E_INTERNAL;
 	if (R.tables.cap < (size_t)(X3S_MAX_SLICES + 2) * nc * (sizeof(X3Slice) + 8)) return X3H_E_INTERNAL; /* (x3s_begin sized it) */
 	X3Slice *d_sl = R.tables.as<X3Slice>() + k * nc;
@@ -932,7 +938,7 @@ int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_for
 	 * HIP streams while this stream is already assembling slice k + 1) */
 	uint32_t *m_segoff = (uint32_t *)(R.tables.as<X3Slice>() + (size_t)(X3S_MAX_SLICES + 2) * nc) + 2 * k * nc, *m_seglen = m_segoff + nc;
 	*seg_off_out = m_segoff; *seg_len_out = m_seglen;
-	HIPCHK(hipMemcpyAsync(d_sl, keep.data(), (size_t)nc * sizeof(X3Slice), hipMemcpyHostToDevice, st));
+	if (phase & 1) HIPCHK(hipMemcpyAsync(d_sl, keep.data(), (size_t)nc * sizeof(X3Slice), hipMemcpyHostToDevice, st));
 	uint64_t nS = 0, nH = 0, nE = 0, nM = 0, nB = 0, maxH = 0;
 	for (uint32_t c = 0; c < nc; c++) {
 		const X3Slice &s = hs[c];
@@ -940,13 +946,13 @@ int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_for
 		if (s.h1 > maxH) maxH = s.h1;
 	}
 	uint32_t *A[X3S_NARR];
-	for (int i = 0; i < X3S_NARR; i++) { if (R.a[i].cap < (nS + 8) * 4) return X3H_E_INTERNAL; A[i] = R.a[i].as<uint32_t>(); }
-	if (R.b[0].cap < (nB + 8) * 4) return X3H_E_INTERNAL;
+	for (int i = 0; i < X3S_NARR; i++) { if (R.a[set][i].cap < (nS + 8) * 4) return X3H_E_INTERNAL; A[i] = R.a[set][i].as<uint32_t>(); }
+	if (R.b[set][0].cap < (nB + 8) * 4) return X3H_E_INTERNAL;
 	uint32_t *s_hb = A[0], *s_mb = A[1], *h_tag = A[2], *h_c1 = A[3], *h_pv = A[4], *h_dk = A[5], *h_step = A[6], *k1 = A[7], *e_tag = A[8], *e_hit = A[9];
 	uint32_t *lval = A[10], *lsm = A[11], *leq = A[12], *h_rank = A[13], *iota = A[14], *kA = A[15], *vA = A[16], *newaddr = A[17], *k0 = A[18];
 	uint32_t *mode = A[19], *pe0 = A[20], *pe1 = A[21], *nzl = A[22], *il_rank = A[23], *il_hit = A[24], *rfreq = A[25], *rcum = A[26], *itot = A[27];
-	uint32_t *bval = R.b[0].as<uint32_t>(), *bsm = R.b[1].as<uint32_t>(), *beq = R.b[2].as<uint32_t>();
-	uint4 *stat1 = R.stat1.as<uint4>(), *stat0 = R.stat0.as<uint4>();
+	uint32_t *bval = R.b[set][0].as<uint32_t>(), *bsm = R.b[set][1].as<uint32_t>(), *beq = R.b[set][2].as<uint32_t>();
+	uint4 *stat1 = R.stat1[set].as<uint4>(), *stat0 = R.stat0[set].as<uint4>();
 	uint32_t *sm = R.small.as<uint32_t>();
 	uint32_t *m_evfinal = sm + X3S_EVFINAL * nc, *m_nnoop = sm + X3S_NNOOP * nc, *m_npairs = sm + X3S_NPAIRS * nc, *m_ord00 = sm + X3S_ORD00 * nc;
 	uint32_t *m_lastord = sm + X3S_LASTORD * nc, *m_ycnt = sm + X3S_YCNT * nc, *m_ydone = sm + X3S_YDONE * nc, *m_top1 = sm + X3S_TOP1 * nc, *m_top0 = sm + X3S_TOP0 * nc;
@@ -959,6 +965,7 @@ int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_for
 	if (dsh + cb > 32 || psh + cb > 32) return X3H_E_ARG;
 	const bool small = max_dict <= 512;
 
+	if (phase & 1) {
 	if (nS) {
 		X3sTokArgs ta;
 		ta.chunks = d_chunks; ta.sl = d_sl; ta.bytes = d_bytes; ta.tok_info = tok_info; ta.dict_len = dict_len; ta.s_hb = s_hb; ta.s_mb = s_mb;
@@ -1095,6 +1102,8 @@ int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_for
 		}
 	}
 	if (nE) HIPCHK(hipStreamWaitEvent(st, ev_join, 0)); /* the ranks */
+	}
+	if (!(phase & 2)) return X3H_OK;
 	/* mode chain: continues from the earlier slices' state (also for streams without a hit in this slice: nothing happens) */
 	x3_foreach(nc, st, X3_LAMBDA(size_t c) { m_nidx0[c] = m_evfinal[4 * c + 3]; });
 	if (nH) {

@@ -198,18 +198,18 @@ struct X3SliceRun {
 	DevBuf lt, idxfreq, idxhist, hdr1, hdr0, pool1, pord1, pool0, sym, states, small, mtf_scratch, ctx_scratch, ctx_pending, ctx_dbg, lt2;
 	bool lt_flip = false;
 	/* temporaries of a slice */
-	DevBuf a[X3S_NARR], b[3], stat1, stat0, est_val, est_cls, tmp, tables;
+	DevBuf a[2][X3S_NARR], b[2][3], stat1[2], stat0[2], est_val, est_cls, tmp, tables; /* two sets: stage A of a slice beside stage B of the slice before */
 	std::vector<std::vector<X3Slice>> slices; /* host copies of the slice tables, kept until the run ends (their H2D copies are asynchronous) */
 	void release()
 	{
-		DevBuf *all[] = { &lt, &idxfreq, &idxhist, &hdr1, &hdr0, &pool1, &pord1, &pool0, &sym, &states, &small, &mtf_scratch, &ctx_scratch, &ctx_pending, &ctx_dbg, &lt2, &b[0], &b[1], &b[2], &stat1, &stat0, &est_val, &est_cls, &tmp, &tables };
+		DevBuf *all[] = { &lt, &idxfreq, &idxhist, &hdr1, &hdr0, &pool1, &pord1, &pool0, &sym, &states, &small, &mtf_scratch, &ctx_scratch, &ctx_pending, &ctx_dbg, &lt2, &est_val, &est_cls, &tmp, &tables };
 		for (DevBuf *d : all) d->release();
-		for (DevBuf &d : a) d.release();
+		for (int q = 0; q < 2; q++) { for (DevBuf &d : a[q]) d.release(); for (DevBuf &d : b[q]) d.release(); stat1[q].release(); stat0[q].release(); }
 	}
 };
 int x3s_begin(X3SliceRun &R, hipStream_t st, uint32_t nc, const X3Chunk *h_chunks, uint64_t max_slice_steps, uint64_t max_slice_bytes);
 int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, const X3Chunk *d_chunks, const std::vector<X3Slice> &hs,
-              uint64_t max_dict, const uint8_t *d_bytes, const uint32_t *tok_info, const uint8_t *dict_len, bool last, bool want_est, uint32_t **seg_off_out, uint32_t **seg_len_out);
+              uint64_t max_dict, const uint8_t *d_bytes, const uint32_t *tok_info, const uint8_t *dict_len, bool last, bool want_est, uint32_t **seg_off_out, uint32_t **seg_len_out, int phase = 3);
 int x3_zero_output_slots(hipStream_t st, uint32_t nc, const X3Chunk *h_chunks, const X3Chunk *d_chunks, uint8_t *d_out);
 
 /* argument blocks of kernels that code2.hip defines and code4.hip launches too */
