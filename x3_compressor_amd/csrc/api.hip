@@ -63,7 +63,9 @@ struct x3h_ctx {
 	bool slice_marks_fixed = false;
 	X3SliceRun sr;
 	hipEvent_t ev_sf[X3S_MAX_SLICES + 2] = {}, ev_sb[X3S_MAX_SLICES + 2] = {}, ev_se[X3S_MAX_SLICES + 2] = {}, ev_sc[X3S_MAX_SLICES + 2] = {}, ev_sa[X3S_MAX_SLICES + 2] = {}, ev_s0 = nullptr;
-	int slice_bstream = 1;                        /* X3H_SLICE_BSTREAM=0: stage B always behind stage A on the handle's stream */
+	int slice_bstream = 0;                        /* X3H_SLICE_BSTREAM=1: stage B of a slice (mode chain, models, assembly) on the parse stream once the parse is done, beside stage A of the
+	                                               * next slice.  Measured (round 4): no gain -- stage A, not B, is what a small slice costs (~1.3 ms of launches and latency-bound
+	                                               * per-stream kernels whatever its size), and config 4's share got 3 % slower (437 against 423 ms): off by default */
 	hipEvent_t ev_sfork = nullptr, ev_sjoin = nullptr;
 	X3ParseCkpt *ckpt = nullptr; /* host-mapped, X3_CKPT_SLOTS per stream */
 	uint32_t ckpt_cap = 0;
