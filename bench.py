@@ -243,7 +243,7 @@ def main():
                 print(f"bench.py: config 4: pinned chunk streams differ from the real reference's: {checked}", file=sys.stderr)
                 line["valid"] = False
             line["stage_ms"] = {k[3:]: round(v, 3) for k, v in ms.items()}
-            line["schedule"] = "pipelined" if int(st.pipelined) else "sequential stages"
+            line["schedule"] = {0: "sequential stages", 1: "pipelined (prefixes)", 2: "K3 in slices"}[int(st.pipelined)]
             line["one_stream_per_rank"] = {"value": round(synth.DICKENS_BYTES * world / float(sdt.item()) / 1e6, 3), "unit": "MB/s",
                                            "note": "every rank one dickens-sized stream (configs[1] shape), no exchange"}
             Yc = int(st.chain_symbols) or int(st.coded_symbols)
@@ -296,13 +296,16 @@ def main():
         "ratio": round(N / comp, 4), "compressed_bytes": comp, "parse_steps": S, "coded_symbols": Y, "chain_symbols": Yc,
         "stream_sha256_equals_reference": sha_ok,
         "stage_ms": {k[3:]: round(v, 3) for k, v in ms.items()},
-        "schedule": ("pipelined: parse / feature passes / coder recurrence overlap on three HIP streams; stage_ms are per-stage sums"
-                     if int(st.pipelined) else "sequential stages"),
+        "schedule": {0: "sequential stages",
+                     1: "pipelined: parse / feature passes / coder recurrence overlap on three HIP streams, the coding stage re-run on growing prefixes; stage_ms are per-stage sums",
+                     2: f"K3 in slices: the parse publishes checkpoints, every slice between two of them gets its features from carried model state ({int(st.coder_launches)} slices), "
+                        "coder and bit emission continue per slice; parse / features / coder overlap on three HIP streams; stage_ms are per-stage sums "
+                        "(features = records, ranks, context statistics; modes = mode chain, index / order-0 models, symbol assembly)"}[int(st.pipelined)],
         "mode_choice_iterations": int(st.mode_iters),
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": round(kernels[dom]["alg_bytes"] / (kernels[dom]["ms"] * 1e-3) / HBM_PEAK, 7), "traffic": traffic,
                      "traffic_source": traffic_src, "algorithmic_bytes": kernels[dom]["alg_bytes"], "kernel_ms": kernels[dom]["ms"],
-                     "launches_per_step": 5 if int(st.pipelined) else 1,
+                     "launches_per_step": int(st.coder_launches) or 1,
                      # SURVEY.md 8(d)'s single figure for the PATH, B_alg = S*W + N + C over the whole step, in the same object
                      "path_algorithmic_bytes": path_bytes, "path_achieved": round(path_bytes / (ms_per_step * 1e-3) / 1e9, 2),
                      "frac_path": round(path_bytes / (ms_per_step * 1e-3) / HBM_PEAK, 5),

@@ -68,11 +68,13 @@ typedef struct x3h_stats {
 	int64_t  mode_iters;    /* K3: fixed-point iterations of the mode choice (0: the serial kernel decided;  */
 	                        /*     < 0: no fixed point within the cap, the serial kernel ran after all)       */
 	uint64_t chain_symbols; /* symbols the coder recurrence processed (coded_symbols minus the no-op ones)   */
-	uint64_t pipelined;     /* 1: single-stream schedule with overlapped stages (ms_parse, ms_features,      */
-	                        /*    ms_modes, ms_coder are then per-stage sums that overlap inside ms_total)    */
+	uint64_t pipelined;     /* 1: overlapped stages, the coding stage re-run on growing prefixes of one stream; 2: K3 in slices (carried   */
+	                        /*    model state, a few long streams).  ms_parse, ms_features, ms_modes, ms_coder are then per-stage sums that   */
+	                        /*    overlap inside ms_total.  0: stage after stage                                                              */
 	double   est_bits[4];   /* sizes[E_CTX0..E_NEW] of x3.c:43: the estimated code length per event class, -log2f(prob) summed
 	                         * per stream in IEEE single IN CODING ORDER like the reference (x3.c:52-55,192-193,253-266), the streams of a
 	                         * batch added up in double.  Only filled after x3h_ctx_set_estimates(ctx, 1); zeros otherwise.            */
+	uint64_t coder_launches; /* launches of the coder recurrence behind ms_coder (1 stage after stage; one per prefix / per slice otherwise) */
 } x3h_stats;
 
 typedef struct x3h_ctx x3h_ctx; /* one per GPU: device, stream, growable workspace */

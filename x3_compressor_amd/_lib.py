@@ -40,7 +40,7 @@ class Stats(C.Structure):
                 ("steps", C.c_uint64), ("ms_total", C.c_double), ("ms_scan", C.c_double), ("ms_parse", C.c_double),
                 ("ms_code", C.c_double), ("ms_copy", C.c_double), ("ms_features", C.c_double), ("ms_modes", C.c_double),
                 ("ms_coder", C.c_double), ("ms_emit", C.c_double), ("coded_symbols", C.c_uint64), ("mode_iters", C.c_int64),
-                ("chain_symbols", C.c_uint64), ("pipelined", C.c_uint64), ("est_bits", C.c_double * 4)]
+                ("chain_symbols", C.c_uint64), ("pipelined", C.c_uint64), ("est_bits", C.c_double * 4), ("coder_launches", C.c_uint64)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("events", "est_bits")}

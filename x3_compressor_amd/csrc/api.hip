@@ -320,7 +320,7 @@ static int stage_inputs(x3h_ctx *c, const x3h_params *prm, const RunIO &io, uint
  * so after the first 2 % it never waits: a step costs about scan + coder instead of scan + parse + features + modes + coder.
  * Results are bit-identical by construction (same kernels, same order of symbols; only WHEN they run changes).
  * ------------------------------------------------------------------------------------------------------------ */
-struct PipeStats { double ms_parse = 0, ms_features = 0, ms_modes = 0, ms_coder = 0; long long mode_iters = 0; };
+struct PipeStats { double ms_parse = 0, ms_features = 0, ms_modes = 0, ms_coder = 0; long long mode_iters = 0; unsigned launches = 0; };
 
 static int pipe_setup(x3h_ctx *c)
 {
@@ -464,6 +464,7 @@ static int run_pipelined_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_byte
 	float ms = 0;
 	(void)hipEventElapsedTime(&ms, c->ev_p0, c->ev_p1); ps->ms_parse = ms;
 	for (int i = 0; i < nseg; i++) { (void)hipEventElapsedTime(&ms, c->ev_cb[i], c->ev_ce[i]); ps->ms_coder += ms; }
+	ps->launches = (unsigned)nseg;
 	if (getenv("X3H_DEBUG")) { /* where the coder segments sit on the time line of the call (ms after the parse started) */
 		(void)hipStreamSynchronize(c->stream);
 		fprintf(stderr, "[x3h] pipelined: parse %.1f ms;", ps->ms_parse);
@@ -690,7 +691,7 @@ static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, 
 		for (int i = 0; i < nslice; i++) { (void)hipEventElapsedTime(&ms, c->ev_sc[i], c->ev_se[i]); tot += ms; }
 		ps->ms_coder = tot;
 	}
-	ps->mode_iters = 0;
+	ps->mode_iters = 0; ps->launches = (unsigned)nslice;
 	c->c2.last.symbols = 0; c->c2.last.chain_symbols = 0;
 	{
 		std::vector<uint32_t> yc(nc);
@@ -891,11 +892,12 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 			stats->coded_symbols = c->c2.last.symbols;
 			stats->mode_iters = c->c2.last.mode_iters;
 			stats->chain_symbols = c->c2.last.chain_symbols;
+			stats->coder_launches = 1;
 		}
 		if (pipe || sliced) { /* overlapped stages: each from its own events (their sum exceeds ms_total) */
 			stats->ms_parse = ps.ms_parse; stats->ms_features = ps.ms_features; stats->ms_modes = ps.ms_modes; stats->ms_coder = ps.ms_coder;
 			stats->ms_emit = 0; stats->mode_iters = ps.mode_iters; stats->coded_symbols = c->c2.last.symbols;
-			stats->chain_symbols = c->c2.last.chain_symbols; stats->pipelined = sliced ? 2 : 1;
+			stats->chain_symbols = c->c2.last.chain_symbols; stats->pipelined = sliced ? 2 : 1; stats->coder_launches = ps.launches;
 		}
 		(void)fell_back;
 	}
@@ -916,6 +918,7 @@ static void stats_add(x3h_stats &acc, const x3h_stats &part)
 	acc.ms_features += part.ms_features; acc.ms_modes += part.ms_modes; acc.ms_coder += part.ms_coder; acc.ms_emit += part.ms_emit;
 	acc.mode_iters += part.mode_iters; acc.chain_symbols += part.chain_symbols; acc.pipelined |= part.pipelined;
 	for (int e = 0; e < 4; e++) acc.est_bits[e] += part.est_bits[e];
+	acc.coder_launches += part.coder_launches;
 }
 
 static int run(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage upto, x3h_stats *stats)
