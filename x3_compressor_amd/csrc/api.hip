@@ -23,6 +23,7 @@
 extern "C" void x3k_launch_scan(const X3ScanArgs *a, uint32_t max_len, uint32_t nchunks, hipStream_t st);
 extern "C" void x3k_launch_parse(const X3ParseArgs *a, uint32_t nchunks, hipStream_t st);
 extern "C" void x3k_launch_decode(const X3DecArgs *a, uint32_t nchunks, hipStream_t st);
+extern "C" void x3k_launch_decode_bytes(const X3DecArgs *a, uint32_t nchunks, uint32_t ntiles, hipStream_t st);
 
 thread_local int x3_last_hip = 0;
 thread_local double x3_alloc_ms = 0;
@@ -76,8 +77,9 @@ struct x3h_ctx {
 	bool dec_batch_from_env = false;
 	uint64_t batch_pad_bytes = (uint64_t)2 << 30; /* X3H_BATCH_PAD_BYTES: padded layout of one sub-batch (K1 needs < 2^32 - 256) */
 	uint64_t pad_total = 0;
-	DevBuf mtf, idxfreq, ctx1, ctx0, items, pkey, pval, out, counts;
-	DevBuf din, dchunks, items_ord; /* decoder: input streams, stream table, pair ordinal per context item */
+	DevBuf mtf, idxfreq, items, pkey, pval, out, counts;
+	DevBuf din, dchunks, dc1, dtok, dlit, dtile, dtfirst; /* decoder: input streams, stream table, context1 block per element, token trace, element bytes, second-stage tiles */
+	std::vector<uint32_t> htfirst;
 	DevBuf g_in, g_out, g_pack, g_final; /* x3h_compress_container_rccl: this device's input block, its strided streams, the packed block, the finished container (root) */
 	std::vector<X3Chunk> hchunks;
 	std::vector<X3ParseResult> hparse;
@@ -200,7 +202,7 @@ extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 	if (c->stream) (void)hipStreamSynchronize(c->stream);
 	DevBuf *bufs[] = { &c->pad, &c->m, &c->dict_pos, &c->dict_len, &c->ht, &c->tok_pos, &c->tok_info, &c->tok_hb, &c->tok_nb, &c->tok_mb, &c->chunks, &c->presult,
 		               &c->c2.tmp, &c->c2.offs, &c->c2.chunkmeta, &c->c2.idxfreq, &c->c2.hsym, &c->c2.maxred, &c->c2.pp[0], &c->c2.pp[1], &c->c2.pp[2], &c->c2.pp[3],
-		               &c->cresult, &c->mtf, &c->idxfreq, &c->ctx1, &c->ctx0, &c->items, &c->pkey, &c->pval, &c->out, &c->counts, &c->din, &c->dchunks, &c->items_ord,
+		               &c->cresult, &c->mtf, &c->idxfreq, &c->items, &c->pkey, &c->pval, &c->out, &c->counts, &c->din, &c->dchunks, &c->dc1, &c->dtok, &c->dlit, &c->dtile, &c->dtfirst,
 		               &c->g_in, &c->g_out, &c->g_pack, &c->g_final };
 	for (DevBuf *b : bufs) b->release();
 	c->coder_state.release(); c->prefix_result.release(); c->srcoff.release(); c->ckpt_pos.release(); c->seg.meta.release(); c->seg.modes_state.release(); c->seg.mode_prev.release();
@@ -1043,7 +1045,7 @@ static int decompress_batch(x3h_ctx *c, const uint8_t *in, const uint64_t *in_of
 	HIPCHK(hipSetDevice(c->device));
 	const int nc = nchunks;
 	std::vector<X3DecChunk> dk((size_t)nc);
-	uint64_t ioff = 0, ooff = 0, toff = 0, c0off = 0, itoff = 0, hoff = 0;
+	uint64_t ioff = 0, ooff = 0, toff = 0, itoff = 0, hoff = 0, koff = 0, loff = 0, max_tiles = 0;
 	for (int i = 0; i < nc; i++) {
 		if (in_offsets[i + 1] < in_offsets[i] || out_offsets[i + 1] < out_offsets[i]) return X3H_E_ARG;
 		const uint64_t ilen = in_offsets[i + 1] - in_offsets[i], cap = out_offsets[i + 1] - out_offsets[i];
@@ -1051,33 +1053,39 @@ static int decompress_batch(x3h_ctx *c, const uint8_t *in, const uint64_t *in_of
 		X3DecChunk &k = dk[(size_t)i];
 		k.in_off = dev ? in_offsets[i] : ioff; k.in_len = (uint32_t)ilen; k.out_cap = (uint32_t)cap; k.out_off = dev ? out_offsets[i] : ooff;
 		if (dev && (in_offsets[i] & 3)) return X3H_E_ARG;
-		k.tag_off = toff; k.ctx0_off = c0off; k.item_off = itoff; k.item_cap = 8 * cap + 64;
+		/* the context pool in 8-byte units, worst case per parse step: an item more in a context0 list (<= 5 units with the blocks it outgrew), a new pair (3),
+		 * an item more in a context1 list (<= 11); a new element costs 7.  Every block is read 64 entries at a time: two of those as slack. */
+		k.tag_off = toff; k.item_off = itoff; k.item_cap = 20 * cap + 512;
 		k.ht_log2 = ceil_log2(2 * (cap + 1)); if (k.ht_log2 < 4) k.ht_log2 = 4; k.ht_off = hoff;
+		k.tok_off = koff; k.lit_off = loff; k._pad = 0;
 		ioff += align_up(ilen, 16) + 16; ooff += align_up(cap, 256) + 256;
-		toff += cap + 8; c0off += cap + 8; itoff += k.item_cap; hoff += (uint64_t)1 << k.ht_log2;
+		toff += cap + 8; itoff += k.item_cap; hoff += (uint64_t)1 << k.ht_log2; koff += cap + 8; loff += align_up(cap + 64, 64);
+		max_tiles += cap / X3_DEC_TILE + 1;
 	}
 	if (dev && (((uintptr_t)in & 3) || (!out && out_offsets[nc] != out_offsets[0]))) return X3H_E_ARG;
+	if (itoff > 0xFFFFFFFF00ull || max_tiles > 0x7FFFFFFFull) return X3H_E_ARG;
 	if (!dev) { CHK(c->din.reserve(ioff + 64)); CHK(c->out.reserve(ooff + 256)); }
 	CHK(c->dchunks.reserve((size_t)nc * sizeof(X3DecChunk)));
 	CHK(c->cresult.reserve((size_t)nc * sizeof(X3CodeResult)));
 	CHK(c->dict_pos.reserve(toff * 4)); CHK(c->dict_len.reserve(toff));
-	CHK(c->mtf.reserve(toff * 4)); CHK(c->idxfreq.reserve(toff * 4));
-	CHK(c->ctx1.reserve(toff * sizeof(X3CtxHdr))); CHK(c->ctx0.reserve(c0off * sizeof(X3CtxHdr)));
-	CHK(c->items.reserve(itoff * 8)); CHK(c->items_ord.reserve(itoff * 4)); CHK(c->ht.reserve(hoff * 4));
+	CHK(c->mtf.reserve(toff * 4)); CHK(c->idxfreq.reserve(toff * 4)); CHK(c->dc1.reserve(toff * 4));
+	CHK(c->items.reserve(itoff * 8)); CHK(c->ht.reserve(hoff * 4));
+	CHK(c->dtok.reserve(koff * 4)); CHK(c->dlit.reserve(loff + 64));
+	CHK(c->dtile.reserve((max_tiles + 1) * 4)); CHK(c->dtfirst.reserve(((size_t)nc + 1) * 4));
 	HIPCHK(hipEventRecord(c->ev[0], c->stream));
 	for (int i = 0; i < nc && !dev; i++)
 		if (dk[(size_t)i].in_len)
 			HIPCHK(hipMemcpyAsync(c->din.as<uint8_t>() + dk[(size_t)i].in_off, in + in_offsets[i], dk[(size_t)i].in_len, hipMemcpyHostToDevice, c->stream));
 	HIPCHK(hipMemcpyAsync(c->dchunks.p, dk.data(), (size_t)nc * sizeof(X3DecChunk), hipMemcpyHostToDevice, c->stream));
-	HIPCHK(hipMemsetAsync(c->ctx1.p, 0, toff * sizeof(X3CtxHdr), c->stream));
-	HIPCHK(hipMemsetAsync(c->ctx0.p, 0, c0off * sizeof(X3CtxHdr), c->stream));
 	HIPCHK(hipMemsetAsync(c->ht.p, 0, hoff * 4, c->stream));
 	X3DecArgs da;
 	da.in = dev ? in : c->din.as<uint8_t>(); da.chunks = c->dchunks.as<X3DecChunk>(); da.out = dev ? out : c->out.as<uint8_t>();
 	da.dict_pos = c->dict_pos.as<uint32_t>(); da.dict_len = c->dict_len.as<uint8_t>(); da.ht = c->ht.as<uint32_t>();
-	da.mtf = c->mtf.as<uint32_t>(); da.idxfreq = c->idxfreq.as<uint32_t>();
-	da.ctx1 = c->ctx1.as<X3CtxHdr>(); da.ctx0 = c->ctx0.as<X3CtxHdr>(); da.items = c->items.as<uint64_t>();
-	da.item_ord = c->items_ord.as<uint32_t>(); da.result = c->cresult.as<X3CodeResult>();
+	da.mtf = c->mtf.as<uint32_t>(); da.idxfreq = c->idxfreq.as<uint32_t>(); da.c1off = c->dc1.as<uint32_t>();
+	da.pool = c->items.as<uint64_t>(); da.tokens = c->dtok.as<uint32_t>(); da.lit = c->dlit.as<uint8_t>();
+	da.tile_sum = c->dtile.as<uint32_t>(); da.tile_first = c->dtfirst.as<uint32_t>(); da.nchunks = (uint32_t)nc; da._pad = 0;
+	da.result = c->cresult.as<X3CodeResult>();
+	/* stage 1: the chains -- one tag per parse step */
 	HIPCHK(hipEventRecord(c->ev[4], c->stream));
 	x3k_launch_decode(&da, (uint32_t)nc, c->stream);
 	HIPCHK(hipGetLastError());
@@ -1085,9 +1093,25 @@ static int decompress_batch(x3h_ctx *c, const uint8_t *in, const uint64_t *in_of
 	c->hcode.resize((size_t)nc);
 	HIPCHK(hipMemcpyAsync(c->hcode.data(), c->cresult.p, (size_t)nc * sizeof(X3CodeResult), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
+	/* stage 2: tags -> bytes, one workgroup per X3_DEC_TILE tokens */
+	c->htfirst.resize((size_t)nc + 1);
+	uint64_t ntiles = 0;
+	for (int i = 0; i < nc; i++) {
+		const X3CodeResult &r = c->hcode[(size_t)i];
+		c->htfirst[(size_t)i] = (uint32_t)ntiles;
+		if (r.status == X3_ST_OK) ntiles += ((uint64_t)r.events[7] + X3_DEC_TILE - 1) / X3_DEC_TILE;
+	}
+	c->htfirst[(size_t)nc] = (uint32_t)ntiles;
+	if (ntiles > max_tiles) return X3H_E_INTERNAL;
+	HIPCHK(hipMemcpyAsync(c->dtfirst.p, c->htfirst.data(), ((size_t)nc + 1) * 4, hipMemcpyHostToDevice, c->stream));
+	x3k_launch_decode_bytes(&da, (uint32_t)nc, (uint32_t)ntiles, c->stream);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(c->ev[1], c->stream));
+	HIPCHK(hipMemcpyAsync(c->hcode.data(), c->cresult.p, (size_t)nc * sizeof(X3CodeResult), hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
 	if (getenv("X3H_DEBUG")) { const X3CodeResult &r = c->hcode[0];
-		fprintf(stderr, "[x3h] decode stream 0: out %u D %u pairs %u events %u %u %u %u | kcycles (profile builds): event %u symbol %u contexts %u tail %u\n",
-		        r.out_len, r._r, r.pairs, r.events[0], r.events[1], r.events[2], r.events[3], r.events[4], r.events[5], r.events[6], r.events[7]); }
+		fprintf(stderr, "[x3h] decode stream 0: out %u tokens %u D %u pairs %u events %u %u %u %u status %u\n",
+		        r.out_len, r.events[7], r._r, r.pairs, r.events[0], r.events[1], r.events[2], r.events[3], r.status); }
 	int rc = X3H_OK;
 	for (int i = 0; i < nc; i++) {
 		const X3CodeResult &r = c->hcode[(size_t)i];
@@ -1110,8 +1134,9 @@ static int decompress_batch(x3h_ctx *c, const uint8_t *in, const uint64_t *in_of
 			stats->ctx0_entries += c->hcode[(size_t)i].pairs;
 		}
 		float ms = 0;
-		(void)hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); stats->ms_code = ms;
-		(void)hipEventElapsedTime(&ms, c->ev[0], c->ev[5]); stats->ms_total = ms;
+		(void)hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); stats->ms_code = ms;  /* stage 1: the chains */
+		(void)hipEventElapsedTime(&ms, c->ev[5], c->ev[1]); stats->ms_emit = ms;  /* stage 2: tags -> bytes (the read-back of the token counts included) */
+		(void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); stats->ms_total = ms;
 	}
 	return rc;
 }

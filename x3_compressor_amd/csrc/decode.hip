@@ -2,105 +2,126 @@
  * decode.hip -- the x3 decoder (reference: decompress() x3.c:285-353, decode_tag() x3.c:58-129, decode_match() x3.c:272-283,
  * arithmetic decoder ac.c:128-198, bit reader bio.c:30-42,74-103).
  *
- * Unlike the encoder, the decoder cannot run ahead of its models: which table is consulted next depends on the symbol
- * just decoded, so the path is one dependent chain per stream.  Mapping: one wavefront per stream; the chain's state
- * (interval, bit reader, contexts) is wave-uniform, and every linear table walk of the reference is a 64-lane sweep:
- *   index_of_value (ac.c:167-179)        -> inclusive wave scan of 64 frequencies + ballot for the first cum > value
- *   dict_get_index_by_tag (dict.c:174-183) -> ballot search of the move-to-front list
- *   dict_query_elem (dict.c:148-157)     -> exact hash lookup; an element is a (pos,len) reference into the OUTPUT
- *   dict_update_costs + qsort            -> move-to-front (dec_mtf_to_front)
- * The chain is latency-bound (a dozen dependent global loads per step in the naive order), so the loop PREFETCHES the next step's
- * context state as soon as it is known: the pair looked up / inserted at the end of a hit step (x3.c:213-222) IS the (prev, context1)
- * pair the next step would look up, so its ordinal is carried over instead of looked up again -- and it needs no hash map at all: a
- * pair (context1, tag) exists exactly when `tag` is in the item list of context1 (x3.c:197-222 add both in the same step), so every
- * item of a context1 list carries the ordinal of its pair.  Both context headers plus the first 64 items of either list are loaded at
- * the end of a step: they are in flight while the next event symbol is decoded.
- * Streams of a batch decode concurrently (grid = streams).  The reference's unchecked 64x output buffer (x3.c:621) is
- * replaced by a capacity check (X3_ST_OUT_FULL), malformed input ends in X3_ST_CORRUPT instead of abort() (ac.c:178).
+ * Unlike the encoder, the decoder cannot run ahead of its models: which table is consulted next depends on the symbol just decoded, so
+ * a stream is one dependent chain, and a lone wavefront pays ~5 cycles for every instruction it issues.  The decoder is therefore split
+ * the way the encoder is (K2 / K3):
+ *
+ *   stage 1, the CHAIN (x3_decode_kernel, one wavefront per stream): events, tags and the models -- nothing else.  It writes ONE TAG PER
+ *     PARSE STEP (a new fragment is the tag of the dictionary element it becomes, or repeats: x3.c:306-326) and the bytes of every new
+ *     element (`lit`, in order of creation).  It never reads or writes the output, keeps no output position and no element lengths.
+ *   stage 2 (x3_dec_lens / x3_dec_scan / x3_dec_copy, the whole chip): element lengths of the tags -> output positions by prefix sum ->
+ *     the bytes, copied from `lit`.  x3.c:332-340.
+ *
+ * The chain's state is wave-uniform and lives in scalar registers; every linear table walk of the reference is a 64-lane sweep:
+ *   index_of_value (ac.c:167-179)          -> inclusive wave scan of 64 frequencies, one multiply-compare per lane, first lane below
+ *   dict_get_index_by_tag (dict.c:174-183) -> compare of the 64 most recent tags, held in a register
+ *   dict_update_costs + qsort              -> move-to-front: one DPP shift of that register
+ *
+ * Context lists (context.c) are BLOCKS of a pool, header first: entry 0 = {total, items}, entry 1 + i = item i = {freq, tag}.  One load of 64
+ * entries brings the header and the first 63 items into the lanes, where they stay while the list is a current context; an update is a
+ * store of the changed entries from the lanes that hold them (header and item in ONE store instruction), never a read-modify-write.
+ * Items are in insertion order (ctx_sort is a no-op, context.c:75-86), so the frequent tags of a long list are among the first 63.
+ * A context1 list (x3.c:100-107; one per tag) has 16-byte entries: its item for `tag` also carries the pool offset of the context0 list of
+ * the pair (list's tag, tag) -- a pair exists exactly when its tag is in that list (x3.c:197-222 add both in one step), so there is no
+ * pair map, no table of context0 headers and no pair ordinal: the context0 list of the next step is named by the context1 item this
+ * step touches anyway.  Lists grow by doubling; a context0 block that moved leaves a forwarding entry behind, and whoever follows it
+ * patches the item that sent it there.
+ *
+ * Streams of a batch decode concurrently (grid = streams).  The reference's unchecked 64x output buffer (x3.c:621) is replaced by a
+ * capacity check (X3_ST_OUT_FULL), malformed input ends in X3_ST_CORRUPT instead of abort() (ac.c:178).
  */
 #include "x3_kernels.h"
 
-struct CtxQ { uint32_t found, pos, freq, cum; }; /* where a tag sits in a context's item list */
-
-/* experiment builds (tools/exp/dec_prof.py): -DX3_DEC_PROFILE=1 cycles per section of a hit step, =2 the context section in four parts,
- * =3 cycles spent in s_waitcnt vmcnt(0) at three points of the step; reported in the unused event slots of the result */
-#if defined(X3_DEC_PROFILE)
-#define DPROF_T(var) const uint64_t var = x3_clock();
-#else
-#define DPROF_T(var)
-#endif
-#if defined(X3_DEC_PROFILE) && X3_DEC_PROFILE == 1
-#define DPROF1_ADD(acc, a, b) acc += (b) - (a);
-#else
-#define DPROF1_ADD(acc, a, b)
-#endif
-#if defined(X3_DEC_PROFILE) && X3_DEC_PROFILE == 2
-#define DPROF2_T(var) const uint64_t var = x3_clock();
-#define DPROF2_ADD(acc, a, b) acc += (b) - (a);
-#else
-#define DPROF2_T(var)
-#define DPROF2_ADD(acc, a, b)
-#endif
-#if defined(X3_DEC_PROFILE) && X3_DEC_PROFILE == 3
-#define DPROF3_WAIT(acc) { const uint64_t w0_ = x3_clock(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); acc += x3_clock() - w0_; }
-#else
-#define DPROF3_WAIT(acc)
-#endif
-
-/* A lone wave pays for every taken branch with an instruction-fetch bubble, and this loop is ~80 branches per step: the likely side of each
- * is marked so that the hot path is laid out as fall-through code. */
+/* A lone wave pays for every taken branch with an instruction-fetch bubble: the likely side of each is marked so that the hot path is
+ * laid out as fall-through code. */
 #define X3_LIKELY(x)   __builtin_expect(!!(x), 1)
 #define X3_UNLIKELY(x) __builtin_expect(!!(x), 0)
 
-/* The chain's state is wave-uniform, but every value that comes out of a (vector) load looks divergent to the compiler: pinning the
- * loaded words with readfirstlane keeps the interval arithmetic, the bit reader and the control flow on the scalar unit. */
-__device__ static __forceinline__ uint64_t uni64(uint64_t v) { return ((uint64_t)x3_uniform((uint32_t)(v >> 32)) << 32) | x3_uniform((uint32_t)v); }
-__device__ static __forceinline__ X3CtxHdr uni_hdr(const X3CtxHdr h) { X3CtxHdr r; r.off = x3_uniform(h.off); r.items = x3_uniform(h.items); r.cap = x3_uniform(h.cap); r.total = x3_uniform(h.total); return r; }
+#define X3D_NONE 0xFFFFFFFFu /* "no position" / "no block"; in the `items` word of a context0 header: the block moved, `total` says where to */
+
+/* return codes of the chain's loop */
+#define X3D_EOF     0u
+#define X3D_MIGRATE 1u /* the LDS tables are full: continue on the tables in global memory */
+#define X3D_FAIL    2u /* + status */
 
 #ifndef X3_EMU
+/* first set bit of a lane mask, X3D_NONE for an empty one (s_ff1_i32_b64 returns -1 for zero: no test needed) */
+__device__ static __forceinline__ uint32_t dec_first(uint64_t m) { return (uint32_t)(__ffsll((long long)m) - 1); }
 __device__ static __forceinline__ uint32_t dec_brev32(uint32_t v) { return __brev(v); }
+/* v of the lane below; lane 0 gets `fill` (wave_shr:1 without bound_ctrl keeps the old value where there is no source lane) */
+__device__ static __forceinline__ uint32_t dec_shr1_fill(uint32_t v, uint32_t fill) { return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false); }
 #else
+static inline uint32_t dec_first(uint64_t m) { return m ? (uint32_t)__builtin_ctzll(m) : 0xFFFFFFFFu; }
 static inline uint32_t dec_brev32(uint32_t v) { uint32_t r = 0; for (int i = 0; i < 32; i++) r |= ((v >> i) & 1u) << (31 - i); return r; }
+static inline uint32_t dec_shr1_fill(uint32_t v, uint32_t fill) { const int l = (int)x3_lane(); const uint32_t u = x3emu_shfl(v, l ? l - 1 : 0); return l ? u : fill; }
 #endif
 
+/* Scalars of the chain that only its rare paths touch live in LDS (s_cold[]), not in registers: the step's state is ~100 scalars, and what the compiler
+ * spills when they do not fit is not ours to choose (it took the token pointer).  Read with dec_cold(), written by lane 0. */
+enum { DC_IN_LO, DC_IN_HI, DC_NWORDS, DC_LITPOS, DC_O00, DC_OFIRST, DC_E3, DC_E4, DC_COUNT, DC_MODELS = DC_COUNT + 2 * X3_WAVE /* behind the two stream blocks */ };
+#ifndef X3_EMU
+__device__ static __forceinline__ uint32_t dec_cold(const uint32_t *s_cold, int i) { return x3_uniform(s_cold[i]); }
+#else
+static inline uint32_t dec_cold(const uint32_t *s_cold, int i) { return x3_bcast_u32(s_cold[i], 0); } /* (a rendezvous: the emulator's lanes run one after the other between those, and lane 0 may be about to overwrite the word) */
+#endif
+__device__ static __forceinline__ void dec_cold_set(uint32_t *s_cold, int i, uint32_t v) { if (x3_lane() == 0) s_cold[i] = v; x3_wave_order(); }
+/* a real s_waitcnt vmcnt(0) (the compiler accounts for it, unlike one in an asm statement): behind a load on a rare path whose result is used much later -- left
+ * pending, it would make the compiler wait for ALL loads at the next use or reuse of that register on the hot path, the prefetched context blocks included */
+__device__ static __forceinline__ void dec_wait_loads()
+{
+#ifndef X3_EMU
+	__builtin_amdgcn_s_waitcnt(0x0F70); /* gfx9 encoding: vmcnt = 0, expcnt = 7, lgkmcnt = 15 (no wait) */
+#endif
+}
+
 struct BitReader { /* bio.c:5-42: bit k of the stream = bit k mod 32 (LSB first) of the little-endian word k / 32 */
-	const uint32_t *base; /* the stream's words; whole words only, like the reference's reader (bio.c:35-39) */
-	uint32_t nwords, wi;  /* ... how many, and the index of the next one to take */
-	uint32_t cur, nxt;    /* lane l: word (block * 64 + l) of the block being consumed and of the one after it -- the stream is read 256 bytes at a
-	                       * time, one block ahead, so taking the next word is a v_readlane and no load ever sits on the chain */
-	uint64_t w;           /* unread bits, next one at bit 0 */
+	uint32_t wi;          /* index of the next word to take (the stream's address and its number of whole words: s_cold[DC_IN_LO, DC_IN_HI, DC_NWORDS]).  The words
+	                       * come through LDS (s_in[128]: the 64-word block being consumed and the one after it, fetched one block ahead), so taking a word is an LDS read
+	                       * and no global load ever sits on the chain */
+	uint64_t w;           /* unread bits, first one at bit 63 */
 	uint32_t nb;          /* how many */
 };
 
-__device__ static __forceinline__ uint32_t br_block(const BitReader &r, uint32_t blk)
+/* words [64 blk, 64 blk + 64) of the stream -> their half of s_in */
+__device__ static __forceinline__ void br_block(uint32_t *s_cold, uint32_t blk)
 {
+	const uint32_t *base = (const uint32_t *)(((uint64_t)dec_cold(s_cold, DC_IN_HI) << 32) | dec_cold(s_cold, DC_IN_LO)); /* whole words only, like the reference's reader (bio.c:35-39) */
 	const uint32_t i = blk * X3_WAVE + x3_lane();
-	return i < r.nwords ? r.base[i] : 0x80000000u; /* bio.c:10,35-39: past the last whole word the reader feeds 0x80000000 */
+	const uint32_t v = i < dec_cold(s_cold, DC_NWORDS) ? base[i] : 0x80000000u; /* bio.c:10,35-39: past the last whole word the reader feeds 0x80000000 */
+	(s_cold + DC_COUNT)[(blk & 1u) * X3_WAVE + x3_lane()] = v;
+	dec_wait_loads();
+	x3_wave_order();
 }
-__device__ static __forceinline__ void br_open(BitReader &r, const uint8_t *in, uint32_t len)
+__device__ static __forceinline__ void br_open(BitReader &r, uint32_t *s_cold, const uint8_t *in, uint32_t len)
 {
-	r.base = (const uint32_t *)in; r.nwords = len >> 2; r.wi = 0; r.w = 0; r.nb = 0; /* bio_open(READ), bio.c:14-15 */
-	r.cur = br_block(r, 0); r.nxt = br_block(r, 1);
+	dec_cold_set(s_cold, DC_IN_LO, (uint32_t)(uintptr_t)in); dec_cold_set(s_cold, DC_IN_HI, (uint32_t)((uint64_t)(uintptr_t)in >> 32)); dec_cold_set(s_cold, DC_NWORDS, len >> 2);
+	r.wi = 0; r.w = 0; r.nb = 0; /* bio_open(READ), bio.c:14-15 */
+	br_block(s_cold, 0); br_block(s_cold, 1);
 }
 
-/* the next n (0..31) bits of the stream, first one most significant -- what n calls of get_bit shifted into mBuffer would leave */
-__device__ static __forceinline__ uint32_t br_take(BitReader &r, uint32_t n)
+/* makes sure the window holds n (0..31) unread bits */
+__device__ static __forceinline__ void br_need(BitReader &r, uint32_t *s_cold, uint32_t n)
 {
-	if (X3_UNLIKELY(r.nb < n)) { /* one more word */
-		const uint32_t nx = x3_readlane_u32(r.cur, r.wi & (X3_WAVE - 1));
+	if (X3_UNLIKELY(r.nb < n)) { /* one more word, turned round once so that taking bits is a shift */
+		const uint32_t nx = dec_brev32(dec_cold(s_cold, DC_COUNT + (r.wi & (2 * X3_WAVE - 1))));
 		r.wi++;
-		if (X3_UNLIKELY((r.wi & (X3_WAVE - 1)) == 0)) { r.cur = r.nxt; r.nxt = br_block(r, (r.wi >> 6) + 1); }
-		r.w |= (uint64_t)nx << r.nb;
+		if (X3_UNLIKELY((r.wi & (X3_WAVE - 1)) == 0)) br_block(s_cold, (r.wi >> 6) + 1); /* the block just finished is replaced by the one after the next */
+		r.w |= (uint64_t)nx << (32 - r.nb); /* nb < n <= 31 */
 		r.nb += 32;
 	}
-	if (X3_UNLIKELY(!n)) return 0;
-	const uint32_t field = (uint32_t)r.w & (0xFFFFFFFFu >> (32 - n));
-	r.w >>= n;
+}
+/* the next n (0..31) bits of the stream, first one most significant -- what n calls of get_bit shifted into mBuffer would leave */
+__device__ static __forceinline__ uint32_t br_take(BitReader &r, uint32_t *s_cold, uint32_t n)
+{
+	br_need(r, s_cold, n);
+	const uint32_t field = (uint32_t)((r.w >> 1) >> (63 - n)); /* n == 0: nothing */
+	r.w <<= n;
 	r.nb -= n;
-	return dec_brev32(field) >> (32 - n);
+	return field;
 }
 
-struct Dec { uint32_t lo, hi, buf; };
+/* The interval as (low, range, buffer - low): the decoder never needs mHigh or mBuffer themselves. */
+struct Dec { uint32_t lo, rng, off; };
 
 /* range / total (ac.c:128-131) on the chain: a double-precision reciprocal and one fix-up step instead of the ~28-instruction integer
  * expansion of a 32-bit division (n <= 2^31, 0 < t < 2^28: the quotient estimate is off by at most one, and q * t cannot overflow) */
@@ -115,209 +136,164 @@ __device__ static __forceinline__ uint32_t dec_div(uint32_t n, uint32_t t)
 	q += rem < 0 ? 0xFFFFFFFFu : (uint32_t)rem >= t ? 1u : 0u;
 	return x3_uniform(q);
 #else
-	return n / t;
+	return t ? n / t : 0xFFFFFFFFu;
 #endif
 }
 
 /* ac_decode_symbol's interval update + ac_decode_scale (ac.c:192-195,142-165) in closed form, like the encoder's chain (code2.hip):
- * all E1/E2/E3 shifts together are  s = clz(D) - 1 - carry  with D = hi - lo after narrowing; lo and the range scale by 2^s, and since
- * every kind of shift removes the same offset from mBuffer as from mLow,  buffer - low  scales too and takes the s new bits.
- * false: not an interval a valid stream can produce (the reference would spin in its E1/E2 loop or read garbage). */
-__device__ static __forceinline__ bool dec_narrow(Dec &d, BitReader &r, uint32_t step, uint32_t cum_lo, uint32_t cum_hi)
+ * the symbol's slice is [lo + cs, lo + cs + rs) with cs = step * cum, rs = step * freq.  All E1/E2/E3 shifts together are
+ * s = clz(D) - 1 - carry with D = rs - 1; low and range scale by 2^s, and since every kind of shift removes the same offset from mBuffer as
+ * from mLow, buffer - low scales too and takes the s new bits: (buffer - low) and the unread bits behind it are shifted as ONE 64-bit value.
+ * No validity test: after a shift the range is >= 2^29 and every total is < 2^28 (one count per parse step or byte, X3H_MAX_CHUNK = 2^27), so
+ * step >= 2, D >= 1; the symbol was chosen as the first with off < step * cum_incl, so cs <= off < cs + rs -- whatever the stream holds. */
+__device__ static __forceinline__ void ac_narrow(Dec &d, BitReader &r, uint32_t *s_cold, uint32_t cs, uint32_t rs)
 {
-	const uint32_t nlo = d.lo + step * cum_lo, nhi = d.lo + step * cum_hi - 1, D = nhi - nlo;
-	if (X3_UNLIKELY(D == 0 || ((nlo | nhi) >> 31) || nhi < nlo || d.buf < nlo || d.buf > nhi)) return false;
-	const uint32_t cz = (uint32_t)x3_clz32(D), t = 31u - cz;
+	const uint32_t nlo = d.lo + cs, D = rs - 1, nhi = nlo + D;
+#ifndef X3_EMU
+	const uint32_t cz = (uint32_t)__builtin_clz(D);
+#else
+	const uint32_t cz = (uint32_t)x3_clz32(D);
+#endif
+	const uint32_t t = 31u - cz;
 	const uint32_t sh = cz - 1 - ((((nlo ^ nhi) >> t) & 1u) ^ 1u);
-	const uint32_t lo = (nlo << sh) & 0x3FFFFFFFu;
-	d.buf = lo + ((d.buf - nlo) << sh) + br_take(r, sh);
-	d.hi = lo + ((D + 1) << sh) - 1;
-	d.lo = lo;
-	return true;
+	br_need(r, s_cold, sh);
+	d.lo = (nlo << sh) & 0x3FFFFFFFu;
+	d.rng = rs << sh;
+	d.off = (uint32_t)(((((uint64_t)(d.off - cs)) << 32 | (r.w >> 32)) << sh) >> 32); /* (off - cs) << sh fits: it is below the new range */
+	r.w <<= sh;
+	r.nb -= sh;
 }
 
-__device__ static __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) { (void)lane; return x3_wave_incl_scan_u32(v); }
-/* value < incl  with  value = off / step (ac.c:128-131), without dividing:  off < incl * step  (step == 0: never, like a value out of range) */
-__device__ static __forceinline__ bool dec_below(uint32_t off, uint32_t step, uint32_t incl) { return (uint64_t)off < (uint64_t)incl * step; }
-
-/* find the symbol of a frequency array (global memory, `count` entries) that holds `value`; returns 0xFFFFFFFF if none */
-__device__ static __forceinline__ uint32_t find_in_array(const uint32_t *freq, uint32_t count, uint32_t off, uint32_t step, uint32_t lane, uint32_t &cum_out, uint32_t &fq_out)
+/* ---- context blocks ------------------------------------------------------------------------------------------------------------
+ * Pool offsets count 8-byte units.  STR = units per entry: 1 for a context0 block, 2 for a context1 block (16-byte entries, the third
+ * word of an item = pool offset of the context0 block of the pair).  Entry 0 is the header {total, items}, entry e >= 1 is item e - 1
+ * {freq, tag}: "where a tag is" is its entry number (lane e holds entry e for e < 64), X3D_NONE if it is not in the list.
+ * Capacities double from 2, so a list of n items is full when n is a power of two >= 2 -- no capacity field. */
+template <int STR> __device__ static __forceinline__ uint32_t *blk_entry(uint64_t *pool, uint32_t o, uint32_t e) { return (uint32_t *)(pool + (uint64_t)o + (uint64_t)e * STR); }
+__device__ static __forceinline__ void blk_load0(uint64_t *pool, uint32_t o, uint32_t lane, uint32_t &f, uint32_t &t)
 {
-	uint32_t carry = 0;
-	for (uint32_t base = 0; base < count; base += X3_WAVE) {
-		const uint32_t i = base + lane;
-		const uint32_t fq = i < count ? freq[i] : 0;
-		const uint32_t incl = wave_incl_scan(fq, lane) + carry;
-		const uint64_t mask = x3_ballot(i < count && dec_below(off, step, incl));
-		if (mask) {
-			const uint32_t l = (uint32_t)x3_ctz64(mask);
-			fq_out = x3_readlane_u32(fq, l);
-			cum_out = x3_readlane_u32(incl, l) - fq_out;
+	const uint64_t e = (pool + o)[lane];
+	f = (uint32_t)e; t = (uint32_t)(e >> 32);
+}
+__device__ static __forceinline__ void blk_load1(uint64_t *pool, uint32_t o, uint32_t lane, uint32_t &f, uint32_t &t, uint32_t &c)
+{
+	const uint32_t *e = (const uint32_t *)(pool + o) + 4 * lane; /* three of the entry's four words (a fourth register would only be a destination to wait for) */
+	const uint64_t ft = *(const uint64_t *)e;
+	f = (uint32_t)ft; t = (uint32_t)(ft >> 32); c = e[2];
+}
+/* lanes 1 .. min(n, 63): the lanes that hold items */
+__device__ static __forceinline__ uint64_t blk_lanes(uint32_t n, uint32_t lane) { return x3_ballot(lane <= n) & ~(uint64_t)1; }
+
+/* The blocks of the NEXT step's contexts are requested at the end of a step and used after the next event has been decoded: two loads that must stay in
+ * flight across the loop's back edge.  Left to the compiler, the registers they write become loop-carried values with several definitions, and it copies them
+ * around right behind the loads -- every such copy is a full wait for the data (measured: 40 % of the step).  So the two loads and the point where their
+ * data is taken over are written out: fixed registers far above anything the kernel allocates (the clobber lists keep them out of the compiler's hands
+ * across each statement, tests/test_build.py checks that nothing else in the kernel names them), one s_waitcnt where the data is first needed.
+ * dec_request: entries [0, 64) of the context1 block at o1 and of the context0 block at o0;  dec_take: wait for them and hand them to the compiler.
+ * The emulator has no latency to hide: it loads at the request, like the hardware, into a struct. */
+struct DecPend { uint32_t f0, t0, f1, t1, c1; };
+#ifndef X3_EMU
+__device__ static __forceinline__ void dec_request(uint64_t *pool, uint32_t o1, uint32_t o0, uint32_t lane, DecPend &)
+{
+	const uint64_t *p0 = pool + o0, *p1 = pool + o1;
+	asm volatile("global_load_dwordx3 v[232:234], %0, %1\n\tglobal_load_dwordx2 v[230:231], %2, %3"
+	             :: "v"(lane * 16u), "s"(p1), "v"(lane * 8u), "s"(p0) : "v230", "v231", "v232", "v233", "v234", "memory");
+}
+__device__ static __forceinline__ void dec_take(const DecPend &, uint32_t &b0f, uint32_t &b0t, uint32_t &b1f, uint32_t &b1t, uint32_t &b1c)
+{
+	asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, v230\n\tv_mov_b32 %1, v231\n\tv_mov_b32 %2, v232\n\tv_mov_b32 %3, v233\n\tv_mov_b32 %4, v234"
+	             : "=v"(b0f), "=v"(b0t), "=v"(b1f), "=v"(b1t), "=v"(b1c) :: "memory");
+}
+#else
+static inline void dec_request(uint64_t *pool, uint32_t o1, uint32_t o0, uint32_t lane, DecPend &p) { blk_load1(pool, o1, lane, p.f1, p.t1, p.c1); blk_load0(pool, o0, lane, p.f0, p.t0); }
+static inline void dec_take(const DecPend &p, uint32_t &b0f, uint32_t &b0t, uint32_t &b1f, uint32_t &b1t, uint32_t &b1c) { b0f = p.f0; b0t = p.t0; b1f = p.f1; b1t = p.t1; b1c = p.c1; }
+#endif
+
+/* entry of `tag` among entries [64, n] (ctx_query_tag_item, context.c:20-40, for the part of a long list that is not in the lanes) */
+template <int STR>
+__device__ static uint32_t blk_find_far(uint64_t *pool, uint32_t o, uint32_t n, uint32_t tag, uint32_t lane)
+{
+	for (uint32_t base = X3_WAVE; base <= n; base += X3_WAVE) {
+		const uint32_t e = base + lane;
+		const uint32_t tg = e <= n ? blk_entry<STR>(pool, o, e)[1] : 0;
+		const uint64_t m = x3_ballot(e <= n && tg == tag);
+		if (m) return base + (uint32_t)x3_ctz64(m);
+	}
+	return X3D_NONE;
+}
+/* index_of_value over entries [64, n]; carry = sum of the frequencies before them */
+template <int STR>
+__device__ static uint32_t blk_decode_far(uint64_t *pool, uint32_t o, uint32_t n, uint32_t off, uint32_t step, uint32_t carry, uint32_t lane, uint32_t &cum, uint32_t &fq, uint32_t &tag)
+{
+	for (uint32_t base = X3_WAVE; base <= n; base += X3_WAVE) {
+		const uint32_t e = base + lane;
+		const uint32_t *p = blk_entry<STR>(pool, o, e <= n ? e : 1);
+		const uint32_t f = e <= n ? p[0] : 0, tg = p[1];
+		const uint32_t incl = x3_wave_incl_scan_u32(f) + carry;
+		const uint64_t m = x3_ballot(e <= n && off < incl * step);
+		if (m) {
+			const uint32_t l = (uint32_t)x3_ctz64(m);
+			fq = x3_readlane_u32(f, l); cum = x3_readlane_u32(incl, l) - fq; tag = x3_readlane_u32(tg, l);
 			return base + l;
 		}
 		carry = x3_readlane_u32(incl, X3_WAVE - 1);
 	}
-	return 0xFFFFFFFFu;
+	return X3D_NONE;
 }
-
-/* ... with entries [0, 64) already in registers (`first`: lane l holds freq[l]) */
-__device__ static __forceinline__ uint32_t find_in_array_pre(const uint32_t *freq, uint32_t first, uint32_t count, uint32_t off, uint32_t step, uint32_t lane, uint32_t &cum_out, uint32_t &fq_out)
-{
-	uint32_t carry;
-	{
-		const uint32_t fq = lane < count ? first : 0;
-		const uint32_t incl = wave_incl_scan(fq, lane);
-		const uint64_t mask = x3_ballot(lane < count && dec_below(off, step, incl));
-		if (X3_LIKELY(mask != 0)) {
-			const uint32_t l = (uint32_t)x3_ctz64(mask);
-			fq_out = x3_readlane_u32(fq, l);
-			cum_out = x3_readlane_u32(incl, l) - fq_out;
-			return l;
-		}
-		carry = x3_readlane_u32(incl, X3_WAVE - 1);
-	}
-	for (uint32_t base = X3_WAVE; base < count; base += X3_WAVE) {
-		const uint32_t i = base + lane;
-		const uint32_t fq = i < count ? freq[i] : 0;
-		const uint32_t incl = wave_incl_scan(fq, lane) + carry;
-		const uint64_t mask = x3_ballot(i < count && dec_below(off, step, incl));
-		if (mask) {
-			const uint32_t l = (uint32_t)x3_ctz64(mask);
-			fq_out = x3_readlane_u32(fq, l);
-			cum_out = x3_readlane_u32(incl, l) - fq_out;
-			return base + l;
-		}
-		carry = x3_readlane_u32(incl, X3_WAVE - 1);
-	}
-	return 0xFFFFFFFFu;
-}
-
-/* same over a context's item list; returns the list position */
-__device__ static uint32_t find_in_ctx(const X3CtxHdr h, const uint64_t *pool, uint32_t off, uint32_t step, uint32_t lane, uint64_t first, uint32_t &cum_out, uint32_t &fq_out, uint32_t &tag_out)
-{
-	uint32_t carry = 0;
-	if (X3_LIKELY(h.items <= X3_WAVE)) { /* the usual case as straight-line code: no load, so nothing here makes the wave wait for loads that are in flight */
-		const uint32_t fq = (uint32_t)first; /* lanes beyond the list hold 0 */
-		const uint32_t incl = wave_incl_scan(fq, lane);
-		const uint64_t mask = x3_ballot(lane < h.items && dec_below(off, step, incl));
-		if (X3_UNLIKELY(!mask)) return 0xFFFFFFFFu;
-		const uint32_t l = (uint32_t)x3_ctz64(mask);
-		fq_out = x3_readlane_u32(fq, l);
-		cum_out = x3_readlane_u32(incl, l) - fq_out;
-		tag_out = x3_readlane_u32((uint32_t)(first >> 32), l);
-		return l;
-	}
-	for (uint32_t base = 0; base < h.items; base += X3_WAVE) {
-		const uint32_t i = base + lane;
-		const uint64_t it = base == 0 ? first : (i < h.items ? pool[(uint64_t)h.off + i] : 0); /* items [0, 64) were prefetched with the header */
-		const uint32_t fq = (uint32_t)it;
-		const uint32_t incl = wave_incl_scan(fq, lane) + carry;
-		const uint64_t mask = x3_ballot(i < h.items && dec_below(off, step, incl));
-		if (mask) {
-			const uint32_t l = (uint32_t)x3_ctz64(mask);
-			fq_out = x3_readlane_u32(fq, l);
-			cum_out = x3_readlane_u32(incl, l) - fq_out;
-			tag_out = x3_readlane_u32((uint32_t)(it >> 32), l);
-			return base + l;
-		}
-		carry = x3_readlane_u32(incl, X3_WAVE - 1);
-	}
-	return 0xFFFFFFFFu;
-}
-
-/* position of `tag` in a context's item list (ctx_query_tag_item, context.c:20-40): all the model update needs -- no frequency sums */
-__device__ static CtxQ ctx_find_tag(const X3CtxHdr h, const uint64_t *pool, uint32_t tag, uint32_t lane, uint64_t first)
-{
-	CtxQ q;
-	q.found = 0; q.pos = 0; q.freq = 0; q.cum = 0;
-	if (X3_LIKELY(h.items <= X3_WAVE)) { /* straight-line, no load (see find_in_ctx) */
-		const uint64_t mask = x3_ballot(lane < h.items && (uint32_t)(first >> 32) == tag);
-		if (mask) { q.found = 1; q.pos = (uint32_t)x3_ctz64(mask); }
-		return q;
-	}
-	for (uint32_t base = 0; base < h.items; base += X3_WAVE) {
-		const uint32_t i = base + lane;
-		const uint64_t it = base == 0 ? first : (i < h.items ? pool[(uint64_t)h.off + i] : 0);
-		const uint64_t mask = x3_ballot(i < h.items && (uint32_t)(it >> 32) == tag);
-		if (mask) { q.found = 1; q.pos = base + (uint32_t)x3_ctz64(mask); break; }
-	}
-	return q;
-}
-
-/* x3.c:197-209 (add the tag with frequency 1 or bump its frequency) for the decoder: the lanes already hold items [0, 64) of the list (`first`), so bumping a frequency is a
- * plain store from the lane that holds the item -- no read-modify-write round trip on the chain.  `first` (and `po`, the pair ordinals
- * of a context1 list: with_ord) come back as the list reads AFTER the update, so a list that is also the next step's context needs no
- * reload; the caller stores the updated header `h` wherever headers of that kind live. */
-__device__ static __forceinline__ void dec_ctx_touch(X3CtxHdr &h, const CtxQ q, uint32_t tag, uint64_t &first, uint32_t &po, bool with_ord, uint32_t ord,
-                                                     uint64_t *pool, uint32_t *pord, uint32_t &pool_top, uint32_t pool_cap, uint32_t &status, uint32_t lane)
-{
-	if (q.found) {
-		if (X3_LIKELY(q.pos < X3_WAVE)) { if (lane == q.pos) { first += 1; pool[(uint64_t)h.off + q.pos] = first; } }
-		else if (lane == 0) pool[(uint64_t)h.off + q.pos] += 1;
-	} else {
-		if (X3_UNLIKELY(h.items == h.cap)) {
-			const uint32_t ncap = h.cap ? 2 * h.cap : 2;
-			if ((uint64_t)pool_top + ncap > pool_cap) { status = X3_ST_POOL_FULL; return; }
-			const uint32_t noff = pool_top;
-			pool_top += ncap;
-			for (uint32_t i = lane; i < h.items; i += X3_WAVE) {
-				pool[(uint64_t)noff + i] = pool[(uint64_t)h.off + i];
-				if (with_ord) pord[(uint64_t)noff + i] = pord[(uint64_t)h.off + i];
-			}
-			h.off = noff;
-			h.cap = ncap;
-		}
-		const uint64_t it = ((uint64_t)tag << 32) | 1u;
-		if (lane == 0) { pool[(uint64_t)h.off + h.items] = it; if (with_ord) pord[(uint64_t)h.off + h.items] = ord; }
-		if (lane == h.items) { first = it; po = ord; } /* items < 64: the lane of the new list position */
-		h.items++;
-	}
-	h.total++;
-}
-/* list capacities only ever double from 2 (above), so the LDS copy of a header does not store one */
-__device__ static __forceinline__ uint32_t dec_cap_of(uint32_t n) { return n == 0 ? 0u : n <= 2 ? 2u : 1u << (32 - x3_clz32(n - 1)); }
 
 #ifndef X3_DEC_LDS
-#define X3_DEC_LDS 4096u /* dictionary elements whose tables live in LDS, 20 bytes each: recency list, index-model frequency, (position, length), header of the element's context1 list */
+#define X3_DEC_LDS 8192u /* dictionary elements whose tables live in LDS, 10 bytes each: recency list, index-model frequency, offset of the element's context1 block */
 #endif
 #ifndef X3_DEC_LDS_MID
-#define X3_DEC_LDS_MID 2048u /* ... in batches of up to 1024 streams: 40 KiB per stream, four streams (one per SIMD) share a CU */
+#define X3_DEC_LDS_MID 4096u /* ... in batches of up to 1024 streams: 40 KiB per stream, four streams (one per SIMD) share a CU */
 #endif
 #ifndef X3_DEC_LDS_SMALL
-#define X3_DEC_LDS_SMALL 512u /* ... in batches of many streams: 10 KiB of LDS per stream, so sixteen streams share a CU (the batch rate is streams in flight x the per-stream rate) */
+#define X3_DEC_LDS_SMALL 1024u /* ... in batches of many streams: 10 KiB of LDS per stream, so sixteen streams share a CU (the batch rate is streams in flight x the per-stream rate) */
 #endif
 
-/* The move-to-front list (dict.c:132-146), typed by where it lives: uint16_t in LDS, uint32_t in global memory.  Separate instantiations
- * on purpose: through one generic pointer every access is a FLAT instruction, and each of those waits for all outstanding global stores. */
+/* The move-to-front list (dict.c:132-146) beyond its first 64 ranks, typed by where it lives: uint16_t in LDS, uint32_t in global memory.
+ * Separate instantiations on purpose: through one generic pointer every access is a FLAT instruction, and each of those waits for all
+ * outstanding global stores. */
 template <typename T>
 __device__ static __forceinline__ void dec_mtf_to_front(T *mtf, uint32_t r, uint32_t tag, uint32_t lane)
 {
-	if (X3_LIKELY(r < X3_WAVE)) { /* recent elements are the usual ones: one read and one write, straight-line */
-		const bool act = lane >= 1 && lane <= r;
-		const T v = act ? mtf[lane - 1] : (T)tag;
-		x3_wave_order(); /* every lane has read before any lane overwrites its neighbour's source */
-		if (lane <= r) mtf[lane] = v;
-		return;
-	}
 	for (int base = (int)(r & ~(uint32_t)(X3_WAVE - 1)); base >= 0; base -= X3_WAVE) {
 		const uint32_t j = (uint32_t)base + lane;
 		const bool act = j >= 1 && j <= r;
 		const T v = act ? mtf[j - 1] : (T)0;
-		x3_wave_order();
+		x3_wave_order(); /* every lane has read before any lane overwrites its neighbour's source */
 		if (act) mtf[j] = v;
 	}
 	if (lane == 0) mtf[0] = (T)tag;
+	x3_wave_order();
 }
-/* dict_get_index_by_tag (dict.c:174-183): rank of `tag`, 0xFFFFFFFF if it is not in the list */
+/* dict_get_index_by_tag (dict.c:174-183) from rank 64 on: rank of `tag`, X3D_NONE if it is not in the list */
 template <typename T>
-__device__ static __forceinline__ uint32_t dec_mtf_rank(const T *mtf, uint32_t D, uint32_t tag, uint32_t lane, uint32_t from = 0)
+__device__ static __forceinline__ uint32_t dec_mtf_rank_far(const T *mtf, uint32_t D, uint32_t tag, uint32_t lane)
 {
-	for (uint32_t base = from; base < D; base += X3_WAVE) {
+	for (uint32_t base = X3_WAVE; base < D; base += X3_WAVE) {
 		const uint32_t i = base + lane;
 		const uint64_t mask = x3_ballot(i < D && (uint32_t)mtf[i] == tag);
 		if (mask) return base + (uint32_t)x3_ctz64(mask);
 	}
-	return 0xFFFFFFFFu;
+	return X3D_NONE;
+}
+/* index_of_value over the index model from rank 64 on */
+__device__ static __forceinline__ uint32_t dec_idx_far(const uint32_t *freq, uint32_t count, uint32_t off, uint32_t step, uint32_t carry, uint32_t lane, uint32_t &cum, uint32_t &fq)
+{
+	for (uint32_t base = X3_WAVE; base < count; base += X3_WAVE) {
+		const uint32_t i = base + lane;
+		const uint32_t f = i < count ? freq[i] : 0;
+		const uint32_t incl = x3_wave_incl_scan_u32(f) + carry;
+		const uint64_t m = x3_ballot(i < count && off < incl * step);
+		if (m) {
+			const uint32_t l = (uint32_t)x3_ctz64(m);
+			fq = x3_readlane_u32(f, l); cum = x3_readlane_u32(incl, l) - fq;
+			return base + l;
+		}
+		carry = x3_readlane_u32(incl, X3_WAVE - 1);
+	}
+	return X3D_NONE;
 }
 
 #define DFNV_OFF 2166136261u
@@ -333,346 +309,540 @@ __device__ static __forceinline__ uint32_t dht_slot(uint32_t h, uint32_t len, ui
 
 /* per-stream tables in global memory + constants (wave-uniform) */
 struct DecT {
-	uint8_t *out;
 	uint32_t *dpos; uint8_t *dlen; uint32_t *ht; uint32_t hlog, hmask;
-	uint32_t *gmtf, *gidx;
-	X3CtxHdr *ctx1, *ctx0;
-	uint64_t *pool; uint32_t *pord; uint32_t pool_cap;
-	uint32_t cap;
+	uint32_t *gmtf, *gidx, *gc1;
+	uint64_t *pool; uint32_t pool_cap;
+	uint32_t *tok; uint8_t *lit;
+	uint32_t cap; /* output capacity = token capacity */
 };
 /* the chain's state, carried from the LDS-resident loop into the spilled one */
 struct DecS {
 	BitReader br; Dec d;
-	uint32_t evf, evtotal;            /* event model: the frequency of event `lane` lives in that lane (an array indexed by the decision would sit in scratch memory: a round trip per read on the chain) */
-	uint32_t lf;                      /* length model, one symbol per lane (its total is 32 + the fragments so far: the event model counts those) */
-	uint32_t cf0, cf1, cf2, cf3;      /* byte model, four symbols per lane (total = their sum, taken when a fragment starts) */
+	uint32_t e0, e1, e2, evtotal;     /* event model (x3.c:236-244), one scalar per hit event (new fragments, end of stream: s_cold[DC_E3, DC_E4]) */
+	/* the models of new fragments live in LDS, one word per lane each (s_cold + DC_MODELS): the length model, one symbol per lane (its total is 32 + the fragments
+	 * so far: the event model counts those), and the byte model, four symbols per lane (total = their sum, taken when a fragment starts) */
 	uint32_t D, npairs, status;       /* (the index model's total is D + the index events so far) */
-	uint32_t pool_top;
-	uint32_t ctx1tag, p;
-	/* the context state of the NEXT hit step, loaded ahead: ctx0 ordinal (0 when the pair is unknown, x3.c:142-145), both headers, items [0,64) of both lists, pair ordinals of the context1 items */
-	uint32_t n_c0id; X3CtxHdr n_h0, n_h1; uint64_t n_it0, n_it1; uint32_t n_po1;
-	uint32_t ord00;                   /* ordinal of the pair (0, 0), what both contexts are after a new fragment (x3.c:321-322); 0xFFFFFFFF while unknown */
-	uint64_t pc_ev, pc_sym, pc_ctx, pc_tail;
+	uint32_t pool_top, ntok;          /* (bytes of the elements so far: s_cold[DC_LITPOS]) */
+	uint32_t ctx1tag;
+	uint32_t o0, o1;                  /* the current contexts: pool offsets of their blocks */
+	uint32_t ref0;                    /* the context1 item (pool offset of its entry) that names the current context0 block; X3D_NONE: reached through o00 / ofirst */
+	/* s_cold[DC_O00]: context0 block of the pair (0, 0), what both contexts are after a new fragment (x3.c:321-322; X3D_NONE while that pair is unknown);
+	 * s_cold[DC_OFIRST]: the block of pair number 0, the default (x3.c:142-145) -- it exists, and learns tags, before the first pair does */
 };
 
-/* One instantiation per residence of the per-element tables: LDS = true while the dictionary has fewer than NLDS elements (recency
- * list, index-model frequencies, element (position, length) and the headers of the context1 lists are LDS arrays: the only global
- * round trip between decoding a tag and having the next step's context1 items is the item load itself), LDS = false after they
- * migrated to global memory.  Returns true when the LDS tables are full (the caller migrates them and continues with the other loop). */
-template <uint32_t NLDS, bool LDS>
-__device__ static __forceinline__ bool dec_loop(const DecT &t, DecS &s, uint16_t *s_mtf, uint32_t *s_idx, uint32_t *s_el, uint32_t *s_c1off, uint32_t *s_c1tot, uint16_t *s_c1n, const uint32_t lane)
+/* a context0 block moved to `noff`: the item that names it (and the lane that holds that item, if the list is the current context1) learns the new place */
+__device__ static __forceinline__ void dec_patch_ref(uint64_t *pool, uint32_t ref0, uint32_t noff, uint32_t o1, uint32_t &b1c, uint32_t lane)
 {
-	uint8_t *const out = t.out;
-	uint64_t *const pool = t.pool;
-	uint32_t *const pord = t.pord;
-	BitReader &br = s.br;
-	Dec &d = s.d;
-	for (;;) {
-		if (LDS && X3_UNLIKELY(s.D == NLDS)) return true;
-		/* ranks [0, 64) of the recency list and of the index model, read ahead of the event symbol: recent elements are the usual ones, and then
-		 * neither the rank search nor the move-to-front waits for an LDS read (lanes >= D hold nothing meaningful; the new-fragment path below
-		 * changes both tables and comes back here) */
-		uint32_t m0 = 0, i0 = 0;
-		if (LDS) { m0 = s_mtf[lane]; i0 = s_idx[lane]; }
-		DPROF_T(t_a)
-		/* ---- the event (x3.c:293-295) ---- */
-		/* ac_decode_target + index_of_value (ac.c:128-131,167-179) without the second division:  (buf-lo)/step < c  <=>  buf-lo < c*step */
-		uint32_t step = dec_div(d.hi - d.lo + 1, s.evtotal);
-		uint32_t decision;
-		{
-			const uint32_t incl = x3_row8_incl_scan_u32(s.evf);
-			const uint64_t mask = x3_ballot(lane < 5 && dec_below(d.buf - d.lo, step, incl));
-			if (X3_UNLIKELY(!mask)) { s.status = X3_ST_CORRUPT; break; } /* the reference abort()s, ac.c:178 */
-			decision = (uint32_t)x3_ctz64(mask);
-			const uint32_t fq = x3_readlane_u32(s.evf, decision), cum = x3_readlane_u32(incl, decision) - fq;
-			if (X3_UNLIKELY(!dec_narrow(d, br, step, cum, cum + fq))) { s.status = X3_ST_CORRUPT; break; }
-			if (lane == decision) s.evf++;
-			s.evtotal++;
-		}
-		if (X3_UNLIKELY(decision == X3_E_EOF)) break;
+	if (ref0 == X3D_NONE) return;
+	if (lane == 0) ((uint32_t *)(pool + ref0))[2] = noff;
+	const uint32_t rel = ref0 - o1; /* entry e of the current context1 block sits at o1 + 2 e */
+	b1c = (ref0 >= o1 && rel < 2 * X3_WAVE && !(rel & 1u) && lane == (rel >> 1)) ? noff : b1c;
+}
 
-		if (X3_UNLIKELY(decision == X3_E_NEW)) {
+/* x3.c:197-209 on a block whose first 64 entries are in the lanes (f, t, c): bump the frequency of entry e, or append `tag` with frequency 1 (e == X3D_NONE).
+ * Returns false when the pool is exhausted.  STR == 1: a context0 block (o, and what refers to it: ref0 / s_cold[DC_O00, DC_OFIRST]); STR == 2: the context1 block of ctx1tag. */
+template <int STR, bool LDS>
+__device__ static __forceinline__ bool dec_touch(uint64_t *pool, uint32_t pool_cap, uint32_t &pool_top, uint32_t &o, uint32_t n, uint32_t e, uint32_t tag, uint32_t c0,
+                                                 uint32_t &f, uint32_t &t, uint32_t &c, uint32_t lane,
+                                                 uint32_t ref0, uint32_t *s_cold, uint32_t o1, uint32_t &b1c,                /* STR == 1 */
+                                                 uint32_t ctx1tag, uint32_t *s_c1, uint32_t *gc1)                               /* STR == 2 */
+{
+	if (X3_LIKELY(e != X3D_NONE)) {
+		if (X3_LIKELY(e < X3_WAVE)) { /* header (total) and item (freq): both in lanes, one store */
+			if (lane == 0 || lane == e) { f += 1; blk_entry<STR>(pool, o, lane)[0] = f; }
+		} else if (lane == 0) { f += 1; blk_entry<STR>(pool, o, 0)[0] = f; blk_entry<STR>(pool, o, e)[0] += 1; }
+		return true;
+	}
+	if (X3_UNLIKELY(n >= 2 && (n & (n - 1)) == 0)) { /* full: twice the capacity somewhere else */
+		const uint32_t top = STR == 2 ? (pool_top + 1) & ~1u : pool_top, units = STR * (1 + 2 * n);
+		if (X3_UNLIKELY((uint64_t)top + units + 2 * X3_WAVE > pool_cap)) return false;
+		for (uint32_t i = lane; i < STR * (1 + n); i += X3_WAVE) pool[(uint64_t)top + i] = pool[(uint64_t)o + i];
+		if (STR == 1) {
+			if (lane == 0) pool[o] = ((uint64_t)X3D_NONE << 32) | top; /* forwarding entry */
+			if (dec_cold(s_cold, DC_O00) == o) dec_cold_set(s_cold, DC_O00, top);
+			if (dec_cold(s_cold, DC_OFIRST) == o) dec_cold_set(s_cold, DC_OFIRST, top);
+			dec_patch_ref(pool, ref0, top, o1, b1c, lane);
+		} else {
+			if (LDS) { if (lane == 0) s_c1[ctx1tag] = top; } else if (lane == 0) gc1[ctx1tag] = top;
+		}
+		o = top; pool_top = top + units;
+		x3_wave_order();
+	}
+	if (X3_LIKELY(n + 1 < X3_WAVE)) {
+		if (lane == 0) { f += 1; t += 1; }
+		if (lane == n + 1) { f = 1; t = tag; c = c0; }
+		if (lane == 0 || lane == n + 1) {
+			uint32_t *p = blk_entry<STR>(pool, o, lane);
+			if (STR == 1) *(uint64_t *)p = ((uint64_t)t << 32) | f;
+			else { *(uint64_t *)p = ((uint64_t)t << 32) | f; p[2] = c; }
+		}
+	} else if (lane == 0) {
+		f += 1; t += 1;
+		uint32_t *h = blk_entry<STR>(pool, o, 0), *p = blk_entry<STR>(pool, o, n + 1);
+		h[0] = f; h[1] = t;
+		p[0] = 1; p[1] = tag; if (STR == 2) p[2] = c0;
+	}
+	return true;
+}
+
+/* One instantiation per residence of the per-element tables: LDS = true while the dictionary has fewer than NLDS elements (recency list,
+ * index-model frequencies and the offsets of the context1 blocks are LDS arrays), LDS = false after they migrated to global memory.
+ * Works on copies of the state and writes them back when it returns X3D_EOF or X3D_MIGRATE: a failing stream (X3D_FAIL + S.status) leaves
+ * through returns that keep nothing alive, so the error exits cost the hot path no registers.
+ * NOTE for whoever edits this loop: every branch on a LANE-dependent condition next to one of the failing exits can make the compiler's
+ * uniformity analysis give up on the loop ("cycle with divergent exit"); the chain's scalars then all become vector registers and the
+ * step takes twice as long.  tests/test_build.py checks the register counts of the compiled kernel for exactly that. */
+template <uint32_t NLDS, bool LDS>
+__device__ static __forceinline__ uint32_t dec_loop(const DecT &T, DecS &S, uint16_t *s_mtf, uint32_t *s_idx, uint32_t *s_c1, uint32_t *s_cold, const uint32_t lane)
+{
+	uint64_t *const pool = T.pool;
+	BitReader br = S.br;
+	Dec d = S.d;
+	uint32_t e0 = S.e0, e1 = S.e1, e2 = S.e2, evtotal = S.evtotal;
+	uint32_t D = S.D, npairs = S.npairs, pool_top = S.pool_top, ctx1tag = S.ctx1tag;
+	uint32_t *tokp = T.tok + S.ntok; /* where the next token goes, and how many more fit */
+	uint32_t tokleft = T.cap - S.ntok;
+	uint32_t o0 = S.o0, o1 = S.o1, ref0 = S.ref0;
+	DecPend pend;
+	uint32_t nouse = 0;
+	/* ranks [0, 64) of the recency list and of the index model stay in registers: recent elements are the usual ones, and then neither the rank
+	 * search nor the move-to-front nor the index model reads a table (lanes >= D: no tag / frequency 0) */
+	uint32_t m0, i0;
+	if (LDS) { m0 = s_mtf[lane]; i0 = s_idx[lane]; } else { m0 = T.gmtf[lane]; i0 = T.gidx[lane]; }
+	uint32_t code;
+	/* The loop is software-pipelined by hand: the blocks of the next step's contexts are requested at ONE place, the last thing before the back edge, and what
+	 * a hit step still has to do after that (interval, recency list, token: `late`) runs at the top of the next iteration while those loads are in flight.
+	 * One definition per iteration of the registers the loads write means no copies of them -- a copy would have to wait for the data where it stands. */
+	bool late = false;
+	uint32_t l_tag = 0, l_rank = 0, l_cs = 0, l_rs = 0;
+	dec_request(pool, o1, o0, lane, pend);
+#define DEC_FAIL(st) { S.status = (st); return X3D_FAIL; }
+	for (;;) {
+		if (X3_LIKELY(late)) {
+			/* ---- the rest of the previous (hit) step: the interval, the recency list, the token ---- */
+			ac_narrow(d, br, s_cold, l_cs, l_rs);
+			uint32_t rank = l_rank;
+			if (rank == X3D_NONE) { /* dict_get_index_by_tag (x3.c:79,84) */
+				rank = dec_first(x3_ballot(m0 == l_tag));
+				if (X3_UNLIKELY(rank == X3D_NONE)) {
+					rank = LDS ? dec_mtf_rank_far(s_mtf, D, l_tag, lane) : dec_mtf_rank_far(T.gmtf, D, l_tag, lane);
+					if (X3_UNLIKELY(rank == X3D_NONE)) DEC_FAIL(X3_ST_CORRUPT)
+				}
+			}
+			/* the element moves to the front (dict.c:132-146): ranks [0, 64) are a register, one DPP shift */
+			if (X3_LIKELY(rank < X3_WAVE)) {
+				const uint32_t below = dec_shr1_fill(m0, l_tag);
+				m0 = lane <= rank ? below : m0;
+				if (lane <= rank) { if (LDS) s_mtf[lane] = (uint16_t)below; else T.gmtf[lane] = below; }
+			} else if (LDS) { dec_mtf_to_front(s_mtf, rank, l_tag, lane); m0 = s_mtf[lane]; }
+			else { dec_mtf_to_front(T.gmtf, rank, l_tag, lane); m0 = T.gmtf[lane]; }
+			/* x3.c:332-348: the element's bytes -- its tag, for the second stage */
+			if (X3_UNLIKELY(tokleft == 0)) DEC_FAIL(X3_ST_OUT_FULL)
+			if (lane == 0) *tokp = l_tag;
+			tokp++; tokleft--;
+		}
+		if (LDS && X3_UNLIKELY(D == NLDS)) { late = false; code = X3D_MIGRATE; break; }
+
+		/* ---- the event (x3.c:293-295): ac_decode_target + index_of_value (ac.c:128-131,167-179) without the second division --
+		 * (buf - lo) / step < c  <=>  buf - lo < c * step -- as a scalar compare chain: the likely events come first */
+		uint32_t step = dec_div(d.rng, evtotal);
+		evtotal++;
+		uint32_t ev;
+		const uint32_t t0 = e0 * step;
+		if (X3_LIKELY(d.off < t0)) { e0++; ac_narrow(d, br, s_cold, 0, t0); ev = X3_E_CTX0; }
+		else {
+			const uint32_t t1 = t0 + e1 * step;
+			if (X3_LIKELY(d.off < t1)) { e1++; ac_narrow(d, br, s_cold, t0, t1 - t0); ev = X3_E_CTX1; }
+			else {
+				const uint32_t t2 = t1 + e2 * step;
+				if (X3_LIKELY(d.off < t2)) { e2++; ac_narrow(d, br, s_cold, t1, t2 - t1); ev = X3_E_IDX1; }
+				else {
+					const uint32_t t3 = t2 + dec_cold(s_cold, DC_E3) * step;
+					if (X3_UNLIKELY(d.off >= t3)) {
+						if (X3_LIKELY(d.off < t3 + dec_cold(s_cold, DC_E4) * step)) { dec_cold_set(s_cold, DC_E4, dec_cold(s_cold, DC_E4) + 1); late = false; code = X3D_EOF; break; } /* E_EOF, x3.c:295 */
+						DEC_FAIL(X3_ST_CORRUPT) /* the reference abort()s, ac.c:178 */
+					}
+					dec_cold_set(s_cold, DC_E3, dec_cold(s_cold, DC_E3) + 1); ac_narrow(d, br, s_cold, t2, t3 - t2); ev = X3_E_NEW;
+				}
+			}
+		}
+
+		if (X3_UNLIKELY(ev == X3_E_NEW)) {
 			/* ---- decode_match, x3.c:272-283 ---- */
+			uint32_t *const models = s_cold + DC_MODELS + lane;
+			uint32_t lf = models[0], cf0 = models[X3_WAVE], cf1 = models[2 * X3_WAVE], cf2 = models[3 * X3_WAVE], cf3 = models[4 * X3_WAVE];
 			uint32_t len;
 			{
-				const uint32_t lftotal = 30u + x3_readlane_u32(s.evf, X3_E_NEW); /* 32 + the fragments before this one: the event model started at 1 and has counted this one already */
-				step = dec_div(d.hi - d.lo + 1, lftotal);
-				const uint32_t incl = wave_incl_scan(lane < 32 ? s.lf : 0u, lane);
-				const uint64_t mask = x3_ballot(lane < 32 && dec_below(d.buf - d.lo, step, incl));
-				if (X3_UNLIKELY(!mask)) { s.status = X3_ST_CORRUPT; break; }
-				const uint32_t l = (uint32_t)x3_ctz64(mask);
-				const uint32_t fq = x3_readlane_u32(s.lf, l), cl = x3_readlane_u32(incl, l) - fq;
-				if (X3_UNLIKELY(!dec_narrow(d, br, step, cl, cl + fq))) { s.status = X3_ST_CORRUPT; break; }
-				if (lane == l) s.lf++;
+				const uint32_t lftotal = 30u + dec_cold(s_cold, DC_E3); /* 32 + the fragments before this one: the event model started at 1 and has counted this one already */
+				step = dec_div(d.rng, lftotal);
+				const uint32_t incl = x3_wave_incl_scan_u32(lane < 32 ? lf : 0u);
+				const uint64_t m = x3_ballot(lane < 32 && d.off < incl * step);
+				if (X3_UNLIKELY(!m)) DEC_FAIL(X3_ST_CORRUPT)
+				const uint32_t l = (uint32_t)x3_ctz64(m);
+				const uint32_t fq = x3_readlane_u32(lf, l), cl = x3_readlane_u32(incl, l) - fq;
+				ac_narrow(d, br, s_cold, cl * step, fq * step);
+				lf += lane == l ? 1u : 0u;
 				len = l + 1;
 			}
-			const uint32_t p = s.p;
-			if (X3_UNLIKELY((uint64_t)p + len > t.cap)) { s.status = X3_ST_OUT_FULL; break; }
-			uint32_t h = DFNV_OFF, cftotal = x3_wave_sum_u32(s.cf0 + s.cf1 + s.cf2 + s.cf3);
-			int bad = 0;
+			const uint32_t litpos = dec_cold(s_cold, DC_LITPOS);
+			if (X3_UNLIKELY(tokleft == 0 || (uint64_t)litpos + len > (uint64_t)T.cap + 32)) DEC_FAIL(X3_ST_OUT_FULL)
+			uint8_t *const frag = T.lit + litpos;
+			uint32_t h = DFNV_OFF, cftotal = x3_wave_sum_u32(cf0 + cf1 + cf2 + cf3);
 			for (uint32_t j = 0; j < len; j++) {
-				step = dec_div(d.hi - d.lo + 1, cftotal);
-				const uint32_t offb = d.buf - d.lo;
-				const uint32_t s4 = s.cf0 + s.cf1 + s.cf2 + s.cf3;
-				const uint32_t incl = wave_incl_scan(s4, lane);
-				const uint64_t mask = x3_ballot(dec_below(offb, step, incl));
-				if (X3_UNLIKELY(!mask)) { bad = 1; break; }
-				const uint32_t l = (uint32_t)x3_ctz64(mask);
-				const uint32_t b0 = x3_readlane_u32(s.cf0, l), b1 = x3_readlane_u32(s.cf1, l), b2 = x3_readlane_u32(s.cf2, l), b3 = x3_readlane_u32(s.cf3, l);
-				uint32_t cl = x3_readlane_u32(incl, l) - (b0 + b1 + b2 + b3), sub, fq;
-				if (dec_below(offb, step, cl + b0)) { sub = 0; fq = b0; }
-				else if (dec_below(offb, step, cl + b0 + b1)) { sub = 1; fq = b1; cl += b0; }
-				else if (dec_below(offb, step, cl + b0 + b1 + b2)) { sub = 2; fq = b2; cl += b0 + b1; }
-				else { sub = 3; fq = b3; cl += b0 + b1 + b2; }
-				if (X3_UNLIKELY(!dec_narrow(d, br, step, cl, cl + fq))) { bad = 1; break; }
-				if (lane == l) { if (sub == 0) s.cf0++; else if (sub == 1) s.cf1++; else if (sub == 2) s.cf2++; else s.cf3++; }
+				step = dec_div(d.rng, cftotal);
+				const uint32_t s4 = cf0 + cf1 + cf2 + cf3;
+				const uint32_t incl = x3_wave_incl_scan_u32(s4);
+				const uint64_t m = x3_ballot(d.off < incl * step);
+				if (X3_UNLIKELY(!m)) DEC_FAIL(X3_ST_CORRUPT)
+				const uint32_t l = (uint32_t)x3_ctz64(m);
+				const uint32_t a0 = x3_readlane_u32(cf0, l), a1 = x3_readlane_u32(cf1, l), a2 = x3_readlane_u32(cf2, l), a3 = x3_readlane_u32(cf3, l);
+				uint32_t cl = x3_readlane_u32(incl, l) - (a0 + a1 + a2 + a3), sub, fq;
+				if (d.off < (cl + a0) * step) { sub = 0; fq = a0; }
+				else if (d.off < (cl + a0 + a1) * step) { sub = 1; fq = a1; cl += a0; }
+				else if (d.off < (cl + a0 + a1 + a2) * step) { sub = 2; fq = a2; cl += a0 + a1; }
+				else { sub = 3; fq = a3; cl += a0 + a1 + a2; }
+				ac_narrow(d, br, s_cold, cl * step, fq * step);
+				cf0 += (lane == l && sub == 0) ? 1u : 0u; cf1 += (lane == l && sub == 1) ? 1u : 0u;
+				cf2 += (lane == l && sub == 2) ? 1u : 0u; cf3 += (lane == l && sub == 3) ? 1u : 0u;
 				cftotal++;
 				const uint32_t ch = 4 * l + sub;
-				if (lane == 0) out[p + j] = (uint8_t)ch;
+				if (lane == 0) frag[j] = (uint8_t)ch;
 				h = (h ^ ch) * DFNV_MUL;
 			}
-			if (X3_UNLIKELY(bad)) { s.status = X3_ST_CORRUPT; break; }
+			models[0] = lf; models[X3_WAVE] = cf0; models[2 * X3_WAVE] = cf1; models[3 * X3_WAVE] = cf2; models[4 * X3_WAVE] = cf3;
 			x3_wave_order(); /* the fragment is in memory for every lane */
-			/* dict_query_elem (x3.c:309): exact lookup of (len, bytes) */
-			int dup = 0;
-			uint32_t slot = dht_slot(h, len, t.hlog);
-			for (uint32_t e = t.ht[slot]; e != 0; slot = (slot + 1) & t.hmask, e = t.ht[slot]) {
+			/* dict_query_elem (x3.c:309): exact lookup of (len, bytes) -- among the elements' own bytes, the output is not involved */
+			uint32_t dup = X3D_NONE;
+			uint32_t slot = dht_slot(h, len, T.hlog);
+			for (uint32_t e = T.ht[slot]; e != 0; slot = (slot + 1) & T.hmask, e = T.ht[slot]) {
 				const uint32_t tg = e - 1;
-				if (t.dlen[tg] != len) continue;
-				const uint8_t *ds = out + t.dpos[tg];
+				if (T.dlen[tg] != len) continue;
+				const uint8_t *ds = T.lit + T.dpos[tg];
 				uint32_t k = 0;
-				while (k < len && ds[k] == out[p + k]) k++;
-				if (k == len) { dup = 1; break; }
+				while (k < len && ds[k] == frag[k]) k++;
+				if (k == len) { dup = tg; break; }
 			}
 			x3_wave_order();
-			if (!dup) { /* x3.c:310-317 */
-				const uint32_t D = s.D;
-				if (lane == 0) { t.dpos[D] = p; t.dlen[D] = (uint8_t)len; t.ht[slot] = D + 1; } /* the hash table reads these two, wherever the other tables live */
+			dup = x3_uniform(dup);
+			uint32_t newtag = dup;
+			if (dup == X3D_NONE) { /* x3.c:310-317: a new element; its bytes stay where they are */
+				newtag = D;
+				uint32_t c1 = 0; /* element 0's context1 block exists from the start (it is the context before any element does) */
+				if (D) {
+					c1 = (pool_top + 1) & ~1u;
+					if (X3_UNLIKELY((uint64_t)c1 + 6 + 2 * X3_WAVE > T.pool_cap)) DEC_FAIL(X3_ST_POOL_FULL)
+					pool_top = c1 + 6;
+					if (lane == 0) { pool[c1] = 0; pool[c1 + 1] = 0; }
+				}
+				if (lane == 0) { T.dpos[D] = litpos; T.dlen[D] = (uint8_t)len; T.ht[slot] = D + 1; } /* the hash table and the second stage read these two, wherever the other tables live */
 				if (LDS) {
 					dec_mtf_to_front(s_mtf, D, D, lane);
-					if (lane == 0) { s_idx[D] = 1; s_el[D] = (p << 5) | (len - 1); s_c1off[D] = 0; s_c1tot[D] = 0; s_c1n[D] = 0; }
+					if (lane == 0) { s_idx[D] = 1; if (D) s_c1[D] = c1; }
 				} else {
-					dec_mtf_to_front(t.gmtf, D, D, lane);
-					if (lane == 0) t.gidx[D] = 1;
+					dec_mtf_to_front(T.gmtf, D, D, lane);
+					if (lane == 0) { T.gidx[D] = 1; T.gc1[D] = c1; }
 				}
-				s.D++;
+				x3_wave_order();
+				if (LDS) { m0 = s_mtf[lane]; i0 = s_idx[lane]; } else { m0 = T.gmtf[lane]; i0 = T.gidx[lane]; }
+				dec_cold_set(s_cold, DC_LITPOS, litpos + len);
+				D++;
 			}
-			s.p = p + len;
-			s.ctx1tag = 0; /* x3.c:321-322: both contexts reset */
-			x3_wave_order();
-			/* the next hit step's contexts: pair (0, 0) if it is known, else context 0 (x3.c:142-145) */
-			s.n_c0id = s.ord00 != 0xFFFFFFFFu ? s.ord00 : 0u;
-			s.n_h0 = t.ctx0[s.n_c0id];
-			if (LDS) { s.n_h1.off = x3_uniform(s_c1off[0]); s.n_h1.items = x3_uniform((uint32_t)s_c1n[0]); s.n_h1.total = x3_uniform(s_c1tot[0]); s.n_h1.cap = dec_cap_of(s.n_h1.items); }
-			else s.n_h1 = t.ctx1[0];
-			s.n_it0 = lane < s.n_h0.items ? pool[(uint64_t)s.n_h0.off + lane] : 0;
-			s.n_it1 = lane < s.n_h1.items ? pool[(uint64_t)s.n_h1.off + lane] : 0;
-			s.n_po1 = lane < s.n_h1.items ? pord[(uint64_t)s.n_h1.off + lane] : 0;
-			continue;
-		}
-
-		/* ---- decode_tag, x3.c:58-129 ---- */
-		DPROF_T(t_b)
-		DPROF1_ADD(s.pc_ev, t_a, t_b)
-		const uint32_t D = s.D;
-		if (X3_UNLIKELY(D == 0)) { s.status = X3_ST_CORRUPT; break; }
-		DPROF3_WAIT(s.pc_ev)
-		const uint32_t c0id = s.n_c0id, ctx1tag = s.ctx1tag;
-		const X3CtxHdr h0 = uni_hdr(s.n_h0), h1 = uni_hdr(s.n_h1); /* pinned here, not where the loads were issued: they stay in flight until now */
-		const uint64_t it0 = s.n_it0, it1 = s.n_it1;
-		const uint32_t po1 = s.n_po1;
-		uint32_t tag = 0, rank = 0, cpos = 0;
-		if (decision == X3_E_IDX1) {
-			const uint32_t idxtotal = D + x3_readlane_u32(s.evf, X3_E_IDX1) - 2u; /* one per element + one per index event before this one */
-			step = dec_div(d.hi - d.lo + 1, idxtotal);
-			uint32_t cl = 0, fq = 0;
-			rank = LDS ? find_in_array_pre(s_idx, i0, D, d.buf - d.lo, step, lane, cl, fq) : find_in_array(t.gidx, D, d.buf - d.lo, step, lane, cl, fq);
-			if (X3_UNLIKELY(rank == 0xFFFFFFFFu)) { s.status = X3_ST_CORRUPT; break; }
-			if (X3_UNLIKELY(!dec_narrow(d, br, step, cl, cl + fq))) { s.status = X3_ST_CORRUPT; break; }
-			if (LDS) { tag = X3_LIKELY(rank < X3_WAVE) ? x3_readlane_u32(m0, rank) : x3_uniform((uint32_t)s_mtf[rank]); x3_wave_order(); if (lane == 0) s_idx[rank] = fq + 1; } /* inc_model(&model_index1, index), x3.c:89 */
-			else { tag = x3_uniform(t.gmtf[rank]); x3_wave_order(); if (lane == 0) t.gidx[rank] = fq + 1; }
+			if (lane == 0) *tokp = newtag;
+			tokp++; tokleft--;
+			/* x3.c:321-322: both contexts reset -- context1 = tag 0, context0 = the pair (0, 0) if it is known, else pair number 0 (x3.c:142-145) */
+			ctx1tag = 0;
+			o1 = LDS ? x3_uniform(s_c1[0]) : x3_uniform(T.gc1[0]);
+			{ const uint32_t o00 = dec_cold(s_cold, DC_O00); o0 = o00 != X3D_NONE ? o00 : dec_cold(s_cold, DC_OFIRST); }
+			ref0 = X3D_NONE;
+			late = false;
 		} else {
-			const X3CtxHdr hc = decision == X3_E_CTX0 ? h0 : h1;
-			if (X3_UNLIKELY(hc.items == 0 || hc.total == 0)) { s.status = X3_ST_CORRUPT; break; }
-			step = dec_div(d.hi - d.lo + 1, hc.total);
-			uint32_t cl = 0, fq = 0;
-			const uint32_t pos = find_in_ctx(hc, pool, d.buf - d.lo, step, lane, decision == X3_E_CTX0 ? it0 : it1, cl, fq, tag);
-			if (X3_UNLIKELY(pos == 0xFFFFFFFFu)) { s.status = X3_ST_CORRUPT; break; }
-			cpos = pos;
-			if (X3_UNLIKELY(!dec_narrow(d, br, step, cl, cl + fq))) { s.status = X3_ST_CORRUPT; break; }
-			/* dict_get_index_by_tag (x3.c:79,84) */
-			if (LDS) {
-				const uint64_t mask = x3_ballot(lane < D && m0 == tag);
-				rank = X3_LIKELY(mask != 0) ? (uint32_t)x3_ctz64(mask) : dec_mtf_rank(s_mtf, D, tag, lane, X3_WAVE);
-			} else rank = dec_mtf_rank(t.gmtf, D, tag, lane);
-			if (X3_UNLIKELY(rank == 0xFFFFFFFFu)) { s.status = X3_ST_CORRUPT; break; }
+			/* ---- decode_tag, x3.c:58-129.  The blocks of both contexts (requested a whole event ago): entry `lane` of each; their headers ---- */
+			uint32_t b0f, b0t, b1f, b1t, b1c;
+			dec_take(pend, b0f, b0t, b1f, b1t, b1c);
+			uint32_t n0 = x3_readlane_u32(b0t, 0);
+			if (X3_UNLIKELY(n0 == X3D_NONE)) { /* the block moved since this offset was written down: follow, and tell the item that sent us here */
+				do { o0 = x3_readlane_u32(b0f, 0); blk_load0(pool, o0, lane, b0f, b0t); n0 = x3_readlane_u32(b0t, 0); } while (n0 == X3D_NONE);
+				dec_patch_ref(pool, ref0, o0, o1, b1c, lane);
+			}
+			const uint32_t n1 = x3_readlane_u32(b1t, 0);
+			const uint64_t vm0 = blk_lanes(n0, lane), vm1 = blk_lanes(n1, lane);
+			uint32_t tag, rank, q0, q1, cs, rs; /* q: entry of the tag in the context's block, X3D_NONE if it is not in the list; [cs, cs + rs): the symbol's slice of the interval */
+			if (ev == X3_E_IDX1) {
+				/* the rank itself, coded with model_index1 (x3.c:86-90) */
+				const uint32_t idxtotal = D + e2 - 2u; /* one per element + one per index event before this one */
+				const uint32_t incl = x3_wave_incl_scan_u32(i0); /* lanes >= D hold 0: the first lane below is never one of them */
+				step = dec_div(d.rng, idxtotal);
+				uint32_t cum, fq;
+				rank = dec_first(x3_ballot(d.off < incl * step));
+				if (X3_LIKELY(rank != X3D_NONE)) {
+					fq = x3_readlane_u32(i0, rank); cum = x3_readlane_u32(incl, rank) - fq;
+					tag = x3_readlane_u32(m0, rank);
+					/* inc_model(&model_index1, index), x3.c:89.  No branch on the lane here: every lane writes its rank's count back (the first 64 table entries mirror the register) */
+					i0 += lane == rank ? 1u : 0u;
+					if (LDS) s_idx[lane] = i0; else T.gidx[lane] = i0;
+				} else {
+					const uint32_t carry = x3_readlane_u32(incl, X3_WAVE - 1);
+					if (D > X3_WAVE) rank = LDS ? dec_idx_far(s_idx, D, d.off, step, carry, lane, cum, fq) : dec_idx_far(T.gidx, D, d.off, step, carry, lane, cum, fq);
+					if (X3_UNLIKELY(rank == X3D_NONE)) DEC_FAIL(X3_ST_CORRUPT)
+					if (LDS) { tag = x3_uniform((uint32_t)s_mtf[rank]); x3_wave_order(); if (lane == 0) s_idx[rank] = fq + 1; }
+					else { tag = x3_uniform(T.gmtf[rank]); x3_wave_order(); if (lane == 0) T.gidx[rank] = fq + 1; }
+				}
+				cs = cum * step; rs = fq * step;
+				q0 = dec_first(x3_ballot(b0t == tag) & vm0);
+				q1 = dec_first(x3_ballot(b1t == tag) & vm1);
+			} else {
+				/* the tag, coded in one of the two contexts (x3.c:68-85) */
+				const bool c0 = ev == X3_E_CTX0;
+				const uint32_t cf = c0 ? b0f : b1f, ct = c0 ? b0t : b1t;
+				const uint32_t Tc = x3_readlane_u32(cf, 0), nc = c0 ? n0 : n1;
+				const uint64_t vmc = c0 ? vm0 : vm1;
+				const uint32_t incl = x3_wave_incl_scan_u32(cf) - Tc; /* lane 0 holds the total */
+				step = dec_div(d.rng, Tc);
+				uint32_t cum, fq;
+				uint32_t qc = dec_first(x3_ballot(d.off < incl * step) & vmc);
+				if (X3_LIKELY(qc != X3D_NONE)) { fq = x3_readlane_u32(cf, qc); cum = x3_readlane_u32(incl, qc) - fq; tag = x3_readlane_u32(ct, qc); }
+				else {
+					if (nc >= X3_WAVE) {
+						const uint32_t carry = x3_readlane_u32(incl, X3_WAVE - 1);
+						qc = c0 ? blk_decode_far<1>(pool, o0, n0, d.off, step, carry, lane, cum, fq, tag) : blk_decode_far<2>(pool, o1, n1, d.off, step, carry, lane, cum, fq, tag);
+					}
+					if (X3_UNLIKELY(qc == X3D_NONE)) DEC_FAIL(X3_ST_CORRUPT)
+				}
+				cs = cum * step; rs = fq * step;
+				/* where the other context has the tag */
+				const uint32_t qo = dec_first(x3_ballot((c0 ? b1t : b0t) == tag) & (c0 ? vm1 : vm0));
+				q0 = c0 ? qc : qo; q1 = c0 ? qo : qc;
+				rank = X3D_NONE; /* looked up later, off the path to the next contexts */
+			}
+			/* ---- the tag is known: first of all whatever stands between it and the requests for the next step's contexts, so that those are in flight for as long as possible ---- */
+			const bool self1 = tag == ctx1tag;
+			const uint32_t c1n = LDS ? s_c1[tag] : T.gc1[tag]; /* the next context1 block: the tag's own */
+			if (X3_UNLIKELY(q0 == X3D_NONE && n0 >= X3_WAVE && ev != X3_E_CTX0)) q0 = blk_find_far<1>(pool, o0, n0, tag, lane);
+			if (X3_UNLIKELY(q1 == X3D_NONE && n1 >= X3_WAVE && ev != X3_E_CTX1)) q1 = blk_find_far<2>(pool, o1, n1, tag, lane);
+			/* the next context0 block: the one of the pair (context1, tag) -- named by the item of `tag` in the context1 list, or new with the pair */
+			uint32_t o0n;
+			if (X3_LIKELY(q1 != X3D_NONE)) o0n = X3_LIKELY(q1 < X3_WAVE) ? x3_readlane_u32(b1c, q1) : x3_uniform(blk_entry<2>(pool, o1, q1)[2]);
+			else { /* x3.c:213-222: (context1, tag) becomes a known pair */
+				if (npairs == 0) o0n = dec_cold(s_cold, DC_OFIRST); /* pair number 0 takes over the default list with whatever it has learnt */
+				else {
+					if (X3_UNLIKELY((uint64_t)pool_top + 3 + 2 * X3_WAVE > T.pool_cap)) DEC_FAIL(X3_ST_POOL_FULL)
+					o0n = pool_top; pool_top += 3;
+					if (lane == 0) pool[o0n] = 0;
+				}
+				if ((ctx1tag | tag) == 0) dec_cold_set(s_cold, DC_O00, o0n);
+				npairs++;
+			}
+			const bool self0 = o0n == o0; /* (before the block below can move) */
+			/* x3.c:99-126: both contexts learn the tag */
+			const bool ok0 = dec_touch<1, LDS>(pool, T.pool_cap, pool_top, o0, n0, q0, tag, 0, b0f, b0t, nouse, lane, ref0, s_cold, o1, b1c, 0, nullptr, nullptr);
+			const bool ok1 = ok0 && dec_touch<2, LDS>(pool, T.pool_cap, pool_top, o1, n1, q1, tag, self0 ? o0 : o0n, b1f, b1t, b1c, lane, 0, nullptr, 0, nouse, ctx1tag, s_c1, T.gc1);
+			if (X3_UNLIKELY(!ok1)) DEC_FAIL(X3_ST_POOL_FULL)
+			ref0 = o1 + 2 * (q1 != X3D_NONE ? q1 : n1 + 1);
+			o1 = self1 ? o1 : x3_uniform(c1n); /* (its own block may just have moved) */
+			ctx1tag = tag;
+			o0 = self0 ? o0 : o0n;
+			late = true; l_tag = tag; l_rank = rank; l_cs = cs; l_rs = rs;
 		}
-		DPROF_T(t_c)
-		DPROF1_ADD(s.pc_sym, t_b, t_c)
-		/* the tag is known: everything the rest of the step and the next step will wait for is requested NOW -- the element's bytes, and the
-		 * next context1 list (the one of the tag just decoded; this step only touches it when the tag follows itself, and then the registers
-		 * updated below are used instead of what is loaded here) */
-		uint32_t len, src;
-		X3CtxHdr e_h1;
-		if (LDS) { /* four LDS reads in flight together */
-			const uint32_t e = s_el[tag], ho = s_c1off[tag], hn = s_c1n[tag], ht = s_c1tot[tag];
-			len = (x3_uniform(e) & 31u) + 1; src = x3_uniform(e) >> 5;
-			e_h1.off = x3_uniform(ho); e_h1.items = x3_uniform(hn); e_h1.total = x3_uniform(ht); e_h1.cap = dec_cap_of(e_h1.items);
-		} else { len = x3_uniform(t.dlen[tag]); src = x3_uniform(t.dpos[tag]); }
-		const uint32_t p = s.p;
-		if (X3_UNLIKELY((uint64_t)p + len > t.cap)) { s.status = X3_ST_OUT_FULL; break; }
-		const uint8_t piece = lane < len ? out[src + lane] : (uint8_t)0; /* len <= 32; src + len <= p */
-		const bool self1 = tag == ctx1tag;
-		uint64_t e_it1 = 0;
-		uint32_t e_po1 = 0;
-		if (LDS) {
-			e_it1 = lane < e_h1.items ? pool[(uint64_t)e_h1.off + lane] : 0;
-			e_po1 = lane < e_h1.items ? pord[(uint64_t)e_h1.off + lane] : 0;
-		} else e_h1 = t.ctx1[tag]; /* into its own registers: nothing below needs it before the updates are done, so the load stays in flight */
-		DPROF2_T(u_a)
-		DPROF2_ADD(s.pc_ev, t_c, u_a)
-		/* x3.c:99-126: both contexts learn the tag, (context1, tag) becomes a known pair */
-		CtxQ q0, q1; /* the context the tag was decoded from already told its list position */
-		if (decision == X3_E_CTX0) { q0.found = 1; q0.pos = cpos; q0.freq = q0.cum = 0; } else q0 = ctx_find_tag(h0, pool, tag, lane, it0);
-		if (decision == X3_E_CTX1) { q1.found = 1; q1.pos = cpos; q1.freq = q1.cum = 0; } else q1 = ctx_find_tag(h1, pool, tag, lane, it1);
-		/* the pair (context1, tag) is this step's item in the context1 list -- and the (prev, context1) pair of the NEXT step */
-		uint32_t ord;
-		if (X3_LIKELY(q1.found)) ord = X3_LIKELY(q1.pos < X3_WAVE) ? x3_readlane_u32(po1, q1.pos) : x3_uniform(pord[(uint64_t)h1.off + q1.pos]);
-		else {
-			ord = s.npairs;
-			if (ctx1tag == 0 && tag == 0) s.ord00 = s.npairs;
-			s.npairs++;
-		}
-		/* the next context0 list: a new pair's header is still all zero (the workspace is cleared per batch), and when the pair repeats itself
-		 * the list is this step's own, updated below */
-		const bool self0 = ord == c0id;
-		const X3CtxHdr e_h0 = t.ctx0[ord]; /* ord <= pairs so far <= output capacity: inside the table */
-		DPROF2_T(u_b)
-		DPROF2_ADD(s.pc_sym, u_a, u_b)
-		X3CtxHdr u0 = h0, u1 = h1;
-		uint64_t p_it0 = it0, p_it1 = it1;
-		uint32_t p_po1 = po1, nopo = 0;
-		dec_ctx_touch(u0, q0, tag, p_it0, nopo, false, 0, pool, pord, s.pool_top, t.pool_cap, s.status, lane);
-		dec_ctx_touch(u1, q1, tag, p_it1, p_po1, true, ord, pool, pord, s.pool_top, t.pool_cap, s.status, lane);
-		if (X3_UNLIKELY(s.status != X3_ST_OK)) break;
-		if (lane == 0) {
-			t.ctx0[c0id] = u0;
-			if (LDS) { s_c1off[ctx1tag] = u1.off; s_c1n[ctx1tag] = (uint16_t)u1.items; s_c1tot[ctx1tag] = u1.total; }
-			else t.ctx1[ctx1tag] = u1;
-		}
-		DPROF2_T(u_c)
-		DPROF2_ADD(s.pc_ctx, u_b, u_c)
-		/* x3.c:332-348: the element moves to the front (LDS work, while the loads above are in flight) */
-		if (LDS) {
-			if (X3_LIKELY(rank < X3_WAVE)) { const uint32_t below = x3_wave_shr1_u32(m0); if (lane <= rank) s_mtf[lane] = (uint16_t)(lane ? below : tag); } /* no read: ranks [0, 64) are in registers */
-			else dec_mtf_to_front(s_mtf, rank, tag, lane);
-		} else dec_mtf_to_front(t.gmtf, rank, tag, lane);
 		x3_wave_order(); /* this step's stores come before the loads below in program order, also for the lanes that did not store */
-		DPROF3_WAIT(s.pc_sym)
-		DPROF_T(t_d)
-		DPROF2_ADD(s.pc_tail, u_c, t_d)
-		DPROF1_ADD(s.pc_ctx, t_c, t_d)
-		if (!LDS) { /* spilled: the header came from global memory, its items are requested only now */
-			e_it1 = lane < e_h1.items ? pool[(uint64_t)e_h1.off + lane] : 0;
-			e_po1 = lane < e_h1.items ? pord[(uint64_t)e_h1.off + lane] : 0;
-		}
-		s.n_c0id = ord;
-		s.n_h1 = self1 ? u1 : e_h1; s.n_it1 = self1 ? p_it1 : e_it1; s.n_po1 = self1 ? p_po1 : e_po1;
-		const uint64_t e_it0 = lane < e_h0.items ? pool[(uint64_t)e_h0.off + lane] : 0; /* in flight while the next event symbol is decoded */
-		s.n_h0 = self0 ? u0 : e_h0; s.n_it0 = self0 ? p_it0 : e_it0;
-		DPROF3_WAIT(s.pc_ctx)
-		if (lane < len) out[p + lane] = piece; /* x3.c:332-340: the element's bytes */
-		s.ctx1tag = tag; /* x3.c:346-347 */
-		s.p = p + len;
-		x3_wave_order();
-		DPROF_T(t_e)
-		DPROF1_ADD(s.pc_tail, t_d, t_e)
+		/* the next step's contexts, requested here and nowhere else.  Unconditional -- a list that stays the context is read back as this step left it (every update
+		 * above was a store from the lanes; a wave's accesses to one address are performed in program order). */
+		dec_request(pool, o1, o0, lane, pend);
 	}
-	return false;
+#undef DEC_FAIL
+	S.br = br; S.d = d;
+	S.e0 = e0; S.e1 = e1; S.e2 = e2; S.evtotal = evtotal;
+	S.D = D; S.npairs = npairs; S.pool_top = pool_top; S.ntok = T.cap - tokleft; S.ctx1tag = ctx1tag;
+	S.o0 = o0; S.o1 = o1; S.ref0 = ref0;
+	return code;
 }
 
 template <uint32_t NLDS>
 __device__ static void x3_decode_body(const X3DecArgs &a)
 {
 	/* per dictionary element while there are fewer than NLDS of them: rank -> tag of the move-to-front list, model_index1 frequency by rank,
-	 * (position << 5 | length - 1) of the element (positions < 2^27 = X3H_MAX_CHUNK), offset / total / item count of its context1 list */
+	 * pool offset of the element's context1 block */
 	X3_LDS uint16_t s_mtf[NLDS];
 	X3_LDS uint32_t s_idx[NLDS];
-	X3_LDS uint32_t s_el[NLDS];
-	X3_LDS uint32_t s_c1off[NLDS];
-	X3_LDS uint32_t s_c1tot[NLDS];
-	X3_LDS uint16_t s_c1n[NLDS];
-	static_assert(NLDS >= X3_WAVE && NLDS <= 65536, "tags and list lengths in the LDS tables are 16 bits wide; ranks [0, 64) are read without a bounds check");
+	X3_LDS uint32_t s_c1[NLDS];
+	X3_LDS uint32_t s_cold[DC_COUNT + 2 * X3_WAVE + 5 * X3_WAVE]; /* the cold scalars, two blocks of the stream, the models of new fragments */
+	static_assert(NLDS >= X3_WAVE && NLDS < 65535, "tags in the LDS recency list are 16 bits wide (0xFFFF: no element); ranks [0, 64) are read without a bounds check");
 	const X3DecChunk ck = a.chunks[blockIdx.x];
 	const uint32_t lane = x3_lane();
 	DecT t;
-	t.out = a.out + ck.out_off;
 	t.dpos = a.dict_pos + ck.tag_off; t.dlen = a.dict_len + ck.tag_off;
 	t.ht = a.ht + ck.ht_off; t.hlog = ck.ht_log2; t.hmask = (1u << ck.ht_log2) - 1;
-	t.gmtf = a.mtf + ck.tag_off; t.gidx = a.idxfreq + ck.tag_off;
-	t.ctx1 = a.ctx1 + ck.tag_off; t.ctx0 = a.ctx0 + ck.ctx0_off;
-	t.pool = a.items + ck.item_off; t.pord = a.item_ord + ck.item_off; t.pool_cap = (uint32_t)ck.item_cap; /* 8 * capacity + 64 <= 2^30 + 64 */
+	t.gmtf = a.mtf + ck.tag_off; t.gidx = a.idxfreq + ck.tag_off; t.gc1 = a.c1off + ck.tag_off;
+	t.pool = a.pool + ck.item_off; t.pool_cap = (uint32_t)ck.item_cap;
+	t.tok = a.tokens + ck.tok_off; t.lit = a.lit + ck.lit_off;
 	t.cap = ck.out_cap;
 
 	DecS s;
-	br_open(s.br, a.in + ck.in_off, ck.in_len);
-	s.d.lo = 0; s.d.hi = 0x7FFFFFFFu; s.d.buf = 0; /* ac_init */
-	s.d.buf = br_take(s.br, 31); /* ac_decode_init, ac.c:133-140 */
-	s.evf = lane < 2 ? 1024u : lane < 5 ? 1u : 0u; s.evtotal = 2051; /* create(), x3.c:236-244 */
-	s.lf = 1;
-	s.cf0 = s.cf1 = s.cf2 = s.cf3 = 1;
+	br_open(s.br, s_cold, a.in + ck.in_off, ck.in_len);
+	s.d.lo = 0; s.d.rng = 0x80000000u; /* ac_init */
+	s.d.off = br_take(s.br, s_cold, 31); /* ac_decode_init, ac.c:133-140 */
+	s.e0 = s.e1 = 1024u; s.e2 = 1u; s.evtotal = 2051; /* create(), x3.c:236-244 */
+	dec_cold_set(s_cold, DC_E3, 1u); dec_cold_set(s_cold, DC_E4, 1u);
+	for (uint32_t k = 0; k < 5; k++) s_cold[DC_MODELS + k * X3_WAVE + lane] = 1;
 	s.D = 0; s.npairs = 0; s.status = X3_ST_OK;
-	s.pool_top = 0;
-	s.ctx1tag = 0; s.p = 0;
-	s.n_c0id = 0;
-	s.n_h0.off = s.n_h0.items = s.n_h0.cap = s.n_h0.total = 0; /* both contexts are empty at the start */
-	s.n_h1 = s.n_h0;
-	s.n_it0 = s.n_it1 = 0; s.n_po1 = 0;
-	s.ord00 = 0xFFFFFFFFu;
-	s.pc_ev = s.pc_sym = s.pc_ctx = s.pc_tail = 0;
-	if (lane == 0) { s_c1off[0] = 0; s_c1tot[0] = 0; s_c1n[0] = 0; } /* the list of context 0 is looked at before element 0 exists */
+	s.ntok = 0;
+	dec_cold_set(s_cold, DC_LITPOS, 0);
+	s.ctx1tag = 0;
+	/* the pool starts with the context1 block of tag 0 (six units: header + two items) and the context0 block of pair number 0 (three units), both empty:
+	 * these are the contexts of the first step, before any element or pair exists */
+	s.o1 = 0; s.o0 = 6; s.ref0 = X3D_NONE;
+	dec_cold_set(s_cold, DC_OFIRST, 6); dec_cold_set(s_cold, DC_O00, X3D_NONE);
+	s.pool_top = 9;
+	if (lane == 0) { t.pool[0] = 0; t.pool[1] = 0; t.pool[6] = 0; }
+	for (uint32_t i = lane; i < X3_WAVE; i += X3_WAVE) { s_mtf[i] = 0xFFFFu; s_idx[i] = 0; }
+	if (lane == 0) s_c1[0] = 0;
 	x3_wave_order();
 
-	if (dec_loop<NLDS, true>(t, s, s_mtf, s_idx, s_el, s_c1off, s_c1tot, s_c1n, lane)) {
+	uint32_t code = dec_loop<NLDS, true>(t, s, s_mtf, s_idx, s_c1, s_cold, lane);
+	if (code == X3D_MIGRATE) {
 		/* NLDS elements: the tables continue in global memory (dpos/dlen were written there from the start) */
-		for (uint32_t i = lane; i < NLDS; i += X3_WAVE) {
-			t.gmtf[i] = s_mtf[i]; t.gidx[i] = s_idx[i];
-			X3CtxHdr h; h.off = s_c1off[i]; h.items = s_c1n[i]; h.cap = dec_cap_of(h.items); h.total = s_c1tot[i];
-			t.ctx1[i] = h;
-		}
+		for (uint32_t i = lane; i < NLDS; i += X3_WAVE) { t.gmtf[i] = s_mtf[i]; t.gidx[i] = s_idx[i]; t.gc1[i] = s_c1[i]; }
 		x3_wave_order();
-		(void)dec_loop<NLDS, false>(t, s, s_mtf, s_idx, s_el, s_c1off, s_c1tot, s_c1n, lane);
+		code = dec_loop<NLDS, false>(t, s, s_mtf, s_idx, s_c1, s_cold, lane);
 	}
 
 	if (lane == 0) {
 		X3CodeResult r;
-		r.out_len = s.p; r.status = s.status; r.pairs = s.npairs; r._r = s.D;
+		const bool ok = code == X3D_EOF;
+		r.out_len = ok ? s.ntok : 0; r.status = ok ? X3_ST_OK : s.status; r.pairs = ok ? s.npairs : 0; r._r = ok ? s.D : 0;
 		for (int i = 0; i < 8; i++) r.events[i] = 0;
-#ifdef X3_DEC_PROFILE
-		r.events[4] = (uint32_t)(s.pc_ev >> 10); r.events[5] = (uint32_t)(s.pc_sym >> 10); r.events[6] = (uint32_t)(s.pc_ctx >> 10); r.events[7] = (uint32_t)(s.pc_tail >> 10);
-#endif
+		r.events[7] = ok ? s.ntok : 0; /* for the second stage */
+		if (ok) { r.events[0] = s.e0 - 1024u; r.events[1] = s.e1 - 1024u; r.events[2] = s.e2 - 1u; r.events[3] = s_cold[DC_E3] - 1u; } /* events decoded = what the model counted */
 		a.result[blockIdx.x] = r;
 	}
-	x3_wave_order();
-	if (lane < 4) a.result[blockIdx.x].events[lane] = s.evf - (lane < 2 ? 1024u : 1u); /* events decoded = what the model counted */
+}
+
+/* ---- stage 2: tags -> bytes ------------------------------------------------------------------------------------------------------------
+ * One workgroup per tile of X3_DEC_TILE tokens; tile_first[] (from the chain's token counts) says which tiles belong to which stream.
+ * The chain left its token count in result.events[7]; result.out_len becomes the number of decoded bytes. */
+#define X3_DEC2_THREADS 256u
+#define X3_DEC2_PER (X3_DEC_TILE / X3_DEC2_THREADS)
+
+__device__ static __forceinline__ uint32_t dec2_stream_of(const uint32_t *tile_first, uint32_t nchunks, uint32_t tile)
+{
+	uint32_t lo = 0, hi = nchunks; /* last stream with tile_first <= tile */
+	while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (tile_first[mid] <= tile) lo = mid; else hi = mid; }
+	return lo;
+}
+
+/* bytes of every tile */
+__device__ static void x3_dec_lens_body(const X3DecArgs &a)
+{
+	X3_LDS uint32_t s_sum[X3_DEC2_THREADS / X3_WAVE];
+	const uint32_t tile = blockIdx.x, s = dec2_stream_of(a.tile_first, a.nchunks, tile);
+	const X3DecChunk ck = a.chunks[s];
+	const uint32_t ntok = a.result[s].events[7], t0 = (tile - a.tile_first[s]) * X3_DEC_TILE + threadIdx.x * X3_DEC2_PER;
+	const uint32_t *tok = a.tokens + ck.tok_off;
+	const uint8_t *dlen = a.dict_len + ck.tag_off;
+	uint32_t sum = 0;
+	for (uint32_t k = 0; k < X3_DEC2_PER; k++) if (t0 + k < ntok) sum += dlen[tok[t0 + k]];
+	sum = x3_wave_sum_u32(sum);
+	if (x3_lane() == 0) s_sum[threadIdx.x / X3_WAVE] = sum;
+	__syncthreads();
+	if (threadIdx.x == 0) { uint32_t tot = 0; for (uint32_t w = 0; w < X3_DEC2_THREADS / X3_WAVE; w++) tot += s_sum[w]; a.tile_sum[tile] = tot; }
+}
+
+/* per stream: exclusive prefix sum of its tiles' bytes (in place), the total checked against the capacity */
+__device__ static void x3_dec_scan_body(const X3DecArgs &a)
+{
+	X3_LDS uint32_t s_part[X3_DEC2_THREADS / X3_WAVE];
+	X3_LDS uint32_t s_carry, s_full;
+	const uint32_t s = blockIdx.x, first = a.tile_first[s], ntile = a.tile_first[s + 1] - first, cap = a.chunks[s].out_cap;
+	if (a.result[s].status != X3_ST_OK) return;
+	if (threadIdx.x == 0) { s_carry = 0; s_full = 0; }
+	__syncthreads();
+	for (uint32_t base = 0; base < ntile; base += X3_DEC2_THREADS) {
+		const uint32_t i = base + threadIdx.x;
+		const uint32_t v = i < ntile ? a.tile_sum[first + i] : 0; /* <= 2048 * 32 per tile: 256 of them fit 32 bits */
+		const uint32_t incl = x3_wave_incl_scan_u32(v);
+		if (x3_lane() == X3_WAVE - 1) s_part[threadIdx.x / X3_WAVE] = incl;
+		__syncthreads();
+		uint32_t before = 0;
+		for (uint32_t w = 0; w < threadIdx.x / X3_WAVE; w++) before += s_part[w];
+		const uint64_t upto = (uint64_t)s_carry + before + incl;
+		if (i < ntile) a.tile_sum[first + i] = (uint32_t)(upto - v);
+		__syncthreads();
+		if (threadIdx.x == X3_DEC2_THREADS - 1) { if (upto > cap) s_full = 1; else s_carry = (uint32_t)upto; }
+		__syncthreads();
+		if (s_full) break; /* (the carry stays <= the capacity <= 2^27: nothing wraps) */
+	}
+	if (threadIdx.x == 0) {
+		if (s_full) a.result[s].status = X3_ST_OUT_FULL;
+		else a.result[s].out_len = s_carry;
+	}
+}
+
+/* the bytes (x3.c:332-340): token i of a tile goes to the tile's base + the lengths of the tokens before it; every thread takes X3_DEC2_PER consecutive tokens */
+__device__ static void x3_dec_copy_body(const X3DecArgs &a)
+{
+	X3_LDS uint32_t s_part[X3_DEC2_THREADS / X3_WAVE];
+	const uint32_t tile = blockIdx.x, s = dec2_stream_of(a.tile_first, a.nchunks, tile);
+	if (a.result[s].status != X3_ST_OK) return; /* (uniform: the whole workgroup leaves) */
+	const X3DecChunk ck = a.chunks[s];
+	const uint32_t ntok = a.result[s].events[7], t0 = (tile - a.tile_first[s]) * X3_DEC_TILE + threadIdx.x * X3_DEC2_PER;
+	const uint32_t *tok = a.tokens + ck.tok_off;
+	const uint8_t *dlen = a.dict_len + ck.tag_off, *lit = a.lit + ck.lit_off;
+	const uint32_t *dpos = a.dict_pos + ck.tag_off;
+	uint8_t *out = a.out + ck.out_off;
+	uint32_t tg[X3_DEC2_PER], ln[X3_DEC2_PER], mine = 0;
+	for (uint32_t k = 0; k < X3_DEC2_PER; k++) {
+		const bool in = t0 + k < ntok;
+		tg[k] = in ? tok[t0 + k] : 0;
+		ln[k] = in ? dlen[tg[k]] : 0;
+		mine += ln[k];
+	}
+	const uint32_t incl = x3_wave_incl_scan_u32(mine);
+	if (x3_lane() == X3_WAVE - 1) s_part[threadIdx.x / X3_WAVE] = incl;
+	__syncthreads();
+	uint32_t pos = a.tile_sum[tile] + incl - mine;
+	for (uint32_t w = 0; w < threadIdx.x / X3_WAVE; w++) pos += s_part[w];
+	for (uint32_t k = 0; k < X3_DEC2_PER; k++) {
+		const uint8_t *src = lit + dpos[tg[k]];
+		for (uint32_t j = 0; j < ln[k]; j++) out[pos + j] = src[j];
+		pos += ln[k];
+	}
 }
 
 #ifndef X3_EMU
 __global__ void __launch_bounds__(X3_WAVE) x3_decode_kernel(X3DecArgs a) { x3_decode_body<X3_DEC_LDS>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_decode_mid_kernel(X3DecArgs a) { x3_decode_body<X3_DEC_LDS_MID>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_decode_many_kernel(X3DecArgs a) { x3_decode_body<X3_DEC_LDS_SMALL>(a); }
+__global__ void __launch_bounds__(X3_DEC2_THREADS) x3_dec_lens_kernel(X3DecArgs a) { x3_dec_lens_body(a); }
+__global__ void __launch_bounds__(X3_DEC2_THREADS) x3_dec_scan_kernel(X3DecArgs a) { x3_dec_scan_body(a); }
+__global__ void __launch_bounds__(X3_DEC2_THREADS) x3_dec_copy_kernel(X3DecArgs a) { x3_dec_copy_body(a); }
 extern "C" void x3k_launch_decode(const X3DecArgs *a, uint32_t nchunks, hipStream_t st)
 {
-	/* one wavefront per stream; the LDS tables decide how many streams share a CU: up to one stream per CU gets the big tables (4096
+	/* one wavefront per stream; the LDS tables decide how many streams share a CU: up to one stream per CU gets the big tables (8192
 	 * elements before they migrate to global memory), up to one per SIMD the middle ones, a batch beyond that the small ones (16 per CU) */
 	if (nchunks > 1024) hipLaunchKernelGGL(x3_decode_many_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, *a);
 	else if (nchunks > 256) hipLaunchKernelGGL(x3_decode_mid_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, *a);
 	else hipLaunchKernelGGL(x3_decode_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, *a);
 }
+extern "C" void x3k_launch_decode_bytes(const X3DecArgs *a, uint32_t nchunks, uint32_t ntiles, hipStream_t st)
+{
+	if (!ntiles) return;
+	hipLaunchKernelGGL(x3_dec_lens_kernel, dim3(ntiles), dim3(X3_DEC2_THREADS), 0, st, *a);
+	hipLaunchKernelGGL(x3_dec_scan_kernel, dim3(nchunks), dim3(X3_DEC2_THREADS), 0, st, *a);
+	hipLaunchKernelGGL(x3_dec_copy_kernel, dim3(ntiles), dim3(X3_DEC2_THREADS), 0, st, *a);
+}
 #else
 static void decode_tramp(void *p) { x3_decode_body<X3_DEC_LDS>(*(const X3DecArgs *)p); }
+static void dec_lens_tramp(void *p) { x3_dec_lens_body(*(const X3DecArgs *)p); }
+static void dec_scan_tramp(void *p) { x3_dec_scan_body(*(const X3DecArgs *)p); }
+static void dec_copy_tramp(void *p) { x3_dec_copy_body(*(const X3DecArgs *)p); }
 extern "C" void x3k_launch_decode(const X3DecArgs *a, uint32_t nchunks, void *)
 {
 	x3emu_launch(decode_tramp, (void *)a, dim3(nchunks), dim3(X3_WAVE));
+}
+extern "C" void x3k_launch_decode_bytes(const X3DecArgs *a, uint32_t nchunks, uint32_t ntiles, void *)
+{
+	if (!ntiles) return;
+	x3emu_launch(dec_lens_tramp, (void *)a, dim3(ntiles), dim3(X3_DEC2_THREADS));
+	x3emu_launch(dec_scan_tramp, (void *)a, dim3(nchunks), dim3(X3_DEC2_THREADS));
+	x3emu_launch(dec_copy_tramp, (void *)a, dim3(ntiles), dim3(X3_DEC2_THREADS));
 }
 #endif

@@ -98,22 +98,34 @@ struct X3DecChunk {          /* one stream to decode; workspace sized from the o
 	uint64_t in_off;
 	uint32_t in_len, out_cap;
 	uint64_t out_off;
-	uint64_t tag_off, ctx0_off, item_off, item_cap, ht_off;
+	uint64_t tag_off;        /* per dictionary element: dict_pos, dict_len, mtf, idxfreq, c1off (capacity out_cap + 8)          */
+	uint64_t item_off, item_cap; /* the stream's share of the context pool, in 8-byte units                                     */
+	uint64_t ht_off;
+	uint64_t tok_off;        /* the chain's output: one tag per parse step (capacity out_cap + 8 tokens)                        */
+	uint64_t lit_off;        /* bytes of the dictionary elements, in order of creation (capacity out_cap + 64)                  */
 	uint32_t ht_log2, _pad;
 };
+
+/* The decoder is two stages.  The CHAIN (x3_decode_kernel, one wavefront per stream) decodes events and tags and keeps the models; it writes
+ * one tag per parse step (a new fragment is the tag of the element it becomes or repeats) and the bytes of every new element -- it never
+ * touches the output.  The second stage turns tags into bytes in parallel: lengths -> positions (prefix sum) -> copy. */
+#define X3_DEC_TILE 2048u    /* tokens per workgroup of the second stage */
 
 struct X3DecArgs {
 	const uint8_t *in;
 	const X3DecChunk *chunks;
 	uint8_t *out;
-	uint32_t *dict_pos;         /* element = out[dict_pos .. +dict_len)                             */
+	uint32_t *dict_pos;         /* element = lit[dict_pos .. +dict_len)                             */
 	uint8_t  *dict_len;
 	uint32_t *ht;
-	uint32_t *mtf, *idxfreq;
-	X3CtxHdr *ctx1, *ctx0;
-	uint64_t *items;
-	uint32_t *item_ord;         /* per item slot of a context1 list: the ordinal of the pair (context1, tag) -- no pair map needed */
-	X3CodeResult *result;       /* out_len = decoded bytes, _r = dictionary elements                */
+	uint32_t *mtf, *idxfreq, *c1off; /* per element once the dictionary has outgrown the LDS tables: recency list, index model, offset of the element's context1 block */
+	uint64_t *pool;             /* context blocks, see decode.hip                                   */
+	uint32_t *tokens;
+	uint8_t  *lit;
+	uint32_t *tile_sum;         /* second stage: output bytes per tile, then their exclusive prefix sum per stream */
+	const uint32_t *tile_first; /* second stage: [nchunks + 1] first tile of every stream (from the chain's token counts) */
+	uint32_t nchunks, _pad;
+	X3CodeResult *result;       /* chain: out_len = tokens, _r = dictionary elements; second stage: out_len = decoded bytes */
 };
 
 #endif /* X3_KERNELS_H */
