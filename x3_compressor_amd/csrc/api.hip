@@ -1110,8 +1110,8 @@ static int decompress_batch(x3h_ctx *c, const uint8_t *in, const uint64_t *in_of
 	HIPCHK(hipMemcpyAsync(c->hcode.data(), c->cresult.p, (size_t)nc * sizeof(X3CodeResult), hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	if (getenv("X3H_DEBUG")) { const X3CodeResult &r = c->hcode[0];
-		fprintf(stderr, "[x3h] decode stream 0: out %u tokens %u D %u pairs %u events %u %u %u %u status %u\n",
-		        r.out_len, r.events[7], r._r, r.pairs, r.events[0], r.events[1], r.events[2], r.events[3], r.status); }
+		fprintf(stderr, "[x3h] decode stream 0: out %u tokens %u D %u pairs %u events %u %u %u %u status %u | kcycles (profile builds): waiting for blocks %u, request to use %u, use to request %u\n",
+		        r.out_len, r.events[7], r._r, r.pairs, r.events[0], r.events[1], r.events[2], r.events[3], r.status, r.events[4], r.events[5], r.events[6]); }
 	int rc = X3H_OK;
 	for (int i = 0; i < nc; i++) {
 		const X3CodeResult &r = c->hcode[(size_t)i];

@@ -245,10 +245,10 @@ __device__ static uint32_t blk_decode_far(uint64_t *pool, uint32_t o, uint32_t n
 #define X3_DEC_LDS 8192u /* dictionary elements whose tables live in LDS, 10 bytes each: recency list, index-model frequency, offset of the element's context1 block */
 #endif
 #ifndef X3_DEC_LDS_MID
-#define X3_DEC_LDS_MID 4096u /* ... in batches of up to 1024 streams: 40 KiB per stream, four streams (one per SIMD) share a CU */
+#define X3_DEC_LDS_MID 3584u /* ... in batches of up to 1024 streams: 35 KiB + the 1.8 KiB of s_cold per stream, so four streams (one per SIMD) share a CU's 160 KiB */
 #endif
 #ifndef X3_DEC_LDS_SMALL
-#define X3_DEC_LDS_SMALL 1024u /* ... in batches of many streams: 10 KiB of LDS per stream, so sixteen streams share a CU (the batch rate is streams in flight x the per-stream rate) */
+#define X3_DEC_LDS_SMALL 768u /* ... in batches of many streams: 9.3 KiB of LDS per stream, so sixteen streams share a CU (the batch rate is streams in flight x the per-stream rate) */
 #endif
 
 /* The move-to-front list (dict.c:132-146) beyond its first 64 ranks, typed by where it lives: uint16_t in LDS, uint32_t in global memory.
@@ -325,6 +325,7 @@ struct DecS {
 	uint32_t pool_top, ntok;          /* (bytes of the elements so far: s_cold[DC_LITPOS]) */
 	uint32_t ctx1tag;
 	uint32_t o0, o1;                  /* the current contexts: pool offsets of their blocks */
+	uint64_t pc_wait, pc_flight, pc_chain; /* (profile builds) */
 	uint32_t ref0;                    /* the context1 item (pool offset of its entry) that names the current context0 block; X3D_NONE: reached through o00 / ofirst */
 	/* s_cold[DC_O00]: context0 block of the pair (0, 0), what both contexts are after a new fragment (x3.c:321-322; X3D_NONE while that pair is unknown);
 	 * s_cold[DC_OFIRST]: the block of pair number 0, the default (x3.c:142-145) -- it exists, and learns tags, before the first pair does */
@@ -416,6 +417,9 @@ __device__ static __forceinline__ uint32_t dec_loop(const DecT &T, DecS &S, uint
 	bool late = false;
 	uint32_t l_tag = 0, l_rank = 0, l_cs = 0, l_rs = 0;
 	dec_request(pool, o1, o0, lane, pend);
+#ifdef X3_DEC_PROFILE /* experiment builds (tools/exp/r04_decprof.sh): shader cycles waiting for the requested blocks / between request and use / from use to the next request */
+	uint64_t pc_wait = 0, pc_flight = 0, pc_chain = 0, pc_req = x3_clock();
+#endif
 #define DEC_FAIL(st) { S.status = (st); return X3D_FAIL; }
 	for (;;) {
 		if (X3_LIKELY(late)) {
@@ -558,7 +562,14 @@ __device__ static __forceinline__ uint32_t dec_loop(const DecT &T, DecS &S, uint
 		} else {
 			/* ---- decode_tag, x3.c:58-129.  The blocks of both contexts (requested a whole event ago): entry `lane` of each; their headers ---- */
 			uint32_t b0f, b0t, b1f, b1t, b1c;
+#ifdef X3_DEC_PROFILE
+			const uint64_t pc_t0 = x3_clock();
+#endif
 			dec_take(pend, b0f, b0t, b1f, b1t, b1c);
+#ifdef X3_DEC_PROFILE
+			const uint64_t pc_t1 = x3_clock();
+			pc_wait += pc_t1 - pc_t0; pc_flight += pc_t0 - pc_req;
+#endif
 			uint32_t n0 = x3_readlane_u32(b0t, 0);
 			if (X3_UNLIKELY(n0 == X3D_NONE)) { /* the block moved since this offset was written down: follow, and tell the item that sent us here */
 				do { o0 = x3_readlane_u32(b0f, 0); blk_load0(pool, o0, lane, b0f, b0t); n0 = x3_readlane_u32(b0t, 0); } while (n0 == X3D_NONE);
@@ -642,17 +653,26 @@ __device__ static __forceinline__ uint32_t dec_loop(const DecT &T, DecS &S, uint
 			ctx1tag = tag;
 			o0 = self0 ? o0 : o0n;
 			late = true; l_tag = tag; l_rank = rank; l_cs = cs; l_rs = rs;
+#ifdef X3_DEC_PROFILE
+			pc_chain += x3_clock() - pc_t1;
+#endif
 		}
 		x3_wave_order(); /* this step's stores come before the loads below in program order, also for the lanes that did not store */
 		/* the next step's contexts, requested here and nowhere else.  Unconditional -- a list that stays the context is read back as this step left it (every update
 		 * above was a store from the lanes; a wave's accesses to one address are performed in program order). */
 		dec_request(pool, o1, o0, lane, pend);
+#ifdef X3_DEC_PROFILE
+		pc_req = x3_clock();
+#endif
 	}
 #undef DEC_FAIL
 	S.br = br; S.d = d;
 	S.e0 = e0; S.e1 = e1; S.e2 = e2; S.evtotal = evtotal;
 	S.D = D; S.npairs = npairs; S.pool_top = pool_top; S.ntok = T.cap - tokleft; S.ctx1tag = ctx1tag;
 	S.o0 = o0; S.o1 = o1; S.ref0 = ref0;
+#ifdef X3_DEC_PROFILE
+	S.pc_wait += pc_wait; S.pc_flight += pc_flight; S.pc_chain += pc_chain;
+#endif
 	return code;
 }
 
@@ -687,6 +707,7 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 	s.ntok = 0;
 	dec_cold_set(s_cold, DC_LITPOS, 0);
 	s.ctx1tag = 0;
+	s.pc_wait = s.pc_flight = s.pc_chain = 0;
 	/* the pool starts with the context1 block of tag 0 (six units: header + two items) and the context0 block of pair number 0 (three units), both empty:
 	 * these are the contexts of the first step, before any element or pair exists */
 	s.o1 = 0; s.o0 = 6; s.ref0 = X3D_NONE;
@@ -711,6 +732,9 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 		r.out_len = ok ? s.ntok : 0; r.status = ok ? X3_ST_OK : s.status; r.pairs = ok ? s.npairs : 0; r._r = ok ? s.D : 0;
 		for (int i = 0; i < 8; i++) r.events[i] = 0;
 		r.events[7] = ok ? s.ntok : 0; /* for the second stage */
+#ifdef X3_DEC_PROFILE
+		r.events[4] = (uint32_t)(s.pc_wait >> 10); r.events[5] = (uint32_t)(s.pc_flight >> 10); r.events[6] = (uint32_t)(s.pc_chain >> 10);
+#endif
 		if (ok) { r.events[0] = s.e0 - 1024u; r.events[1] = s.e1 - 1024u; r.events[2] = s.e2 - 1u; r.events[3] = s_cold[DC_E3] - 1u; } /* events decoded = what the model counted */
 		a.result[blockIdx.x] = r;
 	}
