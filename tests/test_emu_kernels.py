@@ -123,6 +123,25 @@ def test_emulated_decoder_random_streams(emu, oracle):
         assert back == parts, f"case {case}: sizes {sizes} params {kw}"
 
 
+def test_emulated_decoder_reaches_its_rare_paths(emu, oracle):
+    """decode.hip counts, in emulator builds, how often its rare paths run (x3emu_dec_cover[]): a context0 block that moved reached through the item that still holds
+    its old place (forwarding entry followed, the item patched -- also in the lanes when its list is the current context1), symbols and tags beyond entry 63 of a
+    list, blocks moving, ranks beyond 63.  Each input below is built for one of them; all of them must have run, and every round trip is exact."""
+    import ctypes as C
+    cover = (C.c_uint * 8).in_dll(emu.lib, "x3emu_dec_cover")
+    for i in range(8):
+        cover[i] = 0
+    rng = np.random.default_rng(41)
+    words = [bytes(rng.integers(97, 123, 3, dtype=np.uint8)) for _ in range(150)]            # 150 distinct 3-byte words: lists and ranks beyond 64
+    vocab = b"".join(words[int(i)] for i in rng.integers(0, 150, 3000))
+    zeros = bytes(400) + b"ab" + bytes(300) + b"cd" + bytes(500) + b"ab" + bytes(200)       # runs of one tag: pair (0, 0), self-contexts, fragments in between
+    mixed = b"".join(bytes([int(a)]) * int(n) + words[int(w)] for a, n, w in zip(rng.integers(0, 3, 300), rng.integers(1, 9, 300), rng.integers(0, 20, 300)))
+    for data, kw in ((vocab, dict(w_kib=8, t=1)), (zeros, dict(w_kib=1, t=2)), (mixed, dict(w_kib=2, t=2)), (synth.zipf_bytes(6000, offset=9).tobytes(), dict(w_kib=4, t=3))):
+        assert emu.decompress(oracle.compress(data, oracle_lib.params(**kw)), len(data) + 5) == data
+    got = [int(cover[i]) for i in range(6)]
+    assert all(g > 0 for g in got), f"rare paths not reached: forward {got[0]}, far decode {got[1]}, far find {got[2]}, block moved {got[3]}, far rank {got[4]}, lane patch {got[5]}"
+
+
 def test_emulated_device_resident_decode(emu, oracle):
     """x3h_decompress_chunks_dev: streams read and bytes written in place (the emulator's device memory is host memory)"""
     parts = [synth.english_like(900, seed=2).tobytes(), b"", synth.zipf_bytes(700, offset=5).tobytes(), b"z" * 300]

@@ -20,3 +20,4 @@ for d in ("pmc2", "pmc3"):
             if "x3_decode" in r["Kernel_Name"]: acc[r["Counter_Name"]] += float(r["Counter_Value"])
         print({k: round(v / steps, 1) for k, v in acc.items()})
 PY
+timeout -k 10 400 python3 tools/exp/many_decode.py 2>&1 | tee gpurun_out/r04d/many_decode.txt

@@ -37,6 +37,15 @@
 #define X3_LIKELY(x)   __builtin_expect(!!(x), 1)
 #define X3_UNLIKELY(x) __builtin_expect(!!(x), 0)
 
+#ifdef X3_EMU
+/* emulator builds: how often the rare paths ran (tests/test_emu_kernels.py makes sure its inputs reach them): [0] a forwarding entry followed, [1] a symbol decoded
+ * beyond entry 63, [2] a tag looked up beyond entry 63, [3] a block moved, [4] a rank beyond 63, [5] the item that names a moved block patched in the lanes */
+extern "C" { unsigned x3emu_dec_cover[8]; }
+#define DEC_COVER(i) { if (x3_lane() == 0) x3emu_dec_cover[i]++; }
+#else
+#define DEC_COVER(i)
+#endif
+
 #define X3D_NONE 0xFFFFFFFFu /* "no position" / "no block"; in the `items` word of a context0 header: the block moved, `total` says where to */
 
 /* return codes of the chain's loop */
@@ -337,6 +346,7 @@ __device__ static __forceinline__ void dec_patch_ref(uint64_t *pool, uint32_t re
 	if (ref0 == X3D_NONE) return;
 	if (lane == 0) ((uint32_t *)(pool + ref0))[2] = noff;
 	const uint32_t rel = ref0 - o1; /* entry e of the current context1 block sits at o1 + 2 e */
+	if (ref0 >= o1 && rel < 2 * X3_WAVE && !(rel & 1u)) DEC_COVER(5)
 	b1c = (ref0 >= o1 && rel < 2 * X3_WAVE && !(rel & 1u) && lane == (rel >> 1)) ? noff : b1c;
 }
 
@@ -355,6 +365,7 @@ __device__ static __forceinline__ bool dec_touch(uint64_t *pool, uint32_t pool_c
 		return true;
 	}
 	if (X3_UNLIKELY(n >= 2 && (n & (n - 1)) == 0)) { /* full: twice the capacity somewhere else */
+		DEC_COVER(3)
 		const uint32_t top = STR == 2 ? (pool_top + 1) & ~1u : pool_top, units = STR * (1 + 2 * n);
 		if (X3_UNLIKELY((uint64_t)top + units + 2 * X3_WAVE > pool_cap)) return false;
 		for (uint32_t i = lane; i < STR * (1 + n); i += X3_WAVE) pool[(uint64_t)top + i] = pool[(uint64_t)o + i];
@@ -404,7 +415,7 @@ __device__ static __forceinline__ uint32_t dec_loop(const DecT &T, DecS &S, uint
 	uint32_t *tokp = T.tok + S.ntok; /* where the next token goes, and how many more fit */
 	uint32_t tokleft = T.cap - S.ntok;
 	uint32_t o0 = S.o0, o1 = S.o1, ref0 = S.ref0;
-	DecPend pend;
+	DecPend pend = { 0, 0, 0, 0, 0 };
 	uint32_t nouse = 0;
 	/* ranks [0, 64) of the recency list and of the index model stay in registers: recent elements are the usual ones, and then neither the rank
 	 * search nor the move-to-front nor the index model reads a table (lanes >= D: no tag / frequency 0) */
@@ -438,7 +449,7 @@ __device__ static __forceinline__ uint32_t dec_loop(const DecT &T, DecS &S, uint
 				const uint32_t below = dec_shr1_fill(m0, l_tag);
 				m0 = lane <= rank ? below : m0;
 				if (lane <= rank) { if (LDS) s_mtf[lane] = (uint16_t)below; else T.gmtf[lane] = below; }
-			} else if (LDS) { dec_mtf_to_front(s_mtf, rank, l_tag, lane); m0 = s_mtf[lane]; }
+			} else if (LDS) { DEC_COVER(4) dec_mtf_to_front(s_mtf, rank, l_tag, lane); m0 = s_mtf[lane]; }
 			else { dec_mtf_to_front(T.gmtf, rank, l_tag, lane); m0 = T.gmtf[lane]; }
 			/* x3.c:332-348: the element's bytes -- its tag, for the second stage */
 			if (X3_UNLIKELY(tokleft == 0)) DEC_FAIL(X3_ST_OUT_FULL)
@@ -572,6 +583,7 @@ __device__ static __forceinline__ uint32_t dec_loop(const DecT &T, DecS &S, uint
 #endif
 			uint32_t n0 = x3_readlane_u32(b0t, 0);
 			if (X3_UNLIKELY(n0 == X3D_NONE)) { /* the block moved since this offset was written down: follow, and tell the item that sent us here */
+				DEC_COVER(0)
 				do { o0 = x3_readlane_u32(b0f, 0); blk_load0(pool, o0, lane, b0f, b0t); n0 = x3_readlane_u32(b0t, 0); } while (n0 == X3D_NONE);
 				dec_patch_ref(pool, ref0, o0, o1, b1c, lane);
 			}
@@ -614,6 +626,7 @@ __device__ static __forceinline__ uint32_t dec_loop(const DecT &T, DecS &S, uint
 				if (X3_LIKELY(qc != X3D_NONE)) { fq = x3_readlane_u32(cf, qc); cum = x3_readlane_u32(incl, qc) - fq; tag = x3_readlane_u32(ct, qc); }
 				else {
 					if (nc >= X3_WAVE) {
+						DEC_COVER(1)
 						const uint32_t carry = x3_readlane_u32(incl, X3_WAVE - 1);
 						qc = c0 ? blk_decode_far<1>(pool, o0, n0, d.off, step, carry, lane, cum, fq, tag) : blk_decode_far<2>(pool, o1, n1, d.off, step, carry, lane, cum, fq, tag);
 					}
@@ -628,7 +641,7 @@ __device__ static __forceinline__ uint32_t dec_loop(const DecT &T, DecS &S, uint
 			/* ---- the tag is known: first of all whatever stands between it and the requests for the next step's contexts, so that those are in flight for as long as possible ---- */
 			const bool self1 = tag == ctx1tag;
 			const uint32_t c1n = LDS ? s_c1[tag] : T.gc1[tag]; /* the next context1 block: the tag's own */
-			if (X3_UNLIKELY(q0 == X3D_NONE && n0 >= X3_WAVE && ev != X3_E_CTX0)) q0 = blk_find_far<1>(pool, o0, n0, tag, lane);
+			if (X3_UNLIKELY(q0 == X3D_NONE && n0 >= X3_WAVE && ev != X3_E_CTX0)) { DEC_COVER(2) q0 = blk_find_far<1>(pool, o0, n0, tag, lane); }
 			if (X3_UNLIKELY(q1 == X3D_NONE && n1 >= X3_WAVE && ev != X3_E_CTX1)) q1 = blk_find_far<2>(pool, o1, n1, tag, lane);
 			/* the next context0 block: the one of the pair (context1, tag) -- named by the item of `tag` in the context1 list, or new with the pair */
 			uint32_t o0n;
