@@ -182,7 +182,7 @@ extern "C" int x3h_ctx_set_batch_bytes(x3h_ctx *c, uint64_t input_bytes)
 	if (!c || input_bytes < ((uint64_t)1 << 20)) return X3H_E_ARG;
 	if (input_bytes > ((uint64_t)1 << 40)) input_bytes = (uint64_t)1 << 40; /* more than any GPU holds: "no sub-batches" */
 	c->batch_bytes = input_bytes;
-	/* the decoder cuts on output capacity, at ~150 B of workspace per byte; its rate is streams in flight x the per-stream rate.  An explicit
+	/* the decoder cuts on output capacity, at ~200 B of workspace per byte (the context pool is sized for the worst case: 160 B); its rate is streams in flight x the per-stream rate.  An explicit
 	 * X3H_DEC_BATCH_BYTES from the environment stays in force. */
 	if (!c->dec_batch_from_env) c->dec_batch_bytes = 2 * input_bytes;
 	return X3H_OK;
@@ -1141,7 +1141,7 @@ static int decompress_batch(x3h_ctx *c, const uint8_t *in, const uint64_t *in_of
 	return rc;
 }
 
-/* The decoder's tables are sized from the output capacity (~150 B per byte), so a batch whose capacities add up to more than
+/* The decoder's tables are sized from the output capacity (~200 B per byte: context pool 160, token trace 4, hash table 8-16, element tables 17, element bytes 1), so a batch whose capacities add up to more than
  * `dec_batch_bytes` (X3H_DEC_BATCH_BYTES, default 512 MiB) is decoded as consecutive sub-batches; streams are independent. */
 static int decompress_chunks(x3h_ctx *c, const uint8_t *in, const uint64_t *in_offsets, int nchunks,
                              uint8_t *out, const uint64_t *out_offsets, uint64_t *out_lens, x3h_stats *stats, bool dev)

@@ -422,67 +422,52 @@ __device__ static __forceinline__ uint32_t dec_loop(const DecT &T, DecS &S, uint
 	uint32_t m0, i0;
 	if (LDS) { m0 = s_mtf[lane]; i0 = s_idx[lane]; } else { m0 = T.gmtf[lane]; i0 = T.gidx[lane]; }
 	uint32_t code;
-	/* The loop is software-pipelined by hand: the blocks of the next step's contexts are requested at ONE place, the last thing before the back edge, and what
-	 * a hit step still has to do after that (interval, recency list, token: `late`) runs at the top of the next iteration while those loads are in flight.
-	 * One definition per iteration of the registers the loads write means no copies of them -- a copy would have to wait for the data where it stands. */
-	bool late = false;
-	uint32_t l_tag = 0, l_rank = 0, l_cs = 0, l_rs = 0;
+	/* The blocks of the next step's contexts are requested (dec_request) as soon as their addresses are known -- before this step's interval update, rank search,
+	 * move-to-front and token -- and taken over (dec_take) after the NEXT event has been decoded. */
 	dec_request(pool, o1, o0, lane, pend);
 #ifdef X3_DEC_PROFILE /* experiment builds (tools/exp/r04_decprof.sh): shader cycles waiting for the requested blocks / between request and use / from use to the next request */
 	uint64_t pc_wait = 0, pc_flight = 0, pc_chain = 0, pc_req = x3_clock();
 #endif
 #define DEC_FAIL(st) { S.status = (st); return X3D_FAIL; }
+#ifdef X3_DEC_PROFILE
+#define DEC_PROF_REQ pc_req = x3_clock();
+#else
+#define DEC_PROF_REQ
+#endif
 	for (;;) {
-		if (X3_LIKELY(late)) {
-			/* ---- the rest of the previous (hit) step: the interval, the recency list, the token ---- */
-			ac_narrow(d, br, s_cold, l_cs, l_rs);
-			uint32_t rank = l_rank;
-			if (rank == X3D_NONE) { /* dict_get_index_by_tag (x3.c:79,84) */
-				rank = dec_first(x3_ballot(m0 == l_tag));
-				if (X3_UNLIKELY(rank == X3D_NONE)) {
-					rank = LDS ? dec_mtf_rank_far(s_mtf, D, l_tag, lane) : dec_mtf_rank_far(T.gmtf, D, l_tag, lane);
-					if (X3_UNLIKELY(rank == X3D_NONE)) DEC_FAIL(X3_ST_CORRUPT)
-				}
-			}
-			/* the element moves to the front (dict.c:132-146): ranks [0, 64) are a register, one DPP shift */
-			if (X3_LIKELY(rank < X3_WAVE)) {
-				const uint32_t below = dec_shr1_fill(m0, l_tag);
-				m0 = lane <= rank ? below : m0;
-				if (lane <= rank) { if (LDS) s_mtf[lane] = (uint16_t)below; else T.gmtf[lane] = below; }
-			} else if (LDS) { DEC_COVER(4) dec_mtf_to_front(s_mtf, rank, l_tag, lane); m0 = s_mtf[lane]; }
-			else { dec_mtf_to_front(T.gmtf, rank, l_tag, lane); m0 = T.gmtf[lane]; }
-			/* x3.c:332-348: the element's bytes -- its tag, for the second stage */
-			if (X3_UNLIKELY(tokleft == 0)) DEC_FAIL(X3_ST_OUT_FULL)
-			if (lane == 0) *tokp = l_tag;
-			tokp++; tokleft--;
-		}
-		if (LDS && X3_UNLIKELY(D == NLDS)) { late = false; code = X3D_MIGRATE; break; }
+		if (LDS && X3_UNLIKELY(D == NLDS)) { code = X3D_MIGRATE; break; }
 
 		/* ---- the event (x3.c:293-295): ac_decode_target + index_of_value (ac.c:128-131,167-179) without the second division --
 		 * (buf - lo) / step < c  <=>  buf - lo < c * step -- as a scalar compare chain: the likely events come first */
 		uint32_t step = dec_div(d.rng, evtotal);
 		evtotal++;
-		uint32_t ev;
 		const uint32_t t0 = e0 * step;
-		if (X3_LIKELY(d.off < t0)) { e0++; ac_narrow(d, br, s_cold, 0, t0); ev = X3_E_CTX0; }
-		else {
+		if (X3_LIKELY(d.off < t0)) {
+			e0++; ac_narrow(d, br, s_cold, 0, t0);
+#define DEC_EV X3_E_CTX0
+#include "decode_hit.inc"
+#undef DEC_EV
+		} else {
 			const uint32_t t1 = t0 + e1 * step;
-			if (X3_LIKELY(d.off < t1)) { e1++; ac_narrow(d, br, s_cold, t0, t1 - t0); ev = X3_E_CTX1; }
-			else {
+			if (X3_LIKELY(d.off < t1)) {
+				e1++; ac_narrow(d, br, s_cold, t0, t1 - t0);
+#define DEC_EV X3_E_CTX1
+#include "decode_hit.inc"
+#undef DEC_EV
+			} else {
 				const uint32_t t2 = t1 + e2 * step;
-				if (X3_LIKELY(d.off < t2)) { e2++; ac_narrow(d, br, s_cold, t1, t2 - t1); ev = X3_E_IDX1; }
-				else {
+				if (X3_LIKELY(d.off < t2)) {
+					e2++; ac_narrow(d, br, s_cold, t1, t2 - t1);
+#define DEC_EV X3_E_IDX1
+#include "decode_hit.inc"
+#undef DEC_EV
+				} else {
 					const uint32_t t3 = t2 + dec_cold(s_cold, DC_E3) * step;
 					if (X3_UNLIKELY(d.off >= t3)) {
-						if (X3_LIKELY(d.off < t3 + dec_cold(s_cold, DC_E4) * step)) { dec_cold_set(s_cold, DC_E4, dec_cold(s_cold, DC_E4) + 1); late = false; code = X3D_EOF; break; } /* E_EOF, x3.c:295 */
+						if (X3_LIKELY(d.off < t3 + dec_cold(s_cold, DC_E4) * step)) { dec_cold_set(s_cold, DC_E4, dec_cold(s_cold, DC_E4) + 1); code = X3D_EOF; break; } /* E_EOF, x3.c:295 */
 						DEC_FAIL(X3_ST_CORRUPT) /* the reference abort()s, ac.c:178 */
 					}
-					dec_cold_set(s_cold, DC_E3, dec_cold(s_cold, DC_E3) + 1); ac_narrow(d, br, s_cold, t2, t3 - t2); ev = X3_E_NEW;
-				}
-			}
-		}
-
-		if (X3_UNLIKELY(ev == X3_E_NEW)) {
+					dec_cold_set(s_cold, DC_E3, dec_cold(s_cold, DC_E3) + 1); ac_narrow(d, br, s_cold, t2, t3 - t2);
 			/* ---- decode_match, x3.c:272-283 ---- */
 			uint32_t *const models = s_cold + DC_MODELS + lane;
 			uint32_t lf = models[0], cf0 = models[X3_WAVE], cf1 = models[2 * X3_WAVE], cf2 = models[3 * X3_WAVE], cf3 = models[4 * X3_WAVE];
@@ -569,116 +554,15 @@ __device__ static __forceinline__ uint32_t dec_loop(const DecT &T, DecS &S, uint
 			o1 = LDS ? x3_uniform(s_c1[0]) : x3_uniform(T.gc1[0]);
 			{ const uint32_t o00 = dec_cold(s_cold, DC_O00); o0 = o00 != X3D_NONE ? o00 : dec_cold(s_cold, DC_OFIRST); }
 			ref0 = X3D_NONE;
-			late = false;
-		} else {
-			/* ---- decode_tag, x3.c:58-129.  The blocks of both contexts (requested a whole event ago): entry `lane` of each; their headers ---- */
-			uint32_t b0f, b0t, b1f, b1t, b1c;
-#ifdef X3_DEC_PROFILE
-			const uint64_t pc_t0 = x3_clock();
-#endif
-			dec_take(pend, b0f, b0t, b1f, b1t, b1c);
-#ifdef X3_DEC_PROFILE
-			const uint64_t pc_t1 = x3_clock();
-			pc_wait += pc_t1 - pc_t0; pc_flight += pc_t0 - pc_req;
-#endif
-			uint32_t n0 = x3_readlane_u32(b0t, 0);
-			if (X3_UNLIKELY(n0 == X3D_NONE)) { /* the block moved since this offset was written down: follow, and tell the item that sent us here */
-				DEC_COVER(0)
-				do { o0 = x3_readlane_u32(b0f, 0); blk_load0(pool, o0, lane, b0f, b0t); n0 = x3_readlane_u32(b0t, 0); } while (n0 == X3D_NONE);
-				dec_patch_ref(pool, ref0, o0, o1, b1c, lane);
-			}
-			const uint32_t n1 = x3_readlane_u32(b1t, 0);
-			const uint64_t vm0 = blk_lanes(n0, lane), vm1 = blk_lanes(n1, lane);
-			uint32_t tag, rank, q0, q1, cs, rs; /* q: entry of the tag in the context's block, X3D_NONE if it is not in the list; [cs, cs + rs): the symbol's slice of the interval */
-			if (ev == X3_E_IDX1) {
-				/* the rank itself, coded with model_index1 (x3.c:86-90) */
-				const uint32_t idxtotal = D + e2 - 2u; /* one per element + one per index event before this one */
-				const uint32_t incl = x3_wave_incl_scan_u32(i0); /* lanes >= D hold 0: the first lane below is never one of them */
-				step = dec_div(d.rng, idxtotal);
-				uint32_t cum, fq;
-				rank = dec_first(x3_ballot(d.off < incl * step));
-				if (X3_LIKELY(rank != X3D_NONE)) {
-					fq = x3_readlane_u32(i0, rank); cum = x3_readlane_u32(incl, rank) - fq;
-					tag = x3_readlane_u32(m0, rank);
-					/* inc_model(&model_index1, index), x3.c:89.  No branch on the lane here: every lane writes its rank's count back (the first 64 table entries mirror the register) */
-					i0 += lane == rank ? 1u : 0u;
-					if (LDS) s_idx[lane] = i0; else T.gidx[lane] = i0;
-				} else {
-					const uint32_t carry = x3_readlane_u32(incl, X3_WAVE - 1);
-					if (D > X3_WAVE) rank = LDS ? dec_idx_far(s_idx, D, d.off, step, carry, lane, cum, fq) : dec_idx_far(T.gidx, D, d.off, step, carry, lane, cum, fq);
-					if (X3_UNLIKELY(rank == X3D_NONE)) DEC_FAIL(X3_ST_CORRUPT)
-					if (LDS) { tag = x3_uniform((uint32_t)s_mtf[rank]); x3_wave_order(); if (lane == 0) s_idx[rank] = fq + 1; }
-					else { tag = x3_uniform(T.gmtf[rank]); x3_wave_order(); if (lane == 0) T.gidx[rank] = fq + 1; }
+			x3_wave_order();
+			dec_request(pool, o1, o0, lane, pend);
+			DEC_PROF_REQ
 				}
-				cs = cum * step; rs = fq * step;
-				q0 = dec_first(x3_ballot(b0t == tag) & vm0);
-				q1 = dec_first(x3_ballot(b1t == tag) & vm1);
-			} else {
-				/* the tag, coded in one of the two contexts (x3.c:68-85) */
-				const bool c0 = ev == X3_E_CTX0;
-				const uint32_t cf = c0 ? b0f : b1f, ct = c0 ? b0t : b1t;
-				const uint32_t Tc = x3_readlane_u32(cf, 0), nc = c0 ? n0 : n1;
-				const uint64_t vmc = c0 ? vm0 : vm1;
-				const uint32_t incl = x3_wave_incl_scan_u32(cf) - Tc; /* lane 0 holds the total */
-				step = dec_div(d.rng, Tc);
-				uint32_t cum, fq;
-				uint32_t qc = dec_first(x3_ballot(d.off < incl * step) & vmc);
-				if (X3_LIKELY(qc != X3D_NONE)) { fq = x3_readlane_u32(cf, qc); cum = x3_readlane_u32(incl, qc) - fq; tag = x3_readlane_u32(ct, qc); }
-				else {
-					if (nc >= X3_WAVE) {
-						DEC_COVER(1)
-						const uint32_t carry = x3_readlane_u32(incl, X3_WAVE - 1);
-						qc = c0 ? blk_decode_far<1>(pool, o0, n0, d.off, step, carry, lane, cum, fq, tag) : blk_decode_far<2>(pool, o1, n1, d.off, step, carry, lane, cum, fq, tag);
-					}
-					if (X3_UNLIKELY(qc == X3D_NONE)) DEC_FAIL(X3_ST_CORRUPT)
-				}
-				cs = cum * step; rs = fq * step;
-				/* where the other context has the tag */
-				const uint32_t qo = dec_first(x3_ballot((c0 ? b1t : b0t) == tag) & (c0 ? vm1 : vm0));
-				q0 = c0 ? qc : qo; q1 = c0 ? qo : qc;
-				rank = X3D_NONE; /* looked up later, off the path to the next contexts */
 			}
-			/* ---- the tag is known: first of all whatever stands between it and the requests for the next step's contexts, so that those are in flight for as long as possible ---- */
-			const bool self1 = tag == ctx1tag;
-			const uint32_t c1n = LDS ? s_c1[tag] : T.gc1[tag]; /* the next context1 block: the tag's own */
-			if (X3_UNLIKELY(q0 == X3D_NONE && n0 >= X3_WAVE && ev != X3_E_CTX0)) { DEC_COVER(2) q0 = blk_find_far<1>(pool, o0, n0, tag, lane); }
-			if (X3_UNLIKELY(q1 == X3D_NONE && n1 >= X3_WAVE && ev != X3_E_CTX1)) q1 = blk_find_far<2>(pool, o1, n1, tag, lane);
-			/* the next context0 block: the one of the pair (context1, tag) -- named by the item of `tag` in the context1 list, or new with the pair */
-			uint32_t o0n;
-			if (X3_LIKELY(q1 != X3D_NONE)) o0n = X3_LIKELY(q1 < X3_WAVE) ? x3_readlane_u32(b1c, q1) : x3_uniform(blk_entry<2>(pool, o1, q1)[2]);
-			else { /* x3.c:213-222: (context1, tag) becomes a known pair */
-				if (npairs == 0) o0n = dec_cold(s_cold, DC_OFIRST); /* pair number 0 takes over the default list with whatever it has learnt */
-				else {
-					if (X3_UNLIKELY((uint64_t)pool_top + 3 + 2 * X3_WAVE > T.pool_cap)) DEC_FAIL(X3_ST_POOL_FULL)
-					o0n = pool_top; pool_top += 3;
-					if (lane == 0) pool[o0n] = 0;
-				}
-				if ((ctx1tag | tag) == 0) dec_cold_set(s_cold, DC_O00, o0n);
-				npairs++;
-			}
-			const bool self0 = o0n == o0; /* (before the block below can move) */
-			/* x3.c:99-126: both contexts learn the tag */
-			const bool ok0 = dec_touch<1, LDS>(pool, T.pool_cap, pool_top, o0, n0, q0, tag, 0, b0f, b0t, nouse, lane, ref0, s_cold, o1, b1c, 0, nullptr, nullptr);
-			const bool ok1 = ok0 && dec_touch<2, LDS>(pool, T.pool_cap, pool_top, o1, n1, q1, tag, self0 ? o0 : o0n, b1f, b1t, b1c, lane, 0, nullptr, 0, nouse, ctx1tag, s_c1, T.gc1);
-			if (X3_UNLIKELY(!ok1)) DEC_FAIL(X3_ST_POOL_FULL)
-			ref0 = o1 + 2 * (q1 != X3D_NONE ? q1 : n1 + 1);
-			o1 = self1 ? o1 : x3_uniform(c1n); /* (its own block may just have moved) */
-			ctx1tag = tag;
-			o0 = self0 ? o0 : o0n;
-			late = true; l_tag = tag; l_rank = rank; l_cs = cs; l_rs = rs;
-#ifdef X3_DEC_PROFILE
-			pc_chain += x3_clock() - pc_t1;
-#endif
 		}
-		x3_wave_order(); /* this step's stores come before the loads below in program order, also for the lanes that did not store */
-		/* the next step's contexts, requested here and nowhere else.  Unconditional -- a list that stays the context is read back as this step left it (every update
-		 * above was a store from the lanes; a wave's accesses to one address are performed in program order). */
-		dec_request(pool, o1, o0, lane, pend);
-#ifdef X3_DEC_PROFILE
-		pc_req = x3_clock();
-#endif
 	}
 #undef DEC_FAIL
+#undef DEC_PROF_REQ
 	S.br = br; S.d = d;
 	S.e0 = e0; S.e1 = e1; S.e2 = e2; S.evtotal = evtotal;
 	S.D = D; S.npairs = npairs; S.pool_top = pool_top; S.ntok = T.cap - tokleft; S.ctx1tag = ctx1tag;
