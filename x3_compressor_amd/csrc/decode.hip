@@ -441,20 +441,21 @@ __device__ static __forceinline__ uint32_t dec_loop(const DecT &T, DecS &S, uint
 		 * (buf - lo) / step < c  <=>  buf - lo < c * step -- as a scalar compare chain: the likely events come first */
 		uint32_t step = dec_div(d.rng, evtotal);
 		evtotal++;
-		const uint32_t t0 = e0 * step;
-		if (X3_LIKELY(d.off < t0)) {
-			e0++; ac_narrow(d, br, s_cold, 0, t0);
-#define DEC_EV X3_E_CTX0
-#include "decode_hit.inc"
-#undef DEC_EV
-		} else {
-			const uint32_t t1 = t0 + e1 * step;
-			if (X3_LIKELY(d.off < t1)) {
-				e1++; ac_narrow(d, br, s_cold, t0, t1 - t0);
+		/* (E_CTX1 is tested first -- t0 <= off < t1 as ONE unsigned compare -- because it is the usual event: 76 % of the steps of text, 99 % of 16-bit samples) */
+		const uint32_t t0 = e0 * step, w1 = e1 * step;
+		if (X3_LIKELY(d.off - t0 < w1)) {
+			e1++; ac_narrow(d, br, s_cold, t0, w1);
 #define DEC_EV X3_E_CTX1
 #include "decode_hit.inc"
 #undef DEC_EV
+		} else {
+			if (X3_LIKELY(d.off < t0)) {
+				e0++; ac_narrow(d, br, s_cold, 0, t0);
+#define DEC_EV X3_E_CTX0
+#include "decode_hit.inc"
+#undef DEC_EV
 			} else {
+				const uint32_t t1 = t0 + w1;
 				const uint32_t t2 = t1 + e2 * step;
 				if (X3_LIKELY(d.off < t2)) {
 					e2++; ac_narrow(d, br, s_cold, t1, t2 - t1);
