@@ -435,7 +435,6 @@ __device__ static __forceinline__ uint32_t dec_loop(const DecT &T, DecS &S, uint
 #define DEC_PROF_REQ
 #endif
 	for (;;) {
-		if (LDS && X3_UNLIKELY(D == NLDS)) { code = X3D_MIGRATE; break; }
 
 		/* ---- the event (x3.c:293-295): ac_decode_target + index_of_value (ac.c:128-131,167-179) without the second division --
 		 * (buf - lo) / step < c  <=>  buf - lo < c * step -- as a scalar compare chain: the likely events come first */
@@ -469,95 +468,96 @@ __device__ static __forceinline__ uint32_t dec_loop(const DecT &T, DecS &S, uint
 						DEC_FAIL(X3_ST_CORRUPT) /* the reference abort()s, ac.c:178 */
 					}
 					dec_cold_set(s_cold, DC_E3, dec_cold(s_cold, DC_E3) + 1); ac_narrow(d, br, s_cold, t2, t3 - t2);
-			/* ---- decode_match, x3.c:272-283 ---- */
-			uint32_t *const models = s_cold + DC_MODELS + lane;
-			uint32_t lf = models[0], cf0 = models[X3_WAVE], cf1 = models[2 * X3_WAVE], cf2 = models[3 * X3_WAVE], cf3 = models[4 * X3_WAVE];
-			uint32_t len;
-			{
-				const uint32_t lftotal = 30u + dec_cold(s_cold, DC_E3); /* 32 + the fragments before this one: the event model started at 1 and has counted this one already */
-				step = dec_div(d.rng, lftotal);
-				const uint32_t incl = x3_wave_incl_scan_u32(lane < 32 ? lf : 0u);
-				const uint64_t m = x3_ballot(lane < 32 && d.off < incl * step);
-				if (X3_UNLIKELY(!m)) DEC_FAIL(X3_ST_CORRUPT)
-				const uint32_t l = (uint32_t)x3_ctz64(m);
-				const uint32_t fq = x3_readlane_u32(lf, l), cl = x3_readlane_u32(incl, l) - fq;
-				ac_narrow(d, br, s_cold, cl * step, fq * step);
-				lf += lane == l ? 1u : 0u;
-				len = l + 1;
-			}
-			const uint32_t litpos = dec_cold(s_cold, DC_LITPOS);
-			if (X3_UNLIKELY(tokleft == 0 || (uint64_t)litpos + len > (uint64_t)T.cap + 32)) DEC_FAIL(X3_ST_OUT_FULL)
-			uint8_t *const frag = T.lit + litpos;
-			uint32_t h = DFNV_OFF, cftotal = x3_wave_sum_u32(cf0 + cf1 + cf2 + cf3);
-			for (uint32_t j = 0; j < len; j++) {
-				step = dec_div(d.rng, cftotal);
-				const uint32_t s4 = cf0 + cf1 + cf2 + cf3;
-				const uint32_t incl = x3_wave_incl_scan_u32(s4);
-				const uint64_t m = x3_ballot(d.off < incl * step);
-				if (X3_UNLIKELY(!m)) DEC_FAIL(X3_ST_CORRUPT)
-				const uint32_t l = (uint32_t)x3_ctz64(m);
-				const uint32_t a0 = x3_readlane_u32(cf0, l), a1 = x3_readlane_u32(cf1, l), a2 = x3_readlane_u32(cf2, l), a3 = x3_readlane_u32(cf3, l);
-				uint32_t cl = x3_readlane_u32(incl, l) - (a0 + a1 + a2 + a3), sub, fq;
-				if (d.off < (cl + a0) * step) { sub = 0; fq = a0; }
-				else if (d.off < (cl + a0 + a1) * step) { sub = 1; fq = a1; cl += a0; }
-				else if (d.off < (cl + a0 + a1 + a2) * step) { sub = 2; fq = a2; cl += a0 + a1; }
-				else { sub = 3; fq = a3; cl += a0 + a1 + a2; }
-				ac_narrow(d, br, s_cold, cl * step, fq * step);
-				cf0 += (lane == l && sub == 0) ? 1u : 0u; cf1 += (lane == l && sub == 1) ? 1u : 0u;
-				cf2 += (lane == l && sub == 2) ? 1u : 0u; cf3 += (lane == l && sub == 3) ? 1u : 0u;
-				cftotal++;
-				const uint32_t ch = 4 * l + sub;
-				if (lane == 0) frag[j] = (uint8_t)ch;
-				h = (h ^ ch) * DFNV_MUL;
-			}
-			models[0] = lf; models[X3_WAVE] = cf0; models[2 * X3_WAVE] = cf1; models[3 * X3_WAVE] = cf2; models[4 * X3_WAVE] = cf3;
-			x3_wave_order(); /* the fragment is in memory for every lane */
-			/* dict_query_elem (x3.c:309): exact lookup of (len, bytes) -- among the elements' own bytes, the output is not involved */
-			uint32_t dup = X3D_NONE;
-			uint32_t slot = dht_slot(h, len, T.hlog);
-			for (uint32_t e = T.ht[slot]; e != 0; slot = (slot + 1) & T.hmask, e = T.ht[slot]) {
-				const uint32_t tg = e - 1;
-				if (T.dlen[tg] != len) continue;
-				const uint8_t *ds = T.lit + T.dpos[tg];
-				uint32_t k = 0;
-				while (k < len && ds[k] == frag[k]) k++;
-				if (k == len) { dup = tg; break; }
-			}
-			x3_wave_order();
-			dup = x3_uniform(dup);
-			uint32_t newtag = dup;
-			if (dup == X3D_NONE) { /* x3.c:310-317: a new element; its bytes stay where they are */
-				newtag = D;
-				uint32_t c1 = 0; /* element 0's context1 block exists from the start (it is the context before any element does) */
-				if (D) {
-					c1 = (pool_top + 1) & ~1u;
-					if (X3_UNLIKELY((uint64_t)c1 + 6 + 2 * X3_WAVE > T.pool_cap)) DEC_FAIL(X3_ST_POOL_FULL)
-					pool_top = c1 + 6;
-					if (lane == 0) { pool[c1] = 0; pool[c1 + 1] = 0; }
-				}
-				if (lane == 0) { T.dpos[D] = litpos; T.dlen[D] = (uint8_t)len; T.ht[slot] = D + 1; } /* the hash table and the second stage read these two, wherever the other tables live */
-				if (LDS) {
-					dec_mtf_to_front(s_mtf, D, D, lane);
-					if (lane == 0) { s_idx[D] = 1; if (D) s_c1[D] = c1; }
-				} else {
-					dec_mtf_to_front(T.gmtf, D, D, lane);
-					if (lane == 0) { T.gidx[D] = 1; T.gc1[D] = c1; }
-				}
-				x3_wave_order();
-				if (LDS) { m0 = s_mtf[lane]; i0 = s_idx[lane]; } else { m0 = T.gmtf[lane]; i0 = T.gidx[lane]; }
-				dec_cold_set(s_cold, DC_LITPOS, litpos + len);
-				D++;
-			}
-			if (lane == 0) *tokp = newtag;
-			tokp++; tokleft--;
-			/* x3.c:321-322: both contexts reset -- context1 = tag 0, context0 = the pair (0, 0) if it is known, else pair number 0 (x3.c:142-145) */
-			ctx1tag = 0;
-			o1 = LDS ? x3_uniform(s_c1[0]) : x3_uniform(T.gc1[0]);
-			{ const uint32_t o00 = dec_cold(s_cold, DC_O00); o0 = o00 != X3D_NONE ? o00 : dec_cold(s_cold, DC_OFIRST); }
-			ref0 = X3D_NONE;
-			x3_wave_order();
-			dec_request(pool, o1, o0, lane, pend);
-			DEC_PROF_REQ
+					/* ---- decode_match, x3.c:272-283 ---- */
+					uint32_t *const models = s_cold + DC_MODELS + lane;
+					uint32_t lf = models[0], cf0 = models[X3_WAVE], cf1 = models[2 * X3_WAVE], cf2 = models[3 * X3_WAVE], cf3 = models[4 * X3_WAVE];
+					uint32_t len;
+					{
+						const uint32_t lftotal = 30u + dec_cold(s_cold, DC_E3); /* 32 + the fragments before this one: the event model started at 1 and has counted this one already */
+						step = dec_div(d.rng, lftotal);
+						const uint32_t incl = x3_wave_incl_scan_u32(lane < 32 ? lf : 0u);
+						const uint64_t m = x3_ballot(lane < 32 && d.off < incl * step);
+						if (X3_UNLIKELY(!m)) DEC_FAIL(X3_ST_CORRUPT)
+						const uint32_t l = (uint32_t)x3_ctz64(m);
+						const uint32_t fq = x3_readlane_u32(lf, l), cl = x3_readlane_u32(incl, l) - fq;
+						ac_narrow(d, br, s_cold, cl * step, fq * step);
+						lf += lane == l ? 1u : 0u;
+						len = l + 1;
+					}
+					const uint32_t litpos = dec_cold(s_cold, DC_LITPOS);
+					if (X3_UNLIKELY(tokleft == 0 || (uint64_t)litpos + len > (uint64_t)T.cap + 32)) DEC_FAIL(X3_ST_OUT_FULL)
+					uint8_t *const frag = T.lit + litpos;
+					uint32_t h = DFNV_OFF, cftotal = x3_wave_sum_u32(cf0 + cf1 + cf2 + cf3);
+					for (uint32_t j = 0; j < len; j++) {
+						step = dec_div(d.rng, cftotal);
+						const uint32_t s4 = cf0 + cf1 + cf2 + cf3;
+						const uint32_t incl = x3_wave_incl_scan_u32(s4);
+						const uint64_t m = x3_ballot(d.off < incl * step);
+						if (X3_UNLIKELY(!m)) DEC_FAIL(X3_ST_CORRUPT)
+						const uint32_t l = (uint32_t)x3_ctz64(m);
+						const uint32_t a0 = x3_readlane_u32(cf0, l), a1 = x3_readlane_u32(cf1, l), a2 = x3_readlane_u32(cf2, l), a3 = x3_readlane_u32(cf3, l);
+						uint32_t cl = x3_readlane_u32(incl, l) - (a0 + a1 + a2 + a3), sub, fq;
+						if (d.off < (cl + a0) * step) { sub = 0; fq = a0; }
+						else if (d.off < (cl + a0 + a1) * step) { sub = 1; fq = a1; cl += a0; }
+						else if (d.off < (cl + a0 + a1 + a2) * step) { sub = 2; fq = a2; cl += a0 + a1; }
+						else { sub = 3; fq = a3; cl += a0 + a1 + a2; }
+						ac_narrow(d, br, s_cold, cl * step, fq * step);
+						cf0 += (lane == l && sub == 0) ? 1u : 0u; cf1 += (lane == l && sub == 1) ? 1u : 0u;
+						cf2 += (lane == l && sub == 2) ? 1u : 0u; cf3 += (lane == l && sub == 3) ? 1u : 0u;
+						cftotal++;
+						const uint32_t ch = 4 * l + sub;
+						if (lane == 0) frag[j] = (uint8_t)ch;
+						h = (h ^ ch) * DFNV_MUL;
+					}
+					models[0] = lf; models[X3_WAVE] = cf0; models[2 * X3_WAVE] = cf1; models[3 * X3_WAVE] = cf2; models[4 * X3_WAVE] = cf3;
+					x3_wave_order(); /* the fragment is in memory for every lane */
+					/* dict_query_elem (x3.c:309): exact lookup of (len, bytes) -- among the elements' own bytes, the output is not involved */
+					uint32_t dup = X3D_NONE;
+					uint32_t slot = dht_slot(h, len, T.hlog);
+					for (uint32_t e = T.ht[slot]; e != 0; slot = (slot + 1) & T.hmask, e = T.ht[slot]) {
+						const uint32_t tg = e - 1;
+						if (T.dlen[tg] != len) continue;
+						const uint8_t *ds = T.lit + T.dpos[tg];
+						uint32_t k = 0;
+						while (k < len && ds[k] == frag[k]) k++;
+						if (k == len) { dup = tg; break; }
+					}
+					x3_wave_order();
+					dup = x3_uniform(dup);
+					uint32_t newtag = dup;
+					if (dup == X3D_NONE) { /* x3.c:310-317: a new element; its bytes stay where they are */
+						newtag = D;
+						uint32_t c1 = 0; /* element 0's context1 block exists from the start (it is the context before any element does) */
+						if (D) {
+							c1 = (pool_top + 1) & ~1u;
+							if (X3_UNLIKELY((uint64_t)c1 + 6 + 2 * X3_WAVE > T.pool_cap)) DEC_FAIL(X3_ST_POOL_FULL)
+							pool_top = c1 + 6;
+							if (lane == 0) { pool[c1] = 0; pool[c1 + 1] = 0; }
+						}
+						if (lane == 0) { T.dpos[D] = litpos; T.dlen[D] = (uint8_t)len; T.ht[slot] = D + 1; } /* the hash table and the second stage read these two, wherever the other tables live */
+						if (LDS) {
+							dec_mtf_to_front(s_mtf, D, D, lane);
+							if (lane == 0) { s_idx[D] = 1; if (D) s_c1[D] = c1; }
+						} else {
+							dec_mtf_to_front(T.gmtf, D, D, lane);
+							if (lane == 0) { T.gidx[D] = 1; T.gc1[D] = c1; }
+						}
+						x3_wave_order();
+						if (LDS) { m0 = s_mtf[lane]; i0 = s_idx[lane]; } else { m0 = T.gmtf[lane]; i0 = T.gidx[lane]; }
+						dec_cold_set(s_cold, DC_LITPOS, litpos + len);
+						D++;
+					}
+					if (lane == 0) *tokp = newtag;
+					tokp++; tokleft--;
+					/* x3.c:321-322: both contexts reset -- context1 = tag 0, context0 = the pair (0, 0) if it is known, else pair number 0 (x3.c:142-145) */
+					ctx1tag = 0;
+					o1 = LDS ? x3_uniform(s_c1[0]) : x3_uniform(T.gc1[0]);
+					{ const uint32_t o00 = dec_cold(s_cold, DC_O00); o0 = o00 != X3D_NONE ? o00 : dec_cold(s_cold, DC_OFIRST); }
+					ref0 = X3D_NONE;
+					x3_wave_order();
+					dec_request(pool, o1, o0, lane, pend);
+					DEC_PROF_REQ
+					if (LDS && X3_UNLIKELY(D == NLDS)) { code = X3D_MIGRATE; break; } /* (only a new fragment adds an element: the hit steps need no such test) */
 				}
 			}
 		}
