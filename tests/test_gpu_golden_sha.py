@@ -170,3 +170,28 @@ def test_window_smaller_than_input_cases_are_distinct():
     for n in CASES:
         w = int(MAN[n]["args"][MAN[n]["args"].index("-w") + 1]) * 1024
         assert MAN[n]["input_len"] > w, n
+
+
+def test_real_corpus_files_if_the_box_has_them():
+    """X3_CORPUS=DIR: the real Silesia files, pinned by tests/golden/make_golden_sha.py --corpus DIR into tests/golden/manifest_corpus.json with the
+    real reference.  Skipped where there is no corpus (this image has none: Silesia is not available offline)."""
+    import sys
+    cdir = os.environ.get("X3_CORPUS")
+    mpath = os.path.join(golden_util.HERE, "manifest_corpus.json")
+    if not cdir or not os.path.isdir(cdir) or not os.path.exists(mpath):
+        pytest.skip("no corpus directory (X3_CORPUS) or no tests/golden/manifest_corpus.json")
+    sys.path.insert(0, golden_util.HERE)
+    import make_golden_sha
+    man = json.load(open(mpath))
+    checked = 0
+    with _lib.X3Context(0) as ctx:
+        for name, (path, args) in sorted(make_golden_sha.corpus_cases(cdir).items()):
+            e = man.get(name)
+            data = open(path, "rb").read()
+            if e is None or e["input_sha256"] != hashlib.sha256(data).hexdigest() or len(data) > (128 << 20):
+                continue
+            w, t = int(args[args.index("-w") + 1]), int(args[args.index("-t") + 1])
+            s = ctx.compress(data, _lib.make_params(w_kib=w, t=t))
+            assert len(s) == e["output_len"] and hashlib.sha256(s).hexdigest() == e["output_sha256"], name
+            checked += 1
+    assert checked, "a corpus directory and a manifest, but no file of the one is pinned in the other"

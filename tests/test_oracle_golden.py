@@ -81,3 +81,30 @@ def test_count_against_numpy(oracle):
                 ref[k] += 1
                 k += 1
         assert np.array_equal(cnt, ref)
+
+
+def test_corpus_hook_pins_real_files_with_the_real_reference(tmp_path, oracle):
+    """tests/golden/make_golden_sha.py --corpus DIR (pin the real Silesia files the day a box has them): files named like the corpus are run through
+    oracle/_ref/x3 with the arguments of the configs that name them; the manifest holds their sha256.  Here: two small stand-in files under those names; the
+    manifest's streams equal the CPU oracle's for the same arguments."""
+    import hashlib
+    import json
+    import os
+    import subprocess
+    import sys
+    if golden_util.reference_stderr(b"abc", []) is None:
+        pytest.skip("oracle/_ref/x3 not present")
+    from x3_compressor_amd import synth
+    files = {"dickens": synth.english_like(6000, seed=8).tobytes(), "mr": synth.mr_like(5000, seed=9).tobytes(), "notes.txt": b"not a corpus file"}
+    for n, d in files.items():
+        (tmp_path / n).write_bytes(d)
+    out = tmp_path / "manifest.json"
+    script = os.path.join(golden_util.HERE, "make_golden_sha.py")
+    subprocess.run([sys.executable, script, "--corpus", str(tmp_path), "--out", str(out)], check=True, capture_output=True, timeout=600)
+    man = json.load(open(out))
+    assert sorted(man) == ["corpus_cfg2_dickens_w64_t256", "corpus_cfg3_dickens_w256_t1024", "corpus_cfg3_mr_w256_t1024", "corpus_cfg5_mr_w512_t4096"]
+    for name, e in man.items():
+        data = files[e["file"]]
+        w, t = int(e["args"][e["args"].index("-w") + 1]), int(e["args"][e["args"].index("-t") + 1])
+        s = oracle.compress(data, oracle_lib.params(w_kib=w, t=t))
+        assert e["input_sha256"] == hashlib.sha256(data).hexdigest() and e["output_len"] == len(s) and e["output_sha256"] == hashlib.sha256(s).hexdigest(), name

@@ -1,6 +1,9 @@
 """All five BASELINE.json configs at full size on one GPU (synthetic stand-ins for Silesia; config 4 = one GPU's share of the 128 chunks).
-Prints one line per config: bytes, device ms, MB/s, ratio, and the checks made."""
-import hashlib, json, sys, time
+Prints one line per config: bytes, device ms, MB/s, ratio, and the checks made.
+usage: configs_check.py [--corpus DIR [--manifest tests/golden/manifest_corpus.json]]
+       --corpus DIR: ALSO run the real Silesia files found in DIR (configs 2, 3 and 5 name them) and compare every stream's sha256 with the manifest
+       that tests/golden/make_golden_sha.py --corpus DIR wrote with the real reference (files without an entry are reported as "not pinned")."""
+import hashlib, json, os, sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
 from x3_compressor_amd import _lib, synth
@@ -54,3 +57,24 @@ for _ in range(2):
     s = ctx.compress(d, _lib.make_params(w_kib=512, t=4096)); st = ctx.last_stats
 t0 = time.time(); back = ctx.decompress(s, len(d)); dt = time.time() - t0
 line("5: 10.0 MB of mr-like samples, -w 512 -t 4096, round trip", len(d), st, len(s), f"sha256 == real reference: {pinned(f'cfg5_full_mr{len(d)}_w512_t4096', s)}; decode {ctx.last_stats.ms_code:.0f} ms ({len(d)/dt/1e6:.2f} MB/s), round trip ok: {back == d}")
+
+
+# the real corpus, if a directory was given: the same three configs on the files themselves
+if "--corpus" in sys.argv:
+    sys.path.insert(0, 'tests/golden')
+    import make_golden_sha
+    cdir = sys.argv[sys.argv.index("--corpus") + 1]
+    mpath = sys.argv[sys.argv.index("--manifest") + 1] if "--manifest" in sys.argv else 'tests/golden/manifest_corpus.json'
+    cman = json.load(open(mpath)) if os.path.exists(mpath) else {}
+    bad = 0
+    for name, (path, args) in sorted(make_golden_sha.corpus_cases(cdir).items()):
+        d = open(path, "rb").read()
+        if len(d) > (128 << 20):
+            print(f"{name}: {len(d)} bytes exceed one stream (X3H_MAX_CHUNK), skipped"); continue
+        w, t = int(args[args.index("-w") + 1]), int(args[args.index("-t") + 1])
+        s = ctx.compress(d, _lib.make_params(w_kib=w, t=t)); st = ctx.last_stats
+        e = cman.get(name)
+        ok = None if e is None or e["input_sha256"] != hashlib.sha256(d).hexdigest() else (len(s) == e["output_len"] and hashlib.sha256(s).hexdigest() == e["output_sha256"])
+        bad += ok is False
+        line(name, len(d), st, len(s), "sha256 == real reference: " + ("not pinned (run tests/golden/make_golden_sha.py --corpus)" if ok is None else str(ok)))
+    sys.exit(1 if bad else 0)
