@@ -52,7 +52,12 @@ ENVS = [dict(), dict(X3H_PIPE_MIN="1"), dict(X3H_PIPE_MIN="1", X3H_MODES="fixed"
         # round 3, second half: coder chains four to a workgroup (default from 513 streams), context kernel with / without its own tag gather and XCD mapping,
         # move-to-front ranks by one wavefront per stream instead of eight time ranges
         dict(X3H_AC2_WIDE="1", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0"), dict(X3H_CTX_GATHER="0"), dict(X3H_CTX_SUB="64", X3H_CTX_XCD="0"), dict(X3H_CTX_SUB="1", X3H_CTX_XCD="1"),
-        dict(X3H_MTF_PAR="0", X3H_IDX_PAR="0"), dict(X3H_MTF_PAR="0", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0", X3H_CTX_GATHER="0"), dict(X3H_IDX_PAR="0", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0")]
+        dict(X3H_MTF_PAR="0", X3H_IDX_PAR="0"), dict(X3H_MTF_PAR="0", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0", X3H_CTX_GATHER="0"), dict(X3H_IDX_PAR="0", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0"),
+        # round 4: K3 in slices forced on small inputs (many small slices / a few / stage B on the parse stream / several wavefronts per stream's contexts), and switched off
+        dict(X3H_SLICED_MIN="1", X3H_SLICE_GAP="64", X3H_SLICE_MARKS="0.02,0.05,0.10,0.17,0.26,0.36,0.47,0.59,0.72,0.86"),
+        dict(X3H_SLICED_MIN="1", X3H_SLICE_GAP="300", X3H_SLICE_MARKS="0.1,0.3,0.6", X3H_SLICE_SUB="3"),
+        dict(X3H_SLICED_MIN="1", X3H_SLICE_GAP="128", X3H_SLICE_MARKS="0.02,0.05,0.10,0.17,0.26,0.36,0.47,0.59,0.72,0.86", X3H_SLICE_BSTREAM="1", X3H_SLICE_SUB="7"),
+        dict(X3H_SLICED_MIN="1", X3H_SLICE_GAP="1000"), dict(X3H_SLICED="0", X3H_PIPE_MIN="1")]
 t0, cases = time.time(), 0
 while time.time() - t0 < budget:
     nch = int(rng.choice([1, 1, 1, 2, 3, 7, 40, 60, 130, 300, 600]))   # >= 48: the per-stream kernels of code3.hip; 300: above the switch to the small-LDS kernel variants
