@@ -330,8 +330,7 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 	const uint32_t h0 = n0 < c1 ? (uint32_t)n0 : c1, h1 = n1 < c1 ? (uint32_t)n1 : c1;
 	if (h0 >= h1) { if (lane == 0) a.pending[(size_t)c * a.nsub + sub] = make_uint4(NONE32, 0, 0, 0); return; }
 	const uint64_t dbg_t0 = x3_clock();
-	uint64_t dbg_t1 = dbg_t0;
-	uint32_t dbg_nseg = 0, dbg_ntile = 0;
+	uint32_t dbg_nseg = 0;
 	uint64_t dbg_store = 0, dbg_load = 0, dbg_body = 0;
 	for (uint32_t i = lane; i < DMAX; i += X3_WAVE) tpos[i] = NONE16;
 	x3_wave_order();
@@ -388,7 +387,6 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 		ok = ok0 + nnew_total;
 		stale = true; /* the first tile rescans the cum_freqs */
 		x3_wave_order();
-		dbg_t1 = x3_clock();
 	}
 	/* records of the range in tiles of 64, fetched ahead: keys and hits one tile, the gathered tags one tile (their hits two tiles), and every lane the
 	 * header of ITS key's context -- up to 64 headers in flight at once instead of one dependent load per context */
@@ -474,7 +472,6 @@ __device__ static void x3s_ctx_body(const X3sCtxArgs &a)
 				x3_wave_order();
 			}
 		}
-		dbg_ntile++;
 		while (S) {
 			dbg_nseg++;
 			const uint32_t s = (uint32_t)x3_ctz64(S);
