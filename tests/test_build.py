@@ -21,7 +21,7 @@ def decode_isa(tmp_path_factory):
                    cwd=CSRC, check=True, capture_output=True, timeout=600)
     text = open(out).read()
     kernels = {}
-    for name in ("x3_decode_kernel", "x3_decode_mid_kernel", "x3_decode_many_kernel"):
+    for name in ("x3_decode_kernel", "x3_decode_mid_kernel", "x3_decode_eight_kernel", "x3_decode_many_kernel"):
         m = re.search(r"^_Z\d+%s9X3DecArgs:[^\n]*\n(.*?)^\s*\.amdhsa_kernel" % name, text, re.S | re.M)
         assert m, name
         kernels[name] = [l.strip() for l in m.group(1).splitlines() if l.strip() and not l.strip().startswith(";")]
@@ -39,14 +39,16 @@ def test_chain_state_stays_on_the_scalar_unit(decode_isa):
 
 
 def test_requested_blocks_are_touched_by_nothing_but_request_and_take(decode_isa):
-    """dec_request / dec_take (decode.hip): the context blocks of the next step are loaded into v230..v234 by two asm loads and taken over behind one s_waitcnt; no
+    """dec_request / dec_take (decode.hip): the context blocks of the next step are loaded into v120..v124 by two asm loads and taken over behind one s_waitcnt; no
     other instruction of the kernel may name those registers (a compiler temporary there would race with the loads in flight)."""
     for name, lines in decode_isa.items():
-        uses = [l for l in lines if re.search(r"\bv23[0-4]\b|v\[23[0-4]:23[0-4]\]", l)]
+        uses = [l for l in lines if re.search(r"\bv12[0-4]\b|v\[12[0-4]:12[0-4]\]", l)]
         assert uses, name
         for l in uses:
-            ok = (re.match(r"global_load_dwordx3 v\[232:234\], v\d+, s\[\d+:\d+\]$", l) or re.match(r"global_load_dwordx2 v\[230:231\], v\d+, s\[\d+:\d+\]$", l)
-                  or re.match(r"v_mov_b32 v\d+, v23[0-4]$", l))
+            ok = (re.match(r"global_load_dwordx3 v\[122:124\], v\d+, s\[\d+:\d+\]$", l) or re.match(r"global_load_dwordx2 v\[120:121\], v\d+, s\[\d+:\d+\]$", l)
+                  or re.match(r"v_mov_b32 v\d+, v12[0-4]$", l))
             assert ok, f"{name}: unexpected use of the request registers: {l}"
-        takes = [i for i, l in enumerate(lines) if re.match(r"v_mov_b32 v\d+, v230$", l)]
+        nv = max(int(x) for l in lines for x in re.findall(r"\bv(\d+)\b", l))
+        assert nv <= 127, f"{name}: v{nv} in use -- more than 128 vector registers, fewer than four wavefronts per SIMD (the many-stream variant runs sixteen streams per CU)"
+        takes = [i for i, l in enumerate(lines) if re.match(r"v_mov_b32 v\d+, v120$", l)]
         assert takes and all(lines[i - 1] == "s_waitcnt vmcnt(0)" for i in takes), f"{name}: a take without its wait"

@@ -669,10 +669,10 @@ def test_device_resident_batch_round_trip(gpu, oracle):
     assert e.value.status == -1
 
 
-@pytest.mark.parametrize("nstreams,nbytes,vocab,floor", [(1, 1_500_000, 12_000, 8192), (300, 150_000, 5_000, 3584), (1100, 40_000, 1_000, 768)],
-                         ids=["big_tables_8192", "middle_tables_3584", "small_tables_768"])
+@pytest.mark.parametrize("nstreams,nbytes,vocab,floor", [(1, 1_500_000, 12_000, 8192), (300, 150_000, 5_000, 3584), (1100, 40_000, 2_500, 1792), (2100, 20_000, 1_000, 768)],
+                         ids=["big_tables_8192", "middle_tables_3584", "eight_per_cu_tables_1792", "small_tables_768"])
 def test_decoder_tables_migrate_out_of_lds(gpu, nstreams, nbytes, vocab, floor):
-    """dictionaries that outgrow the decoder's LDS tables in each of its three kernel variants (random words of a large vocabulary, window =
+    """dictionaries that outgrow the decoder's LDS tables in each of its four kernel variants (random words of a large vocabulary, window =
     the whole stream, -t 1: every word becomes an element -- ranks beyond 64, context lists beyond 64 items): the tables continue in
     global memory mid-stream and the round trip is exact"""
     rng = np.random.default_rng(77 + nstreams)

@@ -196,7 +196,8 @@ __device__ static __forceinline__ uint64_t blk_lanes(uint32_t n, uint32_t lane) 
 /* The blocks of the NEXT step's contexts are requested at the end of a step and used after the next event has been decoded: two loads that must stay in
  * flight across the loop's back edge.  Left to the compiler, the registers they write become loop-carried values with several definitions, and it copies them
  * around right behind the loads -- every such copy is a full wait for the data (measured: 40 % of the step).  So the two loads and the point where their
- * data is taken over are written out: fixed registers far above anything the kernel allocates (the clobber lists keep them out of the compiler's hands
+ * data is taken over are written out: fixed registers above anything the kernel allocates (v120..v124: the kernel then needs 125 registers, which still lets four wavefronts share a SIMD -- the
+ * sixteen streams per CU of the many-stream variant; with v230.. it was two) (the clobber lists keep them out of the compiler's hands
  * across each statement, tests/test_build.py checks that nothing else in the kernel names them), one s_waitcnt where the data is first needed.
  * dec_request: entries [0, 64) of the context1 block at o1 and of the context0 block at o0;  dec_take: wait for them and hand them to the compiler.
  * The emulator has no latency to hide: it loads at the request, like the hardware, into a struct. */
@@ -205,12 +206,12 @@ struct DecPend { uint32_t f0, t0, f1, t1, c1; };
 __device__ static __forceinline__ void dec_request(uint64_t *pool, uint32_t o1, uint32_t o0, uint32_t lane, DecPend &)
 {
 	const uint64_t *p0 = pool + o0, *p1 = pool + o1;
-	asm volatile("global_load_dwordx3 v[232:234], %0, %1\n\tglobal_load_dwordx2 v[230:231], %2, %3"
-	             :: "v"(lane * 16u), "s"(p1), "v"(lane * 8u), "s"(p0) : "v230", "v231", "v232", "v233", "v234", "memory");
+	asm volatile("global_load_dwordx3 v[122:124], %0, %1\n\tglobal_load_dwordx2 v[120:121], %2, %3"
+	             :: "v"(lane * 16u), "s"(p1), "v"(lane * 8u), "s"(p0) : "v120", "v121", "v122", "v123", "v124", "memory");
 }
 __device__ static __forceinline__ void dec_take(const DecPend &, uint32_t &b0f, uint32_t &b0t, uint32_t &b1f, uint32_t &b1t, uint32_t &b1c)
 {
-	asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, v230\n\tv_mov_b32 %1, v231\n\tv_mov_b32 %2, v232\n\tv_mov_b32 %3, v233\n\tv_mov_b32 %4, v234"
+	asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, v120\n\tv_mov_b32 %1, v121\n\tv_mov_b32 %2, v122\n\tv_mov_b32 %3, v123\n\tv_mov_b32 %4, v124"
 	             : "=v"(b0f), "=v"(b0t), "=v"(b1f), "=v"(b1t), "=v"(b1c) :: "memory");
 }
 #else
@@ -255,6 +256,9 @@ __device__ static uint32_t blk_decode_far(uint64_t *pool, uint32_t o, uint32_t n
 #endif
 #ifndef X3_DEC_LDS_MID
 #define X3_DEC_LDS_MID 3584u /* ... in batches of up to 1024 streams: 35 KiB + the 1.8 KiB of s_cold per stream, so four streams (one per SIMD) share a CU's 160 KiB */
+#endif
+#ifndef X3_DEC_LDS_EIGHT
+#define X3_DEC_LDS_EIGHT 1792u /* ... in batches of up to 2048 streams: 17.5 + 1.8 KiB per stream, eight streams per CU -- with the small tables below such a batch would sit sixteen to a CU on half of the chip */
 #endif
 #ifndef X3_DEC_LDS_SMALL
 #define X3_DEC_LDS_SMALL 768u /* ... in batches of many streams: 9.3 KiB of LDS per stream, so sixteen streams share a CU (the batch rate is streams in flight x the per-stream rate) */
@@ -732,6 +736,7 @@ __device__ static void x3_dec_copy_body(const X3DecArgs &a)
 #ifndef X3_EMU
 __global__ void __launch_bounds__(X3_WAVE) x3_decode_kernel(X3DecArgs a) { x3_decode_body<X3_DEC_LDS>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_decode_mid_kernel(X3DecArgs a) { x3_decode_body<X3_DEC_LDS_MID>(a); }
+__global__ void __launch_bounds__(X3_WAVE) x3_decode_eight_kernel(X3DecArgs a) { x3_decode_body<X3_DEC_LDS_EIGHT>(a); }
 __global__ void __launch_bounds__(X3_WAVE) x3_decode_many_kernel(X3DecArgs a) { x3_decode_body<X3_DEC_LDS_SMALL>(a); }
 __global__ void __launch_bounds__(X3_DEC2_THREADS) x3_dec_lens_kernel(X3DecArgs a) { x3_dec_lens_body(a); }
 __global__ void __launch_bounds__(X3_DEC2_THREADS) x3_dec_scan_kernel(X3DecArgs a) { x3_dec_scan_body(a); }
@@ -739,8 +744,9 @@ __global__ void __launch_bounds__(X3_DEC2_THREADS) x3_dec_copy_kernel(X3DecArgs 
 extern "C" void x3k_launch_decode(const X3DecArgs *a, uint32_t nchunks, hipStream_t st)
 {
 	/* one wavefront per stream; the LDS tables decide how many streams share a CU: up to one stream per CU gets the big tables (8192
-	 * elements before they migrate to global memory), up to one per SIMD the middle ones, a batch beyond that the small ones (16 per CU) */
-	if (nchunks > 1024) hipLaunchKernelGGL(x3_decode_many_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, *a);
+	 * elements before they migrate to global memory), up to one per SIMD the middle ones, up to two per SIMD the next, a batch beyond that the small ones (16 per CU) */
+	if (nchunks > 2048) hipLaunchKernelGGL(x3_decode_many_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, *a);
+	else if (nchunks > 1024) hipLaunchKernelGGL(x3_decode_eight_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, *a);
 	else if (nchunks > 256) hipLaunchKernelGGL(x3_decode_mid_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, *a);
 	else hipLaunchKernelGGL(x3_decode_kernel, dim3(nchunks), dim3(X3_WAVE), 0, st, *a);
 }
