@@ -139,10 +139,11 @@ __device__ static __forceinline__ uint32_t dec_div(uint32_t n, uint32_t t)
 #ifndef X3_EMU
 	const double td = (double)t;
 	double r = __builtin_amdgcn_rcp(td);       /* v_rcp_f64: an approximation ... */
-	r = __builtin_fma(r, __builtin_fma(-td, r, 1.0), r); /* ... one Newton step makes it good to ~2^-50 whatever its accuracy class */
+	/* ... one Newton step makes it good to ~2^-50 whatever its accuracy class -- aimed 2^-43 BELOW 1 / t (the constant is 1 - 2^-43 instead of 1): the
+	 * estimate n * r is then never above n / t and less than 2^-11 below it (n <= 2^31), so the quotient is exact or one short, and the fix-up is one-sided */
+	r = __builtin_fma(r, __builtin_fma(-td, r, 1.0 - 0x1p-43), r);
 	uint32_t q = (uint32_t)((double)n * r);
-	const int32_t rem = (int32_t)(n - q * t);
-	q += rem < 0 ? 0xFFFFFFFFu : (uint32_t)rem >= t ? 1u : 0u;
+	q += n - q * t >= t ? 1u : 0u;
 	return x3_uniform(q);
 #else
 	return t ? n / t : 0xFFFFFFFFu;
