@@ -1,5 +1,7 @@
 """Parity tests proper: the HIP library (through the C ABI) against the golden vectors of the real reference and
 against the oracle on seeded inputs.  Bit-exact is the bar everywhere (byte / integer / index work)."""
+import os
+
 import numpy as np
 import pytest
 import torch  # before libx3hip.so is loaded: torch brings its own HIP runtime, and the process must end up with one (the first one loaded)
@@ -685,3 +687,19 @@ def test_decoder_tables_migrate_out_of_lds(gpu, nstreams, nbytes, vocab, floor):
     st = gpu.last_stats
     assert st.dict_elems / nstreams > floor, f"only {st.dict_elems / nstreams:.0f} elements per stream, the spill path was not taken"
     assert back == parts
+
+
+def test_decoder_division_is_exact(tmp_path):
+    """range / total of the decoder's chain (dec_div, decode.hip: v_rcp_f64 + one Newton step aimed 2^-43 low + a one-sided fix-up) against the device's own integer
+    division on ~1.7 M operand pairs chosen against a reciprocal: exact multiples of the divisor and their neighbours, divisors 1..4096, powers of two +-2, random
+    ones up to 2^28, dividends up to 2^31 (tests/hip/div_check.hip, built here with hipcc)"""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    exe = tmp_path / "div_check"
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hip", "div_check.hip")
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-o", str(exe), src], check=True, capture_output=True, timeout=600)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and " wrong 0" in r.stdout, r.stdout + r.stderr
