@@ -327,7 +327,7 @@ def main():
         # the SAME bytes cut into independent chunks (each its own x3 stream), one batch per chunk count.  The ratio pays for
         # every restart of the models; single stream = the `ratio` above.
         sweep = []
-        for nch in (16, 24, 32, 40, 48, 64, 128, 256, 512):
+        for nch in (16, 24, 32, 40, 48, 64, 80, 96, 128, 256, 512):
             cb = (N + nch - 1) // nch
             cdt, clens, cst, coff, d_cout, cstride = chunk_batch(ctx, d_in, N, cb, prm, dev)
             e = {"chunks": len(coff) - 1, "chunk_bytes": cb, "value": round(N / cdt / 1e6, 3), "unit": "MB/s", "ms": round(cdt * 1e3, 3),

@@ -118,7 +118,9 @@ int x3h_compress_chunks_dev(x3h_ctx *ctx, const x3h_params *prm, const void *d_i
 
 /* Decoder.  Replaces   bio_open(READ); ac_init(); ac_decode_init(); decompress(optr,&bio); bio_close();   (x3.c:635-647).
  * The stream carries neither its length nor -w/-t: `cap` bounds the output (the reference assumes 64x the
- * input, unchecked, x3.c:621); X3H_E_OUTPUT_FULL asks for a larger buffer, X3H_E_CORRUPT replaces the abort() of ac.c:178. */
+ * input, unchecked, x3.c:621); X3H_E_OUTPUT_FULL asks for a larger buffer, X3H_E_CORRUPT replaces the abort() of ac.c:178.
+ * Workspace: ~200 bytes of HBM per byte of `cap` (the context pool is sized for the worst case), so size `cap` to the data, not to 64x.
+ * x3h_stats of a decode: ms_code = the per-stream chains (one tag per parse step), ms_emit = tags -> bytes, ms_total = both + staging. */
 int x3h_decompress(x3h_ctx *ctx, const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *out_len, x3h_stats *stats);
 
 /* Independent streams (e.g. the chunks of an X3C1 container): stream c is in[in_offsets[c] .. in_offsets[c+1]) and decodes
