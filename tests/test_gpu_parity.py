@@ -364,6 +364,27 @@ def test_pipelined_batch_of_long_streams(gpu, gpu_env):
     assert gpu_env(X3H_SLICED="0").compress_chunks(data, off, prm) == streams   # the prefix-wise pipelined schedule of rounds 1-3
 
 
+def test_mid_size_batch_on_masked_streams_equals_plain_streams_and_oracle(gpu, gpu_env, oracle):
+    """a batch of 4..192 streams of at most 2 MiB takes K3 in slices on three CU-masked HIP streams (coder on the top 32 CUs, parse and features on the others: api.hip
+    sliced_masked_setup) with three to five marks by stream length; the same batch with X3H_SLICE_CUMASK=0 (plain streams, the marks of long streams) and stage after
+    stage gives the same streams; two of them are compared with the CPU oracle"""
+    sizes = [260_000, 140_000, 99_000, 410_000, 0, 180_000, 300_000, 120_000, 98_304, 650_000]
+    text = synth.english_like(sum(sizes), seed=41)
+    off = np.cumsum([0] + sizes).astype(np.uint64)
+    data = text.copy()
+    data[int(off[3]):int(off[4])] = synth.zipf_bytes(sizes[3], offset=7 << 20)
+    data[int(off[6]):int(off[7])] = synth.mr_like(sizes[6], seed=12)
+    prm = _lib.make_params(w_kib=64, t=256)
+    mctx = gpu_env(X3H_SLICE_CUMASK="1")
+    masked = mctx.compress_chunks(data, off, prm)
+    assert mctx.last_stats.pipelined == 2
+    plain = gpu_env(X3H_SLICE_CUMASK="0")
+    assert plain.compress_chunks(data, off, prm) == masked and plain.last_stats.pipelined == 2
+    assert gpu_env(X3H_PIPE_MIN="0").compress_chunks(data, off, prm) == masked
+    for i in (2, 7):
+        assert masked[i] == oracle.compress(data[int(off[i]):int(off[i + 1])].tobytes(), oracle_lib.params(w_kib=64, t=256)), f"stream {i}"
+
+
 def test_decode_batch_of_many_streams(gpu):
     """more than 256 streams select the decoder variant with small LDS tables (ten streams per CU); one stream is rich enough to outgrow
     them (> 2048 dictionary elements -> its tables migrate to global memory)"""

@@ -64,6 +64,15 @@ struct x3h_ctx {
 	bool slice_marks_fixed = false;
 	X3SliceRun sr;
 	hipEvent_t ev_sf[X3S_MAX_SLICES + 2] = {}, ev_sb[X3S_MAX_SLICES + 2] = {}, ev_se[X3S_MAX_SLICES + 2] = {}, ev_sc[X3S_MAX_SLICES + 2] = {}, ev_sa[X3S_MAX_SLICES + 2] = {}, ev_s0 = nullptr;
+	/* Mid-size batches (every stream short enough that the parse is a few milliseconds): the coder's lone wavefronts get CUs of their own (the top 32 of the CU mask),
+	 * parse and feature kernels the rest.  A coder wavefront slows the feature workgroups that share its CU (and the neighbour CU: "odd / even" masks do not help) by a
+	 * factor of two to six -- measured with the coder serialised, with a memory-free kernel in its place and with disjoint masks (profiles/r04_midsize_marks_and_timeline.txt);
+	 * what exactly they compete for is not known (neither scalar loads nor scalar stores nor a saturated scalar unit alone reproduce it).  Three more HIP streams,
+	 * created on first use; X3H_SLICE_CUMASK=0: never. */
+	int slice_cumask = 1;
+	uint64_t slice_cumask_max_len = (uint64_t)2 << 20; /* X3H_SLICE_CUMASK_LEN: longest stream of the batch at most this long (long parses stay on the three plain streams: see sliced_setup) */
+	hipStream_t sm_feat = nullptr, sm_parse = nullptr, sm_coder = nullptr;
+	int sm_state = 0; /* 0: not tried, 1: ready, -1: not available on this device */
 	int slice_bstream = 0;                        /* X3H_SLICE_BSTREAM=1: stage B of a slice (mode chain, models, assembly) on the parse stream once the parse is done, beside stage A of the
 	                                               * next slice.  Measured (round 4): no gain -- stage A, not B, is what a small slice costs (~1.3 ms of launches and latency-bound
 	                                               * per-stream kernels whatever its size), and config 4's share got 3 % slower (437 against 423 ms): off by default */
@@ -159,6 +168,8 @@ extern "C" int x3h_ctx_create(x3h_ctx **out, int device)
 	{ const char *e = getenv("X3H_SLICED"); if (e && *e) c->sliced = *e != '0'; }
 	{ const char *e = getenv("X3H_SLICED_MIN"); if (e && *e) c->sliced_min = (uint64_t)atoll(e); }
 	{ const char *e = getenv("X3H_SLICE_BSTREAM"); if (e && *e) c->slice_bstream = *e != '0'; }
+	{ const char *e = getenv("X3H_SLICE_CUMASK"); if (e && *e) c->slice_cumask = *e != '0'; }
+	{ const char *e = getenv("X3H_SLICE_CUMASK_LEN"); if (e && *e) c->slice_cumask_max_len = (uint64_t)atoll(e); }
 	{ const char *e = getenv("X3H_SLICED_STREAMS"); if (e && *e) c->sliced_max_streams = atoi(e); }
 	{ const char *e = getenv("X3H_SLICE_MARKS");
 	  if (e && *e) {
@@ -213,6 +224,9 @@ extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 	c->c2.est_val.release(); c->c2.est_cls.release(); c->c2.est_out.release();
 	if (c->c2.est_stream) { (void)hipStreamSynchronize(c->c2.est_stream); (void)hipStreamDestroy(c->c2.est_stream); (void)hipEventDestroy(c->c2.ev_est_fork); (void)hipEventDestroy(c->c2.ev_est_done); }
 	if (c->ckpt) (void)hipHostFree((void *)c->ckpt);
+	if (c->sm_feat) (void)hipStreamDestroy(c->sm_feat);
+	if (c->sm_parse) (void)hipStreamDestroy(c->sm_parse);
+	if (c->sm_coder) (void)hipStreamDestroy(c->sm_coder);
 	if (c->s_parse) (void)hipStreamDestroy(c->s_parse);
 	if (c->s_coder) (void)hipStreamDestroy(c->s_coder);
 	if (c->s_emit) (void)hipStreamDestroy(c->s_emit);
@@ -505,9 +519,30 @@ static int sliced_setup(x3h_ctx *c)
 	return X3H_OK;
 }
 
+/* the three masked streams of the mid-size layout: coder = the top 32 CUs of the device's CU mask, parse and features = all the others */
+static bool sliced_masked_setup(x3h_ctx *c)
+{
+	if (c->sm_state) return c->sm_state > 0;
+	c->sm_state = -1;
+	int ncu = 0;
+	if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess || ncu < 128 || ncu > 1024) return false;
+	const uint32_t words = ((uint32_t)ncu + 31) / 32;
+	std::vector<uint32_t> top(words, 0), rest(words, 0);
+	for (int i = 0; i < ncu; i++) (i >= ncu - 32 ? top : rest)[(size_t)i / 32] |= 1u << (i % 32);
+	if (hipExtStreamCreateWithCUMask(&c->sm_feat, words, rest.data()) != hipSuccess || hipExtStreamCreateWithCUMask(&c->sm_parse, words, rest.data()) != hipSuccess ||
+	    hipExtStreamCreateWithCUMask(&c->sm_coder, words, top.data()) != hipSuccess) { (void)hipGetLastError(); return false; }
+	c->sm_state = 1;
+	return true;
+}
+
 static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, uint8_t *d_out, PipeStats *ps, std::vector<float> *est)
 {
 	const uint32_t nc = (uint32_t)c->hchunks.size();
+	/* the three streams of the slices: features, parse (+ bit emission), coder -- plain ones, or the masked ones of the mid-size layout */
+	uint64_t longest_len = 0;
+	for (uint32_t i = 0; i < nc; i++) if (c->hchunks[i].len > longest_len) longest_len = c->hchunks[i].len;
+	const bool masked = c->slice_cumask && nc >= 4 && longest_len <= c->slice_cumask_max_len && sliced_masked_setup(c);
+	hipStream_t sF = masked ? c->sm_feat : c->stream, sP = masked ? c->sm_parse : c->s_parse, sC = masked ? c->sm_coder : c->s_coder;
 	/* how many slices: a slice costs a few hundred microseconds of launches and of latency-bound per-stream kernels whatever its size, so the longest stream is cut
 	 * about every 150 KB, into at most the full set of marks (small slices first: the coder starts early); X3H_SLICE_MARKS fixes the set */
 	uint32_t nmarks = c->slice_nmarks;
@@ -519,10 +554,16 @@ static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, 
 			nmarks = 10;
 			for (uint32_t k = 0; k < nmarks; k++) marks[k] = fine[k];
 		}
-		uint64_t longest = 0;
-		for (uint32_t i = 0; i < nc; i++) if (c->hchunks[i].len > longest) longest = c->hchunks[i].len;
+		const uint64_t longest = longest_len;
 		const uint64_t want = longest / (150u << 10);
-		if (want < nmarks + 1) {
+		if (masked && longest < (900u << 10)) {
+			/* mid-size layout: with the coder on CUs of its own the feature kernels of a slice run at full speed beside it, so more and smaller slices pay (the dickens-sized
+			 * bytes as 24 / 40 / 64 / 96 chunks: 20.6 -> 17.6, 14.0 -> 12.9, 11.1 -> 10.2, 9.5 -> 8.4 ms; profiles/r04_midsize_marks_and_timeline.txt) */
+			static const double m3[3] = { 0.13, 0.40, 0.70 }, m4[4] = { 0.10, 0.25, 0.45, 0.70 }, m5[5] = { 0.08, 0.20, 0.35, 0.55, 0.78 };
+			const double *m = longest < (240u << 10) ? m3 : longest < (400u << 10) ? m4 : m5;
+			nmarks = longest < (240u << 10) ? 3 : longest < (400u << 10) ? 4 : 5;
+			for (uint32_t k = 0; k < nmarks; k++) marks[k] = m[k];
+		} else if (want < nmarks + 1) {
 			nmarks = want >= 2 ? (uint32_t)want - 1 : 1u;
 			for (uint32_t k = 0; k < nmarks; k++) marks[k] = (double)(k + 1) / (double)(nmarks + 1);
 		}
@@ -559,13 +600,14 @@ static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, 
 	HIPCHK(hipHostGetDevicePointer(&dck, (void *)c->ckpt, 0));
 	pa.ckpt = (X3ParseCkpt *)dck; pa.ckpt_pos = c->ckpt_pos.as<uint32_t>(); pa.nckpt = nmarks;
 	HIPCHK(hipEventRecord(c->ev_ready, c->stream));
-	HIPCHK(hipStreamWaitEvent(c->s_parse, c->ev_ready, 0));
-	HIPCHK(hipStreamWaitEvent(c->s_coder, c->ev_ready, 0));
-	HIPCHK(hipEventRecord(c->ev_p0, c->s_parse));
-	x3k_launch_parse(&pa, nc, c->s_parse);
+	HIPCHK(hipStreamWaitEvent(sP, c->ev_ready, 0));
+	HIPCHK(hipStreamWaitEvent(sC, c->ev_ready, 0));
+	if (sF != c->stream) HIPCHK(hipStreamWaitEvent(sF, c->ev_ready, 0));
+	HIPCHK(hipEventRecord(c->ev_p0, sP));
+	x3k_launch_parse(&pa, nc, sP);
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipEventRecord(c->ev_p1, c->s_parse));
-	hipStream_t s_emit = c->s_parse; /* see sliced_setup */
+	HIPCHK(hipEventRecord(c->ev_p1, sP));
+	hipStream_t s_emit = sP; /* see sliced_setup */
 
 	X3SliceRun &R = c->sr;
 	uint32_t *sm = R.small.as<uint32_t>();
@@ -630,16 +672,16 @@ static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, 
 		if (nslice >= (int)X3S_MAX_SLICES + 1) return X3H_E_INTERNAL;
 		uint32_t *d_segoff = nullptr, *d_seglen = nullptr;
 		/* stage A (records, ranks, context statistics) on the handle's stream; its slice temporaries are one of two sets, the one stage B of slice k - 2 has read */
-		if (nslice >= 2) HIPCHK(hipStreamWaitEvent(c->stream, c->ev_sf[nslice - 2], 0));
-		HIPCHK(hipEventRecord(c->ev_sb[nslice], c->stream));
-		CHK(x3s_slice(R, c->stream, c->stream, c->ev_sfork, c->ev_sjoin, c->chunks.as<X3Chunk>(), hs, max_dict, d_bytes, pa.tok_info, pa.dict_len, final,
+		if (nslice >= 2) HIPCHK(hipStreamWaitEvent(sF, c->ev_sf[nslice - 2], 0));
+		HIPCHK(hipEventRecord(c->ev_sb[nslice], sF));
+		CHK(x3s_slice(R, sF, sF, c->ev_sfork, c->ev_sjoin, c->chunks.as<X3Chunk>(), hs, max_dict, d_bytes, pa.tok_info, pa.dict_len, final,
 		              c->c2.want_est, &d_segoff, &d_seglen, 1));
-		HIPCHK(hipEventRecord(c->ev_sa[nslice], c->stream));
+		HIPCHK(hipEventRecord(c->ev_sa[nslice], sF));
 		/* stage B (mode chain, index / order-0 models, symbol assembly): once the parse kernel has finished its HIP stream is free, and stage B of this slice runs
 		 * there beside stage A of the next one; while the parse is still running (long streams) it stays behind stage A on this stream */
 		if (!parse_done) { const hipError_t q = hipEventQuery(c->ev_p1); if (q == hipSuccess) parse_done = true; }
-		hipStream_t sB = parse_done && c->slice_bstream ? c->s_parse : c->stream;
-		if (sB != c->stream) {
+		hipStream_t sB = parse_done && c->slice_bstream ? sP : sF;
+		if (sB != sF) {
 			HIPCHK(hipStreamWaitEvent(sB, c->ev_sa[nslice], 0));
 			if (nslice >= 1) HIPCHK(hipStreamWaitEvent(sB, c->ev_sf[nslice - 1], 0));
 		} else if (nslice >= 1) HIPCHK(hipStreamWaitEvent(sB, c->ev_sf[nslice - 1], 0)); /* (stage B of the slice before may have run on the other stream) */
@@ -653,10 +695,10 @@ static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, 
 		}
 		HIPCHK(hipEventRecord(c->ev_sf[nslice], sB));
 		/* coder recurrence of the slice's symbols, then their bits (both carry their state per stream from launch to launch) */
-		HIPCHK(hipStreamWaitEvent(c->s_coder, c->ev_sf[nslice], 0));
-		HIPCHK(hipEventRecord(c->ev_sc[nslice], c->s_coder));
-		CHK(x3s_ac2_launch(R.sym.as<uint4>(), R.states.as<uint32_t>(), sm + X3S_FINALLO * nc, d_segoff, d_seglen, sm + X3S_CODER * nc, nc, c->s_coder));
-		HIPCHK(hipEventRecord(c->ev_se[nslice], c->s_coder));
+		HIPCHK(hipStreamWaitEvent(sC, c->ev_sf[nslice], 0));
+		HIPCHK(hipEventRecord(c->ev_sc[nslice], sC));
+		CHK(x3s_ac2_launch(R.sym.as<uint4>(), R.states.as<uint32_t>(), sm + X3S_FINALLO * nc, d_segoff, d_seglen, sm + X3S_CODER * nc, nc, sC));
+		HIPCHK(hipEventRecord(c->ev_se[nslice], sC));
 		/* the bit emission of a slice is queued on the parse stream ONE SLICE LATE (and the last ones behind the loop): it waits for its coder segment, and
 		 * whatever is queued behind it on that stream -- stage B of a later slice -- must not wait that long */
 		emit_off[nslice] = d_segoff; emit_len[nslice] = d_seglen;
@@ -667,14 +709,14 @@ static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, 
 		if (final) break;
 	}
 	if (fallback) { /* nothing of the slices is kept: wait for everything in flight, the caller codes the batch stage after stage */
-		HIPCHK(hipStreamSynchronize(c->s_parse)); HIPCHK(hipStreamSynchronize(c->stream)); HIPCHK(hipStreamSynchronize(c->s_coder));
+		HIPCHK(hipStreamSynchronize(sP)); HIPCHK(hipStreamSynchronize(sF)); HIPCHK(hipStreamSynchronize(sC)); HIPCHK(hipStreamSynchronize(c->stream));
 		return X3S_FALLBACK;
 	}
 	HIPCHK(hipEventRecord(c->ev_emit, s_emit));
 	HIPCHK(hipStreamWaitEvent(c->stream, c->ev_emit, 0));
 	/* results: what the parse counted (its own records) and, if asked for, the size estimates */
 	c->hparse.resize(nc);
-	HIPCHK(hipStreamSynchronize(c->s_parse));
+	HIPCHK(hipStreamSynchronize(sP));
 	HIPCHK(hipMemcpyAsync(c->hparse.data(), c->presult.p, (size_t)nc * sizeof(X3ParseResult), hipMemcpyDeviceToHost, c->stream));
 	std::vector<uint32_t> hstat(nc);
 	HIPCHK(hipMemcpyAsync(hstat.data(), sm + X3S_STATUS * nc, (size_t)nc * 4, hipMemcpyDeviceToHost, c->stream));
@@ -717,6 +759,7 @@ static int run_sliced(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, uint8
 	const int rc = run_sliced_body(c, pa, d_bytes, d_out, ps, est);
 	if (rc != X3H_OK && rc != X3S_FALLBACK) { /* never return with work in flight on the side streams */
 		(void)hipStreamSynchronize(c->s_parse); (void)hipStreamSynchronize(c->s_coder); (void)hipStreamSynchronize(c->stream);
+		if (c->sm_state > 0) { (void)hipStreamSynchronize(c->sm_parse); (void)hipStreamSynchronize(c->sm_coder); (void)hipStreamSynchronize(c->sm_feat); }
 	}
 	return rc;
 }
