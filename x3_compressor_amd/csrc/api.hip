@@ -633,7 +633,8 @@ static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, 
 		int lowest = X3_MAX_CKPT;
 		for (uint32_t i = 0; i < nc; i++) {
 			const X3ParseCkpt *ck = c->ckpt + (size_t)i * X3_CKPT_SLOTS;
-			if (avail[i] < X3_MAX_CKPT) {
+			if (avail[i] < X3_MAX_CKPT && avail[i] < next) { /* (a stream that has its record for this slice takes no further one while the others are waited for: a slice
+				                                                   * is ONE step of every stream from mark to mark -- that is what the slice buffers are sized for) */
 				int best = avail[i];
 				for (int k = avail[i] + 1; k < (int)nmarks; k++) { if (ck[k].seq == (uint32_t)k + 1) { best = k; if (k >= next) break; } }
 				if ((best < next || best == avail[i]) && ck[X3_MAX_CKPT].seq == X3_MAX_CKPT + 1) best = X3_MAX_CKPT; /* no mark left to take: the stream is done */
@@ -668,7 +669,11 @@ static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, 
 			sh += s.h1 - s.h0; se += (s.h1 - s.h0) + (s.d1 - s.d0); smi += (s.t1 - s.t0) - (s.h1 - s.h0); sb += s.mb1 - s.mb0; ss += s.t1 - s.t0;
 			sy += 2 * (s.t1 - s.t0) + (s.mb1 - s.mb0) + s.last;
 		}
-		if (max_dict > X3S_DMAX || ss > slice_bytes) { fallback = true; break; } /* (the second: cannot happen, see the marks above) */
+		if (max_dict > X3S_DMAX || ss > slice_bytes) { /* (the second: a safety net; slices are single mark-to-mark steps, see above) */
+			if (getenv("X3H_DEBUG")) fprintf(stderr, "[x3h] sliced: falling back in slice %d: dictionary %llu elements (limit %u), slice of %u tokens (limit %llu)\n", nslice, (unsigned long long)max_dict, (unsigned)X3S_DMAX, ss, (unsigned long long)slice_bytes);
+			if (getenv("X3H_DEBUG")) for (uint32_t i = 0; i < nc; i++) fprintf(stderr, "[x3h]   stream %u (%u bytes): tokens %u..%u, record taken %d\n", i, c->hchunks[i].len, hs[i].t0, hs[i].t1, avail[i]);
+			fallback = true; break;
+		}
 		if (nslice >= (int)X3S_MAX_SLICES + 1) return X3H_E_INTERNAL;
 		uint32_t *d_segoff = nullptr, *d_seglen = nullptr;
 		/* stage A (records, ranks, context statistics) on the handle's stream; its slice temporaries are one of two sets, the one stage B of slice k - 2 has read */
@@ -722,7 +727,10 @@ static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, 
 	HIPCHK(hipMemcpyAsync(hstat.data(), sm + X3S_STATUS * nc, (size_t)nc * 4, hipMemcpyDeviceToHost, c->stream));
 	if (est && c->c2.want_est) { est->resize((size_t)nc * 4); HIPCHK(hipMemcpyAsync(est->data(), sm + X3S_EST * nc, (size_t)nc * 16, hipMemcpyDeviceToHost, c->stream)); }
 	HIPCHK(hipStreamSynchronize(c->stream));
-	for (uint32_t i = 0; i < nc; i++) if (hstat[i] != X3_ST_OK) return X3S_FALLBACK; /* a list pool's bound was violated (adversarial input): every stream is idle, the caller codes the batch stage after stage */
+	for (uint32_t i = 0; i < nc; i++) if (hstat[i] != X3_ST_OK) {
+		if (getenv("X3H_DEBUG")) fprintf(stderr, "[x3h] sliced: stream %u ended with status %u: falling back\n", i, hstat[i]);
+		return X3S_FALLBACK;
+	} /* a list pool's bound was violated (adversarial input): every stream is idle, the caller codes the batch stage after stage */
 	float ms = 0;
 	(void)hipEventElapsedTime(&ms, c->ev_p0, c->ev_p1); ps->ms_parse = ms;
 	for (int i = 0; i < nslice; i++) {
