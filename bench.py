@@ -329,7 +329,7 @@ def main():
         sweep = []
         for nch in (16, 24, 32, 40, 48, 64, 80, 96, 128, 256, 512):
             cb = (N + nch - 1) // nch
-            cdt, clens, cst, coff, d_cout, cstride = chunk_batch(ctx, d_in, N, cb, prm, dev)
+            cdt, clens, cst, coff, d_cout, cstride = chunk_batch(ctx, d_in, N, cb, prm, dev, reps=4)  # (best of four: these are 7-25 ms calls)
             e = {"chunks": len(coff) - 1, "chunk_bytes": cb, "value": round(N / cdt / 1e6, 3), "unit": "MB/s", "ms": round(cdt * 1e3, 3),
                  "ratio": round(N / float(clens.sum()), 4),
                  "stage_ms": {"scan": round(cst.ms_scan, 3), "parse": round(cst.ms_parse, 3), "features": round(cst.ms_features, 3),
