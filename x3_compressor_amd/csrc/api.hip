@@ -22,6 +22,8 @@
 
 extern "C" void x3k_launch_scan(const X3ScanArgs *a, uint32_t max_len, uint32_t nchunks, hipStream_t st);
 extern "C" void x3k_launch_parse(const X3ParseArgs *a, uint32_t nchunks, hipStream_t st);
+struct x3h_ctx;
+static bool sliced_masked_setup(x3h_ctx *c);
 extern "C" void x3k_launch_decode(const X3DecArgs *a, uint32_t nchunks, hipStream_t st);
 extern "C" void x3k_launch_decode_bytes(const X3DecArgs *a, uint32_t nchunks, uint32_t ntiles, hipStream_t st);
 
@@ -71,8 +73,7 @@ struct x3h_ctx {
 	 * created on first use; X3H_SLICE_CUMASK=0: never. */
 	int slice_cumask = 1;
 	uint64_t slice_cumask_max_len = (uint64_t)2 << 20; /* X3H_SLICE_CUMASK_LEN: longest stream of the batch at most this long (long parses stay on the three plain streams: see sliced_setup) */
-	uint64_t slice_cumask_min_len = (uint64_t)150 << 10; /* X3H_SLICE_CUMASK_MIN: ... and at least this long.  Below, the gain depends on the process: tools/chunked_dickens.py gains 8-10 % down to
-	                                                       * 100 KB per stream, the same batches inside bench.py lose 4 % (the feature kernels are only partly freed there; not understood) */
+	uint64_t slice_cumask_min_len = 0; /* X3H_SLICE_CUMASK_MIN: ... and at least this long (tuning) */
 	hipStream_t sm_feat = nullptr, sm_parse = nullptr, sm_coder = nullptr;
 	int sm_state = 0; /* 0: not tried, 1: ready, -1: not available on this device */
 	int slice_bstream = 0;                        /* X3H_SLICE_BSTREAM=1: stage B of a slice (mode chain, models, assembly) on the parse stream once the parse is done, beside stage A of the
@@ -183,10 +184,15 @@ extern "C" int x3h_ctx_create(x3h_ctx **out, int device)
 	{ const char *e = getenv("X3H_SEG_EMIT"); if (e && *e) c->seg_emit = *e != '0' ? 1 : 0; }
 	const double t_c2 = x3_now_ms();
 	if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return X3H_E_HIP; }
+	/* the three CU-masked streams of the mid-size layout are made NOW, right behind the handle's own stream: made later (on first use, behind the plain parse and coder streams
+	 * and whatever else the process has created meanwhile) they separated coder and feature kernels only in some processes -- bench.py, which makes its handle before torch
+	 * touches the device, lost what tools/chunked_dickens.py gained (profiles/r04_midsize_marks_and_timeline.txt: creation orders); made here they work in both */
+	const double t_c2b = x3_now_ms();
+	if (c->slice_cumask) (void)sliced_masked_setup(c);
 	const double t_c3 = x3_now_ms();
 	for (int i = 0; i < 6; i++)
 		if (hipEventCreate(&c->ev[i]) != hipSuccess) { x3h_ctx_destroy(c); return X3H_E_HIP; }
-	if (getenv("X3H_DEBUG")) fprintf(stderr, "[x3h] handle: device count (runtime start) %.1f ms, set device %.1f, stream %.1f, events %.1f\n", t_c1 - t_c0, t_c2 - t_c1, t_c3 - t_c2, x3_now_ms() - t_c3);
+	if (getenv("X3H_DEBUG")) fprintf(stderr, "[x3h] handle: device count (runtime start) %.1f ms, set device %.1f, stream %.1f, three masked streams %.1f, events %.1f\n", t_c1 - t_c0, t_c2 - t_c1, t_c2b - t_c2, t_c3 - t_c2b, x3_now_ms() - t_c3);
 	*out = c;
 	return X3H_OK;
 }

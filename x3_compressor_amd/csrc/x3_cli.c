@@ -127,6 +127,8 @@ int main(int argc, char *argv[])
 	g_phase = 1;
 	x3h_default_params(&prm);
 	{ const char *e = getenv("X3_RCCL"); use_rccl = e && *e && *e != '0'; }
+	/* a short-lived process: the three CU-masked streams a handle makes for mid-size batches (~30 ms of queue creation) would cost more than they can save here */
+	(void)setenv("X3H_SLICE_CUMASK", "0", 0);
 	static const struct option longopts[] = { { "chunk-kib", required_argument, NULL, 1000 }, { "gpus", required_argument, NULL, 1001 }, { "batch-mib", required_argument, NULL, 1002 },
 	                                          { "rccl", no_argument, NULL, 1003 }, { NULL, 0, NULL, 0 } };
 
