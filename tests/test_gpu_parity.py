@@ -629,6 +629,8 @@ def test_per_chunk_scan_equals_brute_force_kernel(gpu_env, monkeypatch, env):
         (rng.integers(0, 4, 60_000, dtype=np.uint8).tobytes(), dict(w_kib=64, t=3)),
         (synth.english_like(30_000, seed=6).tobytes(), dict(w_kib=256, t=1024)),
         (b"abc", dict(w_kib=8, t=16)),
+        (synth.english_like(40_000, seed=8).tobytes(), dict(w_kib=64, t=5000)),  # T + 1 beyond a tile: every look-ahead entry comes from memory
+        (synth.zipf_bytes(20_000, offset=5).tobytes(), dict(w_kib=16, t=4094)),    # ... and exactly one tile
     ]
     ctx = gpu_env(**env)
     try:

@@ -249,6 +249,8 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 		if (seg_form == 2) { CHK(B.a[23].reserve(P / 4 + 64)); HIPCHK(hipMemsetAsync(B.a[23].p, 0, P / 4 + 64, st)); ga.gmf = B.a[23].as<uint32_t>(); }
 		if (getenv("X3H_DEBUG")) fprintf(stderr, "[x3h] scan: one workgroup per chunk (%u chunks, longest %llu)\n", nc, (unsigned long long)max_len);
 		ga.prof = nullptr;
+		ga.la_lds = 1u; ga._pad = 0u;
+		if (const char *e = getenv("X3H_SEG_LA_LDS")) ga.la_lds = atoi(e) != 0;
 		const bool prof = getenv("X3H_SEG_PROF") != nullptr;
 		if (prof) { CHK(B.a[22].reserve(128)); HIPCHK(hipMemsetAsync(B.a[22].p, 0, 128, st)); ga.prof = B.a[22].as<uint64_t>(); }
 		CHK(x3_scan_seg_launch(ga, nc, st));

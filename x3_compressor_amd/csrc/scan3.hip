@@ -33,17 +33,52 @@
 
 __device__ static __forceinline__ uint32_t seg_bswap(uint32_t v) { return __builtin_bswap32(v); }
 
-/* mask of the lanes (among `valid` ones) that hold the same 8-bit digit as this lane: one ballot per digit bit */
-__device__ static __forceinline__ uint64_t seg_match8(uint32_t d, bool valid)
+/* the lanes (among `valid` ones) that hold the same NB-bit digit as this lane, as the two halves of a lane mask: one ballot per digit bit.  Per
+ * bit and half ONE three-input operation  m & ~(ballot ^ -bit)  (gfx950: v_bitop3_b32); written on 64-bit values with a per-lane select the
+ * compiler spends eleven vector instructions per bit, and the ranking was half of a sorting pass's instructions. */
+template <uint32_t NB>
+__device__ static __forceinline__ void seg_match(uint32_t d, bool valid, uint32_t &mlo, uint32_t &mhi)
 {
-	uint64_t mask = x3_ballot(valid);
+	const uint64_t v = x3_ballot(valid);
+	mlo = (uint32_t)v; mhi = (uint32_t)(v >> 32);
 #pragma unroll
-	for (uint32_t b = 0; b < 8; b++) {
-		const bool bit = (d >> b) & 1u;
-		const uint64_t bal = x3_ballot(bit);
-		mask &= bit ? bal : ~bal;
+	for (uint32_t b = 0; b < NB; b++) {
+#ifndef X3_EMU
+		const uint32_t sgn = (uint32_t)__builtin_amdgcn_sbfe((int)d, b, 1u);
+		const uint64_t bal = x3_ballot(sgn != 0u);
+		mlo = __builtin_amdgcn_bitop3_b32(mlo, (uint32_t)bal, sgn, 0x90); /* 0x90: a & ~(b ^ c) */
+		mhi = __builtin_amdgcn_bitop3_b32(mhi, (uint32_t)(bal >> 32), sgn, 0x90);
+#else
+		const uint32_t sgn = 0u - ((d >> b) & 1u);
+		const uint64_t bal = x3_ballot(sgn != 0u);
+		mlo &= ~((uint32_t)bal ^ sgn);
+		mhi &= ~((uint32_t)(bal >> 32) ^ sgn);
+#endif
 	}
-	return mask;
+}
+/* this lane's rank among the lanes of the mask, and the mask's size */
+__device__ static __forceinline__ uint32_t seg_lower(uint32_t mlo, uint32_t mhi)
+{
+#ifndef X3_EMU
+	return __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+#else
+	const uint64_t m = ((uint64_t)mhi << 32) | mlo;
+	return (uint32_t)x3_popc64(m & (((uint64_t)1 << x3_lane()) - 1u));
+#endif
+}
+__device__ static __forceinline__ uint32_t seg_size(uint32_t mlo, uint32_t mhi) { return (uint32_t)__builtin_popcount(mlo) + (uint32_t)__builtin_popcount(mhi); }
+
+/* sum of the first `wv` of the workgroup's per-wave totals (wt: X3_SEG_WAVES = 16 words, 16-byte aligned): four wide reads in flight together --
+ * a loop over wv words is a chain of up to fifteen LDS round trips on every tile */
+__device__ static __forceinline__ uint32_t seg_waves_before(const uint32_t *wt, uint32_t wv)
+{
+	static_assert(X3_SEG_WAVES == 16u, "four uint4");
+	const uint4 a = ((const uint4 *)wt)[0], b = ((const uint4 *)wt)[1], c = ((const uint4 *)wt)[2], d = ((const uint4 *)wt)[3];
+	const uint32_t t[16] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w };
+	uint32_t s = 0;
+#pragma unroll
+	for (uint32_t w = 0; w < 16u; w++) s += w < wv ? t[w] : 0u;
+	return s;
 }
 
 /* Padding.  The W zero bytes behind a chunk take part in its windows (x3.c:579,590), but they are not sorted: the lists hold the END positions
@@ -53,10 +88,22 @@ __device__ static __forceinline__ uint64_t seg_match8(uint32_t d, bool valid)
  * inside the window. */
 __device__ static __forceinline__ uint32_t seg_cpad(uint32_t qrel, uint32_t ncand, uint32_t n) { const uint32_t we = qrel + ncand; return we >= n + 3u ? we - n - 2u : 0u; }
 
+/* The list a level test reads.  A test of entry j looks at entries j + 1 .. j + T + 1 only, so while a tile of the list is ranked, the tile and the
+ * X3_SEG_HALO entries behind it stand in LDS in list order (`lds`, entry t0 first) and the tests read them there: asked of memory, every one of
+ * these reads is a round trip of a microsecond that a whole workgroup waits for (level 1 of a byte that is rare in its window searches ~8 entries
+ * one after the other; a third of all positions of Zipf-distributed bytes).  T + 1 > X3_SEG_HALO, or X3H_SEG_LA_LDS=0: `lds` = nullptr, memory. */
+#define X3_SEG_HALO 512u
+struct SegList {
+	const uint2 *g;   /* the list in memory */
+	const uint2 *lds; /* entries t0 .. t0 + X3_SEG_TILE + X3_SEG_HALO - 1 of it, or nullptr */
+	uint32_t t0;
+	__device__ __forceinline__ uint2 at(uint32_t idx) const { return (lds && idx - t0 < X3_SEG_TILE + X3_SEG_HALO) ? lds[idx - t0] : g[idx]; }
+};
+
 /* the test of level lv (gram length lv) for entry j = `it` of list lv; `la` = entry j + T + 1 of the same list (position 0xFFFFFFFF when
  * there is none); list = list lv as (key, position) pairs.  Level 1 fixes K = min(T+1, count_0) (positions with a smaller K are marked in
  * `rbits`, their K goes to kexact); levels 2, 3 add one to the position's 2-bit counter when count_{lv-1} >= K. */
-__device__ static __forceinline__ void seg_level(uint32_t lv, const uint2 it, const uint2 la, uint32_t j, const uint2 *list, uint32_t L, uint32_t n,
+__device__ static __forceinline__ void seg_level(uint32_t lv, const uint2 it, const uint2 la, uint32_t j, const SegList &list, uint32_t L, uint32_t n,
                                                  uint32_t base, uint32_t ncand, uint32_t Tu, uint32_t *mfield, uint32_t *rbits, uint32_t *kexact)
 {
 	if (lv == 1u) {
@@ -69,13 +116,13 @@ __device__ static __forceinline__ void seg_level(uint32_t lv, const uint2 it, co
 		else {
 			if (cpad > Tu) return;
 			const uint32_t u = j + (Tu + 1u - cpad);
-			if (u < L) { const uint2 eu = list[u]; if ((eu.x & 0xFFu) == kj && eu.y - base <= wend) return; }
+			if (u < L) { const uint2 eu = list.at(u); if ((eu.x & 0xFFu) == kj && eu.y - base <= wend) return; }
 		}
 		uint32_t lo = 0, bnd = Tu - cpad; /* count the listed ones: binary search, predicate true at lo */
 		if (j + bnd >= L) bnd = L - 1u - j;
 		while (lo < bnd) {
 			const uint32_t mid = (lo + bnd + 1u) >> 1;
-			const uint2 em = list[j + mid];
+			const uint2 em = list.at(j + mid);
 			if ((em.x & 0xFFu) == kj && em.y - base <= wend) lo = mid; else bnd = mid - 1u;
 		}
 		kexact[it.y] = lo + cpad; /* == count_0 */
@@ -95,14 +142,14 @@ __device__ static __forceinline__ void seg_level(uint32_t lv, const uint2 it, co
 	else {
 		const uint32_t u = j + (Tu + 1u - cpad);
 		pass = false;
-		if (u < L) { const uint2 eu = list[u]; pass = ((eu.x ^ it.x) & msk) == 0u && eu.y - base <= wend; }
+		if (u < L) { const uint2 eu = list.at(u); pass = ((eu.x ^ it.x) & msk) == 0u && eu.y - base <= wend; }
 	}
 	if (!pass && ((rbits[prel >> 5] >> (prel & 31u)) & 1u)) {
 		const uint32_t K = kexact[base + prel];
 		if (K >= 2u) { /* K < 2: count_0 < 2, nothing repeats */
 			if (cpad >= K) pass = true;
 			else if (j + (K - cpad) < L) {
-				const uint2 eu = list[j + (K - cpad)];
+				const uint2 eu = list.at(j + (K - cpad));
 				pass = ((eu.x ^ it.x) & msk) == 0u && eu.y - base <= wend;
 			}
 		}
@@ -128,8 +175,9 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 	X3_LDS uint32_t mfield_l[BIG ? 1 : X3_SEG_MAXLEN / 16]; /* 2 bits per position: levels 1..3 passed so far */
 	X3_LDS uint32_t rbits_l[BIG ? 1 : X3_SEG_MAXLEN / 32];  /* positions whose K is below T+1 */
 	X3_LDS uint32_t cnt[256 * X3_SEG_WAVES];           /* [digit][wave]: counts, then exclusive prefix in tile-sorted order */
-	X3_LDS uint2 stage[X3_SEG_TILE];                   /* the tile in sorted order (phase 0: eight copies of the byte histogram) */
-	X3_LDS uint32_t bbase[256], bcur[256], wtot[X3_SEG_WAVES];
+	X3_LDS uint2 stage[X3_SEG_TILE + X3_SEG_HALO];     /* the tile in list order + the entries behind it (level tests), then the tile in sorted order (phase 0: eight copies of the byte histogram) */
+	X3_LDS uint32_t bbase[256], bcur[256];
+	X3_LDS __attribute__((aligned(16))) uint32_t wtot[X3_SEG_WAVES];
 
 	const uint32_t tid = threadIdx.x, lane = x3_lane(), wv = tid / X3_WAVE;
 	const X3Chunk ck = a.chunks[blockIdx.x];
@@ -137,6 +185,7 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 	/* elements q = 0 .. L-1: the END positions of every l-gram (l <= 4) that starts inside the data; the padding behind is counted, not sorted (seg_cpad) */
 	const uint32_t L = n ? n + 3u : 0u;
 	const uint32_t ncand = a.ncand, Tu = a.Tu;
+	const bool la_lds = a.la_lds != 0u && a.Tu + 1u <= X3_SEG_HALO;
 	uint2 *A = a.la + base, *Bq = a.lb + base;
 	uint32_t *S4 = a.S4 + base, *K4 = a.K4 + base;
 
@@ -179,9 +228,7 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 		}
 		__syncthreads();
 		if (tid < 256u) {
-			uint32_t off = 0;
-			for (uint32_t w = 0; w < wv; w++) off += wtot[w];
-			bbase[tid] = off + incl - h;
+			bbase[tid] = seg_waves_before(wtot, wv) + incl - h;
 		}
 	}
 	__syncthreads();
@@ -200,38 +247,51 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 #pragma unroll
 			for (uint32_t e = 0; e < X3_SEG_E; e++) nx[e] = i0 + e * X3_WAVE < L ? (l == 1u ? seg_gen(a.bytes, base, i0 + e * X3_WAVE) : in[i0 + e * X3_WAVE]) : none;
 		}
+		const bool stg = lv && la_lds;
+		uint2 hx = none; /* one of the X3_SEG_HALO entries behind the tile, asked for a tile ahead */
+		if (stg && tid < X3_SEG_HALO && X3_SEG_TILE + tid < L) hx = in[X3_SEG_TILE + tid];
 		for (uint32_t t0 = 0; t0 < L; t0 += X3_SEG_TILE) {
 			*(uint4 *)&cnt[tid * 4u] = make_uint4(0u, 0u, 0u, 0u);
 			uint2 it[X3_SEG_E], la[X3_SEG_E];
 			uint32_t rk[X3_SEG_E];
-			const uint32_t i0 = t0 + wv * (X3_SEG_E * X3_WAVE) + lane;
+			const uint32_t i0 = t0 + wv * (X3_SEG_E * X3_WAVE) + lane, loc0 = wv * (X3_SEG_E * X3_WAVE) + lane;
+			const SegList list = { in, stg ? stage : nullptr, t0 };
 #pragma unroll
 			for (uint32_t e = 0; e < X3_SEG_E; e++) it[e] = nx[e];
+			if (stg) {
+#pragma unroll
+				for (uint32_t e = 0; e < X3_SEG_E; e++) stage[loc0 + e * X3_WAVE] = it[e];
+				if (tid < X3_SEG_HALO) stage[X3_SEG_TILE + tid] = hx;
+			} else if (lv) {
+#pragma unroll
+				for (uint32_t e = 0; e < X3_SEG_E; e++) { const uint32_t u = i0 + e * X3_WAVE + Tu + 1u; la[e] = u < L ? in[u] : none; }
+			}
 			if (t0 + X3_SEG_TILE < L) { /* the next tile's entries are on their way while this one is ranked */
 #pragma unroll
 				for (uint32_t e = 0; e < X3_SEG_E; e++) { const uint32_t idx = i0 + X3_SEG_TILE + e * X3_WAVE; nx[e] = idx < L ? (l == 1u ? seg_gen(a.bytes, base, idx) : in[idx]) : none; }
-			}
-			if (lv) {
-#pragma unroll
-				for (uint32_t e = 0; e < X3_SEG_E; e++) { const uint32_t u = i0 + e * X3_WAVE + Tu + 1u; la[e] = u < L ? in[u] : none; }
+				if (stg && tid < X3_SEG_HALO) { const uint32_t idx = t0 + 2u * X3_SEG_TILE + tid; hx = idx < L ? in[idx] : none; }
 			}
 			__syncthreads();
 #pragma unroll
 			for (uint32_t e = 0; e < X3_SEG_E; e++) {
 				const bool valid = i0 + e * X3_WAVE < L;
 				const uint32_t d = (it[e].x >> sh) & 0xFFu;
-				const uint64_t mask = seg_match8(d, valid);
-				const uint32_t lower = (uint32_t)x3_popc64(mask & (((uint64_t)1 << lane) - 1u));
+				uint32_t mlo, mhi;
+				seg_match<8>(d, valid, mlo, mhi);
+				const uint32_t lower = seg_lower(mlo, mhi);
 				const uint32_t prev = valid ? cnt[d * X3_SEG_WAVES + wv] : 0u;
 				x3_wave_order();
-				if (valid && lower == 0u) cnt[d * X3_SEG_WAVES + wv] = prev + (uint32_t)x3_popc64(mask);
+				if (valid && lower == 0u) cnt[d * X3_SEG_WAVES + wv] = prev + seg_size(mlo, mhi);
 				x3_wave_order();
 				rk[e] = prev + lower;
 			}
 			if (lv) {
 #pragma unroll
 				for (uint32_t e = 0; e < X3_SEG_E; e++)
-					if (i0 + e * X3_WAVE < L) seg_level(lv, it[e], la[e], i0 + e * X3_WAVE, in, L, n, base, ncand, Tu, mfield, rbits, a.kexact);
+					if (stg) la[e] = stage[loc0 + e * X3_WAVE + Tu + 1u]; /* (entries behind the list's end read as `none`) */
+#pragma unroll
+				for (uint32_t e = 0; e < X3_SEG_E; e++)
+					if (i0 + e * X3_WAVE < L) seg_level(lv, it[e], la[e], i0 + e * X3_WAVE, list, L, n, base, ncand, Tu, mfield, rbits, a.kexact);
 			}
 			__syncthreads();
 			/* exclusive scan of the counter table in (digit, wave) order = the tile-sorted order */
@@ -240,8 +300,7 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 			const uint32_t incl = x3_wave_incl_scan_u32(s);
 			if (lane == X3_WAVE - 1u) wtot[wv] = incl;
 			__syncthreads();
-			uint32_t ex = incl - s;
-			for (uint32_t w = 0; w < wv; w++) ex += wtot[w];
+			const uint32_t ex = incl - s + seg_waves_before(wtot, wv);
 			*(uint4 *)&cnt[tid * 4u] = make_uint4(ex, ex + c.x, ex + c.x + c.y, ex + c.x + c.y + c.z);
 			__syncthreads();
 			const uint32_t tile_n = L - t0 < X3_SEG_TILE ? L - t0 : X3_SEG_TILE;
@@ -272,14 +331,33 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 
 	/* ---- level 4 on list 4: count_3 >= K -> m >= 3, and deeper levels need the candidates themselves (walk kernel) -- unless the class has
 	 * more than dense_at members inside the window: then it is refined instead (scan2.hip) ---- */
+	uint32_t nk[X3_SEG_E], ns[X3_SEG_E];
+#pragma unroll
+	for (uint32_t e = 0; e < X3_SEG_E; e++) { const uint32_t j = e * X3_SEG_THREADS + tid; nk[e] = j < L ? K4[j] : 0u; ns[e] = j < L ? S4[j] : 0xFFFFFFFFu; }
+	uint2 hx4 = make_uint2(0u, 0xFFFFFFFFu); /* (key, position) of one of the entries behind the tile */
+	if (la_lds && tid < X3_SEG_HALO && X3_SEG_TILE + tid < L) hx4 = make_uint2(K4[X3_SEG_TILE + tid], S4[X3_SEG_TILE + tid]);
 	for (uint32_t j0 = 0; j0 < L; j0 += X3_SEG_TILE) { /* uniform trip count: the queue push below is a wave operation */
 		uint32_t kk[X3_SEG_E], ss[X3_SEG_E], ku[X3_SEG_E], su[X3_SEG_E];
 #pragma unroll
 		for (uint32_t e = 0; e < X3_SEG_E; e++) {
-			const uint32_t j = j0 + e * X3_SEG_THREADS + tid, u = j + Tu + 1u;
-			kk[e] = j < L ? K4[j] : 0u; ss[e] = j < L ? S4[j] : 0xFFFFFFFFu;
-			ku[e] = u < L ? K4[u] : 0u; su[e] = u < L ? S4[u] : 0xFFFFFFFFu;
+			const uint32_t loc = e * X3_SEG_THREADS + tid, u = j0 + loc + Tu + 1u;
+			kk[e] = nk[e]; ss[e] = ns[e];
+			if (la_lds) stage[loc] = make_uint2(kk[e], ss[e]);
+			else { ku[e] = u < L ? K4[u] : 0u; su[e] = u < L ? S4[u] : 0xFFFFFFFFu; }
 		}
+		if (la_lds && tid < X3_SEG_HALO) stage[X3_SEG_TILE + tid] = hx4;
+		if (j0 + X3_SEG_TILE < L) { /* the next tile's entries, asked for now */
+#pragma unroll
+			for (uint32_t e = 0; e < X3_SEG_E; e++) { const uint32_t j = j0 + X3_SEG_TILE + e * X3_SEG_THREADS + tid; nk[e] = j < L ? K4[j] : 0u; ns[e] = j < L ? S4[j] : 0xFFFFFFFFu; }
+			if (la_lds && tid < X3_SEG_HALO) { const uint32_t idx = j0 + 2u * X3_SEG_TILE + tid; hx4 = idx < L ? make_uint2(K4[idx], S4[idx]) : make_uint2(0u, 0xFFFFFFFFu); }
+		}
+		if (la_lds) {
+			__syncthreads();
+#pragma unroll
+			for (uint32_t e = 0; e < X3_SEG_E; e++) { const uint2 t = stage[e * X3_SEG_THREADS + tid + Tu + 1u]; ku[e] = t.x; su[e] = t.y; }
+		}
+		/* entry idx of list 4 as (key, position): out of the LDS copy where it has it */
+#define SEG_L4(idx) ((la_lds && (idx) - j0 < X3_SEG_TILE + X3_SEG_HALO) ? stage[(idx) - j0] : make_uint2(K4[idx], S4[idx]))
 #pragma unroll
 		for (uint32_t e = 0; e < X3_SEG_E; e++) {
 			const uint32_t j = j0 + e * X3_SEG_THREADS + tid;
@@ -293,18 +371,20 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 				bool pass;
 				if (cpad == 0u) pass = ku[e] == kk[e] && su[e] - base <= wend;
 				else if (cpad > Tu) pass = true;
-				else { const uint32_t u = j + (Tu + 1u - cpad); pass = u < L && K4[u] == kk[e] && S4[u] - base <= wend; }
+				else { const uint32_t u = j + (Tu + 1u - cpad); pass = false; if (u < L) { const uint2 eu = SEG_L4(u); pass = eu.x == kk[e] && eu.y - base <= wend; } }
 				if (!pass && ((rbits[prel >> 5] >> (prel & 31u)) & 1u)) {
 					K = a.kexact[gp];
 					if (K >= 2u) {
 						if (cpad >= K) pass = true;
-						else if (j + (K - cpad) < L) pass = K4[j + (K - cpad)] == kk[e] && S4[j + (K - cpad)] - base <= wend;
+						else if (j + (K - cpad) < L) { const uint2 eu = SEG_L4(j + (K - cpad)); pass = eu.x == kk[e] && eu.y - base <= wend; }
 					}
 				}
 				if (pass) {
 					atomicAdd(&mfield[prel >> 4], 1u << (2u * (prel & 15u)));
 					const uint32_t ud = j + a.dense_at;
-					if (ud < L && K4[ud] == kk[e] && S4[ud] - base <= wend && S4[ud] - base - 3u < n) { a.nact[1] = 1u; a.dense_chunk[blockIdx.x] = 1u; }
+					uint2 ed = make_uint2(0u, 0u);
+					if (ud < L) ed = SEG_L4(ud);
+					if (ud < L && ed.x == kk[e] && ed.y - base <= wend && ed.y - base - 3u < n) { a.nact[1] = 1u; a.dense_chunk[blockIdx.x] = 1u; }
 					else push = true;
 				}
 			}
@@ -319,7 +399,9 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 				}
 			}
 		}
+		if (la_lds) __syncthreads(); /* (the next tile overwrites the LDS copy) */
 	}
+#undef SEG_L4
 	__syncthreads();
 	SEG_MARK(5);
 
@@ -390,10 +472,8 @@ __device__ static __forceinline__ uint32_t ref_block_excl(uint32_t v, uint32_t *
 	__syncthreads(); /* (the previous use of wt is over) */
 	if (lane == X3_WAVE - 1u) wt[wv] = incl;
 	__syncthreads();
-	uint32_t ex = incl - v, tot = 0;
-	for (uint32_t w = 0; w < X3_SEG_WAVES; w++) { const uint32_t t = wt[w]; if (w < wv) ex += t; tot += t; }
-	total = tot;
-	return ex;
+	total = seg_waves_before(wt, X3_SEG_WAVES);
+	return incl - v + seg_waves_before(wt, wv);
 }
 
 /* one stable counting-sort pass over list `in` (cnt entries) on digit (key >> sh) & 511 with key = class << 8 | byte; hist = this digit's
@@ -433,13 +513,12 @@ __device__ static void ref_sort_pass(const uint2 *in, uint2 *out, uint32_t n, ui
 #pragma unroll
 		for (uint32_t e = 0; e < X3_SEG_E; e++) {
 			const bool valid = i0 + e * X3_WAVE < n;
-			uint64_t mask = x3_ballot(valid);
-#pragma unroll
-			for (uint32_t b = 0; b < X3_REF_DB; b++) { const bool bit = (dg[e] >> b) & 1u; const uint64_t bal = x3_ballot(bit); mask &= bit ? bal : ~bal; }
-			const uint32_t lower = (uint32_t)x3_popc64(mask & (((uint64_t)1 << lane) - 1u));
+			uint32_t mlo, mhi;
+			seg_match<X3_REF_DB>(dg[e], valid, mlo, mhi);
+			const uint32_t lower = seg_lower(mlo, mhi);
 			const uint32_t prev = valid ? cnt_t[dg[e] * X3_SEG_WAVES + wv] : 0u;
 			x3_wave_order();
-			if (valid && lower == 0u) cnt_t[dg[e] * X3_SEG_WAVES + wv] = prev + (uint32_t)x3_popc64(mask);
+			if (valid && lower == 0u) cnt_t[dg[e] * X3_SEG_WAVES + wv] = prev + seg_size(mlo, mhi);
 			x3_wave_order();
 			rk[e] = prev + lower;
 		}
@@ -481,7 +560,8 @@ __device__ static void x3_segrefine_body(const X3SegArgs &a)
 	X3_LDS uint2 stage[X3_SEG_TILE];                       /* 32 KiB */
 	X3_LDS uint32_t keepbits[X3_SEG_MAXLEN / 32 + 2];      /* one bit per class of the current list: a member passed this level */
 	X3_LDS uint32_t kpre[X3_SEG_MAXLEN / 32 + 2];          /* kept classes before each bitmap word */
-	X3_LDS uint32_t hist[X3_REF_MAXPASS][X3_REF_DIGITS], bcur[X3_REF_DIGITS], wt[X3_SEG_WAVES];
+	X3_LDS uint32_t hist[X3_REF_MAXPASS][X3_REF_DIGITS], bcur[X3_REF_DIGITS];
+	X3_LDS __attribute__((aligned(16))) uint32_t wt[X3_SEG_WAVES];
 	const uint32_t tid = threadIdx.x, lane = x3_lane(), wv = tid / X3_WAVE;
 	const uint32_t c = blockIdx.x;
 	if (!a.dense_chunk[c]) return; /* (uniform) no class of this chunk was dense */

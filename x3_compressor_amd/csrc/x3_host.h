@@ -103,6 +103,7 @@ struct X3SegArgs {
 	uint32_t *act, *act_k, *act_j, *nact; /* out: positions for the walk kernel; nact[0] = their number, nact[1] = a dense class was met, nact[2] = the per-chunk refinement gave up */
 	uint32_t *dense_chunk;       /* out, per chunk (zeroed by the caller): a class of this chunk is dense -> x3_segrefine_kernel */
 	uint32_t window, ncand, Tu, dense_at;
+	uint32_t la_lds, _pad;       /* 1: entry j + T + 1 of a tile's entries is read out of LDS where it lies inside the tile (X3H_SEG_LA_LDS; scan3.hip) */
 	uint64_t *prof;              /* nullptr, or 16 cycle counters: phase 0, passes 1-4, levels 1-4 (X3H_SEG_PROF, debugging) */
 };
 int x3_scan_seg_applies(uint32_t nchunks, uint64_t max_len, uint64_t padded_total = 0); /* 0: no, 1: counters in LDS, 2: counters in global memory */
