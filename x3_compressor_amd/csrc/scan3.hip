@@ -104,7 +104,7 @@ struct SegList {
  * there is none); list = list lv as (key, position) pairs.  Level 1 fixes K = min(T+1, count_0) (positions with a smaller K are marked in
  * `rbits`, their K goes to kexact); levels 2, 3 add one to the position's 2-bit counter when count_{lv-1} >= K. */
 __device__ static __forceinline__ void seg_level(uint32_t lv, const uint2 it, const uint2 la, uint32_t j, const SegList &list, uint32_t L, uint32_t n,
-                                                 uint32_t base, uint32_t ncand, uint32_t Tu, uint32_t *mfield, uint32_t *rbits, uint32_t *kexact)
+                                                 uint32_t base, uint32_t ncand, uint32_t Tu, uint32_t *mfield, uint32_t *rbits, uint32_t *kexact, bool mf_lds)
 {
 	if (lv == 1u) {
 		const uint32_t prel = it.y - base;
@@ -144,7 +144,10 @@ __device__ static __forceinline__ void seg_level(uint32_t lv, const uint2 it, co
 		pass = false;
 		if (u < L) { const uint2 eu = list.at(u); pass = ((eu.x ^ it.x) & msk) == 0u && eu.y - base <= wend; }
 	}
-	if (!pass && ((rbits[prel >> 5] >> (prel & 31u)) & 1u)) {
+	/* (levels pass in order -- count_l <= count_{l-1} -- so a marked position whose counter says that it failed the level before fails this one, and
+	 * its K stays where it is: the load is a scattered one, and most marked positions fail level 2.  Timing switches, tools/exp: the small-K path was
+	 * three quarters of what the level tests cost.) */
+	if (!pass && ((rbits[prel >> 5] >> (prel & 31u)) & 1u) && (lv < 3u || !mf_lds || ((mfield[prel >> 4] >> (2u * (prel & 15u))) & 3u) >= lv - 2u)) {
 		const uint32_t K = kexact[base + prel];
 		if (K >= 2u) { /* K < 2: count_0 < 2, nothing repeats */
 			if (cpad >= K) pass = true;
@@ -291,7 +294,7 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 					if (stg) la[e] = stage[loc0 + e * X3_WAVE + Tu + 1u]; /* (entries behind the list's end read as `none`) */
 #pragma unroll
 				for (uint32_t e = 0; e < X3_SEG_E; e++)
-					if (i0 + e * X3_WAVE < L) seg_level(lv, it[e], la[e], i0 + e * X3_WAVE, list, L, n, base, ncand, Tu, mfield, rbits, a.kexact);
+					if (i0 + e * X3_WAVE < L) seg_level(lv, it[e], la[e], i0 + e * X3_WAVE, list, L, n, base, ncand, Tu, mfield, rbits, a.kexact, !BIG);
 			}
 			__syncthreads();
 			/* exclusive scan of the counter table in (digit, wave) order = the tile-sorted order */
@@ -372,7 +375,7 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 				if (cpad == 0u) pass = ku[e] == kk[e] && su[e] - base <= wend;
 				else if (cpad > Tu) pass = true;
 				else { const uint32_t u = j + (Tu + 1u - cpad); pass = false; if (u < L) { const uint2 eu = SEG_L4(u); pass = eu.x == kk[e] && eu.y - base <= wend; } }
-				if (!pass && ((rbits[prel >> 5] >> (prel & 31u)) & 1u)) {
+				if (!pass && ((rbits[prel >> 5] >> (prel & 31u)) & 1u) && (BIG || ((mfield[prel >> 4] >> (2u * (prel & 15u))) & 3u) >= 2u)) { /* (failed level 3: fails this one) */
 					K = a.kexact[gp];
 					if (K >= 2u) {
 						if (cpad >= K) pass = true;
