@@ -798,11 +798,11 @@ int x3_scan_seg_applies(uint32_t nchunks, uint64_t max_len, uint64_t padded_tota
 	uint32_t min_streams = X3_SEG_MIN_STREAMS, min_big = X3_SEG_MIN_STREAMS_BIG;
 	bool forced = false;
 	if (const char *e = getenv("X3H_SEG_MIN")) { const int v = atoi(e); if (v >= 1) { min_streams = min_big = (uint32_t)v; forced = true; } else if (v == 0 && *e == '0') return 0; }
-	/* between 48 and ~100 chunks the chip-wide sort can be the faster one: a workgroup per chunk is a chain whose length is the CHUNK (0.45 ms + 9.3 ns per byte,
-	 * in rounds of 256 chunks), the chip-wide form streams the padded layout of the BATCH (0.9 ms + 45 ns per KB): 64 chunks of 159 KB take 1.93 against 1.45 ms
-	 * (round 4: the dickens-sized bytes as 48 / 64 / 96 chunks, gpurun_out r04a) */
+	/* between 48 and ~70 chunks the chip-wide sort can be the faster one: a workgroup per chunk is a chain whose length is the CHUNK (0.2 ms + 9.2 ns per byte of
+	 * text, in rounds of 256 chunks), the chip-wide form streams the padded layout of the BATCH (0.9 ms + 45 ns per KB): 64 chunks of 159 KB take 1.67 against 1.50 ms,
+	 * 80 chunks of 127 KB 1.39 against 1.50 (round 4: the dickens-sized bytes as 48 .. 256 chunks, tools/exp/r04_segmodel.sh) */
 	if (!forced && padded_total && nchunks >= min_streams && max_len <= X3_SEG_MAXLEN) {
-		const double seg_ms = (0.45 + 9.3e-6 * (double)max_len) * (double)((nchunks + 255) / 256);
+		const double seg_ms = (0.2 + 9.2e-6 * (double)max_len) * (double)((nchunks + 255) / 256);
 		const double chip_ms = 0.9 + 4.5e-8 * (double)padded_total;
 		if (chip_ms < seg_ms) return 0;
 	}
