@@ -396,7 +396,7 @@ def test_emulated_scan_dense_classes_and_padding(emu, oracle, name, data, kw):
 @pytest.mark.parametrize("name,data,kw", CASES + PIPE_CASES[2:4], ids=[c[0] for c in CASES] + ["english9k", "zipf4k"])
 def test_emulated_stream_kernels_forced(emu_env, oracle, name, data, kw):
     """X3H_STREAM_KERNELS=1: the per-stream LDS kernels on single streams (they are the default only for batches of >= 48 streams)"""
-    ctx = emu_env(X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0", X3H_ARRANGE="1" if len(data) % 2 else "0")
+    ctx = emu_env(X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0", X3H_ARRANGE="1" if len(data) % 2 else "0", X3H_SEGSORT="1" if len(data) % 3 else "0")
     assert ctx.compress(data, _lib.make_params(**kw)) == oracle.compress(data, oracle_lib.params(**kw))
 
 
@@ -429,6 +429,13 @@ def test_emulated_stream_kernels_batch_of_52(emu_env, oracle):
     few = emu_env(X3H_ARRANGE="1", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0").compress_chunks(data[:int(off[10])], off[:11], _lib.make_params(**kw))
     for i in range(10):
         assert few[i] == want[i], f"per-stream arrangement: stream {i}"
+    # X3H_SEGSORT=1: the arrangements by one workgroup per stream in 8-bit passes (x3_segsort_kernel; the default from 128 streams on) -- the first twelve streams
+    few = emu_env(X3H_SEGSORT="1", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0").compress_chunks(data[:int(off[12])], off[:13], _lib.make_params(**kw))
+    for i in range(12):
+        assert few[i] == want[i], f"per-stream sort: stream {i}"
+    few = emu_env(X3H_SEGSORT="1", X3H_SEGSORT_PASSES="3", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0").compress_chunks(data[:int(off[12])], off[:13], _lib.make_params(**kw))
+    for i in range(12):
+        assert few[i] == want[i], f"per-stream sort: stream {i}"
 
 
 @pytest.mark.parametrize("env", [{}, dict(X3H_PIPE_MIN="1"), dict(X3H_PIPE_MIN="1", X3H_SEG_EMIT="1"), dict(X3H_STREAM_KERNELS="1")],

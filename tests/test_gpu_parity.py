@@ -642,6 +642,29 @@ def test_per_chunk_scan_equals_brute_force_kernel(gpu_env, monkeypatch, env):
         brute.close()
 
 
+def test_per_stream_sort_of_the_arrangements_equals_the_chip_wide_sort_and_oracle(gpu_env, oracle):
+    """x3_segsort_kernel (code3.hip: a stream's hits grouped by context by the stream's own workgroup; default from 128 streams on) against the chip-wide
+    radix sort it replaces and the oracle: 130 ragged streams, among them an empty one, one byte, one long stream (dictionary and tag pairs of
+    several thousand: two passes), and every stream again with three passes forced"""
+    rng = np.random.default_rng(77)
+    parts = []
+    for i in range(130):
+        n = int(rng.integers(2_000, 30_000))
+        parts.append(synth.english_like(n, seed=100 + i).tobytes() if i % 3 else synth.zipf_bytes(n, offset=17 * i).tobytes())
+    parts[5], parts[9], parts[40] = b"", b"q", synth.english_like(700_000, seed=3).tobytes()
+    data = np.frombuffer(b"".join(parts), np.uint8)
+    off = np.cumsum([0] + [len(p) for p in parts]).astype(np.uint64)
+    prm = _lib.make_params(w_kib=64, t=256)
+    by_default = gpu_env().compress_chunks(data, off, prm)  # (the switches are read when a batch runs: the default first, before any is set)
+    want = gpu_env(X3H_SEGSORT="0").compress_chunks(data, off, prm)
+    three = gpu_env(X3H_SEGSORT="1", X3H_SEGSORT_PASSES="3").compress_chunks(data, off, prm)
+    for i in range(len(parts)):
+        assert by_default[i] == want[i], f"per-stream sort: stream {i}"
+        assert three[i] == want[i], f"per-stream sort, three passes: stream {i}"
+    for i in (0, 1, 5, 9):
+        assert want[i] == oracle.compress(parts[i], oracle_lib.params(w_kib=64, t=256)), f"stream {i} against the oracle"
+
+
 def test_many_streams_with_one_oversized_dictionary(gpu, oracle):
     """50 streams, one of which has more dictionary elements (> 8192) than the LDS tables of the per-stream kernels hold: the whole batch
     takes the chip-wide passes instead (x3_code_v2_run derives the token prefix sums itself in that case) -- same bytes as stream by stream"""

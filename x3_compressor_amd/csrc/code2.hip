@@ -1310,8 +1310,15 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 			if (const char *e = getenv("X3H_ARRANGE")) seg_arrange = e[0] == '1';
 			bool ctx_gather = true; /* the context kernel fetches the tags of its arrangement itself (X3H_CTX_GATHER=0: an element-wise pass writes them out first) */
 			if (const char *e = getenv("X3H_CTX_GATHER")) ctx_gather = e[0] != '0';
+			/* default from X3_SEGSORT_MIN_STREAMS streams on: one workgroup per stream with the tile machinery of scan3.hip (x3_segsort_kernel, code3.hip), as many
+			 * 8-bit passes as the stream-local keys need -- the same order; X3H_SEGSORT=0: the chip-wide sort */
+			bool seg_sort = !seg_arrange && nc >= X3_SEGSORT_MIN_STREAMS;
+			if (const char *e = getenv("X3H_SEGSORT")) seg_sort = !seg_arrange && e[0] != '0';
 			if (seg_arrange) CHK(x3_arrange_run(st, nc, d_ho, d_dof, maxDict, h_c1, h_tag, kA, vA, tA, T[7], T[8]));
-			else {
+			else if (seg_sort && maxDict <= X3_SEGSORT_MAX_LOCAL) {
+				CHK(x3_segsort_run(st, nc, d_ho, d_dof, maxDict, h_c1, kA, vA, T[7], T[8]));
+				if (!ctx_gather) x3_foreach(nH, st, X3_LAMBDA(size_t i) { tA[i] = h_tag[vA[i]]; });
+			} else {
 				x3_foreach(nH, st, X3_LAMBDA(size_t i) { iota[i] = (uint32_t)i; });
 				CHK(x3p_sort_pairs(B.tmp, h_c1, kA, iota, vA, nH, bits_for(nD), st));
 				if (!ctx_gather) x3_foreach(nH, st, X3_LAMBDA(size_t i) { tA[i] = h_tag[vA[i]]; });
@@ -1342,8 +1349,11 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 			for (uint32_t c = 0; c < nc; c++) if (hnp[c] > maxPairs) maxPairs = hnp[c];
 			/* by ctx0 (pair ordinal; a stream's ordinals start at m_pairbase): the same segmented counting sort, two passes beyond 2048 pairs */
 			if (seg_arrange && maxPairs <= X3_ARRANGE_MAX_LOCAL) CHK(x3_arrange_run(st, nc, d_ho, m_pairbase, maxPairs, G0, h_tag, kA, vA, tA, T[7], T[8]));
-			else {
-				if (seg_arrange) x3_foreach(nH, st, X3_LAMBDA(size_t i) { iota[i] = (uint32_t)i; });
+			else if (seg_sort && maxPairs <= X3_SEGSORT_MAX_LOCAL) {
+				CHK(x3_segsort_run(st, nc, d_ho, m_pairbase, maxPairs, G0, kA, vA, T[7], T[8]));
+				if (!ctx_gather) x3_foreach(nH, st, X3_LAMBDA(size_t i) { tA[i] = h_tag[vA[i]]; });
+			} else {
+				if (seg_arrange || seg_sort) x3_foreach(nH, st, X3_LAMBDA(size_t i) { iota[i] = (uint32_t)i; });
 				CHK(x3p_sort_pairs(B.tmp, G0, kA, iota, vA, nH, bits_for(npairs_total ? npairs_total : 1), st));
 				if (!ctx_gather) x3_foreach(nH, st, X3_LAMBDA(size_t i) { tA[i] = h_tag[vA[i]]; });
 			}

@@ -16,6 +16,7 @@
  * sort-based passes of code2.hip remain for anything else (and for the pipelined schedule of a few long streams).
  */
 #include "k3_wave.h"
+#include "seg_rank.h"
 #include <stdlib.h>
 
 template <uint32_t DMAX>
@@ -723,5 +724,159 @@ int x3_arrange_run(hipStream_t st, uint32_t nc, const uint32_t *d_ho, const uint
 #endif
 		HIPCHK(hipGetLastError());
 	}
+	return X3H_OK;
+}
+
+/* ============================================================================================================
+ * The hits of every stream grouped by (key, time), by ONE WORKGROUP PER STREAM with the tile machinery of scan3.hip (seg_rank.h): the two
+ * arrangements of the context statistics (key = context1 = the previous tag, then key = the ordinal of the tag pair; reference: context.c:20-56
+ * keeps one list per context and appends in time order -- the arrangement IS those lists laid end to end).  Keys are global numbers whose
+ * stream-local part (key - kbase[stream]) decides; a stream's hits are a contiguous segment of the hit arrays, so the stable sort of a segment on
+ * the local key equals what the chip-wide stable radix sort of all hits on the global key gives (rocPRIM onesweep, 3 + 4 passes of 8 bits over
+ * ~100 M pairs for 1024 streams = 9.8 ms and 35.7 GB of HBM traffic on the many-chunk batch: scattered 8-byte stores into 256 runs spread
+ * over the whole array).  Here a pass scatters into 256 runs inside the stream's own segment (a few hundred KB: they stay in the XCD's L2 between
+ * tiles), and a stream needs only as many passes as ITS local keys have digits:
+ *   sweep 0  one histogram per pass of the local keys (eight copies in LDS, as in scan3.hip);
+ *   pass p   stable counting-sort pass on digit p of the local key in tiles of 4096: ballot ranking per wavefront, [digit][wave] counters, tile
+ *            staged in LDS, out as runs.  The first pass makes the values (hit numbers) itself; the last adds kbase back.
+ * x3_arrange_kernel above (four wavefronts per stream, 11-bit digits, each wavefront a chain of LDS round trips over its quarter) was slower than
+ * rocPRIM and stays behind X3H_ARRANGE=1. */
+#define X3_SSORT_MAXPASS 3u
+struct X3SegSortArgs {
+	const uint32_t *ho, *kbase; /* hit offsets (nstreams + 1) and key base per stream */
+	const uint32_t *kin;        /* global keys per hit */
+	uint32_t *kout, *vout;      /* sorted: global key, hit number */
+	uint32_t *tk, *tv;          /* temporaries (more than one pass) */
+	uint32_t npass, _pad;
+};
+__device__ static void x3_segsort_body(const X3SegSortArgs &a)
+{
+	X3_LDS uint32_t cnt[256 * X3_SEG_WAVES];
+	X3_LDS uint32_t stk[X3_SEG_TILE], stv[X3_SEG_TILE]; /* the tile in sorted order (sweep 0: the histograms, 8 copies x 256 x passes) */
+	X3_LDS uint32_t bbase[X3_SSORT_MAXPASS][256], bcur[256];
+	X3_LDS __attribute__((aligned(16))) uint32_t wtot[X3_SEG_WAVES];
+	const uint32_t tid = threadIdx.x, lane = x3_lane(), wv = tid / X3_WAVE;
+	const uint32_t lo = a.ho[blockIdx.x], n = a.ho[blockIdx.x + 1] - lo, kb = a.kbase[blockIdx.x], npass = a.npass;
+	if (!n) return;
+	/* sweep 0: [copy][digit] counters of pass 0 in stk[0..2047], of pass 1 in stk[2048..4095], of pass 2 in stv[0..2047] */
+	for (uint32_t i = tid; i < 8u * 256u; i += X3_SEG_THREADS) { stk[i] = 0u; stk[2048u + i] = 0u; stv[i] = 0u; }
+	__syncthreads();
+	for (uint32_t i = tid; i < n; i += X3_SEG_THREADS) {
+		const uint32_t k = a.kin[lo + i] - kb;
+		atomicAdd(&stk[(lane & 7u) * 256u + (k & 0xFFu)], 1u);
+		if (npass > 1u) atomicAdd(&stk[2048u + (lane & 7u) * 256u + ((k >> 8) & 0xFFu)], 1u);
+		if (npass > 2u) atomicAdd(&stv[(lane & 7u) * 256u + ((k >> 16) & 0xFFu)], 1u);
+	}
+	__syncthreads();
+	for (uint32_t ps = 0; ps < npass; ps++) { /* bucket bases of every pass: exclusive scan of its histogram */
+		const uint32_t *h8 = ps == 0u ? stk : ps == 1u ? stk + 2048u : stv;
+		uint32_t h = 0, incl = 0;
+		if (tid < 256u) {
+#pragma unroll
+			for (uint32_t k = 0; k < 8; k++) h += h8[k * 256u + tid];
+			incl = x3_wave_incl_scan_u32(h);
+			if (lane == X3_WAVE - 1u) wtot[wv] = incl;
+		}
+		__syncthreads();
+		if (tid < 256u) bbase[ps][tid] = seg_waves_before(wtot, wv) + incl - h;
+		__syncthreads();
+	}
+	for (uint32_t ps = 0; ps < npass; ps++) {
+		const bool first = ps == 0u, last = ps + 1u == npass;
+		/* buffers: the last pass lands in (kout, vout); the ones before alternate so that no pass reads what it writes */
+		const bool to_out = ((npass - 1u - ps) & 1u) == 0u;
+		const uint32_t *ink = first ? a.kin + lo : (to_out ? a.tk : a.kout) + lo, *inv = first ? nullptr : (to_out ? a.tv : a.vout) + lo;
+		uint32_t *outk = (to_out ? a.kout : a.tk) + lo, *outv = (to_out ? a.vout : a.tv) + lo;
+		const uint32_t sh = 8u * ps, ksub = first ? kb : 0u, kadd = last ? kb : 0u;
+		if (tid < 256u) bcur[tid] = bbase[ps][tid];
+		uint32_t nk[X3_SEG_E], nv[X3_SEG_E];
+		{
+			const uint32_t i0 = wv * (X3_SEG_E * X3_WAVE) + lane;
+#pragma unroll
+			for (uint32_t e = 0; e < X3_SEG_E; e++) {
+				const uint32_t i = i0 + e * X3_WAVE;
+				nk[e] = i < n ? ink[i] - ksub : 0u; nv[e] = i < n ? (first ? lo + i : inv[i]) : 0u;
+			}
+		}
+		for (uint32_t t0 = 0; t0 < n; t0 += X3_SEG_TILE) {
+			*(uint4 *)&cnt[tid * 4u] = make_uint4(0u, 0u, 0u, 0u);
+			uint32_t ik[X3_SEG_E], iv[X3_SEG_E], rk[X3_SEG_E];
+			const uint32_t i0 = t0 + wv * (X3_SEG_E * X3_WAVE) + lane;
+#pragma unroll
+			for (uint32_t e = 0; e < X3_SEG_E; e++) { ik[e] = nk[e]; iv[e] = nv[e]; }
+			if (t0 + X3_SEG_TILE < n) { /* the next tile's entries are on their way while this one is ranked */
+#pragma unroll
+				for (uint32_t e = 0; e < X3_SEG_E; e++) {
+					const uint32_t i = i0 + X3_SEG_TILE + e * X3_WAVE;
+					nk[e] = i < n ? ink[i] - ksub : 0u; nv[e] = i < n ? (first ? lo + i : inv[i]) : 0u;
+				}
+			}
+			__syncthreads();
+#pragma unroll
+			for (uint32_t e = 0; e < X3_SEG_E; e++) {
+				const bool valid = i0 + e * X3_WAVE < n;
+				const uint32_t d = (ik[e] >> sh) & 0xFFu;
+				uint32_t mlo, mhi;
+				seg_match<8>(d, valid, mlo, mhi);
+				const uint32_t lower = seg_lower(mlo, mhi);
+				const uint32_t prev = valid ? cnt[d * X3_SEG_WAVES + wv] : 0u;
+				x3_wave_order();
+				if (valid && lower == 0u) cnt[d * X3_SEG_WAVES + wv] = prev + seg_size(mlo, mhi);
+				x3_wave_order();
+				rk[e] = prev + lower;
+			}
+			__syncthreads();
+			/* exclusive scan of the counter table in (digit, wave) order = the tile-sorted order */
+			const uint4 c = *(const uint4 *)&cnt[tid * 4u];
+			const uint32_t s = c.x + c.y + c.z + c.w;
+			const uint32_t incl = x3_wave_incl_scan_u32(s);
+			if (lane == X3_WAVE - 1u) wtot[wv] = incl;
+			__syncthreads();
+			const uint32_t ex = incl - s + seg_waves_before(wtot, wv);
+			*(uint4 *)&cnt[tid * 4u] = make_uint4(ex, ex + c.x, ex + c.x + c.y, ex + c.x + c.y + c.z);
+			__syncthreads();
+			const uint32_t tile_n = n - t0 < X3_SEG_TILE ? n - t0 : X3_SEG_TILE;
+			uint32_t delta = 0; /* entries of digit `tid` in this tile */
+			if (tid < 256u) delta = (tid < 255u ? cnt[(tid + 1u) * X3_SEG_WAVES] : tile_n) - cnt[tid * X3_SEG_WAVES];
+#pragma unroll
+			for (uint32_t e = 0; e < X3_SEG_E; e++) {
+				if (i0 + e * X3_WAVE < n) { const uint32_t at = cnt[((ik[e] >> sh) & 0xFFu) * X3_SEG_WAVES + wv] + rk[e]; stk[at] = ik[e]; stv[at] = iv[e]; }
+			}
+			__syncthreads();
+#pragma unroll
+			for (uint32_t e = 0; e < X3_SEG_E; e++) {
+				const uint32_t i = e * X3_SEG_THREADS + tid;
+				if (i < tile_n) {
+					const uint32_t k = stk[i], d = (k >> sh) & 0xFFu;
+					const uint32_t dest = bcur[d] + (i - cnt[d * X3_SEG_WAVES]);
+					outk[dest] = k + kadd; outv[dest] = stv[i];
+				}
+			}
+			__syncthreads();
+			if (tid < 256u) bcur[tid] += delta; /* (read again only behind the next tile's barriers) */
+		}
+		__syncthreads();
+	}
+}
+#ifndef X3_EMU
+__global__ void __launch_bounds__(X3_SEG_THREADS) x3_segsort_kernel(X3SegSortArgs a) { x3_segsort_body(a); }
+#else
+static void segsort_tramp(void *p) { x3_segsort_body(*(const X3SegSortArgs *)p); }
+#endif
+/* -> X3H_OK; the caller keeps the chip-wide sort when max_local needs more than three 8-bit passes */
+int x3_segsort_run(hipStream_t st, uint32_t nc, const uint32_t *d_ho, const uint32_t *kbase, uint64_t max_local, const uint32_t *key,
+                   uint32_t *kA, uint32_t *vA, uint32_t *tmpk, uint32_t *tmpv)
+{
+	if (max_local >= ((uint64_t)1 << (8u * X3_SSORT_MAXPASS))) return X3H_E_INTERNAL;
+	X3SegSortArgs a;
+	a.ho = d_ho; a.kbase = kbase; a.kin = key; a.kout = kA; a.vout = vA; a.tk = tmpk; a.tv = tmpv;
+	a.npass = max_local < 256u ? 1u : max_local < 65536u ? 2u : 3u; a._pad = 0u;
+	if (const char *e = getenv("X3H_SEGSORT_PASSES")) { const int v = atoi(e); if (v > (int)a.npass && v <= (int)X3_SSORT_MAXPASS) a.npass = (uint32_t)v; } /* (tests: more passes than the keys need) */
+#ifndef X3_EMU
+	hipLaunchKernelGGL(x3_segsort_kernel, dim3(nc), dim3(X3_SEG_THREADS), 0, st, a);
+#else
+	x3emu_launch(segsort_tramp, (void *)&a, dim3(nc), dim3(X3_SEG_THREADS));
+#endif
+	HIPCHK(hipGetLastError());
 	return X3H_OK;
 }
