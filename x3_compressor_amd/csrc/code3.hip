@@ -740,8 +740,26 @@ int x3_arrange_run(hipStream_t st, uint32_t nc, const uint32_t *d_ho, const uint
  *   pass p   stable counting-sort pass on digit p of the local key in tiles of 4096: ballot ranking per wavefront, [digit][wave] counters, tile
  *            staged in LDS, out as runs.  The first pass makes the values (hit numbers) itself; the last adds kbase back.
  * x3_arrange_kernel above (four wavefronts per stream, 11-bit digits, each wavefront a chain of LDS round trips over its quarter) was slower than
- * rocPRIM and stays behind X3H_ARRANGE=1. */
+ * rocPRIM and stays behind X3H_ARRANGE=1.
+ * Measured (1024 streams, 106 M hits; tools/exp/r04_kt_many.sh): by context1 (local keys < 282: one real pass + one of two runs) 4.9 ms, by pair (local keys
+ * < 41 289: two passes) 2.9 ms, against 9.8 ms + two index fills for the two rocPRIM sorts.  A pass costs 1.0 ms when its digits make one run, 1.3 ms when they
+ * are spread evenly, and 3.3 ms when they are Zipf-distributed (context1 of incompressible streams): the rare digits' runs grow by a few bytes per tile,
+ * 64 workgroups per XCD x 256 runs x 2 arrays of partly written lines do not fit the 4 MB L2, and partly written lines go to HBM and come back.  Next:
+ * collect a digit's entries in LDS until a line is full. */
 #define X3_SSORT_MAXPASS 3u
+/* one more entry of digit d in a [copy][digit] histogram in LDS.  The lanes that hold the same digit as the wavefront's first valid lane are counted by
+ * that lane alone: context1 of an incompressible stream is 0 for most hits (both contexts restart behind a new fragment, x3.c:424-425), a stream's
+ * higher key digits are 0 for all -- and 64 atomics on one LDS word are executed one after the other (measured: the histogram sweep of such a batch
+ * took longer than its two sorting passes). */
+__device__ static __forceinline__ void segsort_count(uint32_t *hist8, uint32_t d, bool valid, uint32_t lane)
+{
+	const uint64_t v = x3_ballot(valid);
+	if (!v) return;
+	const uint32_t first = (uint32_t)x3_ctz64(v), d0 = x3_readlane_u32(d, first);
+	const uint64_t same = x3_ballot(valid && d == d0);
+	if (lane == first) atomicAdd(&hist8[(lane & 7u) * 256u + d0], (uint32_t)x3_popc64(same));
+	else if (valid && d != d0) atomicAdd(&hist8[(lane & 7u) * 256u + d], 1u);
+}
 struct X3SegSortArgs {
 	const uint32_t *ho, *kbase; /* hit offsets (nstreams + 1) and key base per stream */
 	const uint32_t *kin;        /* global keys per hit */
@@ -761,11 +779,13 @@ __device__ static void x3_segsort_body(const X3SegSortArgs &a)
 	/* sweep 0: [copy][digit] counters of pass 0 in stk[0..2047], of pass 1 in stk[2048..4095], of pass 2 in stv[0..2047] */
 	for (uint32_t i = tid; i < 8u * 256u; i += X3_SEG_THREADS) { stk[i] = 0u; stk[2048u + i] = 0u; stv[i] = 0u; }
 	__syncthreads();
-	for (uint32_t i = tid; i < n; i += X3_SEG_THREADS) {
-		const uint32_t k = a.kin[lo + i] - kb;
-		atomicAdd(&stk[(lane & 7u) * 256u + (k & 0xFFu)], 1u);
-		if (npass > 1u) atomicAdd(&stk[2048u + (lane & 7u) * 256u + ((k >> 8) & 0xFFu)], 1u);
-		if (npass > 2u) atomicAdd(&stv[(lane & 7u) * 256u + ((k >> 16) & 0xFFu)], 1u);
+	for (uint32_t b0 = 0; b0 < n; b0 += X3_SEG_THREADS) { /* (uniform trip count: wave operations inside) */
+		const uint32_t i = b0 + tid;
+		const bool valid = i < n;
+		const uint32_t k = valid ? a.kin[lo + i] - kb : 0u;
+		segsort_count(stk, k & 0xFFu, valid, lane);
+		if (npass > 1u) segsort_count(stk + 2048u, (k >> 8) & 0xFFu, valid, lane);
+		if (npass > 2u) segsort_count(stv, (k >> 16) & 0xFFu, valid, lane);
 	}
 	__syncthreads();
 	for (uint32_t ps = 0; ps < npass; ps++) { /* bucket bases of every pass: exclusive scan of its histogram */
@@ -859,7 +879,7 @@ __device__ static void x3_segsort_body(const X3SegSortArgs &a)
 	}
 }
 #ifndef X3_EMU
-__global__ void __launch_bounds__(X3_SEG_THREADS) x3_segsort_kernel(X3SegSortArgs a) { x3_segsort_body(a); }
+__global__ void __launch_bounds__(X3_SEG_THREADS, 8) x3_segsort_kernel(X3SegSortArgs a) { x3_segsort_body(a); }
 #else
 static void segsort_tramp(void *p) { x3_segsort_body(*(const X3SegSortArgs *)p); }
 #endif
@@ -872,6 +892,7 @@ int x3_segsort_run(hipStream_t st, uint32_t nc, const uint32_t *d_ho, const uint
 	a.ho = d_ho; a.kbase = kbase; a.kin = key; a.kout = kA; a.vout = vA; a.tk = tmpk; a.tv = tmpv;
 	a.npass = max_local < 256u ? 1u : max_local < 65536u ? 2u : 3u; a._pad = 0u;
 	if (const char *e = getenv("X3H_SEGSORT_PASSES")) { const int v = atoi(e); if (v > (int)a.npass && v <= (int)X3_SSORT_MAXPASS) a.npass = (uint32_t)v; } /* (tests: more passes than the keys need) */
+	if (getenv("X3H_DEBUG")) fprintf(stderr, "[x3h] per-stream sort: %u streams, largest local key %llu, %u passes\n", nc, (unsigned long long)max_local, a.npass);
 #ifndef X3_EMU
 	hipLaunchKernelGGL(x3_segsort_kernel, dim3(nc), dim3(X3_SEG_THREADS), 0, st, a);
 #else
