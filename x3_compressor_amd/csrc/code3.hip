@@ -765,7 +765,7 @@ struct X3SegSortArgs {
 	const uint32_t *kin;        /* global keys per hit */
 	uint32_t *kout, *vout;      /* sorted: global key, hit number */
 	uint32_t *tk, *tv;          /* temporaries (more than one pass) */
-	uint32_t npass, _pad;
+	uint32_t npass, dbits;      /* passes, bits per digit (<= 8): the key's bits spread evenly over the passes */
 };
 __device__ static void x3_segsort_body(const X3SegSortArgs &a)
 {
@@ -774,7 +774,7 @@ __device__ static void x3_segsort_body(const X3SegSortArgs &a)
 	X3_LDS uint32_t bbase[X3_SSORT_MAXPASS][256], bcur[256];
 	X3_LDS __attribute__((aligned(16))) uint32_t wtot[X3_SEG_WAVES];
 	const uint32_t tid = threadIdx.x, lane = x3_lane(), wv = tid / X3_WAVE;
-	const uint32_t lo = a.ho[blockIdx.x], n = a.ho[blockIdx.x + 1] - lo, kb = a.kbase[blockIdx.x], npass = a.npass;
+	const uint32_t lo = a.ho[blockIdx.x], n = a.ho[blockIdx.x + 1] - lo, kb = a.kbase[blockIdx.x], npass = a.npass, db = a.dbits, dmask = (1u << db) - 1u;
 	if (!n) return;
 	/* sweep 0: [copy][digit] counters of pass 0 in stk[0..2047], of pass 1 in stk[2048..4095], of pass 2 in stv[0..2047] */
 	for (uint32_t i = tid; i < 8u * 256u; i += X3_SEG_THREADS) { stk[i] = 0u; stk[2048u + i] = 0u; stv[i] = 0u; }
@@ -783,9 +783,9 @@ __device__ static void x3_segsort_body(const X3SegSortArgs &a)
 		const uint32_t i = b0 + tid;
 		const bool valid = i < n;
 		const uint32_t k = valid ? a.kin[lo + i] - kb : 0u;
-		segsort_count(stk, k & 0xFFu, valid, lane);
-		if (npass > 1u) segsort_count(stk + 2048u, (k >> 8) & 0xFFu, valid, lane);
-		if (npass > 2u) segsort_count(stv, (k >> 16) & 0xFFu, valid, lane);
+		segsort_count(stk, k & dmask, valid, lane);
+		if (npass > 1u) segsort_count(stk + 2048u, (k >> db) & dmask, valid, lane);
+		if (npass > 2u) segsort_count(stv, (k >> (2u * db)) & dmask, valid, lane);
 	}
 	__syncthreads();
 	for (uint32_t ps = 0; ps < npass; ps++) { /* bucket bases of every pass: exclusive scan of its histogram */
@@ -807,7 +807,7 @@ __device__ static void x3_segsort_body(const X3SegSortArgs &a)
 		const bool to_out = ((npass - 1u - ps) & 1u) == 0u;
 		const uint32_t *ink = first ? a.kin + lo : (to_out ? a.tk : a.kout) + lo, *inv = first ? nullptr : (to_out ? a.tv : a.vout) + lo;
 		uint32_t *outk = (to_out ? a.kout : a.tk) + lo, *outv = (to_out ? a.vout : a.tv) + lo;
-		const uint32_t sh = 8u * ps, ksub = first ? kb : 0u, kadd = last ? kb : 0u;
+		const uint32_t sh = db * ps, ksub = first ? kb : 0u, kadd = last ? kb : 0u;
 		if (tid < 256u) bcur[tid] = bbase[ps][tid];
 		uint32_t nk[X3_SEG_E], nv[X3_SEG_E];
 		{
@@ -835,7 +835,7 @@ __device__ static void x3_segsort_body(const X3SegSortArgs &a)
 #pragma unroll
 			for (uint32_t e = 0; e < X3_SEG_E; e++) {
 				const bool valid = i0 + e * X3_WAVE < n;
-				const uint32_t d = (ik[e] >> sh) & 0xFFu;
+				const uint32_t d = (ik[e] >> sh) & dmask;
 				uint32_t mlo, mhi;
 				seg_match<8>(d, valid, mlo, mhi);
 				const uint32_t lower = seg_lower(mlo, mhi);
@@ -860,14 +860,14 @@ __device__ static void x3_segsort_body(const X3SegSortArgs &a)
 			if (tid < 256u) delta = (tid < 255u ? cnt[(tid + 1u) * X3_SEG_WAVES] : tile_n) - cnt[tid * X3_SEG_WAVES];
 #pragma unroll
 			for (uint32_t e = 0; e < X3_SEG_E; e++) {
-				if (i0 + e * X3_WAVE < n) { const uint32_t at = cnt[((ik[e] >> sh) & 0xFFu) * X3_SEG_WAVES + wv] + rk[e]; stk[at] = ik[e]; stv[at] = iv[e]; }
+				if (i0 + e * X3_WAVE < n) { const uint32_t at = cnt[((ik[e] >> sh) & dmask) * X3_SEG_WAVES + wv] + rk[e]; stk[at] = ik[e]; stv[at] = iv[e]; }
 			}
 			__syncthreads();
 #pragma unroll
 			for (uint32_t e = 0; e < X3_SEG_E; e++) {
 				const uint32_t i = e * X3_SEG_THREADS + tid;
 				if (i < tile_n) {
-					const uint32_t k = stk[i], d = (k >> sh) & 0xFFu;
+					const uint32_t k = stk[i], d = (k >> sh) & dmask;
 					const uint32_t dest = bcur[d] + (i - cnt[d * X3_SEG_WAVES]);
 					outk[dest] = k + kadd; outv[dest] = stv[i];
 				}
@@ -890,9 +890,13 @@ int x3_segsort_run(hipStream_t st, uint32_t nc, const uint32_t *d_ho, const uint
 	if (max_local >= ((uint64_t)1 << (8u * X3_SSORT_MAXPASS))) return X3H_E_INTERNAL;
 	X3SegSortArgs a;
 	a.ho = d_ho; a.kbase = kbase; a.kin = key; a.kout = kA; a.vout = vA; a.tk = tmpk; a.tv = tmpv;
-	a.npass = max_local < 256u ? 1u : max_local < 65536u ? 2u : 3u; a._pad = 0u;
+	a.npass = max_local < 256u ? 1u : max_local < 65536u ? 2u : 3u;
 	if (const char *e = getenv("X3H_SEGSORT_PASSES")) { const int v = atoi(e); if (v > (int)a.npass && v <= (int)X3_SSORT_MAXPASS) a.npass = (uint32_t)v; } /* (tests: more passes than the keys need) */
-	if (getenv("X3H_DEBUG")) fprintf(stderr, "[x3h] per-stream sort: %u streams, largest local key %llu, %u passes\n", nc, (unsigned long long)max_local, a.npass);
+	/* the key's bits in equal shares: 9 bits are two passes of 5 and 4, not of 8 and 1 -- a pass of 2^5 runs keeps its partly written lines in L2 (header) */
+	uint32_t kbits = 1; while (kbits < 24u && (max_local >> kbits)) kbits++;
+	a.dbits = (kbits + a.npass - 1u) / a.npass;
+	if (getenv("X3H_SEGSORT_DBITS8")) a.dbits = 8u; /* (tests / measurements: whole bytes) */
+	if (getenv("X3H_DEBUG")) fprintf(stderr, "[x3h] per-stream sort: %u streams, largest local key %llu, %u passes of %u bits\n", nc, (unsigned long long)max_local, a.npass, a.dbits);
 #ifndef X3_EMU
 	hipLaunchKernelGGL(x3_segsort_kernel, dim3(nc), dim3(X3_SEG_THREADS), 0, st, a);
 #else
