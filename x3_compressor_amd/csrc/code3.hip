@@ -747,6 +747,7 @@ int x3_arrange_run(hipStream_t st, uint32_t nc, const uint32_t *d_ho, const uint
  * 64 workgroups per XCD x 256 runs x 2 arrays of partly written lines do not fit the 4 MB L2, and partly written lines go to HBM and come back.  Next:
  * collect a digit's entries in LDS until a line is full. */
 #define X3_SSORT_MAXPASS 3u
+#define X3_SSORT_CS (X3_SEG_WAVES + 1u)
 /* one more entry of digit d in a [copy][digit] histogram in LDS.  The lanes that hold the same digit as the wavefront's first valid lane are counted by
  * that lane alone: context1 of an incompressible stream is 0 for most hits (both contexts restart behind a new fragment, x3.c:424-425), a stream's
  * higher key digits are 0 for all -- and 64 atomics on one LDS word are executed one after the other (measured: the histogram sweep of such a batch
@@ -769,7 +770,7 @@ struct X3SegSortArgs {
 };
 __device__ static void x3_segsort_body(const X3SegSortArgs &a)
 {
-	X3_LDS uint32_t cnt[256 * X3_SEG_WAVES];
+	X3_LDS uint32_t cnt[256 * X3_SSORT_CS]; /* [digit][wave], a digit's sixteen counters X3_SSORT_CS words apart: the lanes of a wavefront (one wave number, many digits) meet in every bank, not in two */
 	X3_LDS uint32_t stk[X3_SEG_TILE], stv[X3_SEG_TILE]; /* the tile in sorted order (sweep 0: the histograms, 8 copies x 256 x passes) */
 	X3_LDS uint32_t bbase[X3_SSORT_MAXPASS][256], bcur[256];
 	X3_LDS __attribute__((aligned(16))) uint32_t wtot[X3_SEG_WAVES];
@@ -819,7 +820,7 @@ __device__ static void x3_segsort_body(const X3SegSortArgs &a)
 			}
 		}
 		for (uint32_t t0 = 0; t0 < n; t0 += X3_SEG_TILE) {
-			*(uint4 *)&cnt[tid * 4u] = make_uint4(0u, 0u, 0u, 0u);
+			for (uint32_t i = tid; i < 256u * X3_SSORT_CS; i += X3_SEG_THREADS) cnt[i] = 0u;
 			uint32_t ik[X3_SEG_E], iv[X3_SEG_E], rk[X3_SEG_E];
 			const uint32_t i0 = t0 + wv * (X3_SEG_E * X3_WAVE) + lane;
 #pragma unroll
@@ -839,28 +840,29 @@ __device__ static void x3_segsort_body(const X3SegSortArgs &a)
 				uint32_t mlo, mhi;
 				seg_match<8>(d, valid, mlo, mhi);
 				const uint32_t lower = seg_lower(mlo, mhi);
-				const uint32_t prev = valid ? cnt[d * X3_SEG_WAVES + wv] : 0u;
+				const uint32_t prev = valid ? cnt[d * X3_SSORT_CS + wv] : 0u;
 				x3_wave_order();
-				if (valid && lower == 0u) cnt[d * X3_SEG_WAVES + wv] = prev + seg_size(mlo, mhi);
+				if (valid && lower == 0u) cnt[d * X3_SSORT_CS + wv] = prev + seg_size(mlo, mhi);
 				x3_wave_order();
 				rk[e] = prev + lower;
 			}
 			__syncthreads();
 			/* exclusive scan of the counter table in (digit, wave) order = the tile-sorted order */
-			const uint4 c = *(const uint4 *)&cnt[tid * 4u];
+			uint32_t *const c4 = &cnt[(tid >> 2) * X3_SSORT_CS + (tid & 3u) * 4u]; /* four waves' counters of digit tid / 4 */
+			const uint4 c = make_uint4(c4[0], c4[1], c4[2], c4[3]);
 			const uint32_t s = c.x + c.y + c.z + c.w;
 			const uint32_t incl = x3_wave_incl_scan_u32(s);
 			if (lane == X3_WAVE - 1u) wtot[wv] = incl;
 			__syncthreads();
 			const uint32_t ex = incl - s + seg_waves_before(wtot, wv);
-			*(uint4 *)&cnt[tid * 4u] = make_uint4(ex, ex + c.x, ex + c.x + c.y, ex + c.x + c.y + c.z);
+			c4[0] = ex; c4[1] = ex + c.x; c4[2] = ex + c.x + c.y; c4[3] = ex + c.x + c.y + c.z;
 			__syncthreads();
 			const uint32_t tile_n = n - t0 < X3_SEG_TILE ? n - t0 : X3_SEG_TILE;
 			uint32_t delta = 0; /* entries of digit `tid` in this tile */
-			if (tid < 256u) delta = (tid < 255u ? cnt[(tid + 1u) * X3_SEG_WAVES] : tile_n) - cnt[tid * X3_SEG_WAVES];
+			if (tid < 256u) delta = (tid < 255u ? cnt[(tid + 1u) * X3_SSORT_CS] : tile_n) - cnt[tid * X3_SSORT_CS];
 #pragma unroll
 			for (uint32_t e = 0; e < X3_SEG_E; e++) {
-				if (i0 + e * X3_WAVE < n) { const uint32_t at = cnt[((ik[e] >> sh) & dmask) * X3_SEG_WAVES + wv] + rk[e]; stk[at] = ik[e]; stv[at] = iv[e]; }
+				if (i0 + e * X3_WAVE < n) { const uint32_t at = cnt[((ik[e] >> sh) & dmask) * X3_SSORT_CS + wv] + rk[e]; stk[at] = ik[e]; stv[at] = iv[e]; }
 			}
 			__syncthreads();
 #pragma unroll
@@ -868,7 +870,7 @@ __device__ static void x3_segsort_body(const X3SegSortArgs &a)
 				const uint32_t i = e * X3_SEG_THREADS + tid;
 				if (i < tile_n) {
 					const uint32_t k = stk[i], d = (k >> sh) & dmask;
-					const uint32_t dest = bcur[d] + (i - cnt[d * X3_SEG_WAVES]);
+					const uint32_t dest = bcur[d] + (i - cnt[d * X3_SSORT_CS]);
 					outk[dest] = k + kadd; outv[dest] = stv[i];
 				}
 			}
