@@ -747,7 +747,7 @@ int x3_arrange_run(hipStream_t st, uint32_t nc, const uint32_t *d_ho, const uint
  * 64 workgroups per XCD x 256 runs x 2 arrays of partly written lines do not fit the 4 MB L2, and partly written lines go to HBM and come back.  Next:
  * collect a digit's entries in LDS until a line is full. */
 #define X3_SSORT_MAXPASS 3u
-#define X3_SSORT_CS (X3_SEG_WAVES + 1u)
+#define X3_SSORT_CS X3_SEG_CS
 /* one more entry of digit d in a [copy][digit] histogram in LDS.  The lanes that hold the same digit as the wavefront's first valid lane are counted by
  * that lane alone: context1 of an incompressible stream is 0 for most hits (both contexts restart behind a new fragment, x3.c:424-425), a stream's
  * higher key digits are 0 for all -- and 64 atomics on one LDS word are executed one after the other (measured: the histogram sweep of such a batch

@@ -127,7 +127,8 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 {
 	X3_LDS uint32_t mfield_l[BIG ? 1 : X3_SEG_MAXLEN / 16]; /* 2 bits per position: levels 1..3 passed so far */
 	X3_LDS uint32_t rbits_l[BIG ? 1 : X3_SEG_MAXLEN / 32];  /* positions whose K is below T+1 */
-	X3_LDS uint32_t cnt[256 * X3_SEG_WAVES];           /* [digit][wave]: counts, then exclusive prefix in tile-sorted order */
+	X3_LDS uint32_t cnt[256 * X3_SEG_CS];              /* [digit][wave]: counts, then exclusive prefix in tile-sorted order; a digit's counters X3_SEG_CS = 17 words apart: the lanes
+	                                                    * of a wavefront (one wave number, many digits) meet in every LDS bank instead of two (bank conflicts were 63 % of the LDS cycles) */
 	X3_LDS uint2 stage[X3_SEG_TILE + X3_SEG_HALO];     /* the tile in list order + the entries behind it (level tests), then the tile in sorted order (phase 0: eight copies of the byte histogram) */
 	X3_LDS uint32_t bbase[256], bcur[256];
 	X3_LDS __attribute__((aligned(16))) uint32_t wtot[X3_SEG_WAVES];
@@ -204,7 +205,7 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 		uint2 hx = none; /* one of the X3_SEG_HALO entries behind the tile, asked for a tile ahead */
 		if (stg && tid < X3_SEG_HALO && X3_SEG_TILE + tid < L) hx = in[X3_SEG_TILE + tid];
 		for (uint32_t t0 = 0; t0 < L; t0 += X3_SEG_TILE) {
-			*(uint4 *)&cnt[tid * 4u] = make_uint4(0u, 0u, 0u, 0u);
+			for (uint32_t i = tid; i < 256u * X3_SEG_CS; i += X3_SEG_THREADS) cnt[i] = 0u;
 			uint2 it[X3_SEG_E], la[X3_SEG_E];
 			uint32_t rk[X3_SEG_E];
 			const uint32_t i0 = t0 + wv * (X3_SEG_E * X3_WAVE) + lane, loc0 = wv * (X3_SEG_E * X3_WAVE) + lane;
@@ -232,9 +233,9 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 				uint32_t mlo, mhi;
 				seg_match<8>(d, valid, mlo, mhi);
 				const uint32_t lower = seg_lower(mlo, mhi);
-				const uint32_t prev = valid ? cnt[d * X3_SEG_WAVES + wv] : 0u;
+				const uint32_t prev = valid ? cnt[d * X3_SEG_CS + wv] : 0u;
 				x3_wave_order();
-				if (valid && lower == 0u) cnt[d * X3_SEG_WAVES + wv] = prev + seg_size(mlo, mhi);
+				if (valid && lower == 0u) cnt[d * X3_SEG_CS + wv] = prev + seg_size(mlo, mhi);
 				x3_wave_order();
 				rk[e] = prev + lower;
 			}
@@ -248,20 +249,21 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 			}
 			__syncthreads();
 			/* exclusive scan of the counter table in (digit, wave) order = the tile-sorted order */
-			const uint4 c = *(const uint4 *)&cnt[tid * 4u];
+			uint32_t *const c4 = &cnt[(tid >> 2) * X3_SEG_CS + (tid & 3u) * 4u]; /* four waves' counters of digit tid / 4 */
+			const uint4 c = make_uint4(c4[0], c4[1], c4[2], c4[3]);
 			const uint32_t s = c.x + c.y + c.z + c.w;
 			const uint32_t incl = x3_wave_incl_scan_u32(s);
 			if (lane == X3_WAVE - 1u) wtot[wv] = incl;
 			__syncthreads();
 			const uint32_t ex = incl - s + seg_waves_before(wtot, wv);
-			*(uint4 *)&cnt[tid * 4u] = make_uint4(ex, ex + c.x, ex + c.x + c.y, ex + c.x + c.y + c.z);
+			c4[0] = ex; c4[1] = ex + c.x; c4[2] = ex + c.x + c.y; c4[3] = ex + c.x + c.y + c.z;
 			__syncthreads();
 			const uint32_t tile_n = L - t0 < X3_SEG_TILE ? L - t0 : X3_SEG_TILE;
 			uint32_t delta = 0; /* entries of digit `tid` in this tile */
-			if (tid < 256u) delta = (tid < 255u ? cnt[(tid + 1u) * X3_SEG_WAVES] : tile_n) - cnt[tid * X3_SEG_WAVES];
+			if (tid < 256u) delta = (tid < 255u ? cnt[(tid + 1u) * X3_SEG_CS] : tile_n) - cnt[tid * X3_SEG_CS];
 #pragma unroll
 			for (uint32_t e = 0; e < X3_SEG_E; e++) {
-				if (i0 + e * X3_WAVE < L) stage[cnt[((it[e].x >> sh) & 0xFFu) * X3_SEG_WAVES + wv] + rk[e]] = it[e];
+				if (i0 + e * X3_WAVE < L) stage[cnt[((it[e].x >> sh) & 0xFFu) * X3_SEG_CS + wv] + rk[e]] = it[e];
 			}
 			__syncthreads();
 #pragma unroll
@@ -270,7 +272,7 @@ __device__ static void x3_segscan_body(const X3SegArgs &a)
 				if (i < tile_n) {
 					const uint2 item = stage[i];
 					const uint32_t d = (item.x >> sh) & 0xFFu;
-					const uint32_t dest = bcur[d] + (i - cnt[d * X3_SEG_WAVES]);
+					const uint32_t dest = bcur[d] + (i - cnt[d * X3_SEG_CS]);
 					if (l < 4u) out[dest] = item;
 					else { S4[dest] = item.y; K4[dest] = item.x; }
 				}

@@ -8,6 +8,7 @@
 #define X3_SEG_WAVES (X3_SEG_THREADS / X3_WAVE)
 #define X3_SEG_E     4u                            /* elements per thread and tile */
 #define X3_SEG_TILE  (X3_SEG_THREADS * X3_SEG_E)
+#define X3_SEG_CS    (X3_SEG_WAVES + 1u)            /* words between two digits' counters in the [digit][wave] tables */
 
 
 /* the lanes (among `valid` ones) that hold the same NB-bit digit as this lane, as the two halves of a lane mask: one ballot per digit bit.  Per
