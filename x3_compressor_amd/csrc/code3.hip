@@ -741,11 +741,11 @@ int x3_arrange_run(hipStream_t st, uint32_t nc, const uint32_t *d_ho, const uint
  *            staged in LDS, out as runs.  The first pass makes the values (hit numbers) itself; the last adds kbase back.
  * x3_arrange_kernel above (four wavefronts per stream, 11-bit digits, each wavefront a chain of LDS round trips over its quarter) was slower than
  * rocPRIM and stays behind X3H_ARRANGE=1.
- * Measured (1024 streams, 106 M hits; tools/exp/r04_kt_many.sh): by context1 (local keys < 282: one real pass + one of two runs) 4.9 ms, by pair (local keys
- * < 41 289: two passes) 2.9 ms, against 9.8 ms + two index fills for the two rocPRIM sorts.  A pass costs 1.0 ms when its digits make one run, 1.3 ms when they
- * are spread evenly, and 3.3 ms when they are Zipf-distributed (context1 of incompressible streams): the rare digits' runs grow by a few bytes per tile,
- * 64 workgroups per XCD x 256 runs x 2 arrays of partly written lines do not fit the 4 MB L2, and partly written lines go to HBM and come back.  Next:
- * collect a digit's entries in LDS until a line is full. */
+ * Measured (1024 streams, 106 M hits, nothing else on the chip: tools/exp/r04_segsort_q.sh): by context1 (local keys < 282: two passes of 5 + 4 bits) 2.3 ms,
+ * by pair (local keys < 41 289: two passes of 8 bits) 2.7 ms, 16.4 GB of HBM traffic -- against 9.8 ms + two index fills and 35.7 GB for the two rocPRIM sorts.
+ * (In a kernel trace of the product the first sort shows 5 ms: the move-to-front ranks run beside it on their own stream, by design.)  One more pass
+ * over all-zero digits costs 1.0 ms, the histogram sweep 0.3-0.7 ms; LDS bank conflicts were 74 % of the LDS cycles with the counters of a digit 16
+ * words apart (every lane of a wavefront in one of two banks): X3_SEG_CS = 17. */
 #define X3_SSORT_MAXPASS 3u
 #define X3_SSORT_CS X3_SEG_CS
 /* one more entry of digit d in a [copy][digit] histogram in LDS.  The lanes that hold the same digit as the wavefront's first valid lane are counted by
