@@ -432,7 +432,7 @@ __device__ static __forceinline__ uint32_t ref_block_excl(uint32_t v, uint32_t *
 }
 
 /* one stable counting-sort pass over list `in` (cnt entries) on digit (key >> sh) & 511 with key = class << 8 | byte; hist = this digit's
- * histogram (512 counters, consumed); LDS: cnt_t (512 x 16 counters), stage (4096 entries), bcur (512), wt */
+ * histogram (512 counters, consumed); LDS: cnt_t (512 digits x 16 waves, rows X3_SEG_CS words apart), stage (4096 entries), bcur (512), wt */
 __device__ static void ref_sort_pass(const uint2 *in, uint2 *out, uint32_t n, uint32_t sh, uint32_t *hist, uint32_t *cnt_t, uint2 *stage,
                                      uint32_t *bcur, uint32_t *wt, uint32_t tid, uint32_t lane, uint32_t wv)
 {
@@ -451,7 +451,7 @@ __device__ static void ref_sort_pass(const uint2 *in, uint2 *out, uint32_t n, ui
 		for (uint32_t e = 0; e < X3_SEG_E; e++) { if (i0 + e * X3_WAVE < n) nx[e] = in[i0 + e * X3_WAVE]; else { nx[e].x = 0u; nx[e].y = 0u; } }
 	}
 	for (uint32_t t0 = 0; t0 < n; t0 += X3_SEG_TILE) {
-		for (uint32_t k = 0; k < (X3_REF_DIGITS * X3_SEG_WAVES) / X3_SEG_THREADS; k++) cnt_t[tid * ((X3_REF_DIGITS * X3_SEG_WAVES) / X3_SEG_THREADS) + k] = 0u;
+		for (uint32_t i = tid; i < X3_REF_DIGITS * X3_SEG_CS; i += X3_SEG_THREADS) cnt_t[i] = 0u;
 		uint2 it[X3_SEG_E];
 		uint32_t rk[X3_SEG_E], dg[X3_SEG_E];
 		const uint32_t i0 = t0 + wv * (X3_SEG_E * X3_WAVE) + lane;
@@ -471,9 +471,9 @@ __device__ static void ref_sort_pass(const uint2 *in, uint2 *out, uint32_t n, ui
 			uint32_t mlo, mhi;
 			seg_match<X3_REF_DB>(dg[e], valid, mlo, mhi);
 			const uint32_t lower = seg_lower(mlo, mhi);
-			const uint32_t prev = valid ? cnt_t[dg[e] * X3_SEG_WAVES + wv] : 0u;
+			const uint32_t prev = valid ? cnt_t[dg[e] * X3_SEG_CS + wv] : 0u;
 			x3_wave_order();
-			if (valid && lower == 0u) cnt_t[dg[e] * X3_SEG_WAVES + wv] = prev + seg_size(mlo, mhi);
+			if (valid && lower == 0u) cnt_t[dg[e] * X3_SEG_CS + wv] = prev + seg_size(mlo, mhi);
 			x3_wave_order();
 			rk[e] = prev + lower;
 		}
@@ -481,18 +481,19 @@ __device__ static void ref_sort_pass(const uint2 *in, uint2 *out, uint32_t n, ui
 		{ /* exclusive scan of the counter table in (digit, wave) order: 8 counters per thread */
 			const uint32_t per = (X3_REF_DIGITS * X3_SEG_WAVES) / X3_SEG_THREADS;
 			uint32_t c[8], sum = 0, tot;
+			uint32_t *const cp = &cnt_t[((tid * per) / X3_SEG_WAVES) * X3_SEG_CS + (tid * per) % X3_SEG_WAVES]; /* (a digit's counters are X3_SEG_CS words apart) */
 #pragma unroll
-			for (uint32_t k = 0; k < 8; k++) { c[k] = k < per ? cnt_t[tid * per + k] : 0u; sum += c[k]; }
+			for (uint32_t k = 0; k < 8; k++) { c[k] = k < per ? cp[k] : 0u; sum += c[k]; }
 			uint32_t ex = ref_block_excl(sum, wt, lane, wv, tot);
 #pragma unroll
-			for (uint32_t k = 0; k < 8; k++) if (k < per) { cnt_t[tid * per + k] = ex; ex += c[k]; }
+			for (uint32_t k = 0; k < 8; k++) if (k < per) { cp[k] = ex; ex += c[k]; }
 		}
 		__syncthreads();
 		const uint32_t tile_n = n - t0 < X3_SEG_TILE ? n - t0 : X3_SEG_TILE;
 		uint32_t delta = 0;
-		if (tid < X3_REF_DIGITS) delta = (tid + 1u < X3_REF_DIGITS ? cnt_t[(tid + 1u) * X3_SEG_WAVES] : tile_n) - cnt_t[tid * X3_SEG_WAVES];
+		if (tid < X3_REF_DIGITS) delta = (tid + 1u < X3_REF_DIGITS ? cnt_t[(tid + 1u) * X3_SEG_CS] : tile_n) - cnt_t[tid * X3_SEG_CS];
 #pragma unroll
-		for (uint32_t e = 0; e < X3_SEG_E; e++) if (i0 + e * X3_WAVE < n) stage[cnt_t[dg[e] * X3_SEG_WAVES + wv] + rk[e]] = it[e];
+		for (uint32_t e = 0; e < X3_SEG_E; e++) if (i0 + e * X3_WAVE < n) stage[cnt_t[dg[e] * X3_SEG_CS + wv] + rk[e]] = it[e];
 		__syncthreads();
 #pragma unroll
 		for (uint32_t e = 0; e < X3_SEG_E; e++) {
@@ -500,7 +501,7 @@ __device__ static void ref_sort_pass(const uint2 *in, uint2 *out, uint32_t n, ui
 			if (i < tile_n) {
 				const uint2 item = stage[i];
 				const uint32_t d = (uint32_t)(((((uint64_t)X3_REF_CLS(item.y)) << 8) | X3_REF_BYTE(item.x)) >> sh) & (X3_REF_DIGITS - 1u);
-				out[bcur[d] + (i - cnt_t[d * X3_SEG_WAVES])] = item;
+				out[bcur[d] + (i - cnt_t[d * X3_SEG_CS])] = item;
 			}
 		}
 		__syncthreads();
@@ -511,7 +512,7 @@ __device__ static void ref_sort_pass(const uint2 *in, uint2 *out, uint32_t n, ui
 
 __device__ static void x3_segrefine_body(const X3SegArgs &a)
 {
-	X3_LDS uint32_t cnt_t[X3_REF_DIGITS * X3_SEG_WAVES];   /* 32 KiB */
+	X3_LDS uint32_t cnt_t[X3_REF_DIGITS * X3_SEG_CS];      /* 34 KiB */
 	X3_LDS uint2 stage[X3_SEG_TILE];                       /* 32 KiB */
 	X3_LDS uint32_t keepbits[X3_SEG_MAXLEN / 32 + 2];      /* one bit per class of the current list: a member passed this level */
 	X3_LDS uint32_t kpre[X3_SEG_MAXLEN / 32 + 2];          /* kept classes before each bitmap word */
