@@ -658,9 +658,11 @@ def test_per_stream_sort_of_the_arrangements_equals_the_chip_wide_sort_and_oracl
     by_default = gpu_env().compress_chunks(data, off, prm)  # (the switches are read when a batch runs: the default first, before any is set)
     want = gpu_env(X3H_SEGSORT="0").compress_chunks(data, off, prm)
     three = gpu_env(X3H_SEGSORT="1", X3H_SEGSORT_PASSES="3").compress_chunks(data, off, prm)
+    made_keys = gpu_env(X3H_SEGSORT_GEN="1").compress_chunks(data, off, prm)  # the context0 groups made by the sort itself instead of the element-wise pass
     for i in range(len(parts)):
         assert by_default[i] == want[i], f"per-stream sort: stream {i}"
         assert three[i] == want[i], f"per-stream sort, three passes: stream {i}"
+        assert made_keys[i] == want[i], f"per-stream sort making its keys: stream {i}"
     for i in (0, 1, 5, 9):
         assert want[i] == oracle.compress(parts[i], oracle_lib.params(w_kib=64, t=256)), f"stream {i} against the oracle"
 

@@ -1333,15 +1333,22 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 				m_npairs[c] = P[d_ho[c + 1]] - P[d_ho[c]];
 				m_ord00[c] = m_first00[c] != NONE32 ? P[m_first00[c]] : 0u; /* the pair (0,0) of the stream: both contexts after a new fragment (x3.c:424-425); found by the context kernel */
 			});
-			x3_foreach(nH, st, X3_LAMBDA(size_t gh) {
-				uint32_t g;
-				if (h_pv[gh]) g = P[stat[gh - 1].w & 0x7FFFFFFFu]; /* (prev_context1, context1) is the pair the previous hit registered: its ordinal = rank of the hit that first used it */
-				else {
-					const uint32_t c = find_chunk(d_ho, nc, (uint32_t)gh);
-					g = (m_first00[c] != NONE32 && m_first00[c] < gh) ? m_ord00[c] : m_pairbase[c]; /* unknown pair -> context 0 */
-				}
-				G0[gh] = g;
-			});
+			/* the context0 group of every hit: by this element-wise pass.  X3H_SEGSORT_GEN=1: made by the per-stream sort itself (X3SegSortArgs::gen) -- its scattered reads
+			 * of P then stay in one XCD's L2, but a lone workgroup per stream waits for each of them: features 21.8 -> 23.6 ms on the 1024-stream batch, so not the default */
+			bool gen_in_sort = false;
+			if (const char *e = getenv("X3H_SEGSORT_GEN")) gen_in_sort = seg_sort && e[0] == '1';
+			auto groups_elementwise = [&]() {
+				x3_foreach(nH, st, X3_LAMBDA(size_t gh) {
+					uint32_t g;
+					if (h_pv[gh]) g = P[stat[gh - 1].w & 0x7FFFFFFFu]; /* (prev_context1, context1) is the pair the previous hit registered: its ordinal = rank of the hit that first used it */
+					else {
+						const uint32_t c = find_chunk(d_ho, nc, (uint32_t)gh);
+						g = (m_first00[c] != NONE32 && m_first00[c] < gh) ? m_ord00[c] : m_pairbase[c]; /* unknown pair -> context 0 */
+					}
+					G0[gh] = g;
+				});
+			};
+			if (!gen_in_sort) groups_elementwise();
 			std::vector<uint32_t> hnp(nc);
 			HIPCHK(hipMemcpyAsync(hnp.data(), m_npairs, (size_t)nc * 4, hipMemcpyDeviceToHost, st));
 			HIPCHK(hipStreamSynchronize(st)); /* npairs_total, pairs per stream */
@@ -1350,9 +1357,11 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 			/* by ctx0 (pair ordinal; a stream's ordinals start at m_pairbase): the same segmented counting sort, two passes beyond 2048 pairs */
 			if (seg_arrange && maxPairs <= X3_ARRANGE_MAX_LOCAL) CHK(x3_arrange_run(st, nc, d_ho, m_pairbase, maxPairs, G0, h_tag, kA, vA, tA, T[7], T[8]));
 			else if (seg_sort && maxPairs <= X3_SEGSORT_MAX_LOCAL) {
-				CHK(x3_segsort_run(st, nc, d_ho, m_pairbase, maxPairs, G0, kA, vA, T[7], T[8]));
+				const X3SegSortGen gen = { G0, h_pv, P, m_first00, m_ord00, stat };
+				CHK(x3_segsort_run(st, nc, d_ho, m_pairbase, maxPairs, G0, kA, vA, T[7], T[8], gen_in_sort ? &gen : nullptr));
 				if (!ctx_gather) x3_foreach(nH, st, X3_LAMBDA(size_t i) { tA[i] = h_tag[vA[i]]; });
 			} else {
+				if (gen_in_sort) groups_elementwise(); /* (a stream with more pairs than the per-stream sort takes) */
 				if (seg_arrange || seg_sort) x3_foreach(nH, st, X3_LAMBDA(size_t i) { iota[i] = (uint32_t)i; });
 				CHK(x3p_sort_pairs(B.tmp, G0, kA, iota, vA, nH, bits_for(npairs_total ? npairs_total : 1), st));
 				if (!ctx_gather) x3_foreach(nH, st, X3_LAMBDA(size_t i) { tA[i] = h_tag[vA[i]]; });

@@ -767,6 +767,13 @@ struct X3SegSortArgs {
 	uint32_t *kout, *vout;      /* sorted: global key, hit number */
 	uint32_t *tk, *tv;          /* temporaries (more than one pass) */
 	uint32_t npass, dbits;      /* passes, bits per digit (<= 8): the key's bits spread evenly over the passes */
+	/* gen != nullptr: the keys are not read but MADE in sweep 0 and stored to gen (then read from there) -- the context0 group of every hit (x3.c:139-147):
+	 * the ordinal of the pair (previous context1, context1), which is the pair the previous hit registered = the rank of the hit that first used it
+	 * (P[first hit]); hits without a previous hit in their fragment: the stream's pair (0, 0) once it exists, else context 0.  Made here, the scattered
+	 * reads of P stay inside the stream's own segment and the L2 of the one XCD its workgroup runs on (as a chip-wide element-wise pass: 19 GB, 5 ms). */
+	uint32_t *gen;
+	const uint32_t *h_pv, *P, *first00, *ord00;
+	const uint4 *stat;
 };
 __device__ static void x3_segsort_body(const X3SegSortArgs &a)
 {
@@ -783,7 +790,15 @@ __device__ static void x3_segsort_body(const X3SegSortArgs &a)
 	for (uint32_t b0 = 0; b0 < n; b0 += X3_SEG_THREADS) { /* (uniform trip count: wave operations inside) */
 		const uint32_t i = b0 + tid;
 		const bool valid = i < n;
-		const uint32_t k = valid ? a.kin[lo + i] - kb : 0u;
+		uint32_t k = 0u;
+		if (valid) {
+			if (a.gen) {
+				const uint32_t gh = lo + i, f00 = a.first00[blockIdx.x];
+				const uint32_t g = a.h_pv[gh] ? a.P[a.stat[gh - 1u].w & 0x7FFFFFFFu] : ((f00 != NONE32 && f00 < gh) ? a.ord00[blockIdx.x] : kb);
+				a.gen[gh] = g;
+				k = g - kb;
+			} else k = a.kin[lo + i] - kb;
+		}
 		segsort_count(stk, k & dmask, valid, lane);
 		if (npass > 1u) segsort_count(stk + 2048u, (k >> db) & dmask, valid, lane);
 		if (npass > 2u) segsort_count(stv, (k >> (2u * db)) & dmask, valid, lane);
@@ -806,7 +821,7 @@ __device__ static void x3_segsort_body(const X3SegSortArgs &a)
 		const bool first = ps == 0u, last = ps + 1u == npass;
 		/* buffers: the last pass lands in (kout, vout); the ones before alternate so that no pass reads what it writes */
 		const bool to_out = ((npass - 1u - ps) & 1u) == 0u;
-		const uint32_t *ink = first ? a.kin + lo : (to_out ? a.tk : a.kout) + lo, *inv = first ? nullptr : (to_out ? a.tv : a.vout) + lo;
+		const uint32_t *ink = first ? (a.gen ? a.gen : a.kin) + lo : (to_out ? a.tk : a.kout) + lo, *inv = first ? nullptr : (to_out ? a.tv : a.vout) + lo;
 		uint32_t *outk = (to_out ? a.kout : a.tk) + lo, *outv = (to_out ? a.vout : a.tv) + lo;
 		const uint32_t sh = db * ps, ksub = first ? kb : 0u, kadd = last ? kb : 0u;
 		if (tid < 256u) bcur[tid] = bbase[ps][tid];
@@ -887,11 +902,13 @@ static void segsort_tramp(void *p) { x3_segsort_body(*(const X3SegSortArgs *)p);
 #endif
 /* -> X3H_OK; the caller keeps the chip-wide sort when max_local needs more than three 8-bit passes */
 int x3_segsort_run(hipStream_t st, uint32_t nc, const uint32_t *d_ho, const uint32_t *kbase, uint64_t max_local, const uint32_t *key,
-                   uint32_t *kA, uint32_t *vA, uint32_t *tmpk, uint32_t *tmpv)
+                   uint32_t *kA, uint32_t *vA, uint32_t *tmpk, uint32_t *tmpv, const X3SegSortGen *gen)
 {
 	if (max_local >= ((uint64_t)1 << (8u * X3_SSORT_MAXPASS))) return X3H_E_INTERNAL;
 	X3SegSortArgs a;
 	a.ho = d_ho; a.kbase = kbase; a.kin = key; a.kout = kA; a.vout = vA; a.tk = tmpk; a.tv = tmpv;
+	a.gen = nullptr; a.h_pv = a.P = a.first00 = a.ord00 = nullptr; a.stat = nullptr;
+	if (gen) { a.gen = gen->out; a.h_pv = gen->h_pv; a.P = gen->P; a.first00 = gen->first00; a.ord00 = gen->ord00; a.stat = gen->stat; }
 	a.npass = max_local < 256u ? 1u : max_local < 65536u ? 2u : 3u;
 	if (const char *e = getenv("X3H_SEGSORT_PASSES")) { const int v = atoi(e); if (v > (int)a.npass && v <= (int)X3_SSORT_MAXPASS) a.npass = (uint32_t)v; } /* (tests: more passes than the keys need) */
 	/* the key's bits in equal shares: 9 bits are two passes of 5 and 4, not of 8 and 1 -- a pass of 2^5 runs keeps its partly written lines in L2 (header) */

@@ -290,8 +290,9 @@ int x3_mtf_ranks_run(hipStream_t st, uint32_t nc, uint64_t max_dict, const uint3
                      const uint32_t *e_hit, uint32_t *h_rank);
 int x3_arrange_run(hipStream_t st, uint32_t nc, const uint32_t *d_ho, const uint32_t *kbase, uint64_t max_local, const uint32_t *key, const uint32_t *h_tag,
                    uint32_t *kA, uint32_t *vA, uint32_t *tA, uint32_t *tmpk, uint32_t *tmpv);
+struct X3SegSortGen { uint32_t *out; const uint32_t *h_pv, *P, *first00, *ord00; const uint4 *stat; }; /* the keys (context0 groups) made by the sort itself: X3SegSortArgs::gen */
 int x3_segsort_run(hipStream_t st, uint32_t nc, const uint32_t *d_ho, const uint32_t *kbase, uint64_t max_local, const uint32_t *key,
-                   uint32_t *kA, uint32_t *vA, uint32_t *tmpk, uint32_t *tmpv); /* one workgroup per stream, 8-bit passes (code3.hip) */
+                   uint32_t *kA, uint32_t *vA, uint32_t *tmpk, uint32_t *tmpv, const X3SegSortGen *gen = nullptr); /* one workgroup per stream, <= 8-bit passes (code3.hip) */
 #define X3_SEGSORT_MAX_LOCAL (((uint64_t)1 << 24) - 1)
 #define X3_SEGSORT_MIN_STREAMS 128u  /* fewer streams: the chip-wide sort (a stream's passes are a chain on one CU) */
 #ifndef X3_ARR_DBITS
