@@ -433,7 +433,10 @@ def test_emulated_stream_kernels_batch_of_52(emu_env, oracle):
     few = emu_env(X3H_SEGSORT="1", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0").compress_chunks(data[:int(off[12])], off[:13], _lib.make_params(**kw))
     for i in range(12):
         assert few[i] == want[i], f"per-stream sort: stream {i}"
-    few = emu_env(X3H_SEGSORT="1", X3H_SEGSORT_PASSES="3", X3H_SEGSORT_GEN="1", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0").compress_chunks(data[:int(off[12])], off[:13], _lib.make_params(**kw))
+    few = emu_env(X3H_SEGSORT="1", X3H_SEGSORT_NINE="1", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0").compress_chunks(data[:int(off[12])], off[:13], _lib.make_params(**kw))
+    for i in range(12):
+        assert few[i] == want[i], f"per-stream sort, one pass of nine bits: stream {i}"
+    few = emu_env(X3H_SEGSORT="1", X3H_SEGSORT_NINE="0", X3H_SEGSORT_PASSES="3", X3H_SEGSORT_GEN="1", X3H_STREAM_KERNELS="1", X3H_PIPE_MIN="0").compress_chunks(data[:int(off[12])], off[:13], _lib.make_params(**kw))
     for i in range(12):
         assert few[i] == want[i], f"per-stream sort: stream {i}"
 

@@ -659,10 +659,12 @@ def test_per_stream_sort_of_the_arrangements_equals_the_chip_wide_sort_and_oracl
     want = gpu_env(X3H_SEGSORT="0").compress_chunks(data, off, prm)
     three = gpu_env(X3H_SEGSORT="1", X3H_SEGSORT_PASSES="3").compress_chunks(data, off, prm)
     made_keys = gpu_env(X3H_SEGSORT_GEN="1").compress_chunks(data, off, prm)  # the context0 groups made by the sort itself instead of the element-wise pass
+    nine = gpu_env(X3H_SEGSORT_PASSES="1", X3H_SEGSORT_GEN="0", X3H_SEGSORT_NINE="1").compress_chunks(data, off, prm)  # one pass of 9-bit digits wherever the keys fit
     for i in range(len(parts)):
         assert by_default[i] == want[i], f"per-stream sort: stream {i}"
         assert three[i] == want[i], f"per-stream sort, three passes: stream {i}"
         assert made_keys[i] == want[i], f"per-stream sort making its keys: stream {i}"
+        assert nine[i] == want[i], f"per-stream sort, nine-bit digits: stream {i}"
     for i in (0, 1, 5, 9):
         assert want[i] == oracle.compress(parts[i], oracle_lib.params(w_kib=64, t=256)), f"stream {i} against the oracle"
 

@@ -752,14 +752,15 @@ int x3_arrange_run(hipStream_t st, uint32_t nc, const uint32_t *d_ho, const uint
  * that lane alone: context1 of an incompressible stream is 0 for most hits (both contexts restart behind a new fragment, x3.c:424-425), a stream's
  * higher key digits are 0 for all -- and 64 atomics on one LDS word are executed one after the other (measured: the histogram sweep of such a batch
  * took longer than its two sorting passes). */
+template <uint32_t ND>
 __device__ static __forceinline__ void segsort_count(uint32_t *hist8, uint32_t d, bool valid, uint32_t lane)
 {
 	const uint64_t v = x3_ballot(valid);
 	if (!v) return;
 	const uint32_t first = (uint32_t)x3_ctz64(v), d0 = x3_readlane_u32(d, first);
 	const uint64_t same = x3_ballot(valid && d == d0);
-	if (lane == first) atomicAdd(&hist8[(lane & 7u) * 256u + d0], (uint32_t)x3_popc64(same));
-	else if (valid && d != d0) atomicAdd(&hist8[(lane & 7u) * 256u + d], 1u);
+	if (lane == first) atomicAdd(&hist8[(lane & 7u) * ND + d0], (uint32_t)x3_popc64(same));
+	else if (valid && d != d0) atomicAdd(&hist8[(lane & 7u) * ND + d], 1u);
 }
 struct X3SegSortArgs {
 	const uint32_t *ho, *kbase; /* hit offsets (nstreams + 1) and key base per stream */
@@ -775,17 +776,21 @@ struct X3SegSortArgs {
 	const uint32_t *h_pv, *P, *first00, *ord00;
 	const uint4 *stat;
 };
+/* DB = 8: digits of up to 8 bits, up to three passes.  DB = 9: ONE pass of 9-bit digits -- context1 of streams with 256..511 dictionary elements (text at -t 256)
+ * is sorted in one pass instead of two (the histogram's eight copies of 512 counters fill the staging buffer: no room for a second pass's) */
+template <uint32_t DB>
 __device__ static void x3_segsort_body(const X3SegSortArgs &a)
 {
-	X3_LDS uint32_t cnt[256 * X3_SSORT_CS]; /* [digit][wave], a digit's sixteen counters X3_SSORT_CS words apart: the lanes of a wavefront (one wave number, many digits) meet in every bank, not in two */
+	constexpr uint32_t ND = 1u << DB, PER = ND * X3_SEG_WAVES / X3_SEG_THREADS; /* digits; counters per thread in the table scan (4 or 8) */
+	X3_LDS uint32_t cnt[ND * X3_SSORT_CS]; /* [digit][wave], a digit's sixteen counters X3_SSORT_CS words apart: the lanes of a wavefront (one wave number, many digits) meet in every bank, not in two */
 	X3_LDS uint32_t stk[X3_SEG_TILE], stv[X3_SEG_TILE]; /* the tile in sorted order (sweep 0: the histograms, 8 copies x 256 x passes) */
-	X3_LDS uint32_t bbase[X3_SSORT_MAXPASS][256], bcur[256];
+	X3_LDS uint32_t bbase[X3_SSORT_MAXPASS][ND], bcur[ND];
 	X3_LDS __attribute__((aligned(16))) uint32_t wtot[X3_SEG_WAVES];
 	const uint32_t tid = threadIdx.x, lane = x3_lane(), wv = tid / X3_WAVE;
 	const uint32_t lo = a.ho[blockIdx.x], n = a.ho[blockIdx.x + 1] - lo, kb = a.kbase[blockIdx.x], npass = a.npass, db = a.dbits, dmask = (1u << db) - 1u;
 	if (!n) return;
 	/* sweep 0: [copy][digit] counters of pass 0 in stk[0..2047], of pass 1 in stk[2048..4095], of pass 2 in stv[0..2047] */
-	for (uint32_t i = tid; i < 8u * 256u; i += X3_SEG_THREADS) { stk[i] = 0u; stk[2048u + i] = 0u; stv[i] = 0u; }
+	for (uint32_t i = tid; i < 2048u; i += X3_SEG_THREADS) { stk[i] = 0u; stk[2048u + i] = 0u; stv[i] = 0u; } /* (DB = 9: pass 0 alone, all of stk) */
 	__syncthreads();
 	for (uint32_t b0 = 0; b0 < n; b0 += X3_SEG_THREADS) { /* (uniform trip count: wave operations inside) */
 		const uint32_t i = b0 + tid;
@@ -799,22 +804,22 @@ __device__ static void x3_segsort_body(const X3SegSortArgs &a)
 				k = g - kb;
 			} else k = a.kin[lo + i] - kb;
 		}
-		segsort_count(stk, k & dmask, valid, lane);
-		if (npass > 1u) segsort_count(stk + 2048u, (k >> db) & dmask, valid, lane);
-		if (npass > 2u) segsort_count(stv, (k >> (2u * db)) & dmask, valid, lane);
+		segsort_count<ND>(stk, k & dmask, valid, lane);
+		if (npass > 1u) segsort_count<ND>(stk + 2048u, (k >> db) & dmask, valid, lane);
+		if (npass > 2u) segsort_count<ND>(stv, (k >> (2u * db)) & dmask, valid, lane);
 	}
 	__syncthreads();
 	for (uint32_t ps = 0; ps < npass; ps++) { /* bucket bases of every pass: exclusive scan of its histogram */
 		const uint32_t *h8 = ps == 0u ? stk : ps == 1u ? stk + 2048u : stv;
 		uint32_t h = 0, incl = 0;
-		if (tid < 256u) {
+		if (tid < ND) {
 #pragma unroll
-			for (uint32_t k = 0; k < 8; k++) h += h8[k * 256u + tid];
+			for (uint32_t k = 0; k < 8; k++) h += h8[k * ND + tid];
 			incl = x3_wave_incl_scan_u32(h);
 			if (lane == X3_WAVE - 1u) wtot[wv] = incl;
 		}
 		__syncthreads();
-		if (tid < 256u) bbase[ps][tid] = seg_waves_before(wtot, wv) + incl - h;
+		if (tid < ND) bbase[ps][tid] = seg_waves_before(wtot, wv) + incl - h;
 		__syncthreads();
 	}
 	for (uint32_t ps = 0; ps < npass; ps++) {
@@ -824,7 +829,7 @@ __device__ static void x3_segsort_body(const X3SegSortArgs &a)
 		const uint32_t *ink = first ? (a.gen ? a.gen : a.kin) + lo : (to_out ? a.tk : a.kout) + lo, *inv = first ? nullptr : (to_out ? a.tv : a.vout) + lo;
 		uint32_t *outk = (to_out ? a.kout : a.tk) + lo, *outv = (to_out ? a.vout : a.tv) + lo;
 		const uint32_t sh = db * ps, ksub = first ? kb : 0u, kadd = last ? kb : 0u;
-		if (tid < 256u) bcur[tid] = bbase[ps][tid];
+		if (tid < ND) bcur[tid] = bbase[ps][tid];
 		uint32_t nk[X3_SEG_E], nv[X3_SEG_E];
 		{
 			const uint32_t i0 = wv * (X3_SEG_E * X3_WAVE) + lane;
@@ -835,7 +840,7 @@ __device__ static void x3_segsort_body(const X3SegSortArgs &a)
 			}
 		}
 		for (uint32_t t0 = 0; t0 < n; t0 += X3_SEG_TILE) {
-			for (uint32_t i = tid; i < 256u * X3_SSORT_CS; i += X3_SEG_THREADS) cnt[i] = 0u;
+			for (uint32_t i = tid; i < ND * X3_SSORT_CS; i += X3_SEG_THREADS) cnt[i] = 0u;
 			uint32_t ik[X3_SEG_E], iv[X3_SEG_E], rk[X3_SEG_E];
 			const uint32_t i0 = t0 + wv * (X3_SEG_E * X3_WAVE) + lane;
 #pragma unroll
@@ -853,7 +858,7 @@ __device__ static void x3_segsort_body(const X3SegSortArgs &a)
 				const bool valid = i0 + e * X3_WAVE < n;
 				const uint32_t d = (ik[e] >> sh) & dmask;
 				uint32_t mlo, mhi;
-				seg_match<8>(d, valid, mlo, mhi);
+				seg_match<DB>(d, valid, mlo, mhi);
 				const uint32_t lower = seg_lower(mlo, mhi);
 				const uint32_t prev = valid ? cnt[d * X3_SSORT_CS + wv] : 0u;
 				x3_wave_order();
@@ -863,18 +868,20 @@ __device__ static void x3_segsort_body(const X3SegSortArgs &a)
 			}
 			__syncthreads();
 			/* exclusive scan of the counter table in (digit, wave) order = the tile-sorted order */
-			uint32_t *const c4 = &cnt[(tid >> 2) * X3_SSORT_CS + (tid & 3u) * 4u]; /* four waves' counters of digit tid / 4 */
-			const uint4 c = make_uint4(c4[0], c4[1], c4[2], c4[3]);
-			const uint32_t s = c.x + c.y + c.z + c.w;
+			uint32_t *const cp = &cnt[((tid * PER) / X3_SEG_WAVES) * X3_SSORT_CS + (tid * PER) % X3_SEG_WAVES]; /* PER waves' counters of one digit */
+			uint32_t c[PER], s = 0;
+#pragma unroll
+			for (uint32_t k = 0; k < PER; k++) { c[k] = cp[k]; s += c[k]; }
 			const uint32_t incl = x3_wave_incl_scan_u32(s);
 			if (lane == X3_WAVE - 1u) wtot[wv] = incl;
 			__syncthreads();
-			const uint32_t ex = incl - s + seg_waves_before(wtot, wv);
-			c4[0] = ex; c4[1] = ex + c.x; c4[2] = ex + c.x + c.y; c4[3] = ex + c.x + c.y + c.z;
+			uint32_t ex = incl - s + seg_waves_before(wtot, wv);
+#pragma unroll
+			for (uint32_t k = 0; k < PER; k++) { cp[k] = ex; ex += c[k]; }
 			__syncthreads();
 			const uint32_t tile_n = n - t0 < X3_SEG_TILE ? n - t0 : X3_SEG_TILE;
 			uint32_t delta = 0; /* entries of digit `tid` in this tile */
-			if (tid < 256u) delta = (tid < 255u ? cnt[(tid + 1u) * X3_SSORT_CS] : tile_n) - cnt[tid * X3_SSORT_CS];
+			if (tid < ND) delta = (tid < ND - 1u ? cnt[(tid + 1u) * X3_SSORT_CS] : tile_n) - cnt[tid * X3_SSORT_CS];
 #pragma unroll
 			for (uint32_t e = 0; e < X3_SEG_E; e++) {
 				if (i0 + e * X3_WAVE < n) { const uint32_t at = cnt[((ik[e] >> sh) & dmask) * X3_SSORT_CS + wv] + rk[e]; stk[at] = ik[e]; stv[at] = iv[e]; }
@@ -890,15 +897,17 @@ __device__ static void x3_segsort_body(const X3SegSortArgs &a)
 				}
 			}
 			__syncthreads();
-			if (tid < 256u) bcur[tid] += delta; /* (read again only behind the next tile's barriers) */
+			if (tid < ND) bcur[tid] += delta; /* (read again only behind the next tile's barriers) */
 		}
 		__syncthreads();
 	}
 }
 #ifndef X3_EMU
-__global__ void __launch_bounds__(X3_SEG_THREADS, 8) x3_segsort_kernel(X3SegSortArgs a) { x3_segsort_body(a); }
+__global__ void __launch_bounds__(X3_SEG_THREADS, 8) x3_segsort_kernel(X3SegSortArgs a) { x3_segsort_body<8>(a); }
+__global__ void __launch_bounds__(X3_SEG_THREADS, 8) x3_segsort9_kernel(X3SegSortArgs a) { x3_segsort_body<9>(a); }
 #else
-static void segsort_tramp(void *p) { x3_segsort_body(*(const X3SegSortArgs *)p); }
+static void segsort_tramp(void *p) { x3_segsort_body<8>(*(const X3SegSortArgs *)p); }
+static void segsort9_tramp(void *p) { x3_segsort_body<9>(*(const X3SegSortArgs *)p); }
 #endif
 /* -> X3H_OK; the caller keeps the chip-wide sort when max_local needs more than three 8-bit passes */
 int x3_segsort_run(hipStream_t st, uint32_t nc, const uint32_t *d_ho, const uint32_t *kbase, uint64_t max_local, const uint32_t *key,
@@ -915,11 +924,15 @@ int x3_segsort_run(hipStream_t st, uint32_t nc, const uint32_t *d_ho, const uint
 	uint32_t kbits = 1; while (kbits < 24u && (max_local >> kbits)) kbits++;
 	a.dbits = (kbits + a.npass - 1u) / a.npass;
 	if (getenv("X3H_SEGSORT_DBITS8")) a.dbits = 8u; /* (tests / measurements: whole bytes) */
+	bool nine = kbits == 9u && a.npass == 2u && !getenv("X3H_SEGSORT_DBITS8"); /* one pass of nine bits instead of 5 + 4 */
+	if (const char *e = getenv("X3H_SEGSORT_NINE")) nine = e[0] == '1' ? (kbits <= 9u && a.npass <= 2u) : false; /* (1: also for shorter keys -- tests; 0: never) */
+	if (nine) { a.npass = 1u; a.dbits = 9u; }
 	if (getenv("X3H_DEBUG")) fprintf(stderr, "[x3h] per-stream sort: %u streams, largest local key %llu, %u passes of %u bits\n", nc, (unsigned long long)max_local, a.npass, a.dbits);
 #ifndef X3_EMU
-	hipLaunchKernelGGL(x3_segsort_kernel, dim3(nc), dim3(X3_SEG_THREADS), 0, st, a);
+	if (nine) hipLaunchKernelGGL(x3_segsort9_kernel, dim3(nc), dim3(X3_SEG_THREADS), 0, st, a);
+	else hipLaunchKernelGGL(x3_segsort_kernel, dim3(nc), dim3(X3_SEG_THREADS), 0, st, a);
 #else
-	x3emu_launch(segsort_tramp, (void *)&a, dim3(nc), dim3(X3_SEG_THREADS));
+	x3emu_launch(nine ? segsort9_tramp : segsort_tramp, (void *)&a, dim3(nc), dim3(X3_SEG_THREADS));
 #endif
 	HIPCHK(hipGetLastError());
 	return X3H_OK;
