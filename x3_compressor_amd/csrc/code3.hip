@@ -741,8 +741,9 @@ int x3_arrange_run(hipStream_t st, uint32_t nc, const uint32_t *d_ho, const uint
  *            staged in LDS, out as runs.  The first pass makes the values (hit numbers) itself; the last adds kbase back.
  * x3_arrange_kernel above (four wavefronts per stream, 11-bit digits, each wavefront a chain of LDS round trips over its quarter) was slower than
  * rocPRIM and stays behind X3H_ARRANGE=1.
- * Measured (1024 streams, 106 M hits, nothing else on the chip: tools/exp/r04_segsort_q.sh): by context1 (local keys < 282: two passes of 5 + 4 bits) 2.3 ms,
- * by pair (local keys < 41 289: two passes of 8 bits) 2.7 ms, 16.4 GB of HBM traffic -- against 9.8 ms + two index fills and 35.7 GB for the two rocPRIM sorts.
+ * Measured (1024 streams, 106 M hits, nothing else on the chip: profiles/r04_many_chunks_pmc_traffic.json): by context1 (local keys < 282: one pass of 9 bits;
+ * as 5 + 4 bits: 2.3 ms) 1.5 ms, by pair (local keys < 41 289: two passes of 8 bits) 2.7 ms, 11.9 GB of HBM traffic -- against 9.8 ms + two index fills and
+ * 35.7 GB for the two rocPRIM sorts.
  * (In a kernel trace of the product the first sort shows 5 ms: the move-to-front ranks run beside it on their own stream, by design.)  One more pass
  * over all-zero digits costs 1.0 ms, the histogram sweep 0.3-0.7 ms; LDS bank conflicts were 74 % of the LDS cycles with the counters of a digit 16
  * words apart (every lane of a wavefront in one of two banks): X3_SEG_CS = 17. */

@@ -21,7 +21,8 @@
  *            counters in global memory) hand list 4 to the walk kernel / the chip-wide refinement of scan2.hip (same list layout: chunk
  *            c's list occupies the entries of its slot of the padded layout).
  * HBM traffic: 16 B per element and pass + 8 B of keys + the level-4 sweep, all of it sequential or in digit runs (80 B per element
- * algorithmic; measured 2.2x that: short digit runs pay whole sectors).
+ * algorithmic; measured 1.3x that since the level tests read their list entries out of LDS -- round 3: 2.1x).  What limits the kernel is
+ * instruction issue and LDS, not HBM: sixteen wavefronts, six barriers per tile, one workgroup per CU.
  */
 #include "x3_host.h"
 
