@@ -58,6 +58,20 @@ def run_reference(sample: bytes, w_kib: int, t: int):
         return sec, open(o, "rb").read(), "port"
 
 
+def run_reference_decode(stream: bytes):
+    """the real reference's decoder (oracle/_ref/x3 -d, x3.c:613-645) on one stream, one core -> (seconds of its own 'elapsed time', bytes), or None"""
+    if not os.path.exists(REF):
+        return None
+    with tempfile.TemporaryDirectory() as d:
+        i, o = os.path.join(d, "in.x3"), os.path.join(d, "out")
+        open(i, "wb").write(stream)
+        r = subprocess.run([REF, "-d", "-f", i, o], capture_output=True, text=True)
+        if r.returncode != 0:
+            return None
+        sec = float([l for l in r.stderr.splitlines() if l.startswith("elapsed time:")][0].split(":")[1])
+        return sec, open(o, "rb").read()
+
+
 def newest_profile(suffix):
     """profiles/rNN_<suffix> of the latest round that has one (PMC numbers come from separate profiling passes, tools/r03_refresh.sh)"""
     import glob
@@ -96,6 +110,23 @@ def pinned_chunk_ok(manifest, chunk, stream: bytes):
     if e is None:
         return None
     return bool(len(stream) == e["output_len"] and hashlib.sha256(stream).hexdigest() == e["output_sha256"])
+
+
+def pinned_pieces_ok(manifest, base, stream_of, chunk_bytes=None, names=None):
+    """the chunks of one of the timed many-stream batches whose streams the REAL reference wrote (tests/golden/make_golden_sha.py, `piece` entries of `base`):
+    stream_of(chunk index) -> bytes of the TIMED call's output.  -> (sorted chunk indices checked, all equal?)"""
+    checked, ok = [], True
+    for n, e in sorted(manifest.items()):
+        if e.get("generator") != "piece" or e["generator_args"]["base"] != base or (names is not None and n not in names):
+            continue
+        c = names[n] if names is not None else e["generator_args"]["start"] // chunk_bytes
+        s = stream_of(c)
+        good = len(s) == e["output_len"] and hashlib.sha256(s).hexdigest() == e["output_sha256"]
+        if not good:
+            print(f"bench.py: {n}: chunk {c} of the timed batch differs from the real reference's stream", file=sys.stderr)
+        checked.append(c)
+        ok = ok and good
+    return sorted(checked), bool(checked) and ok
 
 
 def emit_line(line):
@@ -290,6 +321,9 @@ def main():
             traffic = e["hbm_bytes_per_step"]
             traffic_src = f"profiles/{os.path.basename(pmc_path)}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (per step = all launches of the kernel; FETCH doubled per MI355X_MICROARCH.md)"
     path_bytes = S * W + N + comp  # the path's algorithmic bytes B_alg = S*W + N + C
+    step_traffic = None  # HBM bytes of the WHOLE step (every kernel), same PMC profile, same staleness rule
+    if pmc_path and traffic is not None:
+        step_traffic = int(sum(k.get("hbm_bytes_per_step", 0) for k in pmc.get("kernels", {}).values()))
     line.update({
         "config": {"workload": f"dickens-like: {N} bytes of synthetic English-like text, ONE x3 stream, -w {args.w} -t {args.t}, bit-exact x3 code stream",
                    "window_kib": args.w, "max_match_count": args.t, "streams_per_gpu": 1},
@@ -306,6 +340,8 @@ def main():
                      "frac": round(kernels[dom]["alg_bytes"] / (kernels[dom]["ms"] * 1e-3) / HBM_PEAK, 7), "traffic": traffic,
                      "traffic_source": traffic_src, "algorithmic_bytes": kernels[dom]["alg_bytes"], "kernel_ms": kernels[dom]["ms"],
                      "launches_per_step": int(st.coder_launches) or 1,
+                     # the compulsory-traffic floor N + C and the whole step's measured HBM traffic beside every fraction
+                     "compulsory_bytes": N + comp, "step_traffic_bytes": step_traffic,
                      # SURVEY.md 8(d)'s single figure for the PATH, B_alg = S*W + N + C over the whole step, in the same object
                      "path_algorithmic_bytes": path_bytes, "path_achieved": round(path_bytes / (ms_per_step * 1e-3) / 1e9, 2),
                      "frac_path": round(path_bytes / (ms_per_step * 1e-3) / HBM_PEAK, 5),
@@ -326,6 +362,7 @@ def main():
 
         # the SAME bytes cut into independent chunks (each its own x3 stream), one batch per chunk count.  The ratio pays for
         # every restart of the models; single stream = the `ratio` above.
+        man_all = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest_sha.json")))
         sweep = []
         for nch in (16, 24, 32, 40, 48, 64, 80, 96, 128, 256, 512):
             cb = (N + nch - 1) // nch
@@ -334,6 +371,11 @@ def main():
                  "ratio": round(N / float(clens.sum()), 4),
                  "stage_ms": {"scan": round(cst.ms_scan, 3), "parse": round(cst.ms_parse, 3), "features": round(cst.ms_features, 3),
                               "modes": round(cst.ms_modes, 3), "coder": round(cst.ms_coder, 3), "emit": round(cst.ms_emit, 3)}}
+            if nch in (40, 64, 128) and default_workload:  # first and last chunk of the TIMED call against the real reference's stream of that chunk alone
+                hsl = lambda i: d_cout[i * cstride:i * cstride + int(clens[i])].cpu().numpy().tobytes()
+                e["pinned_chunks_checked"], e["pinned_chunks_ok"] = pinned_pieces_ok(man_all, "english_like", hsl, names={f"csb_dickens_{nch}x_chunk{i}_w64_t256": i for i in (0, nch - 1)})
+                if not e["pinned_chunks_ok"]:
+                    e["valid"] = False
             if nch == 64:  # decoder (x3.c:285-353): the chunk streams decoded as one batch; and every 8th stream against the oracle-free check: round trip
                 hout = d_cout.cpu().numpy()
                 cstreams = [hout[i * cstride:i * cstride + int(clens[i])].tobytes() for i in range(len(coff) - 1)]
@@ -345,7 +387,7 @@ def main():
                                "round_trip_ok": bool(b"".join(back) == data.tobytes())}
             sweep.append(e)
             del d_cout
-        at1g = [e for e in sweep if e["value"] >= 1000.0]
+        at1g = [e for e in sweep if e["value"] >= 1000.0 and e.get("valid", True)]
         line["chunked_same_bytes"] = {"single_stream_ratio": round(N / comp, 4), "sweep": sweep,
                                       "best": max(sweep, key=lambda e: e["value"])["value"],
                                       # the >= 1 GB/s point that keeps the most of the single stream's ratio (every restart of the models costs ratio)
@@ -356,7 +398,7 @@ def main():
             # bytes -- nothing repeated)
             mtot, mcb = args.many_chunks_mib << 20, 256 << 10
             q = mtot // 2
-            mdata = np.concatenate([synth.english_like(q, seed=0xBA7C4), synth.zipf_bytes(mtot - q, offset=1 << 33)])
+            mdata = synth.many_chunks_mix(mtot)
             d_min = torch.from_numpy(mdata).to(dev)
             mdt, mlens, mst, moff, d_mout, mstride = chunk_batch(ctx, d_min, mtot, mcb, prm, dev)
             line["many_chunks_batch"] = {
@@ -364,6 +406,13 @@ def main():
                 "value": round(mtot / mdt / 1e6, 2), "unit": "MB/s", "ms": round(mdt * 1e3, 2), "ratio": round(mtot / float(mlens.sum()), 4),
                 "stage_ms": {"scan": round(mst.ms_scan, 2), "parse": round(mst.ms_parse, 2), "features": round(mst.ms_features, 2),
                              "modes": round(mst.ms_modes, 2), "coder": round(mst.ms_coder, 2), "emit": round(mst.ms_emit, 2)}}
+            if mtot == synth.MANY_CHUNKS_MIB << 20 and (args.w, args.t) == (64, 256):
+                # bit-exactness of the TIMED form: fourteen chunks -- first / middle / last of the text half and of the Zipf half, both sides of the
+                # text -> Zipf boundary -- against the real reference's `x3 -z -w 64 -t 256` of that chunk alone (x3.c:372-434,593-611)
+                mcheck, mok = pinned_pieces_ok(man_all, "many_chunks_mix", lambda c: d_mout[c * mstride:c * mstride + int(mlens[c])].cpu().numpy().tobytes(), mcb)
+                line["many_chunks_batch"].update({"pinned_chunks_checked": mcheck, "pinned_chunks_ok": mok})
+                if not mok:
+                    line["many_chunks_batch"]["valid"] = False
             # K1 of this batch is the one HBM-bound hand-written kernel family of the path (scan3.hip: per-chunk radix sort + level tests, dense classes
             # refined by the same workgroup): algorithmic bytes = 80 per list element (8 keys out + 4 passes x 16 + 8 for the level-4 re-read), n + 3 elements per chunk
             k1_alg = 80 * (mtot + 3 * (len(moff) - 1))
@@ -404,12 +453,17 @@ def main():
             del d_min, d_mout, d_tout
             # data with DENSE classes (sparse 16-bit samples: thousands of repeats of a gram inside every window): K1 refines such classes byte
             # by byte instead of sweeping them (scan2.hip) -- bounded, but the scan dominates
-            ddata = synth.mr_like(64 << 20, seed=0xBA7)
+            ddata = synth.dense_batch()
             d_din = torch.from_numpy(ddata).to(dev)
-            ddt, dlens, dst_, _, d_dout, _ = chunk_batch(ctx, d_din, ddata.size, mcb, prm, dev, reps=1)
+            ddt, dlens, dst_, _, d_dout, dstride = chunk_batch(ctx, d_din, ddata.size, mcb, prm, dev, reps=1)
             line["many_chunks_dense_classes"] = {"content": "mr-like 16-bit samples (zero background, sparse noise)", "total_bytes": int(ddata.size), "chunks": ddata.size // mcb,
                                                  "value": round(ddata.size / ddt / 1e6, 2), "unit": "MB/s", "ratio": round(ddata.size / float(dlens.sum()), 4),
                                                  "stage_ms": {"scan": round(dst_.ms_scan, 2), "parse": round(dst_.ms_parse, 2), "code": round(dst_.ms_code, 2)}}
+            if (args.w, args.t) == (64, 256):
+                dcheck, dok = pinned_pieces_ok(man_all, "dense_batch", lambda c: d_dout[c * dstride:c * dstride + int(dlens[c])].cpu().numpy().tobytes(), mcb)
+                line["many_chunks_dense_classes"].update({"pinned_chunks_checked": dcheck, "pinned_chunks_ok": dok})
+                if not dok:
+                    line["many_chunks_dense_classes"]["valid"] = False
             del d_din, d_dout
 
         # one GPU's share of config 4 (16 chunks x 8 MiB of the Zipf stream): what every rank does at N > 1, without the gather
@@ -418,7 +472,6 @@ def main():
         zdt, zlens, zst, _, d_zout, zstride = chunk_batch(ctx, d_zin, 16 * CHUNK4, CHUNK4, prm, dev, reps=1)
         # the 16-chunk batch takes its own schedule (pipelined, segment-wise bit emission): its pinned chunks are compared with the real
         # reference's streams HERE, on the output of the timed call (bit-exactness asserted in the same run)
-        man_all = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest_sha.json")))
         z_ok = {c: pinned_chunk_ok(man_all, c, d_zout[c * zstride:c * zstride + int(zlens[c])].cpu().numpy().tobytes()) for c in PINNED4 if c < 16} \
             if (args.w, args.t) == (64, 256) else {}
         z_bad = sorted(c for c, v in z_ok.items() if v is not True)
@@ -489,6 +542,21 @@ def main():
                                               "parse_steps": int(st5.steps), "stream_sha256_equals_reference": ok5,
                                               "round_trip_ok": bool(int(dl5[0]) == d5.size and torch.equal(d_5back, d_5in)),
                                               "content": "mr-like 16-bit samples (synth.mr_like), the size of Silesia 'mr'"}
+                # the reference's decoder beside the GPU's (x3.c:641-645 prints its own elapsed time), on a BOUNDED sample: the first MiB of this input, coded on the
+                # GPU with config 5's parameters (the stream a reference encoder would write), decoded by oracle/_ref/x3 -d on one host core and by the GPU
+                if not args.no_cpu:
+                    samp = d5[:1 << 20]
+                    s_samp = ctx.compress(samp, prm5)
+                    rd = run_reference_decode(s_samp)
+                    ctx.decompress(s_samp, samp.size)
+                    gdt, gback = timed(lambda: ctx.decompress(s_samp, samp.size), torch.cuda.synchronize)
+                    if rd is not None:
+                        line["config5_round_trip"]["cpu_baseline_decode"] = {
+                            "value": round(samp.size / rd[0] / 1e6, 5), "unit": "MB/s", "cores": 1, "kind": "reference", "seconds": round(rd[0], 3),
+                            "sample": f"first {samp.size} bytes of config 5's input as one -w 512 -t 4096 stream ({len(s_samp)} bytes), `x3 -d`'s own 'elapsed time' (x3.c:641-645)",
+                            "reference_output_equals_input": bool(rd[1] == samp.tobytes()),
+                            "gpu_decode_same_stream": {"value": round(samp.size / gdt / 1e6, 3), "unit": "MB/s", "ms": round(gdt * 1e3, 2), "round_trip_ok": bool(gback == samp.tobytes()),
+                                                       "note": "x3h_decompress, host buffers (H2D + D2H included)"}}
                 if ok5 is False or not line["config5_round_trip"]["round_trip_ok"]:
                     line["config5_round_trip"] = {"valid": False, "stream_sha256_equals_reference": ok5, "round_trip_ok": line["config5_round_trip"]["round_trip_ok"]}
                 del d_5in, d_5out, d_5back

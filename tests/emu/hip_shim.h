@@ -19,7 +19,8 @@ static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
-static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+/* X3EMU_DEVICES=N: N emulated devices (they share the host's memory; a handle per device exercises the multi-device code of api.hip) */
+static inline hipError_t hipGetDeviceCount(int *n) { const char *e = getenv("X3EMU_DEVICES"); const int v = e ? atoi(e) : 1; *n = v >= 1 && v <= 64 ? v : 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 1 };
 static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 256; return hipSuccess; } /* (the emulated device: the masked streams of the sliced schedule are created like on the real one) */

@@ -533,3 +533,51 @@ def test_emulated_sliced_falls_back_on_a_large_dictionary(oracle, monkeypatch):
         assert ost.dict_elems > 2048
         assert ctx.compress(data, _lib.make_params(**kw)) == want
         assert ctx.last_stats.pipelined == 0 and ctx.last_stats.dict_elems == ost.dict_elems
+
+
+@pytest.mark.parametrize("ndev", [2, 3, 8])
+def test_emulated_rccl_container_over_several_devices(monkeypatch, oracle, ndev):
+    """x3h_compress_container_rccl at ndevices = 2, 3, 8 (one rank: tests/test_gpu_parity.py, through the real RCCL; VERDICT r04: the C multi-rank code had only ever run as a one-rank self-send): N emulated devices
+    (tests/emu/hip_shim.h, X3EMU_DEVICES), a handle each, librccl replaced by tests/emu/rccl_stub.h -- sends and receives recorded inside the group, paired and
+    executed as memcpy at ncclGroupEnd, failing on any unmatched operation or size mismatch.  What runs is api.hip's own partition of the chunks over the devices, the
+    per-device pack, the offsets `at` of every block behind the header, the send / receive pairing and the header placement; the bytes must equal
+    x3h_compress_container's (host-staged concat), every chunk the oracle's stream, and the exchange must be ONE group of ndev - 1 pairs with exact sizes."""
+    import ctypes as C
+    subprocess.run(["make", "-C", os.path.join(HERE, "emu")], check=True, capture_output=True)
+    monkeypatch.setenv("X3EMU_DEVICES", str(ndev))
+    monkeypatch.setenv("X3H_MULTI_SERIAL", "1")   # the fiber emulator runs one device at a time on the calling thread
+    ctxs = [_lib.X3Context(d, library=EMU_SO) for d in range(ndev)]
+    try:
+        lib = ctxs[0].lib
+        kw = dict(w_kib=1, t=4)
+        prm, oprm = _lib.make_params(**kw), oracle_lib.params(**kw)
+        from x3_compressor_amd import container
+        # 11 chunks (the last one short) over ndev devices: uneven blocks at 2 and 3 devices, devices with ONE chunk and a 3-chunk tail at 8; then fewer chunks than devices
+        sets = [(synth.english_like(10 * 600 + 250, seed=9).tobytes(), 600)] + ([(synth.zipf_bytes(3 * 400).tobytes(), 400)] if ndev > 3 else [])
+        for data, cb in sets:
+            nch = (len(data) + cb - 1) // cb
+            groups0, pairs, nbytes = C.c_uint64(), C.c_uint64(), C.c_uint64()
+            lib.x3emu_rccl_last_group(C.byref(groups0), C.byref(pairs), C.byref(nbytes))
+            got = _lib.compress_container(ctxs, data, prm, cb, rccl=True)
+            groups1 = C.c_uint64()
+            lib.x3emu_rccl_last_group(C.byref(groups1), C.byref(pairs), C.byref(nbytes))
+            want = _lib.compress_container(ctxs, data, prm, cb)
+            assert got == want
+            params, chunks = container.unpack(got)
+            assert len(chunks) == nch
+            for i, (raw, s) in enumerate(chunks):
+                assert s == oracle.compress(data[i * cb:(i + 1) * cb], oprm), f"chunk {i}"
+            nd = min(ndev, nch)
+            assert groups1.value == groups0.value + 1, "the final concat is ONE send/receive group"
+            assert pairs.value == (1 if nd == 1 else nd - 1)
+            # exact sizes: what travels is every block but the root's (one rank: its own block, to itself)
+            base, rem = divmod(nch, nd)   # api.hip shard() == dist.shard_range
+            lo_hi = [(d * base + min(d, rem), d * base + min(d, rem) + base + (1 if d < rem else 0)) for d in range(nd)]
+            sizes = [sum(len(chunks[i][1]) for i in range(lo, hi)) for lo, hi in lo_hi]
+            assert sum(sizes) == len(got) - lib.x3h_container_header_bytes(nch)
+            assert nbytes.value in (sum(sizes[1:]) if nd > 1 else sizes[0],), (nbytes.value, sizes)
+            assert _lib.decompress_container(ctxs, got, len(data)) == data
+    finally:
+        ctxs[0].lib.x3h_rccl_release()
+        for c in ctxs:
+            c.close()

@@ -17,7 +17,8 @@ from x3_compressor_amd import _lib, synth
 
 pytestmark = pytest.mark.gpu
 MAN = json.load(open(os.path.join(golden_util.HERE, "manifest_sha.json")))
-CASES = sorted(n for n in MAN if not n.startswith("cli_"))
+PIECES = sorted(n for n in MAN if MAN[n]["generator"] == "piece")   # chunks of the batches bench.py times (round 5): tested in their batch, below
+CASES = sorted(n for n in MAN if not n.startswith("cli_") and n not in PIECES)
 LONG = [n for n in CASES if n.startswith(("big_", "cfg3_full_", "cfg5_full_"))]   # minutes to hours of reference time each
 PAST_2_24 = [n for n in LONG if MAN[n]["input_len"] >= (24 << 20)]   # 0.5-0.8 parse steps per byte: more than 2^24 steps (asserted below)
 
@@ -133,6 +134,93 @@ def test_config4_share_in_the_form_that_is_timed():
         dl, _ = ctx.decompress_chunks_dev(d_cmp.data_ptr(), ioff, d_back.data_ptr(), off)
         torch.cuda.synchronize()
         assert int(dl.sum()) == per * CHUNK4 and torch.equal(d_back, d_in)
+
+
+def _batch_on_gpu(ctx, data, cb, prm):
+    """one batch of independent `cb`-byte chunks, device-resident in and out, exactly as bench.py's chunk_batch() runs it -> (streams getter, stats)"""
+    import numpy as np
+    total = int(data.size)
+    off = np.array(list(range(0, total, cb)) + [total], dtype=np.uint64)
+    stride = (cb + (cb >> 1) + 4096 + 3) & ~3
+    dev = torch.device("cuda", 0)
+    d_in = torch.from_numpy(data).to(dev)
+    d_out = torch.empty(stride * (len(off) - 1), dtype=torch.uint8, device=dev)
+    lens, st = ctx.compress_chunks_dev(d_in.data_ptr(), off, prm, d_out.data_ptr(), stride)
+    torch.cuda.synchronize()
+    return (lambda c: d_out[c * stride:c * stride + int(lens[c])].cpu().numpy().tobytes()), st, len(off) - 1
+
+
+def _pieces_of(base, prefix):
+    return {n: MAN[n] for n in PIECES if n.startswith(prefix) and MAN[n]["generator_args"]["base"] == base}
+
+
+MANY_STREAM_SWITCHES = {"default-switches": {}, "chip-wide-sorts": {"X3H_SEGSORT": "0", "X3H_SEG_MIN": "0"}}
+
+
+@pytest.mark.parametrize("switches", list(MANY_STREAM_SWITCHES))
+def test_many_chunks_batch_in_the_form_that_is_timed(monkeypatch, switches):
+    """bench.py's `many_chunks_batch`: 1024 x 256 KiB chunks (half English-like text, half Zipf bytes) as ONE device-resident batch under `-w 64 -t 256` --
+    the window is smaller than a chunk's padded slot, the per-chunk K1 sort (scan3.hip), the per-stream kernels of code3.hip incl. the one-pass 9-bit arrangement
+    sort and four coder chains per workgroup are what runs.  Fourteen chunks (first / middle / last of either half and both sides of the text -> Zipf boundary)
+    must equal the real reference's `x3 -z -w 64 -t 256` of that chunk alone (x3.c:372-434,593-611); once more with the chip-wide sorts (X3H_SEGSORT=0 X3H_SEG_MIN=0)."""
+    for k, v in MANY_STREAM_SWITCHES[switches].items():
+        monkeypatch.setenv(k, v)
+    pinned = _pieces_of("many_chunks_mix", "mcb_mix256m_")
+    assert len(pinned) >= 12
+    data = synth_base("many_chunks_mix")
+    with _lib.X3Context(0) as ctx:
+        stream_of, st, nch = _batch_on_gpu(ctx, data, synth.MANY_CHUNK_BYTES, _lib.make_params(w_kib=64, t=256))
+        assert nch == 1024 and st.pipelined == 0
+        for n, e in pinned.items():
+            c = e["generator_args"]["start"] // synth.MANY_CHUNK_BYTES
+            assert hashlib.sha256(data[c * synth.MANY_CHUNK_BYTES:(c + 1) * synth.MANY_CHUNK_BYTES].tobytes()).hexdigest() == e["input_sha256"], n
+            assert golden_util.pinned_stream_ok(e, stream_of(c)), f"{n}: chunk {c} of the timed batch differs from the real reference's stream"
+
+
+def synth_base(base):
+    """one of bench.py's batches (generated once per process, golden_util keeps it)"""
+    golden_util.sha_input(dict(generator="piece", generator_args=dict(base=base, start=0, n=0), input_sha256=hashlib.sha256(b"").hexdigest()))
+    return golden_util._BASES[base]
+
+
+def test_dense_class_batch_in_the_form_that_is_timed():
+    """bench.py's `many_chunks_dense_classes`: 64 MiB of mr-like 16-bit samples as 256 x 256 KiB chunks (zero runs: the per-chunk refinement of K1, 24-32 dictionary
+    lengths hitting at every position of K2); four chunks against the real reference"""
+    pinned = _pieces_of("dense_batch", "mcb_dense64m_")
+    assert len(pinned) >= 4
+    data = synth_base("dense_batch")
+    with _lib.X3Context(0) as ctx:
+        stream_of, st, nch = _batch_on_gpu(ctx, data, synth.MANY_CHUNK_BYTES, _lib.make_params(w_kib=64, t=256))
+        assert nch == 256
+        for n, e in pinned.items():
+            c = e["generator_args"]["start"] // synth.MANY_CHUNK_BYTES
+            assert golden_util.pinned_stream_ok(e, stream_of(c)), f"{n}: chunk {c}"
+
+
+@pytest.mark.parametrize("nch", [40, 64, 128])
+def test_chunked_same_bytes_in_the_form_that_is_timed(nch):
+    """bench.py's `chunked_same_bytes`: the dickens-sized text cut into 40 / 64 (K3 in slices on the CU-masked streams) / 128 chunks (per-stream kernels); the first and
+    the (shorter) last chunk against the real reference"""
+    data = synth_base("english_like")
+    cb = (int(data.size) + nch - 1) // nch
+    with _lib.X3Context(0) as ctx:
+        stream_of, st, got_nch = _batch_on_gpu(ctx, data, cb, _lib.make_params(w_kib=64, t=256))
+        assert got_nch == nch
+        if nch <= 96:
+            assert st.pipelined == 2
+        for i in (0, nch - 1):
+            e = MAN[f"csb_dickens_{nch}x_chunk{i}_w64_t256"]
+            assert (e["generator_args"]["start"], e["generator_args"]["n"]) == synth.same_bytes_chunk_range(nch, i)
+            assert golden_util.pinned_stream_ok(e, stream_of(i)), f"{nch} chunks: chunk {i}"
+
+
+@pytest.mark.parametrize("name", PIECES)
+def test_pinned_piece_as_a_stream_of_its_own(name):
+    """every pinned chunk once more as ONE stream through x3h_compress (the schedule a lone 80-256 KiB stream takes)"""
+    e = MAN[name]
+    with _lib.X3Context(0) as ctx:
+        got = ctx.compress(golden_util.sha_input(e), _lib.params_from_args(e["args"]))
+    assert golden_util.pinned_stream_ok(e, got)
 
 
 def test_container_rccl_over_every_gpu_of_the_box():

@@ -1391,9 +1391,12 @@ extern "C" int x3h_decompress_container(x3h_ctx *const *ctxs, int ndevices, cons
  * is laid down there; the finished container crosses PCIe once.  No host staging of the streams (x3h_compress_container goes through a
  * host buffer per device).  librccl is loaded on first use (dlopen): a process that never calls this never pays for it.
  * ------------------------------------------------------------------------------------------------------------ */
+#include <mutex>
 #ifndef X3_EMU
 #include <dlfcn.h>
-#include <mutex>
+#else
+#include "rccl_stub.h" /* tests/emu: sends and receives recorded inside the group, executed as memcpy at its end -- the code below runs with 2..8 emulated devices */
+#endif
 
 /* The six entry points of librccl this file uses, declared here (the library is dlopen'ed: building libx3hip.so needs no RCCL headers).
  * Values as in rccl.h: ncclSuccess == 0, ncclUint8 == 1. */
@@ -1418,6 +1421,7 @@ struct RcclApi {
 };
 RcclApi g_rccl;
 
+#ifndef X3_EMU
 bool rccl_load()
 {
 	if (g_rccl.lib) return true;
@@ -1431,6 +1435,15 @@ bool rccl_load()
 	g_rccl.lib = h;
 	return true;
 }
+#else
+bool rccl_load()
+{
+	g_rccl.lib = (void *)&g_rccl;
+	g_rccl.CommInitAll = x3emu_rccl::CommInitAll; g_rccl.CommDestroy = x3emu_rccl::CommDestroy; g_rccl.Send = x3emu_rccl::Send; g_rccl.Recv = x3emu_rccl::Recv;
+	g_rccl.GroupStart = x3emu_rccl::GroupStart; g_rccl.GroupEnd = x3emu_rccl::GroupEnd;
+	return true;
+}
+#endif
 
 void rccl_drop_comms()
 {
@@ -1595,11 +1608,3 @@ extern "C" int x3h_compress_container_rccl(x3h_ctx *const *ctxs, int ndevices, c
 	*out_len = (size_t)total;
 	return X3H_OK;
 }
-#else
-extern "C" void x3h_rccl_release(void) {}
-extern "C" int x3h_compress_container_rccl(x3h_ctx *const *, int, const x3h_params *, const uint8_t *, size_t, size_t, uint8_t *, size_t, size_t *out_len, x3h_stats *)
-{
-	if (out_len) *out_len = 0;
-	return X3H_E_RCCL; /* the SIMT emulator build (tests) has no RCCL */
-}
-#endif

@@ -205,6 +205,43 @@ def config3_part(i: int) -> np.ndarray:
     return globals()[g](**kw)
 
 
+MANY_CHUNKS_MIB = 256       # bench.py's many_chunks_batch: 1024 x 256 KiB
+MANY_CHUNK_BYTES = 256 << 10
+DENSE_BATCH_BYTES = 64 << 20
+
+
+def many_chunks_mix(mtot: int = MANY_CHUNKS_MIB << 20) -> np.ndarray:
+    """bench.py's `many_chunks_batch` input: fresh content, first half English-like text, second half Zipf(s=1) bytes"""
+    q = mtot // 2
+    return np.concatenate([english_like(q, seed=0xBA7C4), zipf_bytes(mtot - q, offset=1 << 33)])
+
+
+def dense_batch(n: int = DENSE_BATCH_BYTES) -> np.ndarray:
+    """bench.py's `many_chunks_dense_classes` input: mr-like 16-bit samples (zero background: dense n-gram classes)"""
+    return mr_like(n, seed=0xBA7)
+
+
+def same_bytes_chunk_range(nch: int, i: int, n: int = DICKENS_BYTES) -> tuple[int, int]:
+    """(start, length) of chunk i when bench.py's `chunked_same_bytes` cuts the dickens-sized stream into `nch` chunks"""
+    cb = (n + nch - 1) // nch
+    return i * cb, min(cb, n - i * cb)
+
+
+# pieces of the batches above whose reference streams are pinned (tests/golden/make_golden_sha.py): name -> (base generator, start, length)
+def pinned_pieces() -> dict[str, tuple[str, int, int]]:
+    out = {}
+    cb = MANY_CHUNK_BYTES
+    # text half: chunks 0..511, Zipf half: 512..1023 (the text -> Zipf boundary lies between 511 and 512)
+    for c in (0, 1, 100, 255, 256, 400, 511, 512, 513, 600, 767, 768, 900, 1023):
+        out[f"mcb_mix256m_chunk{c}_256k_w64_t256"] = ("many_chunks_mix", c * cb, cb)
+    for c in (0, 85, 170, 255):
+        out[f"mcb_dense64m_chunk{c}_256k_w64_t256"] = ("dense_batch", c * cb, cb)
+    for nch in (40, 64, 128):
+        for i in (0, nch - 1):
+            out[f"csb_dickens_{nch}x_chunk{i}_w64_t256"] = ("english_like", *same_bytes_chunk_range(nch, i))
+    return out
+
+
 def workload(name: str, n: int | None = None) -> np.ndarray:
     """Named workloads used by bench.py / tests: 'dickens-like', 'zipf', 'mr-like'."""
     if name == "mr-like":
