@@ -34,7 +34,12 @@ enum {
 	X3H_E_RCCL        = -8  /* librccl could not be loaded, or a send / receive of the gather failed */
 };
 
-#define X3H_MAX_CHUNK ((size_t)1 << 27) /* one stream <= 128 MiB: keeps every model total < 2^28, which the coder kernel relies on */
+/* The longest ONE stream: 2^28 - 4096 bytes (256 MiB less a page).  Why not more: every adaptive model counts one per coded symbol on top of at most 2051 initial counts
+ * (x3.c:225-249), and a stream of n bytes codes at most n + 1 events, n fragment lengths, n literal bytes, n tags -- so n <= 2^28 - 4096 keeps every model total
+ * < 2^28.  After a renormalisation the range is > 2^29 (ac.c:46-75), hence step = range / total >= 2 and the narrowed interval is never a single value: the one
+ * assumption the closed-form renormalisation of the coder and decoder chains makes (code2.hip x3_ac2_sym, decode.hip ac_narrow: D = step * freq - 1 != 0).  The
+ * reference itself stops working when a total passes the range (> 2^29, SURVEY trap 9: ~2^29 parse steps).  Longer inputs are coded as X3C1 containers. */
+#define X3H_MAX_CHUNK (((size_t)1 << 28) - 4096)
 
 /* The tunables the reference keeps in file-scope globals.  Defaults: x3h_default_params().
  *   window_bytes    set_forward_window()   backend.c:8-18   (CLI -w N means N*1024, x3.c:503)
@@ -73,7 +78,10 @@ typedef struct x3h_stats {
 	                        /*    overlap inside ms_total.  0: stage after stage                                                              */
 	double   est_bits[4];   /* sizes[E_CTX0..E_NEW] of x3.c:43: the estimated code length per event class, -log2f(prob) summed
 	                         * per stream in IEEE single IN CODING ORDER like the reference (x3.c:52-55,192-193,253-266), the streams of a
-	                         * batch added up in double.  Only filled after x3h_ctx_set_estimates(ctx, 1); zeros otherwise.            */
+	                         * batch added up in double.  Only filled after x3h_ctx_set_estimates(ctx, 1); zeros otherwise.
+	                         * Tolerance: each term is -log2 evaluated in double and rounded to single, which differs from glibc's log2f by an
+	                         * ulp now and then -- the sums equal the reference's up to float rounding (tests: 1e-6 relative), not bit for bit, so
+	                         * a printed size can differ by one near a ceil() boundary; for chunked input they are sums the reference never forms. */
 	uint64_t coder_launches; /* launches of the coder recurrence behind ms_coder (1 stage after stage; one per prefix / per slice otherwise) */
 } x3h_stats;
 

@@ -277,6 +277,19 @@ def test_emulated_csb_count_kernel_body(emu_env, oracle):
     assert ctx.compress(data, _lib.make_params(**kw)) == oracle.compress(data, oracle_lib.params(**kw))
 
 
+@pytest.mark.parametrize("sched", ["stage-after-stage", "sliced"])
+def test_emulated_sort_and_scan_kernels(emu_env, oracle, sched):
+    """prims.hip's hand-written radix sort (histogram / scan / ranked scatter) and prefix scans themselves on the emulator (X3_EMU_PRIM_KERNELS=1; the other tests
+    answer these calls with host loops, for speed): K1 of a single stream sorts every padded position (several tiles of 4096, four 8-bit passes, the last tile
+    ragged), the generic coding stage sorts and scans hits, touch events and symbols (odd bit counts: a narrower last pass)"""
+    env = dict(X3_EMU_PRIM_KERNELS="1")
+    env.update({"X3H_PIPE_MIN": "0"} if sched == "stage-after-stage" else {"X3H_SLICED_MIN": "1024", "X3H_SLICE_GAP": "700", "X3H_SLICE_ARRANGE": "0"})
+    ctx = emu_env(**env)
+    sets = [(synth.english_like(5200, seed=3).tobytes(), dict(w_kib=4, t=6))] if sched == "stage-after-stage" else [(synth.mr_like(3000).tobytes(), dict(w_kib=1, t=3))]
+    for data, kw in sets:
+        assert ctx.compress(data, _lib.make_params(**kw)) == oracle.compress(data, oracle_lib.params(**kw))
+
+
 # ---- chunking behind the C boundary: sub-batches, several handles, X3C1 container (api.hip, x3_container.c) -------------------------
 def test_emulated_sub_batching_by_padded_bytes(emu_env, oracle):
     """many small chunks under a large window: the sub-batches are cut on the PADDED layout (len + W + slack per chunk), which K1

@@ -105,10 +105,10 @@ def test_cli_statistics_block_equals_reference(tmp_path, golden, name):
 
 
 def test_cli_says_when_it_writes_a_container_the_reference_cannot_read(tmp_path):
-    """x3.c:577-611 codes any input as ONE stream; this build's longest stream is X3H_MAX_CHUNK (128 MiB): a larger input without --chunk-kib
-    becomes an X3C1 container, and the CLI must say that the reference's `x3 -d` cannot read it.  (zeros: cheap to code, 129 MiB)"""
+    """x3.c:577-611 codes any input as ONE stream; this build's longest stream is X3H_MAX_CHUNK (2^28 - 4096 bytes): a larger input without --chunk-kib
+    becomes an X3C1 container, and the CLI must say that the reference's `x3 -d` cannot read it.  (zeros: cheap to code, 257 MiB)"""
     f, z, b = tmp_path / "big", tmp_path / "big.x3", tmp_path / "back"
-    n = (129 << 20) + 5
+    n = (257 << 20) + 5
     with open(f, "wb") as fh:
         fh.truncate(n)
     r = run(["-z", "-w", "8", "-t", "16", str(f)])
@@ -119,6 +119,8 @@ def test_cli_says_when_it_writes_a_container_the_reference_cannot_read(tmp_path)
     r = run(["-d", str(z), str(b)])
     assert r.returncode == 0, r.stderr.decode()
     assert os.path.getsize(b) == n and not any(open(b, "rb").read(1 << 20))
+    import struct
+    assert struct.unpack_from("<Q", blob, 32)[0] == (1 << 28) - 4096   # raw length of the first chunk: the longest single stream
     small = tmp_path / "small"
     small.write_bytes(b"abc" * 1000)
     r = run(["-z", str(small)])

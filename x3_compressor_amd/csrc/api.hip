@@ -229,7 +229,9 @@ extern "C" void x3h_ctx_destroy(x3h_ctx *c)
 	c->c2.yfin.release(); c->c2.yfinrec.release();
 	c->sr.release();
 	for (uint32_t i = 0; i < X3S_MAX_SLICES + 2; i++) { if (c->ev_sf[i]) (void)hipEventDestroy(c->ev_sf[i]); if (c->ev_sb[i]) (void)hipEventDestroy(c->ev_sb[i]); if (c->ev_se[i]) (void)hipEventDestroy(c->ev_se[i]); if (c->ev_sc[i]) (void)hipEventDestroy(c->ev_sc[i]); if (c->ev_sa[i]) (void)hipEventDestroy(c->ev_sa[i]); }
-	if (c->ev_s0) { (void)hipEventDestroy(c->ev_s0); (void)hipEventDestroy(c->ev_sfork); (void)hipEventDestroy(c->ev_sjoin); }
+	if (c->ev_s0) (void)hipEventDestroy(c->ev_s0);
+	if (c->ev_sfork) (void)hipEventDestroy(c->ev_sfork);
+	if (c->ev_sjoin) (void)hipEventDestroy(c->ev_sjoin);
 	c->c2.est_val.release(); c->c2.est_cls.release(); c->c2.est_out.release();
 	if (c->c2.est_stream) { (void)hipStreamSynchronize(c->c2.est_stream); (void)hipStreamDestroy(c->c2.est_stream); (void)hipEventDestroy(c->c2.ev_est_fork); (void)hipEventDestroy(c->c2.ev_est_done); }
 	if (c->ckpt) (void)hipHostFree((void *)c->ckpt);
@@ -522,8 +524,13 @@ static int sliced_setup(x3h_ctx *c)
 	if (!c->s_coder) HIPCHK(hipStreamCreate(&c->s_coder));
 	if (!c->ev_emit) HIPCHK(hipEventCreate(&c->ev_emit));
 	if (!c->ev_p0) { HIPCHK(hipEventCreate(&c->ev_p0)); HIPCHK(hipEventCreate(&c->ev_p1)); HIPCHK(hipEventCreate(&c->ev_ready)); }
-	HIPCHK(hipEventCreate(&c->ev_sfork)); HIPCHK(hipEventCreate(&c->ev_sjoin));
-	for (uint32_t i = 0; i < X3S_MAX_SLICES + 2; i++) { HIPCHK(hipEventCreate(&c->ev_sf[i])); HIPCHK(hipEventCreate(&c->ev_sb[i])); HIPCHK(hipEventCreate(&c->ev_se[i])); HIPCHK(hipEventCreate(&c->ev_sc[i])); HIPCHK(hipEventCreate(&c->ev_sa[i])); }
+	/* (each event is made once: a call that failed halfway is completed by the next one, nothing leaks) */
+	if (!c->ev_sfork) HIPCHK(hipEventCreate(&c->ev_sfork));
+	if (!c->ev_sjoin) HIPCHK(hipEventCreate(&c->ev_sjoin));
+	for (uint32_t i = 0; i < X3S_MAX_SLICES + 2; i++) {
+		hipEvent_t *evs[5] = { &c->ev_sf[i], &c->ev_sb[i], &c->ev_se[i], &c->ev_sc[i], &c->ev_sa[i] };
+		for (hipEvent_t *e : evs) if (!*e) HIPCHK(hipEventCreate(e));
+	}
 	HIPCHK(hipEventCreate(&c->ev_s0));
 	return X3H_OK;
 }
@@ -645,7 +652,12 @@ static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, 
 			if (avail[i] < X3_MAX_CKPT && avail[i] < next) { /* (a stream that has its record for this slice takes no further one while the others are waited for: a slice
 				                                                   * is ONE step of every stream from mark to mark -- that is what the slice buffers are sized for) */
 				int best = avail[i];
-				for (int k = avail[i] + 1; k < (int)nmarks; k++) { if (ck[k].seq == (uint32_t)k + 1) { best = k; if (k >= next) break; } }
+				for (int k = avail[i] + 1; k < (int)nmarks; k++) {
+					if (ck[k].seq != (uint32_t)k + 1) break; /* marks are published in order: behind the first unpublished one nothing is taken (a later one seen here means
+					                                           * this thread was descheduled between two reads, and taking it would make ONE slice of two gaps) */
+					best = k;
+					if (k >= next) break;
+				}
 				if ((best < next || best == avail[i]) && ck[X3_MAX_CKPT].seq == X3_MAX_CKPT + 1) best = X3_MAX_CKPT; /* no mark left to take: the stream is done */
 				avail[i] = best;
 			}
@@ -678,7 +690,7 @@ static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, 
 			sh += s.h1 - s.h0; se += (s.h1 - s.h0) + (s.d1 - s.d0); smi += (s.t1 - s.t0) - (s.h1 - s.h0); sb += s.mb1 - s.mb0; ss += s.t1 - s.t0;
 			sy += 2 * (s.t1 - s.t0) + (s.mb1 - s.mb0) + s.last;
 		}
-		if (max_dict > X3S_DMAX || ss > slice_bytes) { /* (the second: a safety net; slices are single mark-to-mark steps, see above) */
+		if (max_dict > X3S_DMAX || ss > slice_bytes || sb > slice_bytes) { /* (the last two: a safety net for the slice buffers -- tokens and new-fragment bytes; slices are single mark-to-mark steps, see above) */
 			if (getenv("X3H_DEBUG")) fprintf(stderr, "[x3h] sliced: falling back in slice %d: dictionary %llu elements (limit %u), slice of %u tokens (limit %llu)\n", nslice, (unsigned long long)max_dict, (unsigned)X3S_DMAX, ss, (unsigned long long)slice_bytes);
 			if (getenv("X3H_DEBUG")) for (uint32_t i = 0; i < nc; i++) fprintf(stderr, "[x3h]   stream %u (%u bytes): tokens %u..%u, record taken %d\n", i, c->hchunks[i].len, hs[i].t0, hs[i].t1, avail[i]);
 			fallback = true; break;
@@ -887,6 +899,7 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 		const int r = run_sliced(c, pa, sa.bytes, d_out, &ps, &hest);
 		if (r == X3S_FALLBACK) { /* a dictionary outgrew the sliced kernels: the parse is complete, the coding stage runs stage after stage */
 			fell_back = true; sliced = false; hest.clear();
+			c->sr.release(); /* the carried state of the slices (~240 B per input byte) makes room for the stage-after-stage workspace */
 			c->hparse.resize((size_t)nc);
 			HIPCHK(hipMemcpyAsync(c->hparse.data(), c->presult.p, (size_t)nc * sizeof(X3ParseResult), hipMemcpyDeviceToHost, c->stream));
 			HIPCHK(hipStreamSynchronize(c->stream));

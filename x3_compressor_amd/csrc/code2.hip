@@ -405,7 +405,7 @@ struct X3Ac2Args {
  * X3_AC2_G = 8 symbols (at the slot of the group's first symbol); the emit stage re-runs the eight steps of every group in parallel
  * (x3_expand_records) to get the per-symbol intervals (nlo, nhi), and derives n (E1/E2 count), k (E3 count), the mScale bookkeeping
  * and the bit placement from those with prefix sums.  (A record store per symbol pair cost the chain 7 %.)
- * D != 0 always: sf >= step >= 2^29 / total, and a model total stays < 2^28 (a stream is at most 2^27 bytes, X3H_MAX_CHUNK).
+ * D != 0 always: sf >= step >= 2^29 / total, and a model total stays < 2^28 (a stream is at most 2^28 - 4096 bytes, X3H_MAX_CHUNK: x3hip.h has the bound).
  */
 /* ONE definition of a chain step for every user: the scalar-unit chain of x3_ac2_kernel, the emulator build of that kernel (tests/emu runs
  * exactly this arithmetic, not a restatement) and the parallel re-run of a group in the emit stage (x3_chain_step).  Advances (lo, R) and

@@ -992,7 +992,7 @@ int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_for
 		/* arrangement by (context1, time).  Small slices: one workgroup per stream, a counting sort on the stream-local key in LDS (x3_arrange_kernel, code3.hip: one
 		 * launch per 11 key bits; a slice's arrays are L2-resident, so its scattered stores cost nothing -- on whole streams they made this kernel lose against
 		 * the library sort).  Large slices: the chip-wide radix sort (a workgroup of four wavefronts per stream would be the bottleneck). */
-		bool arrange = nH / nc <= 32768;
+		bool arrange = nH / nc <= 32768, segsorted = false;
 		if (const char *e = getenv("X3H_SLICE_ARRANGE")) arrange = e[0] == '1';
 		uint32_t *d_aho = A[30], *d_akb = A[31]; /* (nc + 1 <= steps + 8 entries each) */
 		if ((uint64_t)nc + 1 > nS + 8) arrange = false;
@@ -1000,6 +1000,13 @@ int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_for
 			const uint32_t nHs = (uint32_t)nH, ksh = dsh;
 			x3_foreach((size_t)nc + 1, st, X3_LAMBDA(size_t c) { d_aho[c] = c < nc ? d_sl[c].sh : nHs; d_akb[c] = (uint32_t)c << ksh; });
 			CHK(x3_arrange_run(st, nc, d_aho, d_akb, max_dict ? max_dict - 1 : 0, k1, nullptr, kA, vA, nullptr, A[28], A[29]));
+		} else if ((uint64_t)nc + 1 <= nS + 8) {
+			/* large slices: one workgroup per stream sorts its segment on the stream-local key in tiles of 4096 (x3_segsort_kernel, code3.hip) -- the chip-wide
+			 * library sort of rounds 1-4 is gone from this path (412 launches and 3.4 GB of HBM traffic per step of the dickens-sized stream) */
+			const uint32_t nHs = (uint32_t)nH, ksh = dsh;
+			x3_foreach((size_t)nc + 1, st, X3_LAMBDA(size_t c) { d_aho[c] = c < nc ? d_sl[c].sh : nHs; d_akb[c] = (uint32_t)c << ksh; });
+			CHK(x3_segsort_run(st, nc, d_aho, d_akb, max_dict ? max_dict - 1 : 0, k1, kA, vA, A[28], A[29], nullptr));
+			segsorted = true;
 		} else {
 			x3_foreach(nH, st, X3_LAMBDA(size_t i) { iota[i] = (uint32_t)i; });
 			CHK(x3p_sort_pairs(R.tmp, k1, kA, iota, vA, nH, (int)dsh + cb, st));
@@ -1075,8 +1082,12 @@ int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_for
 			const uint32_t ksh = psh;
 			x3_foreach((size_t)nc, st, X3_LAMBDA(size_t c) { d_akb[c] = (uint32_t)c << ksh; });
 			CHK(x3_arrange_run(st, nc, d_aho, d_akb, maxH, k0, nullptr, kA, vA, nullptr, A[28], A[29]));
+		} else if ((arrange || segsorted) && maxH <= X3_SEGSORT_MAX_LOCAL) {
+			const uint32_t ksh = psh;
+			x3_foreach((size_t)nc, st, X3_LAMBDA(size_t c) { d_akb[c] = (uint32_t)c << ksh; });
+			CHK(x3_segsort_run(st, nc, d_aho, d_akb, maxH, k0, kA, vA, A[28], A[29], nullptr));
 		} else {
-			if (arrange) x3_foreach(nH, st, X3_LAMBDA(size_t i) { iota[i] = (uint32_t)i; });
+			x3_foreach(nH, st, X3_LAMBDA(size_t i) { iota[i] = (uint32_t)i; });
 			CHK(x3p_sort_pairs(R.tmp, k0, kA, iota, vA, nH, (int)psh + cb, st));
 		}
 		ca.stat = stat0; ca.hdr = R.hdr0.as<X3CtxHdr>(); ca.pool = R.pool0.as<uint64_t>(); ca.pord = nullptr; ca.newaddr = nullptr; ca.top = m_top0; ca.first00 = nullptr;

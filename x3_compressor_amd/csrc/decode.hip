@@ -154,7 +154,7 @@ __device__ static __forceinline__ uint32_t dec_div(uint32_t n, uint32_t t)
  * the symbol's slice is [lo + cs, lo + cs + rs) with cs = step * cum, rs = step * freq.  All E1/E2/E3 shifts together are
  * s = clz(D) - 1 - carry with D = rs - 1; low and range scale by 2^s, and since every kind of shift removes the same offset from mBuffer as
  * from mLow, buffer - low scales too and takes the s new bits: (buffer - low) and the unread bits behind it are shifted as ONE 64-bit value.
- * No validity test: after a shift the range is >= 2^29 and every total is < 2^28 (one count per parse step or byte, X3H_MAX_CHUNK = 2^27), so
+ * No validity test: after a shift the range is >= 2^29 and every total is < 2^28 (one count per parse step or byte on top of <= 2051 initial counts, X3H_MAX_CHUNK = 2^28 - 4096), so
  * step >= 2, D >= 1; the symbol was chosen as the first with off < step * cum_incl, so cs <= off < cs + rs -- whatever the stream holds. */
 __device__ static __forceinline__ void ac_narrow(Dec &d, BitReader &r, uint32_t *s_cold, uint32_t cs, uint32_t rs)
 {
@@ -493,6 +493,9 @@ __device__ static __forceinline__ uint32_t dec_loop(const DecT &T, DecS &S, uint
 					if (X3_UNLIKELY(tokleft == 0 || (uint64_t)litpos + len > (uint64_t)T.cap + 32)) DEC_FAIL(X3_ST_OUT_FULL)
 					uint8_t *const frag = T.lit + litpos;
 					uint32_t h = DFNV_OFF, cftotal = x3_wave_sum_u32(cf0 + cf1 + cf2 + cf3);
+					/* every new fragment -- one that repeats an element too -- puts its bytes into the output (x3.c:306-326), so a valid stream has coded at most `cap` of them:
+					 * an adversarial run of duplicate fragments would otherwise take the byte model's total (256 + bytes coded so far) past the 2^28 the divisions assume */
+					if (X3_UNLIKELY(cftotal - 256u + len > T.cap)) DEC_FAIL(X3_ST_OUT_FULL)
 					for (uint32_t j = 0; j < len; j++) {
 						step = dec_div(d.rng, cftotal);
 						const uint32_t s4 = cf0 + cf1 + cf2 + cf3;
@@ -695,7 +698,7 @@ __device__ static void x3_dec_scan_body(const X3DecArgs &a)
 		__syncthreads();
 		if (threadIdx.x == X3_DEC2_THREADS - 1) { if (upto > cap) s_full = 1; else s_carry = (uint32_t)upto; }
 		__syncthreads();
-		if (s_full) break; /* (the carry stays <= the capacity <= 2^27: nothing wraps) */
+		if (s_full) break; /* (the carry stays <= the capacity < 2^28: nothing wraps) */
 	}
 	if (threadIdx.x == 0) {
 		if (s_full) a.result[s].status = X3_ST_OUT_FULL;

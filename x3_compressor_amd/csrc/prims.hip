@@ -1,86 +1,223 @@
 /*
- * prims.hip -- the three device-wide library primitives the v2 coding stage is built from (rocPRIM, gfx950):
- * stable radix sort of (key,value) pairs, exclusive sum scan, inclusive max scan.  Plain library calls for plain
- * library jobs; every x3-specific step is a hand-written kernel in code2.hip.
- * (X3_EMU test builds replace them with the obvious host loops so the rest of code2.hip can run on the CPU emulator.)
+ * prims.hip -- the chip-wide primitives of the generic paths (K1 of a few long streams: scan2.hip; K3 stage after stage and the prefix-wise
+ * schedule: code2.hip; slices whose local keys outgrow the per-stream sort: code4.hip): a stable LSD radix sort of (key, value) pairs and three
+ * prefix scans.  Hand-written for gfx950 since round 5 (rounds 1-4 called rocPRIM here); the same sources run on the SIMT emulator (tests/emu).
+ *
+ * Radix sort, one pass per 8 key bits, three launches per pass:
+ *   x3p_hist_kernel    one workgroup per tile of 4096 pairs counts its digits in LDS -> counts[digit][tile]                       (4 B read per pair)
+ *   exclusive scan     of counts in [digit][tile] order = where each tile's run of each digit starts in the output            (256 x tiles words)
+ *   x3p_scatter_kernel the tile again: every wavefront ranks its lanes' digits with one ballot per digit bit (seg_rank.h, the tile machinery of
+ *                      scan3.hip), a [digit][wave] counter table and one workgroup scan turn that into the tile-sorted order, the tile is staged
+ *                      in LDS in that order and leaves as one contiguous run per digit                                 (8 B read + 8 B written per pair)
+ *   Stable: tile order is (wave, element, lane), runs of a digit are laid out tile after tile.  Bound: HBM, 20 B per pair and pass (a one-sweep sort
+ *   with decoupled look-back moves 16 B; this form needs no spinning workgroup, i.e. no way to hang the GPU).
+ * Scans: reduce per tile of 4096 -> one workgroup scans the tile totals -> every tile scans itself behind its offset (reads the input twice; no look-back).
  */
 #include "x3_host.h"
+#include "seg_rank.h"
+
+#define X3P_THREADS 512u
+#define X3P_WAVES   (X3P_THREADS / X3_WAVE)
+#define X3P_E       8u
+#define X3P_TILE    (X3P_THREADS * X3P_E)
+#define X3P_CS      (X3P_WAVES + 1u) /* words between two digits' per-wave counters (an odd stride: a wavefront's lanes -- one wave number, many digits -- meet in every LDS bank) */
+
+/* ---- scans ----------------------------------------------------------------------------------------------------------------------------------- */
+enum { X3P_SUM = 0, X3P_TOPBIT = 1, X3P_MAX = 2 };
+struct X3pScanArgs {
+	const uint32_t *in;     /* X3P_SUM / X3P_MAX: values; X3P_TOPBIT: uint4 records, the value is bit 31 of .w */
+	uint32_t *out;
+	uint32_t *part;         /* one word per tile */
+	size_t n;               /* entries that carry a value */
+	size_t nout;            /* entries written: n + 1 for the exclusive forms (out[n] = total), n for the inclusive maximum */
+};
+
+template <int MODE> __device__ static __forceinline__ uint32_t x3p_scan_load(const X3pScanArgs &a, size_t i)
+{
+	if (i >= a.n) return 0u;
+	return MODE == X3P_TOPBIT ? ((const uint4 *)a.in)[i].w >> 31 : a.in[i];
+}
+template <int MODE> __device__ static __forceinline__ uint32_t x3p_op(uint32_t x, uint32_t y) { return MODE == X3P_MAX ? (x > y ? x : y) : x + y; }
+/* inclusive scan over the wavefront under MODE's operator */
+template <int MODE> __device__ static __forceinline__ uint32_t x3p_wave_incl(uint32_t v)
+{
+	if (MODE != X3P_MAX) return x3_wave_incl_scan_u32(v);
+	for (uint32_t d = 1; d < X3_WAVE; d <<= 1) { const uint32_t u = x3_shfl_up_u32(v, d); if (x3_lane() >= d) v = v > u ? v : u; }
+	return v;
+}
+/* the workgroup's threads each hold `mine`: -> the operator over the threads before this one (identity 0), and the workgroup's total in *total */
+template <int MODE> __device__ static __forceinline__ uint32_t x3p_block_excl(uint32_t mine, uint32_t *s_w, uint32_t *total)
+{
+	const uint32_t lane = x3_lane(), wv = threadIdx.x / X3_WAVE;
+	const uint32_t incl = x3p_wave_incl<MODE>(mine);
+	if (lane == X3_WAVE - 1) s_w[wv] = incl;
+	__syncthreads();
+	uint32_t before = 0, tot = 0;
+	for (uint32_t w = 0; w < X3P_WAVES; w++) { const uint32_t t = s_w[w]; if (w < wv) before = x3p_op<MODE>(before, t); tot = x3p_op<MODE>(tot, t); }
+	const uint32_t up = x3_shfl_up_u32(incl, 1);
+	if (lane) before = x3p_op<MODE>(before, up);
+	*total = tot;
+	__syncthreads(); /* s_w is free again */
+	return before;
+}
+
+template <int MODE> __device__ static void x3p_scan_reduce_body(const X3pScanArgs &a)
+{
+	X3_LDS uint32_t s_w[X3P_WAVES];
+	const size_t base = (size_t)blockIdx.x * X3P_TILE + (size_t)threadIdx.x * X3P_E;
+	uint32_t acc = 0;
+	for (uint32_t k = 0; k < X3P_E; k++) acc = x3p_op<MODE>(acc, x3p_scan_load<MODE>(a, base + k));
+	uint32_t tot;
+	(void)x3p_block_excl<MODE>(acc, s_w, &tot);
+	if (threadIdx.x == 0) a.part[blockIdx.x] = tot;
+}
+/* one workgroup: part[] -> its exclusive scan, in place */
+template <int MODE> __device__ static void x3p_scan_mid_body(const X3pScanArgs &a, uint32_t ntiles)
+{
+	X3_LDS uint32_t s_w[X3P_WAVES];
+	uint32_t carry = 0;
+	for (uint32_t b0 = 0; b0 < ntiles; b0 += X3P_THREADS) {
+		const uint32_t i = b0 + threadIdx.x;
+		const uint32_t v = i < ntiles ? a.part[i] : 0u;
+		uint32_t tot;
+		const uint32_t before = x3p_block_excl<MODE>(v, s_w, &tot);
+		if (i < ntiles) a.part[i] = x3p_op<MODE>(carry, before);
+		carry = x3p_op<MODE>(carry, tot);
+	}
+}
+template <int MODE> __device__ static void x3p_scan_apply_body(const X3pScanArgs &a)
+{
+	X3_LDS uint32_t s_w[X3P_WAVES];
+	const size_t base = (size_t)blockIdx.x * X3P_TILE + (size_t)threadIdx.x * X3P_E;
+	uint32_t v[X3P_E], acc = 0;
+	for (uint32_t k = 0; k < X3P_E; k++) { v[k] = x3p_scan_load<MODE>(a, base + k); acc = x3p_op<MODE>(acc, v[k]); }
+	uint32_t tot;
+	uint32_t run = x3p_op<MODE>(a.part[blockIdx.x], x3p_block_excl<MODE>(acc, s_w, &tot));
+	for (uint32_t k = 0; k < X3P_E; k++) {
+		const uint32_t incl = x3p_op<MODE>(run, v[k]);
+		if (base + k < a.nout) a.out[base + k] = MODE == X3P_MAX ? incl : run;
+		run = incl;
+	}
+}
+
+/* ---- radix sort -------------------------------------------------------------------------------------------------------------------------------- */
+struct X3pSortArgs {
+	const uint32_t *kin, *vin;
+	uint32_t *kout, *vout;
+	uint32_t *counts;       /* [digit][tile]: counted by the histogram kernel, scanned in place (exclusive, one more entry behind the last) */
+	size_t n;
+	uint32_t shift, mask, ntiles, ndig;
+};
+
+__device__ static void x3p_hist_body(const X3pSortArgs &a)
+{
+	X3_LDS uint32_t s_h[256];
+	if (threadIdx.x < 256u) s_h[threadIdx.x] = 0u;
+	__syncthreads();
+	const size_t base = (size_t)blockIdx.x * X3P_TILE;
+	for (uint32_t e = 0; e < X3P_E; e++) {
+		const size_t i = base + (size_t)e * X3P_THREADS + threadIdx.x;
+		if (i < a.n) atomicAdd(&s_h[(a.kin[i] >> a.shift) & a.mask], 1u);
+	}
+	__syncthreads();
+	if (threadIdx.x < a.ndig) a.counts[(size_t)threadIdx.x * a.ntiles + blockIdx.x] = s_h[threadIdx.x];
+}
+
+__device__ static void x3p_scatter_body(const X3pSortArgs &a)
+{
+	X3_LDS uint32_t s_cnt[256u * X3P_CS]; /* [digit][wave]: the wave's count of the digit, then the count of the waves before it */
+	X3_LDS uint32_t s_start[256];          /* first tile-sorted slot of the digit */
+	X3_LDS uint32_t s_gbase[256];          /* output index of tile-sorted slot j of digit d = s_gbase[d] + j */
+	X3_LDS uint32_t s_w[X3P_WAVES];
+	X3_LDS uint32_t s_k[X3P_TILE], s_v[X3P_TILE];
+	const uint32_t lane = x3_lane(), wv = threadIdx.x / X3_WAVE;
+	const size_t base = (size_t)blockIdx.x * X3P_TILE;
+	const uint32_t cnt = a.n - base < X3P_TILE ? (uint32_t)(a.n - base) : X3P_TILE;
+	for (uint32_t i = threadIdx.x; i < 256u * X3P_CS; i += X3P_THREADS) s_cnt[i] = 0u;
+	/* tile order: (wave, element, lane) -- a wavefront owns X3P_E * 64 consecutive pairs, 64 consecutive ones per element slot: coalesced loads */
+	uint32_t k[X3P_E], v[X3P_E], rank[X3P_E];
+	const uint32_t w0 = wv * (X3P_E * X3_WAVE) + lane;
+	for (uint32_t e = 0; e < X3P_E; e++) {
+		const uint32_t t = w0 + e * X3_WAVE;
+		k[e] = t < cnt ? a.kin[base + t] : 0u;
+		v[e] = t < cnt ? a.vin[base + t] : 0u;
+	}
+	__syncthreads();
+	for (uint32_t e = 0; e < X3P_E; e++) {
+		const bool valid = w0 + e * X3_WAVE < cnt;
+		const uint32_t d = (k[e] >> a.shift) & a.mask;
+		uint32_t mlo, mhi;
+		seg_match<8>(d, valid, mlo, mhi);
+		const uint32_t lower = seg_lower(mlo, mhi), size = seg_size(mlo, mhi);
+		const uint32_t old = valid ? s_cnt[d * X3P_CS + wv] : 0u;
+		rank[e] = old + lower;
+		x3_wave_sync(); /* every lane has read the counter ... */
+		if (valid && lower == 0) s_cnt[d * X3P_CS + wv] = old + size;
+		x3_wave_sync(); /* ... and the next element slot sees the update */
+	}
+	__syncthreads();
+	/* per digit: the waves' counts become "pairs of this digit in the waves before", the digit's total goes through a workgroup scan */
+	uint32_t tot = 0;
+	if (threadIdx.x < 256u) for (uint32_t w = 0; w < X3P_WAVES; w++) { const uint32_t c = s_cnt[threadIdx.x * X3P_CS + w]; s_cnt[threadIdx.x * X3P_CS + w] = tot; tot += c; }
+	uint32_t all;
+	const uint32_t start = x3p_block_excl<X3P_SUM>(tot, s_w, &all);
+	if (threadIdx.x < 256u) {
+		s_start[threadIdx.x] = start;
+		s_gbase[threadIdx.x] = (threadIdx.x < a.ndig ? a.counts[(size_t)threadIdx.x * a.ntiles + blockIdx.x] : 0u) - start;
+	}
+	__syncthreads();
+	for (uint32_t e = 0; e < X3P_E; e++) {
+		if (w0 + e * X3_WAVE >= cnt) continue;
+		const uint32_t d = (k[e] >> a.shift) & a.mask;
+		const uint32_t slot = s_start[d] + s_cnt[d * X3P_CS + wv] + rank[e];
+		s_k[slot] = k[e]; s_v[slot] = v[e];
+	}
+	__syncthreads();
+	for (uint32_t j = threadIdx.x; j < cnt; j += X3P_THREADS) {
+		const uint32_t kk = s_k[j], d = (kk >> a.shift) & a.mask;
+		const size_t o = (size_t)(s_gbase[d] + j); /* (32-bit wrap-around arithmetic: base - start + j) */
+		a.kout[o] = kk; a.vout[o] = s_v[j];
+	}
+}
 
 #ifndef X3_EMU
-#include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
-
-int x3p_sort_pairs(DevBuf &tmp, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, int bits, hipStream_t st)
+template <int MODE> __global__ void __launch_bounds__(X3P_THREADS) x3p_scan_reduce_kernel(X3pScanArgs a) { x3p_scan_reduce_body<MODE>(a); }
+template <int MODE> __global__ void __launch_bounds__(X3P_THREADS) x3p_scan_mid_kernel(X3pScanArgs a, uint32_t ntiles) { x3p_scan_mid_body<MODE>(a, ntiles); }
+template <int MODE> __global__ void __launch_bounds__(X3P_THREADS) x3p_scan_apply_kernel(X3pScanArgs a) { x3p_scan_apply_body<MODE>(a); }
+__global__ void __launch_bounds__(X3P_THREADS) x3p_hist_kernel(X3pSortArgs a) { x3p_hist_body(a); }
+__global__ void __launch_bounds__(X3P_THREADS) x3p_scatter_kernel(X3pSortArgs a) { x3p_scatter_body(a); }
+template <int MODE> static void x3p_scan_launch(const X3pScanArgs &a, uint32_t ntiles, hipStream_t st)
 {
-	if (!n) return X3H_OK;
-	if (bits < 1) bits = 1;
-	if (bits > 32) bits = 32;
-	size_t need = 0;
-	HIPCHK(rocprim::radix_sort_pairs(nullptr, need, kin, kout, vin, vout, n, 0u, (unsigned)bits, st));
-	CHK(tmp.reserve(need));
-	HIPCHK(rocprim::radix_sort_pairs(tmp.p, need, kin, kout, vin, vout, n, 0u, (unsigned)bits, st));
-	return X3H_OK;
+	hipLaunchKernelGGL(x3p_scan_reduce_kernel<MODE>, dim3(ntiles), dim3(X3P_THREADS), 0, st, a);
+	hipLaunchKernelGGL(x3p_scan_mid_kernel<MODE>, dim3(1), dim3(X3P_THREADS), 0, st, a, ntiles);
+	hipLaunchKernelGGL(x3p_scan_apply_kernel<MODE>, dim3(ntiles), dim3(X3P_THREADS), 0, st, a);
 }
-
-int x3p_sort_pairs_bits(DevBuf &tmp, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, int begin_bit, int end_bit, hipStream_t st)
-{
-	if (!n) return X3H_OK;
-	size_t need = 0;
-	HIPCHK(rocprim::radix_sort_pairs(nullptr, need, kin, kout, vin, vout, n, (unsigned)begin_bit, (unsigned)end_bit, st));
-	CHK(tmp.reserve(need));
-	HIPCHK(rocprim::radix_sort_pairs(tmp.p, need, kin, kout, vin, vout, n, (unsigned)begin_bit, (unsigned)end_bit, st));
-	return X3H_OK;
-}
-
-int x3p_excl_scan(DevBuf &tmp, const uint32_t *in, uint32_t *out, size_t n, hipStream_t st)
-{
-	size_t need = 0;
-	HIPCHK(rocprim::exclusive_scan(nullptr, need, in, out, 0u, n + 1, rocprim::plus<uint32_t>(), st));
-	CHK(tmp.reserve(need));
-	HIPCHK(rocprim::exclusive_scan(tmp.p, need, in, out, 0u, n + 1, rocprim::plus<uint32_t>(), st));
-	return X3H_OK;
-}
-
-struct X3TopBitW { __device__ __host__ uint32_t operator()(const uint4 &r) const { return r.w >> 31; } };
-int x3p_excl_scan_top_bit_w(DevBuf &tmp, const uint4 *rec, uint32_t *out, size_t n, hipStream_t st)
-{
-	auto in = rocprim::make_transform_iterator(rec, X3TopBitW());
-	size_t need = 0;
-	HIPCHK(rocprim::exclusive_scan(nullptr, need, in, out, 0u, n + 1, rocprim::plus<uint32_t>(), st));
-	CHK(tmp.reserve(need));
-	HIPCHK(rocprim::exclusive_scan(tmp.p, need, in, out, 0u, n + 1, rocprim::plus<uint32_t>(), st));
-	return X3H_OK;
-}
-
-int x3p_incl_max_scan(DevBuf &tmp, const uint32_t *in, uint32_t *out, size_t n, hipStream_t st)
-{
-	if (!n) return X3H_OK;
-	size_t need = 0;
-	HIPCHK(rocprim::inclusive_scan(nullptr, need, in, out, n, rocprim::maximum<uint32_t>(), st));
-	CHK(tmp.reserve(need));
-	HIPCHK(rocprim::inclusive_scan(tmp.p, need, in, out, n, rocprim::maximum<uint32_t>(), st));
-	return X3H_OK;
-}
-
+static void x3p_hist_launch(const X3pSortArgs &a, hipStream_t st) { hipLaunchKernelGGL(x3p_hist_kernel, dim3(a.ntiles), dim3(X3P_THREADS), 0, st, a); }
+static void x3p_scatter_launch(const X3pSortArgs &a, hipStream_t st) { hipLaunchKernelGGL(x3p_scatter_kernel, dim3(a.ntiles), dim3(X3P_THREADS), 0, st, a); }
 #else
-#include <algorithm>
-#include <vector>
-
-int x3p_sort_pairs(DevBuf &, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, int bits, hipStream_t)
+struct X3pMidCall { X3pScanArgs a; uint32_t ntiles; };
+template <int MODE> static void x3p_reduce_tramp(void *p) { x3p_scan_reduce_body<MODE>(*(const X3pScanArgs *)p); }
+template <int MODE> static void x3p_mid_tramp(void *p) { const X3pMidCall &c = *(const X3pMidCall *)p; x3p_scan_mid_body<MODE>(c.a, c.ntiles); }
+template <int MODE> static void x3p_apply_tramp(void *p) { x3p_scan_apply_body<MODE>(*(const X3pScanArgs *)p); }
+static void x3p_hist_tramp(void *p) { x3p_hist_body(*(const X3pSortArgs *)p); }
+static void x3p_scatter_tramp(void *p) { x3p_scatter_body(*(const X3pSortArgs *)p); }
+template <int MODE> static void x3p_scan_launch(const X3pScanArgs &a, uint32_t ntiles, hipStream_t)
 {
-	const uint32_t mask = bits >= 32 ? 0xFFFFFFFFu : ((1u << bits) - 1);
-	std::vector<size_t> idx(n);
-	for (size_t i = 0; i < n; i++) idx[i] = i;
-	std::stable_sort(idx.begin(), idx.end(), [&](size_t x, size_t y) { return (kin[x] & mask) < (kin[y] & mask); });
-	std::vector<uint32_t> k(n), v(n);
-	for (size_t i = 0; i < n; i++) { k[i] = kin[idx[i]]; v[i] = vin[idx[i]]; }
-	for (size_t i = 0; i < n; i++) { kout[i] = k[i]; vout[i] = v[i]; }
-	return X3H_OK;
+	X3pMidCall mc = { a, ntiles };
+	x3emu_launch(x3p_reduce_tramp<MODE>, (void *)&a, dim3(ntiles), dim3(X3P_THREADS));
+	x3emu_launch(x3p_mid_tramp<MODE>, (void *)&mc, dim3(1), dim3(X3P_THREADS));
+	x3emu_launch(x3p_apply_tramp<MODE>, (void *)&a, dim3(ntiles), dim3(X3P_THREADS));
 }
+static void x3p_hist_launch(const X3pSortArgs &a, hipStream_t) { x3emu_launch(x3p_hist_tramp, (void *)&a, dim3(a.ntiles), dim3(X3P_THREADS)); }
+static void x3p_scatter_launch(const X3pSortArgs &a, hipStream_t) { x3emu_launch(x3p_scatter_tramp, (void *)&a, dim3(a.ntiles), dim3(X3P_THREADS)); }
+#endif
 
-int x3p_sort_pairs_bits(DevBuf &, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, int begin_bit, int end_bit, hipStream_t)
+#ifdef X3_EMU
+/* The emulator runs a 512-fiber workgroup per tile and launch: with ~40 sorts and scans per coding stage the CPU suite would spend its time here.  So the emulated
+ * library answers these calls with the obvious host loops unless X3_EMU_PRIM_KERNELS=1 asks for the kernels above (tests/test_emu_kernels.py runs both). */
+#include <algorithm>
+static bool x3p_emu_kernels() { const char *e = getenv("X3_EMU_PRIM_KERNELS"); return e && e[0] == '1'; }
+static void x3p_host_sort(const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, int begin_bit, int end_bit)
 {
 	const uint32_t mask = (end_bit - begin_bit) >= 32 ? 0xFFFFFFFFu : ((1u << (end_bit - begin_bit)) - 1);
 	std::vector<size_t> idx(n);
@@ -89,27 +226,89 @@ int x3p_sort_pairs_bits(DevBuf &, const uint32_t *kin, uint32_t *kout, const uin
 	std::vector<uint32_t> k(n), v(n);
 	for (size_t i = 0; i < n; i++) { k[i] = kin[idx[i]]; v[i] = vin[idx[i]]; }
 	for (size_t i = 0; i < n; i++) { kout[i] = k[i]; vout[i] = v[i]; }
-	return X3H_OK;
-}
-
-int x3p_excl_scan(DevBuf &, const uint32_t *in, uint32_t *out, size_t n, hipStream_t)
-{
-	uint32_t acc = 0;
-	for (size_t i = 0; i <= n; i++) { uint32_t v = i < n ? in[i] : 0; out[i] = acc; acc += v; }
-	return X3H_OK;
-}
-
-int x3p_excl_scan_top_bit_w(DevBuf &, const uint4 *rec, uint32_t *out, size_t n, hipStream_t)
-{
-	uint32_t acc = 0;
-	for (size_t i = 0; i <= n; i++) { out[i] = acc; if (i < n) acc += rec[i].w >> 31; }
-	return X3H_OK;
-}
-
-int x3p_incl_max_scan(DevBuf &, const uint32_t *in, uint32_t *out, size_t n, hipStream_t)
-{
-	uint32_t acc = 0;
-	for (size_t i = 0; i < n; i++) { acc = in[i] > acc ? in[i] : acc; out[i] = acc; }
-	return X3H_OK;
 }
 #endif
+
+static inline size_t x3p_tiles(size_t n) { return (n + X3P_TILE - 1) / X3P_TILE; }
+static inline size_t x3p_al(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+
+/* `part` needs x3p_tiles(nout) words */
+template <int MODE> static int x3p_scan_run(const uint32_t *in, uint32_t *out, size_t n, size_t nout, uint32_t *part, hipStream_t st)
+{
+	if (!nout) return X3H_OK;
+	if (x3p_tiles(nout) > 0x7FFFFFFFull) return X3H_E_ARG;
+	X3pScanArgs a;
+	a.in = in; a.out = out; a.part = part; a.n = n; a.nout = nout;
+	x3p_scan_launch<MODE>(a, (uint32_t)x3p_tiles(nout), st);
+	HIPCHK(hipGetLastError());
+	return X3H_OK;
+}
+
+int x3p_excl_scan(DevBuf &tmp, const uint32_t *in, uint32_t *out, size_t n, hipStream_t st)
+{
+#ifdef X3_EMU
+	if (!x3p_emu_kernels()) { uint32_t acc = 0; for (size_t i = 0; i <= n; i++) { const uint32_t v = i < n ? in[i] : 0; out[i] = acc; acc += v; } return X3H_OK; }
+#endif
+	CHK(tmp.reserve(x3p_al(x3p_tiles(n + 1) * 4)));
+	return x3p_scan_run<X3P_SUM>(in, out, n, n + 1, tmp.as<uint32_t>(), st);
+}
+
+int x3p_excl_scan_top_bit_w(DevBuf &tmp, const uint4 *rec, uint32_t *out, size_t n, hipStream_t st)
+{
+#ifdef X3_EMU
+	if (!x3p_emu_kernels()) { uint32_t acc = 0; for (size_t i = 0; i <= n; i++) { out[i] = acc; if (i < n) acc += rec[i].w >> 31; } return X3H_OK; }
+#endif
+	CHK(tmp.reserve(x3p_al(x3p_tiles(n + 1) * 4)));
+	return x3p_scan_run<X3P_TOPBIT>((const uint32_t *)rec, out, n, n + 1, tmp.as<uint32_t>(), st);
+}
+
+int x3p_incl_max_scan(DevBuf &tmp, const uint32_t *in, uint32_t *out, size_t n, hipStream_t st)
+{
+	if (!n) return X3H_OK;
+#ifdef X3_EMU
+	if (!x3p_emu_kernels()) { uint32_t acc = 0; for (size_t i = 0; i < n; i++) { acc = in[i] > acc ? in[i] : acc; out[i] = acc; } return X3H_OK; }
+#endif
+	CHK(tmp.reserve(x3p_al(x3p_tiles(n) * 4)));
+	return x3p_scan_run<X3P_MAX>(in, out, n, n, tmp.as<uint32_t>(), st);
+}
+
+/* stable sort on key bits [begin_bit, end_bit): ceil(bits / 8) passes; the pairs travel kin -> (scratch <->) kout so that the last pass writes kout / vout */
+int x3p_sort_pairs_bits(DevBuf &tmp, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, int begin_bit, int end_bit, hipStream_t st)
+{
+	if (!n) return X3H_OK;
+	if (begin_bit < 0) begin_bit = 0;
+	if (end_bit > 32) end_bit = 32;
+	if (end_bit <= begin_bit) end_bit = begin_bit + 1;
+#ifdef X3_EMU
+	if (!x3p_emu_kernels()) { x3p_host_sort(kin, kout, vin, vout, n, begin_bit, end_bit); return X3H_OK; }
+#endif
+	if (n >= ((size_t)1 << 32) - X3P_TILE) return X3H_E_ARG; /* output indices are 32-bit */
+	const uint32_t npass = ((uint32_t)(end_bit - begin_bit) + 7u) / 8u;
+	const size_t nt = x3p_tiles(n), ncounts = 256 * nt + 1;
+	const size_t o_counts = 0, o_part = o_counts + x3p_al(ncounts * 4), o_k = o_part + x3p_al(x3p_tiles(ncounts) * 4), o_v = o_k + x3p_al(npass > 1 ? n * 4 : 0);
+	CHK(tmp.reserve(o_v + x3p_al(npass > 1 ? n * 4 : 0)));
+	uint8_t *t8 = tmp.as<uint8_t>();
+	uint32_t *counts = (uint32_t *)(t8 + o_counts), *part = (uint32_t *)(t8 + o_part), *sk = (uint32_t *)(t8 + o_k), *sv = (uint32_t *)(t8 + o_v);
+	const uint32_t *ck = kin, *cv = vin;
+	for (uint32_t p = 0; p < npass; p++) {
+		const uint32_t lo = (uint32_t)begin_bit + 8u * p, width = (uint32_t)end_bit - lo < 8u ? (uint32_t)end_bit - lo : 8u;
+		const bool to_out = ((npass - 1u - p) & 1u) == 0u;
+		X3pSortArgs a;
+		a.kin = ck; a.vin = cv; a.kout = to_out ? kout : sk; a.vout = to_out ? vout : sv; a.counts = counts; a.n = n;
+		a.shift = lo; a.mask = (1u << width) - 1u; a.ntiles = (uint32_t)nt; a.ndig = 1u << width;
+		x3p_hist_launch(a, st);
+		HIPCHK(hipGetLastError());
+		const size_t used = (size_t)a.ndig * nt; /* [digit][tile], scanned in place */
+		CHK(x3p_scan_run<X3P_SUM>(counts, counts, used, used + 1, part, st));
+		x3p_scatter_launch(a, st);
+		HIPCHK(hipGetLastError());
+		ck = a.kout; cv = a.vout;
+	}
+	return X3H_OK;
+}
+
+int x3p_sort_pairs(DevBuf &tmp, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout, size_t n, int bits, hipStream_t st)
+{
+	if (bits < 1) bits = 1;
+	return x3p_sort_pairs_bits(tmp, kin, kout, vin, vout, n, 0, bits > 32 ? 32 : bits, st);
+}

@@ -273,10 +273,7 @@ int x3_scan_v2_run(X3Scan2Bufs &B, DevBuf &tmp, hipStream_t st, int nchunks, con
 	S = B.a[3].as<uint32_t>();
 	for (uint32_t l = 1; l <= 4; l++) {
 		/* pass l of the LSD sort: the list is now ordered by the l-gram starting at p = q-(l-1) (stable: ascending positions inside a class) */
-		/* (rocPRIM 4.2's small-input merge path builds its digit mask with 1 << end_bit, which is wrong for end_bit == 32: below its
-		 * switch-over the last pass is a full-key stable sort of the pass-3 list instead -- the same order, and the cost does not matter there) */
-		if (l == 4 && P <= ((size_t)8 << 20)) CHK(x3p_sort_pairs(tmp, kin, ks, vin, S, P, 32, st));
-		else CHK(x3p_sort_pairs_bits(tmp, kin, ks, vin, S, P, 8 * ((int)l - 1), 8 * (int)l, st));
+		CHK(x3p_sort_pairs_bits(tmp, kin, ks, vin, S, P, 8 * ((int)l - 1), 8 * (int)l, st)); /* prims.hip: histogram, scan, ranked scatter */
 		const uint32_t msk = l >= 4 ? 0xFFFFFFFFu : ((1u << (8 * l)) - 1), back = l - 1;
 		const uint32_t *ksc = ks, *Sc = S;
 		if (l == 1) {

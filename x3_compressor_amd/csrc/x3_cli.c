@@ -15,7 +15,7 @@
  *                    (x3h_compress_container_rccl; also X3_RCCL=1).  Same bytes; any failure of that path falls back to the host concat.
  *   --chunk-kib N    cut the input into independent chunks of N KiB, each coded as its own x3 stream, and write the X3C1
  *                    container (include/x3hip.h); an input of one chunk is still written as the raw stream.  Inputs above
- *                    128 MiB (X3H_MAX_CHUNK) are always chunked -- the reference codes them as ONE stream (x3.c:577-611), so that
+ *                    2^28 - 4096 bytes (X3H_MAX_CHUNK) are always chunked -- the reference codes them as ONE stream (x3.c:577-611), so that
  *                    output is NOT readable by the reference's `x3 -d`: the CLI says so on stderr.
  *   --batch-mib N    chunks are coded in sub-batches of at most N MiB of input: bounds the workspace in HBM (~350 B per byte).  Default: 64 MiB,
  *                    but never fewer than 32 chunks side by side (a chunk is one serial coder chain: long chunks need company)
@@ -147,7 +147,7 @@ int main(int argc, char *argv[])
 			case 'g': ngpu = 1; gpus[0] = atoi(optarg); break;
 			case 1000: {
 				long k = atol(optarg);
-				if (k <= 0 || (size_t)k * 1024 > X3H_MAX_CHUNK) die("--chunk-kib: between 1 and 131072");
+				if (k <= 0 || (size_t)k * 1024 > X3H_MAX_CHUNK) die("--chunk-kib: between 1 and 262140");
 				chunk_bytes = (size_t)k * 1024;
 				break;
 			}
@@ -205,7 +205,7 @@ int main(int argc, char *argv[])
 	 * profiles/r03_cli_first_call.txt), but a chunk is ONE serial coder chain, so long chunks need at least 32 of them side by side per GPU:
 	 * 64 MiB for chunks up to 2 MiB, 32 chunks beyond (config 4's 8 MiB chunks: 256 MiB, all 16 of a GPU's share in one go) */
 	if (!batch_mib) {
-		const uint64_t cb = chunk_bytes ? chunk_bytes : X3H_MAX_CHUNK; /* no --chunk-kib: one stream, or 128 MiB chunks for a larger input */
+		const uint64_t cb = chunk_bytes ? chunk_bytes : X3H_MAX_CHUNK; /* no --chunk-kib: one stream, or chunks of the longest stream (X3H_MAX_CHUNK) for a larger input */
 		batch_mib = 64;
 		if (((32 * cb) >> 20) > batch_mib) batch_mib = (32 * cb) >> 20;
 		if (batch_mib > 512) batch_mib = 512; /* the library's own default bound */
@@ -273,7 +273,7 @@ int main(int argc, char *argv[])
 				rc = x3h_decompress(ctxs[0], iptr, isize, optr, cap, &osize, &st);
 				if (rc != X3H_E_OUTPUT_FULL) break;
 				free(optr);
-				if (cap == X3H_MAX_CHUNK) die("x3: decompress failed: the stream decodes to more than 128 MiB");
+				if (cap == X3H_MAX_CHUNK) die("x3: decompress failed: the stream decodes to more than X3H_MAX_CHUNK (2^28 - 4096) bytes");
 				cap = cap > X3H_MAX_CHUNK / 4 ? X3H_MAX_CHUNK : cap * 4;
 			}
 		}
