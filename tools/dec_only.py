@@ -1,5 +1,5 @@
 """experiment: ONE decode of one text stream (for rocprofv3 --pmc SQ_* : instructions per parse step by kind); prints the step count.
-usage: dec_only.py [bytes]   e.g.  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace -d out -- python3 tools/exp/dec_only.py"""
+usage: dec_only.py [bytes]   e.g.  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace -d out -- python3 tools/dec_only.py"""
 import sys
 sys.path.insert(0, '.')
 from x3_compressor_amd import _lib, synth

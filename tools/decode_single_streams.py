@@ -2,7 +2,7 @@
 import os, sys, time
 sys.path.insert(0, '.')
 from x3_compressor_amd import _lib, synth
-ctx = _lib.X3Context(0, library=os.environ.get('X3_LIB'))  # X3_LIB: an experiment build of the library (tools/exp/r04_decprof.sh)
+ctx = _lib.X3Context(0, library=os.environ.get('X3_LIB'))  # X3_LIB: an experiment build of the library 
 for name, data, kw in (("config5 mr-like", synth.mr_like(9970564).tobytes(), dict(w_kib=512, t=4096)),
                        ("dickens-like", synth.english_like(synth.DICKENS_BYTES).tobytes(), dict(w_kib=64, t=256))):
     stream = ctx.compress(data, _lib.make_params(**kw))

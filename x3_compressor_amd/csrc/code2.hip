@@ -610,7 +610,7 @@ static void launch_modes(const X3ModesArgs &a, uint32_t nchunks, hipStream_t st,
 }
 /* One-wavefront workgroups are not spread evenly over a CU's four SIMDs: with four chains per CU (1024 streams) two of them share a SIMD's
  * issue slot and a symbol costs 49 ns instead of 25; as four wavefronts of ONE workgroup they get a SIMD each (31.5 ns; 8 per CU: 52 against
- * 73; tools/exp/ac2_wide.sh).  Up to two streams per CU the narrow form keeps every chain on its own CU.  X3H_AC2_WIDE = smallest stream
+ * 73; profiles/r03_coder_chains_per_workgroup.txt).  Up to two streams per CU the narrow form keeps every chain on its own CU.  X3H_AC2_WIDE = smallest stream
  * count that takes the wide form (0: never). */
 static void launch_ac2(X3Ac2Args a, uint32_t nchunks, hipStream_t st)
 {

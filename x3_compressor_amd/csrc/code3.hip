@@ -639,7 +639,7 @@ int x3_ctx_stats_run(hipStream_t st, uint32_t nc, uint64_t max_dict, uint64_t nh
 	 * all wavefronts of a stream on one XCD (see X3CtxSegArgs::xcd).  The kernel's cost is its scattered 16-byte result stores (without them it
 	 * takes half the time): with a handful of wavefronts per stream the chip works on every stream's 1-2 MB of results at once, no cache holds
 	 * them and every store is its own HBM write; with a stream's results finished by ~100 wavefronts within microseconds the lines fill in L2
-	 * (1024 x 256 KiB of text: features 28 -> 20 ms; tools/exp/ctx_xcd.sh) */
+	 * (1024 x 256 KiB of text: features 28 -> 20 ms; profiles/r03_ctx_wavefronts_per_stream_sweep.txt) */
 	uint64_t want = nc ? (nhits / nc + 511) / 512 : 1;
 	uint32_t nsub = want < 1 ? 1u : want > 1024 ? 1024u : (uint32_t)want;
 	if (const char *e = getenv("X3H_CTX_SUB")) { const int v = atoi(e); if (v >= 1 && v <= 1024) nsub = (uint32_t)v; }

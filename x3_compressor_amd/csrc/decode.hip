@@ -430,7 +430,7 @@ __device__ static __forceinline__ uint32_t dec_loop(const DecT &T, DecS &S, uint
 	/* The blocks of the next step's contexts are requested (dec_request) as soon as their addresses are known -- before this step's interval update, rank search,
 	 * move-to-front and token -- and taken over (dec_take) after the NEXT event has been decoded. */
 	dec_request(pool, o1, o0, lane, pend);
-#ifdef X3_DEC_PROFILE /* experiment builds (tools/exp/r04_decprof.sh): shader cycles waiting for the requested blocks / between request and use / from use to the next request */
+#ifdef X3_DEC_PROFILE /* experiment builds (-DX3_DEC_PROFILE): shader cycles waiting for the requested blocks / between request and use / from use to the next request */
 	uint64_t pc_wait = 0, pc_flight = 0, pc_chain = 0, pc_req = x3_clock();
 #endif
 #define DEC_FAIL(st) { S.status = (st); return X3D_FAIL; }

@@ -96,7 +96,7 @@ __device__ static __forceinline__ void seg_level(uint32_t lv, const uint2 it, co
 		if (u < L) { const uint2 eu = list.at(u); pass = ((eu.x ^ it.x) & msk) == 0u && eu.y - base <= wend; }
 	}
 	/* (levels pass in order -- count_l <= count_{l-1} -- so a marked position whose counter says that it failed the level before fails this one, and
-	 * its K stays where it is: the load is a scattered one, and most marked positions fail level 2.  Timing switches, tools/exp: the small-K path was
+	 * its K stays where it is: the load is a scattered one, and most marked positions fail level 2.  Timing switches (round 4, profiles/r04_segscan_phase_counters.txt): the small-K path was
 	 * three quarters of what the level tests cost.) */
 	if (!pass && ((rbits[prel >> 5] >> (prel & 31u)) & 1u) && (lv < 3u || !mf_lds || ((mfield[prel >> 4] >> (2u * (prel & 15u))) & 3u) >= lv - 2u)) {
 		const uint32_t K = kexact[base + prel];
@@ -754,7 +754,7 @@ int x3_scan_seg_applies(uint32_t nchunks, uint64_t max_len, uint64_t padded_tota
 	if (const char *e = getenv("X3H_SEG_MIN")) { const int v = atoi(e); if (v >= 1) { min_streams = min_big = (uint32_t)v; forced = true; } else if (v == 0 && *e == '0') return 0; }
 	/* between 48 and ~70 chunks the chip-wide sort can be the faster one: a workgroup per chunk is a chain whose length is the CHUNK (0.2 ms + 9.2 ns per byte of
 	 * text, in rounds of 256 chunks), the chip-wide form streams the padded layout of the BATCH (0.9 ms + 45 ns per KB): 64 chunks of 159 KB take 1.67 against 1.50 ms,
-	 * 80 chunks of 127 KB 1.39 against 1.50 (round 4: the dickens-sized bytes as 48 .. 256 chunks, tools/exp/r04_segmodel.sh) */
+	 * 80 chunks of 127 KB 1.39 against 1.50 (round 4: the dickens-sized bytes as 48 .. 256 chunks; profiles/r04_midsize_marks_and_timeline.txt) */
 	if (!forced && padded_total && nchunks >= min_streams && max_len <= X3_SEG_MAXLEN) {
 		const double seg_ms = (0.2 + 9.2e-6 * (double)max_len) * (double)((nchunks + 255) / 256);
 		const double chip_ms = 0.9 + 4.5e-8 * (double)padded_total;
