@@ -200,11 +200,15 @@ def main():
         offsets = np.arange(0, (per + 1) * CHUNK4, CHUNK4, dtype=np.uint64)
         unit_bytes = per * CHUNK4
         slot = xdist.default_slot_bytes(per * CHUNK4, per)
-        container_bytes, keep_last = [0], [None]
+        container_bytes, keep_last, gather_s = [0], [None], [0.0]
 
         def step():
             lens, st = ctx.compress_chunks_dev(d_in.data_ptr(), offsets, prm, d_out.data_ptr(), stride)
+            torch.cuda.synchronize()
+            g0 = time.perf_counter()
             got = xdist.gather_device_streams(d_out, stride, lens, slot, per, to_host=False)  # the ONE exchange step of the path (RCCL over xGMI)
+            torch.cuda.synchronize()
+            gather_s[0] += time.perf_counter() - g0  # (this rank's view: pack + one gather; rank 0 also waits for the slowest sender)
             if rank == 0:  # final bitstream concat, left in HBM like every output: X3C1 frame + the ranks' payloads back to back
                 all_lens, payloads = got
                 head = container.header([CHUNK4] * len(all_lens), all_lens, prm)
@@ -216,6 +220,8 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    if config4_leg:
+        gather_s[0] = 0.0
     t0 = time.perf_counter()
     acc = {k: 0.0 for k in ("ms_scan", "ms_parse", "ms_code", "ms_features", "ms_modes", "ms_coder", "ms_emit", "ms_total")}
     for _ in range(args.steps):
@@ -261,6 +267,11 @@ def main():
                               "parallelism": f"chunks over {world} GPUs, no data-path collective, one gather"}
             line["ratio"] = round(unit_bytes / out_len, 4)
             line["container_bytes"] = container_bytes[0]
+            # the exchange step, so that the first real multi-GPU run validates itself: how many ranks took part in the ONE gather, and what it cost rank 0 per step
+            line["rccl_ranks"] = int(dist.get_world_size())
+            line["gather_backend"] = str(dist.get_backend())
+            line["gather_ms"] = round(gather_s[0] * 1e3 / args.steps, 3)
+            line["gather_frame_bytes_per_rank"] = int(8 * (3 + per) + slot)
             prm_echo, chunks = container.unpack(keep_last[0].cpu().numpy().tobytes())  # (outside the timed region) the container parses back
             line["container_ok"] = bool(prm_echo is not None and len(chunks) == per * world and all(r == CHUNK4 for r, _ in chunks))
             # bit-exactness of the timed form, asserted in the run: rank 0 holds every rank's streams -- those of the pinned chunks are compared

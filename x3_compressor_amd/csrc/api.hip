@@ -566,8 +566,9 @@ static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, 
 	for (uint32_t k = 0; k < nmarks; k++) marks[k] = c->slice_marks[k];
 	if (!c->slice_marks_fixed) {
 		if (nc <= 2) { /* one or two streams: no other stream's segment to wait for in a coder launch, so more and smaller slices (297 against 299 ms on the dickens-sized stream) */
-			static const double fine[10] = { 0.02, 0.05, 0.10, 0.17, 0.26, 0.36, 0.47, 0.59, 0.72, 0.86 };
-			nmarks = 10;
+			/* (round 5: a first mark after 0.4 % -- the coder's first symbol waits for scan + parse to the first mark + that slice's stages: 296.9 -> 295.2 ms) */
+			static const double fine[11] = { 0.004, 0.02, 0.05, 0.10, 0.17, 0.26, 0.36, 0.47, 0.59, 0.72, 0.86 };
+			nmarks = 11;
 			for (uint32_t k = 0; k < nmarks; k++) marks[k] = fine[k];
 		}
 		const uint64_t longest = longest_len;

@@ -10,8 +10,8 @@
  *                      scan3.hip), a [digit][wave] counter table and one workgroup scan turn that into the tile-sorted order, the tile is staged
  *                      in LDS in that order and leaves as one contiguous run per digit                                 (8 B read + 8 B written per pair)
  *   Stable: tile order is (wave, element, lane), runs of a digit are laid out tile after tile.  Bound: HBM, 20 B per pair and pass (a one-sweep sort
- *   with decoupled look-back moves 16 B; this form needs no spinning workgroup, i.e. no way to hang the GPU).
- * Scans: reduce per tile of 4096 -> one workgroup scans the tile totals -> every tile scans itself behind its offset (reads the input twice; no look-back).
+ *   with decoupled look-back moves 16 B; the offsets here come from the chained scan below, the passes themselves never wait for one another).
+ * Scans: one pass, tiles of 4096 chained by decoupled look-back with a bounded wait (below).
  */
 #include "x3_host.h"
 #include "seg_rank.h"
@@ -23,13 +23,23 @@
 #define X3P_CS      (X3P_WAVES + 1u) /* words between two digits' per-wave counters (an odd stride: a wavefront's lanes -- one wave number, many digits -- meet in every LDS bank) */
 
 /* ---- scans ----------------------------------------------------------------------------------------------------------------------------------- */
+/* ONE pass over the data: a tile takes a ticket (tiles are numbered in the order their workgroups START, so every tile with a smaller number is running or done),
+ * scans itself, publishes its total and looks back over its predecessors' status words -- {state, value} in one 64-bit word, so a reader never sees half of one --
+ * adding totals until it meets a tile that already knows its prefix (decoupled look-back).  A predecessor publishes its total without waiting for anybody, so the
+ * wait is short and cannot deadlock; it is bounded all the same (X3P_SPIN_MAX polls, then the error word is set and the tile goes on): a kernel of this library never
+ * spins without an exit.  Loads and stores are striped (row k of a tile = 512 consecutive entries, one per thread): a wavefront's access is one contiguous run. */
 enum { X3P_SUM = 0, X3P_TOPBIT = 1, X3P_MAX = 2 };
+#define X3P_ST_EMPTY 0u
+#define X3P_ST_AGG   1u
+#define X3P_ST_INCL  2u
+#define X3P_SPIN_MAX (1u << 22)
 struct X3pScanArgs {
 	const uint32_t *in;     /* X3P_SUM / X3P_MAX: values; X3P_TOPBIT: uint4 records, the value is bit 31 of .w */
 	uint32_t *out;
-	uint32_t *part;         /* one word per tile */
+	uint64_t *status;       /* one word per tile, zeroed by the caller; behind them (status[ntiles]): the ticket counter (low word) and the error word (high word) */
 	size_t n;               /* entries that carry a value */
 	size_t nout;            /* entries written: n + 1 for the exclusive forms (out[n] = total), n for the inclusive maximum */
+	uint32_t ntiles, _pad;
 };
 
 template <int MODE> __device__ static __forceinline__ uint32_t x3p_scan_load(const X3pScanArgs &a, size_t i)
@@ -61,42 +71,83 @@ template <int MODE> __device__ static __forceinline__ uint32_t x3p_block_excl(ui
 	return before;
 }
 
-template <int MODE> __device__ static void x3p_scan_reduce_body(const X3pScanArgs &a)
+__device__ static __forceinline__ uint64_t x3p_status_load(const uint64_t *p)
 {
-	X3_LDS uint32_t s_w[X3P_WAVES];
-	const size_t base = (size_t)blockIdx.x * X3P_TILE + (size_t)threadIdx.x * X3P_E;
-	uint32_t acc = 0;
-	for (uint32_t k = 0; k < X3P_E; k++) acc = x3p_op<MODE>(acc, x3p_scan_load<MODE>(a, base + k));
-	uint32_t tot;
-	(void)x3p_block_excl<MODE>(acc, s_w, &tot);
-	if (threadIdx.x == 0) a.part[blockIdx.x] = tot;
+#ifndef X3_EMU
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+	return *p;
+#endif
 }
-/* one workgroup: part[] -> its exclusive scan, in place */
-template <int MODE> __device__ static void x3p_scan_mid_body(const X3pScanArgs &a, uint32_t ntiles)
+__device__ static __forceinline__ void x3p_status_store(uint64_t *p, uint32_t state, uint32_t value)
 {
-	X3_LDS uint32_t s_w[X3P_WAVES];
-	uint32_t carry = 0;
-	for (uint32_t b0 = 0; b0 < ntiles; b0 += X3P_THREADS) {
-		const uint32_t i = b0 + threadIdx.x;
-		const uint32_t v = i < ntiles ? a.part[i] : 0u;
-		uint32_t tot;
-		const uint32_t before = x3p_block_excl<MODE>(v, s_w, &tot);
-		if (i < ntiles) a.part[i] = x3p_op<MODE>(carry, before);
-		carry = x3p_op<MODE>(carry, tot);
-	}
+	const uint64_t w = ((uint64_t)state << 32) | value;
+#ifndef X3_EMU
+	__hip_atomic_store(p, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+	*p = w;
+#endif
 }
-template <int MODE> __device__ static void x3p_scan_apply_body(const X3pScanArgs &a)
+
+template <int MODE> __device__ static void x3p_scan_body(const X3pScanArgs &a)
 {
-	X3_LDS uint32_t s_w[X3P_WAVES];
-	const size_t base = (size_t)blockIdx.x * X3P_TILE + (size_t)threadIdx.x * X3P_E;
-	uint32_t v[X3P_E], acc = 0;
-	for (uint32_t k = 0; k < X3P_E; k++) { v[k] = x3p_scan_load<MODE>(a, base + k); acc = x3p_op<MODE>(acc, v[k]); }
-	uint32_t tot;
-	uint32_t run = x3p_op<MODE>(a.part[blockIdx.x], x3p_block_excl<MODE>(acc, s_w, &tot));
+	static_assert(X3P_E * X3P_WAVES == X3_WAVE, "the (row, wave) totals of a tile are scanned by one wavefront");
+	X3_LDS uint32_t s_tab[X3_WAVE]; /* [row][wave]: total of that wavefront's 64 entries of that row, then the operator over everything of the tile before them */
+	X3_LDS uint32_t s_tile, s_prefix;
+	const uint32_t lane = x3_lane(), wv = threadIdx.x / X3_WAVE;
+	if (threadIdx.x == 0) s_tile = atomicAdd((uint32_t *)(a.status + a.ntiles), 1u);
+	__syncthreads();
+	const uint32_t tile = s_tile;
+	const size_t base = (size_t)tile * X3P_TILE + threadIdx.x;
+	uint32_t v[X3P_E], incl[X3P_E];
+	for (uint32_t k = 0; k < X3P_E; k++) v[k] = x3p_scan_load<MODE>(a, base + (size_t)k * X3P_THREADS);
 	for (uint32_t k = 0; k < X3P_E; k++) {
-		const uint32_t incl = x3p_op<MODE>(run, v[k]);
-		if (base + k < a.nout) a.out[base + k] = MODE == X3P_MAX ? incl : run;
-		run = incl;
+		incl[k] = x3p_wave_incl<MODE>(v[k]);
+		if (lane == X3_WAVE - 1) s_tab[k * X3P_WAVES + wv] = incl[k];
+	}
+	__syncthreads();
+	if (wv == 0) {
+		const uint32_t mine = s_tab[lane];
+		const uint32_t inc = x3p_wave_incl<MODE>(mine);
+		const uint32_t agg = x3_bcast_u32(inc, X3_WAVE - 1);
+		const uint32_t up = x3_shfl_up_u32(inc, 1);
+		s_tab[lane] = lane ? up : 0u;
+		uint32_t excl = 0;
+		if (tile == 0) { if (lane == 0) x3p_status_store(a.status, X3P_ST_INCL, agg); }
+		else {
+			if (lane == 0) x3p_status_store(a.status + tile, X3P_ST_AGG, agg);
+			int64_t idx = (int64_t)tile - 1;
+			uint32_t polls = 0;
+			for (;;) {
+				const int64_t mi = idx - (int64_t)lane; /* lane 0: the nearest predecessor */
+				uint64_t w = mi >= 0 ? x3p_status_load(a.status + mi) : ((uint64_t)X3P_ST_INCL << 32);
+				while (x3_ballot((uint32_t)(w >> 32) == X3P_ST_EMPTY) && polls < X3P_SPIN_MAX) { /* a predecessor has not published yet (it is running: tiles are numbered as they start) */
+					polls++;
+#ifndef X3_EMU
+					__builtin_amdgcn_s_sleep(1);
+#endif
+					if ((uint32_t)(w >> 32) == X3P_ST_EMPTY) w = x3p_status_load(a.status + mi);
+				}
+				if (x3_ballot((uint32_t)(w >> 32) == X3P_ST_EMPTY)) { if (lane == 0) atomicOr((uint32_t *)(a.status + a.ntiles) + 1, 1u); break; } /* gave up (never seen): results are wrong, nothing hangs */
+				const uint64_t known = x3_ballot((uint32_t)(w >> 32) == X3P_ST_INCL);
+				const uint32_t upto = known ? (uint32_t)x3_ctz64(known) : X3_WAVE - 1; /* lanes 0..upto contribute */
+				const uint32_t part = x3p_wave_incl<MODE>(lane <= upto ? (uint32_t)w : 0u);
+				excl = x3p_op<MODE>(excl, x3_bcast_u32(part, X3_WAVE - 1));
+				if (known) break;
+				idx -= X3_WAVE;
+			}
+			if (lane == 0) x3p_status_store(a.status + tile, X3P_ST_INCL, x3p_op<MODE>(excl, agg));
+		}
+		if (lane == 0) s_prefix = excl;
+	}
+	__syncthreads();
+	const uint32_t pre = s_prefix;
+	for (uint32_t k = 0; k < X3P_E; k++) {
+		const size_t i = base + (size_t)k * X3P_THREADS;
+		if (i >= a.nout) continue;
+		const uint32_t before = x3p_op<MODE>(pre, s_tab[k * X3P_WAVES + wv]);
+		if (MODE == X3P_MAX) a.out[i] = x3p_op<MODE>(before, incl[k]);
+		else a.out[i] = before + incl[k] - v[k];
 	}
 }
 
@@ -181,33 +232,17 @@ __device__ static void x3p_scatter_body(const X3pSortArgs &a)
 }
 
 #ifndef X3_EMU
-template <int MODE> __global__ void __launch_bounds__(X3P_THREADS) x3p_scan_reduce_kernel(X3pScanArgs a) { x3p_scan_reduce_body<MODE>(a); }
-template <int MODE> __global__ void __launch_bounds__(X3P_THREADS) x3p_scan_mid_kernel(X3pScanArgs a, uint32_t ntiles) { x3p_scan_mid_body<MODE>(a, ntiles); }
-template <int MODE> __global__ void __launch_bounds__(X3P_THREADS) x3p_scan_apply_kernel(X3pScanArgs a) { x3p_scan_apply_body<MODE>(a); }
+template <int MODE> __global__ void __launch_bounds__(X3P_THREADS) x3p_scan_kernel(X3pScanArgs a) { x3p_scan_body<MODE>(a); }
 __global__ void __launch_bounds__(X3P_THREADS) x3p_hist_kernel(X3pSortArgs a) { x3p_hist_body(a); }
 __global__ void __launch_bounds__(X3P_THREADS) x3p_scatter_kernel(X3pSortArgs a) { x3p_scatter_body(a); }
-template <int MODE> static void x3p_scan_launch(const X3pScanArgs &a, uint32_t ntiles, hipStream_t st)
-{
-	hipLaunchKernelGGL(x3p_scan_reduce_kernel<MODE>, dim3(ntiles), dim3(X3P_THREADS), 0, st, a);
-	hipLaunchKernelGGL(x3p_scan_mid_kernel<MODE>, dim3(1), dim3(X3P_THREADS), 0, st, a, ntiles);
-	hipLaunchKernelGGL(x3p_scan_apply_kernel<MODE>, dim3(ntiles), dim3(X3P_THREADS), 0, st, a);
-}
+template <int MODE> static void x3p_scan_launch(const X3pScanArgs &a, hipStream_t st) { hipLaunchKernelGGL(x3p_scan_kernel<MODE>, dim3(a.ntiles), dim3(X3P_THREADS), 0, st, a); }
 static void x3p_hist_launch(const X3pSortArgs &a, hipStream_t st) { hipLaunchKernelGGL(x3p_hist_kernel, dim3(a.ntiles), dim3(X3P_THREADS), 0, st, a); }
 static void x3p_scatter_launch(const X3pSortArgs &a, hipStream_t st) { hipLaunchKernelGGL(x3p_scatter_kernel, dim3(a.ntiles), dim3(X3P_THREADS), 0, st, a); }
 #else
-struct X3pMidCall { X3pScanArgs a; uint32_t ntiles; };
-template <int MODE> static void x3p_reduce_tramp(void *p) { x3p_scan_reduce_body<MODE>(*(const X3pScanArgs *)p); }
-template <int MODE> static void x3p_mid_tramp(void *p) { const X3pMidCall &c = *(const X3pMidCall *)p; x3p_scan_mid_body<MODE>(c.a, c.ntiles); }
-template <int MODE> static void x3p_apply_tramp(void *p) { x3p_scan_apply_body<MODE>(*(const X3pScanArgs *)p); }
+template <int MODE> static void x3p_scan_tramp(void *p) { x3p_scan_body<MODE>(*(const X3pScanArgs *)p); }
 static void x3p_hist_tramp(void *p) { x3p_hist_body(*(const X3pSortArgs *)p); }
 static void x3p_scatter_tramp(void *p) { x3p_scatter_body(*(const X3pSortArgs *)p); }
-template <int MODE> static void x3p_scan_launch(const X3pScanArgs &a, uint32_t ntiles, hipStream_t)
-{
-	X3pMidCall mc = { a, ntiles };
-	x3emu_launch(x3p_reduce_tramp<MODE>, (void *)&a, dim3(ntiles), dim3(X3P_THREADS));
-	x3emu_launch(x3p_mid_tramp<MODE>, (void *)&mc, dim3(1), dim3(X3P_THREADS));
-	x3emu_launch(x3p_apply_tramp<MODE>, (void *)&a, dim3(ntiles), dim3(X3P_THREADS));
-}
+template <int MODE> static void x3p_scan_launch(const X3pScanArgs &a, hipStream_t) { x3emu_launch(x3p_scan_tramp<MODE>, (void *)&a, dim3(a.ntiles), dim3(X3P_THREADS)); }
 static void x3p_hist_launch(const X3pSortArgs &a, hipStream_t) { x3emu_launch(x3p_hist_tramp, (void *)&a, dim3(a.ntiles), dim3(X3P_THREADS)); }
 static void x3p_scatter_launch(const X3pSortArgs &a, hipStream_t) { x3emu_launch(x3p_scatter_tramp, (void *)&a, dim3(a.ntiles), dim3(X3P_THREADS)); }
 #endif
@@ -232,14 +267,16 @@ static void x3p_host_sort(const uint32_t *kin, uint32_t *kout, const uint32_t *v
 static inline size_t x3p_tiles(size_t n) { return (n + X3P_TILE - 1) / X3P_TILE; }
 static inline size_t x3p_al(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
 
-/* `part` needs x3p_tiles(nout) words */
-template <int MODE> static int x3p_scan_run(const uint32_t *in, uint32_t *out, size_t n, size_t nout, uint32_t *part, hipStream_t st)
+/* `status` needs x3p_status_bytes(nout) bytes */
+static inline size_t x3p_status_bytes(size_t nout) { return x3p_al((x3p_tiles(nout) + 1) * 8); }
+template <int MODE> static int x3p_scan_run(const uint32_t *in, uint32_t *out, size_t n, size_t nout, void *status, hipStream_t st)
 {
 	if (!nout) return X3H_OK;
 	if (x3p_tiles(nout) > 0x7FFFFFFFull) return X3H_E_ARG;
 	X3pScanArgs a;
-	a.in = in; a.out = out; a.part = part; a.n = n; a.nout = nout;
-	x3p_scan_launch<MODE>(a, (uint32_t)x3p_tiles(nout), st);
+	a.in = in; a.out = out; a.status = (uint64_t *)status; a.n = n; a.nout = nout; a.ntiles = (uint32_t)x3p_tiles(nout); a._pad = 0;
+	HIPCHK(hipMemsetAsync(status, 0, ((size_t)a.ntiles + 1) * 8, st));
+	x3p_scan_launch<MODE>(a, st);
 	HIPCHK(hipGetLastError());
 	return X3H_OK;
 }
@@ -249,8 +286,8 @@ int x3p_excl_scan(DevBuf &tmp, const uint32_t *in, uint32_t *out, size_t n, hipS
 #ifdef X3_EMU
 	if (!x3p_emu_kernels()) { uint32_t acc = 0; for (size_t i = 0; i <= n; i++) { const uint32_t v = i < n ? in[i] : 0; out[i] = acc; acc += v; } return X3H_OK; }
 #endif
-	CHK(tmp.reserve(x3p_al(x3p_tiles(n + 1) * 4)));
-	return x3p_scan_run<X3P_SUM>(in, out, n, n + 1, tmp.as<uint32_t>(), st);
+	CHK(tmp.reserve(x3p_status_bytes(n + 1)));
+	return x3p_scan_run<X3P_SUM>(in, out, n, n + 1, tmp.p, st);
 }
 
 int x3p_excl_scan_top_bit_w(DevBuf &tmp, const uint4 *rec, uint32_t *out, size_t n, hipStream_t st)
@@ -258,8 +295,8 @@ int x3p_excl_scan_top_bit_w(DevBuf &tmp, const uint4 *rec, uint32_t *out, size_t
 #ifdef X3_EMU
 	if (!x3p_emu_kernels()) { uint32_t acc = 0; for (size_t i = 0; i <= n; i++) { out[i] = acc; if (i < n) acc += rec[i].w >> 31; } return X3H_OK; }
 #endif
-	CHK(tmp.reserve(x3p_al(x3p_tiles(n + 1) * 4)));
-	return x3p_scan_run<X3P_TOPBIT>((const uint32_t *)rec, out, n, n + 1, tmp.as<uint32_t>(), st);
+	CHK(tmp.reserve(x3p_status_bytes(n + 1)));
+	return x3p_scan_run<X3P_TOPBIT>((const uint32_t *)rec, out, n, n + 1, tmp.p, st);
 }
 
 int x3p_incl_max_scan(DevBuf &tmp, const uint32_t *in, uint32_t *out, size_t n, hipStream_t st)
@@ -268,8 +305,8 @@ int x3p_incl_max_scan(DevBuf &tmp, const uint32_t *in, uint32_t *out, size_t n, 
 #ifdef X3_EMU
 	if (!x3p_emu_kernels()) { uint32_t acc = 0; for (size_t i = 0; i < n; i++) { acc = in[i] > acc ? in[i] : acc; out[i] = acc; } return X3H_OK; }
 #endif
-	CHK(tmp.reserve(x3p_al(x3p_tiles(n) * 4)));
-	return x3p_scan_run<X3P_MAX>(in, out, n, n, tmp.as<uint32_t>(), st);
+	CHK(tmp.reserve(x3p_status_bytes(n)));
+	return x3p_scan_run<X3P_MAX>(in, out, n, n, tmp.p, st);
 }
 
 /* stable sort on key bits [begin_bit, end_bit): ceil(bits / 8) passes; the pairs travel kin -> (scratch <->) kout so that the last pass writes kout / vout */
@@ -285,10 +322,10 @@ int x3p_sort_pairs_bits(DevBuf &tmp, const uint32_t *kin, uint32_t *kout, const 
 	if (n >= ((size_t)1 << 32) - X3P_TILE) return X3H_E_ARG; /* output indices are 32-bit */
 	const uint32_t npass = ((uint32_t)(end_bit - begin_bit) + 7u) / 8u;
 	const size_t nt = x3p_tiles(n), ncounts = 256 * nt + 1;
-	const size_t o_counts = 0, o_part = o_counts + x3p_al(ncounts * 4), o_k = o_part + x3p_al(x3p_tiles(ncounts) * 4), o_v = o_k + x3p_al(npass > 1 ? n * 4 : 0);
+	const size_t o_counts = 0, o_part = o_counts + x3p_al(ncounts * 4), o_k = o_part + x3p_status_bytes(ncounts), o_v = o_k + x3p_al(npass > 1 ? n * 4 : 0);
 	CHK(tmp.reserve(o_v + x3p_al(npass > 1 ? n * 4 : 0)));
 	uint8_t *t8 = tmp.as<uint8_t>();
-	uint32_t *counts = (uint32_t *)(t8 + o_counts), *part = (uint32_t *)(t8 + o_part), *sk = (uint32_t *)(t8 + o_k), *sv = (uint32_t *)(t8 + o_v);
+	uint32_t *counts = (uint32_t *)(t8 + o_counts); void *part = t8 + o_part; uint32_t *sk = (uint32_t *)(t8 + o_k), *sv = (uint32_t *)(t8 + o_v);
 	const uint32_t *ck = kin, *cv = vin;
 	for (uint32_t p = 0; p < npass; p++) {
 		const uint32_t lo = (uint32_t)begin_bit + 8u * p, width = (uint32_t)end_bit - lo < 8u ? (uint32_t)end_bit - lo : 8u;
