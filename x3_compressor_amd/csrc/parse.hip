@@ -35,8 +35,40 @@
 #endif
 static_assert(X3_LDS_DICT < 2048, "a mirror entry holds tag + 1 in 11 bits beside the element's length - 1 in 5");
 
-#define FNV_OFF 2166136261u
-#define FNV_MUL 16777619u
+/* The hash of an element / of l bytes at a position: a polynomial (Horner) hash  H(s[0..l)) = sum (s[k] + 1) * B^(l-1-k)  mod 2^32, so that with the
+ * prefix hashes P[j] = H(block[0..j)) of the staged block the hash of ANY (position, length) is  P[i+l] - P[i] * B^l  -- two LDS reads and a multiply-subtract,
+ * no walk over the bytes.  That is what lets the block fill probe the lengths LONGEST FIRST and stop at the first match: on zero-heavy data (config 5: 24-32
+ * element lengths, every one of them matching at every position of a zero run) a position costs one probe instead of one per length -- the incremental
+ * hash of rounds 1-4 had to walk up through every shorter length first (fill 393 of 571 Mcycles of config 5's parse).  x3_ph_final mixes the sum before its bits
+ * are used (table slot, the 16 tag bits of a mirrored entry, the per-length filter): the top bits of a short string's polynomial hash are nearly constant. */
+#define X3_PH_B 0x9E3779B1u
+/* inclusive scan of affine maps x -> x * m + a over the wavefront (composition, earlier lane first): the DPP pattern of x3_wave_incl_scan_u32 -- row shifts by 1, 2, 4, 8, then
+ * the last lane of a row broadcast to the rows behind it -- with the identity map (1, 0) where a lane has no source; twelve register moves instead of twelve LDS round trips */
+__device__ static __forceinline__ void x3_affine_wave_scan(uint32_t &m, uint32_t &a, uint32_t lane)
+{
+#ifndef X3_EMU
+#define X3_AFF_STEP(CTRL, ROWMASK)                                                                                              \
+	{                                                                                                                           \
+		const uint32_t um = (uint32_t)__builtin_amdgcn_update_dpp(1, (int)m, CTRL, ROWMASK, 0xf, false);                         \
+		const uint32_t ua = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a, CTRL, ROWMASK, 0xf, false);                         \
+		a = ua * m + a; m = um * m;                                                                                             \
+	}
+	X3_AFF_STEP(0x111, 0xf) X3_AFF_STEP(0x112, 0xf) X3_AFF_STEP(0x114, 0xf) X3_AFF_STEP(0x118, 0xf) /* row_shr:1,2,4,8 */
+	X3_AFF_STEP(0x142, 0xa) /* row_bcast:15 -> rows 1, 3 */
+	X3_AFF_STEP(0x143, 0xc) /* row_bcast:31 -> rows 2, 3 */
+#undef X3_AFF_STEP
+	(void)lane;
+#else
+	for (uint32_t dd = 1; dd < X3_WAVE; dd <<= 1) {
+		const uint32_t um = x3_shfl_up_u32(m, dd), ua = x3_shfl_up_u32(a, dd);
+		if (lane >= dd) { a = ua * m + a; m = um * m; }
+	}
+#endif
+}
+#define X3_PRE_BUCKETS 512u
+__device__ static __forceinline__ uint32_t x3_pre_bucket(uint32_t first4) { return (first4 * 0x85EBCA6Bu) >> 23; }
+__device__ static __forceinline__ uint32_t x3_ph_step(uint32_t h, uint32_t byte) { return h * X3_PH_B + byte + 1u; }
+__device__ static __forceinline__ uint32_t x3_ph_final(uint32_t h) { h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; return h; }
 
 __device__ static __forceinline__ uint32_t ht_slot(uint32_t h, uint32_t len, uint32_t hlog)
 {
@@ -98,8 +130,13 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 	X3_LDS uint8_t sDlen[X3_LDS_DICT];
 	X3_LDS uint2 sD8[X3_LDS_DICT];   /* the first eight bytes of each mirrored element (zero beyond its length): most candidates are settled without touching global memory */
 	X3_LDS uint32_t sDh[X3_LDS_DICT];  /* ... and its 32-bit hash (the one the table is addressed with) */
-	X3_LDS uint32_t sBloom[32][X3_BLOOM_WORDS]; /* per element length: a 256-bit filter on the top bits of the element's FNV hash -- a probe whose bit is clear has no element to find
+	X3_LDS uint32_t sBloom[32][X3_BLOOM_WORDS]; /* per element length: a 256-bit filter on the top bits of the element's (mixed) hash -- a probe whose bit is clear has no element to find
 	                                              * (the filter never forgets: the dictionary only grows) */
+	X3_LDS uint32_t sPre[X3_PRE_BUCKETS]; /* by the first four bytes (hashed): the lengths >= 4 of the elements that begin with them, one bit per length -- ONE read tells a position
+	                                       * which of the 24-32 lengths present can match at all (a filter: it never forgets, the dictionary only grows) */
+	X3_LDS uint32_t sP[PBB + 1];  /* prefix hashes of the staged bytes: sP[j] = H(sb[0..j)) */
+	X3_LDS uint32_t sPow[33];     /* B^l */
+	X3_LDS uint2 sPw[X3_PARSE_THREADS / X3_WAVE]; /* the prefix scan's per-wave totals */
 	X3_LDS ParseShared S;
 
 	const X3Chunk ck = a.chunks[blockIdx.x];
@@ -120,6 +157,8 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 	for (uint32_t i = tid; i < (1u << (X3_HT_LOG2_MIN < ck.ht_log2_max ? X3_HT_LOG2_MIN : ck.ht_log2_max)); i += X3_PARSE_THREADS) ht[i] = 0;
 	for (uint32_t i = tid; i < X3_LDS_HT; i += X3_PARSE_THREADS) sHT[i] = 0;
 	for (uint32_t i = tid; i < 32u * X3_BLOOM_WORDS; i += X3_PARSE_THREADS) (&sBloom[0][0])[i] = 0;
+	for (uint32_t i = tid; i < X3_PRE_BUCKETS; i += X3_PARSE_THREADS) sPre[i] = 0;
+	if (tid == 0) { uint32_t pw = 1u; for (uint32_t l = 0; l <= 32u; l++) { sPow[l] = pw; pw *= X3_PH_B; } }
 	__syncthreads();
 
 	uint64_t cyc_fill = 0, cyc_patch = 0, cyc_table = 0, cyc_walk = 0, t_prev = x3_clock();
@@ -132,24 +171,57 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 			for (uint32_t i = tid; i < PBB; i += X3_PARSE_THREADS) sb[i] = b[(uint64_t)blk + i];
 			for (uint32_t i = tid; i < PB; i += X3_PARSE_THREADS) sM[i] = mm[(uint64_t)blk + i];
 			__syncthreads();
-			const uint32_t maxlen = lenmask ? 32 - (uint32_t)x3_clz32(lenmask) : 0;
+			/* prefix hashes of the block: every thread folds its PER consecutive bytes into an affine map x -> x * mul + add, the maps are composed by a scan over the
+			 * workgroup (wavefront: six shuffle steps; the sixteen wave totals: a short serial fold), and every thread writes the PER prefixes behind its start value */
+			{
+				constexpr uint32_t PER = (PBB + X3_PARSE_THREADS - 1) / X3_PARSE_THREADS;
+				const uint32_t j0 = tid * PER;
+				uint32_t mul = 1u, add = 0u;
+				for (uint32_t k = 0; k < PER; k++) if (j0 + k < PBB) { add = x3_ph_step(add, sb[j0 + k]); mul *= X3_PH_B; }
+				uint32_t im = mul, ia = add; /* inclusive composition over the lanes up to this one */
+				x3_affine_wave_scan(im, ia, lane);
+				if (lane == X3_WAVE - 1) sPw[wave] = make_uint2(im, ia);
+				__syncthreads();
+				uint32_t x = 0u; /* value before this wave's first byte */
+				for (uint32_t w = 0; w < wave; w++) { const uint2 t = sPw[w]; x = x * t.x + t.y; }
+				/* value before this thread's first byte: the wave's start through the lanes before this one */
+				const uint32_t pm = x3_wave_shr1_u32(im), pa = x3_wave_shr1_u32(ia);
+				if (lane) x = x * pm + pa;
+				if (tid == 0) sP[0] = 0u;
+				for (uint32_t k = 0; k < PER; k++) if (j0 + k < PBB) { x = x3_ph_step(x, sb[j0 + k]); sP[j0 + k + 1] = x; }
+			}
+			__syncthreads();
 			for (uint32_t i = tid; i < PBL; i += X3_PARSE_THREADS) {
 				uint32_t best = 0, btag = 0;
 				const uint64_t my8 = x3_lds_load8(sb, i); /* the position's first eight bytes, compared with the mirrored elements' */
-				/* Mirrored dictionary: a candidate is accepted on the 16 hash bits its table entry carries (one LDS access per probe) and only the LONGEST
-				 * one is compared -- first 8 bytes in LDS, the rest with the element in global memory -- once the search is over.  On zero-heavy data
-				 * every one of 24-32 lengths hits at every position, and comparing each of them was 80 % of the parse (config 5: 717 of 900 Mcycles).
-				 * Should that one comparison fail (a hash collision, ~2^-16 per probe), the position is searched again with every candidate compared in
-				 * full: the result is exact either way.
-				 * (Probing from the longest length down with an early exit -- the hash of l bytes from the hash of l + 1 by undoing an FNV step -- was
-				 * measured too: it walks the hash twice and is slower on text, 8.9 against 8.2 ms per 1024 chunks, and no faster on zero-heavy data.) */
+				const uint32_t Pi = sP[i];
+				/* Lengths are probed LONGEST FIRST and the search stops at the first match (header of the hash above).  Mirrored dictionary: a candidate is accepted on
+				 * the 16 hash bits its table entry carries (one LDS access per probe) and compared in full -- first 8 bytes in LDS, the rest with the element in global
+				 * memory -- once the search is over.  Should that comparison fail (a hash collision, ~2^-16 per probe), the position is searched again with every
+				 * candidate compared in full: the result is exact either way. */
+				/* the lengths worth a probe: 1-3 if present, longer ones only if some element of that length begins with this position's first four bytes */
+				const uint32_t cand0 = lenmask & (7u | sPre[x3_pre_bucket((uint32_t)my8)]);
+				/* ... of those, the lengths whose hash passes the per-length filter: four candidates per trip, no branch on what the LDS returns, so that the reads of a trip
+				 * (two per candidate) are in flight together -- one candidate after the other, every probe was three dependent LDS round trips */
+				uint32_t surv = 0;
+				for (uint32_t cand = cand0; cand; ) {
+					uint32_t l4[4], h4[4];
+#pragma unroll
+					for (uint32_t u = 0; u < 4; u++) { l4[u] = 32u - (uint32_t)x3_clz32(cand); cand &= ~(l4[u] ? 1u << (l4[u] - 1u) : 0u); } /* (cand == 0: l = 0, nothing cleared; l = 32 is a length like any other: no shift by 32) */
+#pragma unroll
+					for (uint32_t u = 0; u < 4; u++) h4[u] = x3_ph_final(sP[i + l4[u]] - Pi * sPow[l4[u]]);
+#pragma unroll
+					for (uint32_t u = 0; u < 4; u++) {
+						const uint32_t bit = (sBloom[(l4[u] - 1u) & 31u][h4[u] >> 29] >> ((h4[u] >> 24) & 31u)) & 1u;
+						surv |= l4[u] ? bit << (l4[u] - 1u) : 0u;
+					}
+				}
 				for (uint32_t pass = 0; pass < 2; pass++) {
-					uint32_t h = FNV_OFF;
 					best = 0; btag = 0;
-					for (uint32_t l = 1; l <= maxlen; l++) {
-						h = (h ^ sb[i + l - 1]) * FNV_MUL;
-						if (!((lenmask >> (l - 1)) & 1)) continue;
-						if (!((sBloom[l - 1][h >> 29] >> ((h >> 24) & 31u)) & 1u)) continue; /* no element of this length with these hash bits: skip the table (a random LDS / L2 access) */
+					for (uint32_t cand = surv; cand && !best; ) {
+						const uint32_t l = 32u - (uint32_t)x3_clz32(cand);
+						cand ^= 1u << (l - 1);
+						const uint32_t h = x3_ph_final(sP[i + l] - Pi * sPow[l]);
 						uint32_t slot = ht_slot(h, l, hlog);
 						if (hlog <= X3_LDS_HT_LOG2) { /* wave-uniform: the whole dictionary is mirrored in LDS */
 							const uint64_t m8 = l >= 8 ? ~(uint64_t)0 : (((uint64_t)1 << (8 * l)) - 1);
@@ -193,8 +265,9 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 				for (uint32_t t = tid; t < D; t += X3_PARSE_THREADS) {
 					const uint8_t *ds = b + dpos[t];
 					const uint32_t l = dlen[t];
-					uint32_t h = FNV_OFF;
-					for (uint32_t k = 0; k < l; k++) h = (h ^ ds[k]) * FNV_MUL;
+					uint32_t h = 0u;
+					for (uint32_t k = 0; k < l; k++) h = x3_ph_step(h, ds[k]);
+					h = x3_ph_final(h);
 					uint32_t slot = ht_slot(h, l, hlog);
 					while (atomicCAS(&ht[slot], 0u, t + 1) != 0u) slot = (slot + 1) & hmask;
 				}
@@ -289,8 +362,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 				int dup = 0;
 				if (L0 == len) dup = 1;
 				else if (L0 > len && ((lenmask >> (len - 1)) & 1)) {
-					uint32_t h = FNV_OFF;
-					for (uint32_t k = 0; k < len; k++) h = (h ^ sb[idx + k]) * FNV_MUL;
+					const uint32_t h = x3_ph_final(sP[idx + len] - sP[idx] * sPow[len]);
 					const uint32_t hmask = (1u << hlog) - 1;
 					uint32_t slot = ht_slot(h, len, hlog);
 					for (uint32_t e = ht[slot]; e != 0; slot = (slot + 1) & hmask, e = ht[slot]) {
@@ -319,9 +391,9 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 							for (uint32_t k = 0; k < len && k < 8; k++) v8 |= (uint64_t)sb[idx + k] << (8 * k);
 							sD8[ntag] = make_uint2((uint32_t)v8, (uint32_t)(v8 >> 32));
 						}
-						uint32_t h = FNV_OFF;
-						for (uint32_t k = 0; k < len; k++) h = (h ^ sb[idx + k]) * FNV_MUL;
+						const uint32_t h = x3_ph_final(sP[idx + len] - sP[idx] * sPow[len]);
 						sBloom[len - 1][h >> 29] |= 1u << ((h >> 24) & 31u);
+						if (len >= 4) sPre[x3_pre_bucket((uint32_t)sb[idx] | (uint32_t)sb[idx + 1] << 8 | (uint32_t)sb[idx + 2] << 16 | (uint32_t)sb[idx + 3] << 24)] |= 1u << (len - 1);
 						if (ntag < X3_LDS_DICT) sDh[ntag] = h;
 						if (!rebuild) {
 							const uint32_t hmask = (1u << hlog) - 1;
