@@ -132,6 +132,7 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 	X3_LDS uint32_t sDh[X3_LDS_DICT];  /* ... and its 32-bit hash (the one the table is addressed with) */
 	X3_LDS uint32_t sBloom[32][X3_BLOOM_WORDS]; /* per element length: a 256-bit filter on the top bits of the element's (mixed) hash -- a probe whose bit is clear has no element to find
 	                                              * (the filter never forgets: the dictionary only grows) */
+	X3_LDS uint32_t sSm[(PBL + 2 * X3_WAVE) / 32 + 2]; /* one bit per cached position: an element matching there is short enough to let a candidate length through (step table) */
 	X3_LDS uint32_t sPre[X3_PRE_BUCKETS]; /* by the first four bytes (hashed): the lengths >= 4 of the elements that begin with them, one bit per length -- ONE read tells a position
 	                                       * which of the 24-32 lengths present can match at all (a filter: it never forgets, the dictionary only grows) */
 	X3_LDS uint32_t sP[PBB + 1];  /* prefix hashes of the staged bytes: sP[j] = H(sb[0..j)) */
@@ -191,8 +192,10 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 				for (uint32_t k = 0; k < PER; k++) if (j0 + k < PBB) { x = x3_ph_step(x, sb[j0 + k]); sP[j0 + k + 1] = x; }
 			}
 			__syncthreads();
-			for (uint32_t i = tid; i < PBL; i += X3_PARSE_THREADS) {
+			for (uint32_t i0 = 0; i0 < PBL; i0 += X3_PARSE_THREADS) { /* (every thread takes every trip: the ballot at the end is the wave's) */
+				const uint32_t i = i0 + tid;
 				uint32_t best = 0, btag = 0;
+				if (i < PBL) {
 				const uint64_t my8 = x3_lds_load8(sb, i); /* the position's first eight bytes, compared with the mirrored elements' */
 				const uint32_t Pi = sP[i];
 				/* Lengths are probed LONGEST FIRST and the search stops at the first match (header of the hash above).  Mirrored dictionary: a candidate is accepted on
@@ -205,13 +208,14 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 				 * (two per candidate) are in flight together -- one candidate after the other, every probe was three dependent LDS round trips */
 				uint32_t surv = 0;
 				for (uint32_t cand = cand0; cand; ) {
-					uint32_t l4[4], h4[4];
+					constexpr uint32_t U = 4u;
+					uint32_t l4[U], h4[U];
 #pragma unroll
-					for (uint32_t u = 0; u < 4; u++) { l4[u] = 32u - (uint32_t)x3_clz32(cand); cand &= ~(l4[u] ? 1u << (l4[u] - 1u) : 0u); } /* (cand == 0: l = 0, nothing cleared; l = 32 is a length like any other: no shift by 32) */
+					for (uint32_t u = 0; u < U; u++) { l4[u] = 32u - (uint32_t)x3_clz32(cand); cand &= ~(l4[u] ? 1u << (l4[u] - 1u) : 0u); } /* (cand == 0: l = 0, nothing cleared; l = 32 is a length like any other: no shift by 32) */
 #pragma unroll
-					for (uint32_t u = 0; u < 4; u++) h4[u] = x3_ph_final(sP[i + l4[u]] - Pi * sPow[l4[u]]);
+					for (uint32_t u = 0; u < U; u++) h4[u] = x3_ph_final(sP[i + l4[u]] - Pi * sPow[l4[u]]);
 #pragma unroll
-					for (uint32_t u = 0; u < 4; u++) {
+					for (uint32_t u = 0; u < U; u++) {
 						const uint32_t bit = (sBloom[(l4[u] - 1u) & 31u][h4[u] >> 29] >> ((h4[u] >> 24) & 31u)) & 1u;
 						surv |= l4[u] ? bit << (l4[u] - 1u) : 0u;
 					}
@@ -253,6 +257,10 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 				}
 				sL[i] = (uint8_t)best;
 				sE[i] = btag;
+				}
+				/* the step table's filter (below): one bit per cached position, "an element matching here is short enough to let a candidate length through" */
+				const uint64_t bal = x3_ballot(i < PBL && (best == 0 || (uint64_t)best * f1 <= 33u));
+				if (lane == 0 && i < PBL + X3_WAVE) { sSm[i >> 5] = (uint32_t)bal; sSm[(i >> 5) + 1] = (uint32_t)(bal >> 32); } /* (one wavefront behind the last position too: zeros a window may read) */
 			}
 			if (tid == 0) S.blk = blk;
 		} else if (flag == FLAG_PATCH) {
@@ -278,11 +286,16 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 			}
 			const uint32_t first = S.p - blk; /* positions before the parse pointer are never read again */
 			const uint32_t src = np - blk;    /* the element's bytes are inside the staged block */
-			for (uint32_t i = first + tid; i < PBL; i += X3_PARSE_THREADS) {
-				if (sL[i] >= nl) continue;
-				uint32_t k = 0;
-				while (k < nl && sb[i + k] == sb[src + k]) k++;
-				if (k == nl) { sL[i] = (uint8_t)nl; sE[i] = nt; }
+			for (uint32_t i0 = first & ~(X3_WAVE - 1u); i0 < PBL; i0 += X3_PARSE_THREADS) { /* (whole wavefronts, every thread every trip: the filter bits of a wavefront's 64 positions are one ballot) */
+				const uint32_t i = i0 + tid;
+				uint32_t Li = i < PBL ? sL[i] : 1u;
+				if (i >= first && i < PBL && Li < nl) {
+					uint32_t k = 0;
+					while (k < nl && sb[i + k] == sb[src + k]) k++;
+					if (k == nl) { sL[i] = (uint8_t)nl; sE[i] = nt; Li = nl; }
+				}
+				const uint64_t bal = x3_ballot(i < PBL && (Li == 0 || (uint64_t)Li * f1 <= 33u));
+				if (lane == 0 && i < PBL + X3_WAVE) { sSm[i >> 5] = (uint32_t)bal; sSm[(i >> 5) + 1] = (uint32_t)(bal >> 32); }
 			}
 		}
 		__syncthreads();
@@ -292,12 +305,29 @@ __device__ static void x3_parse_body(const X3ParseArgs &a)
 			 * x3.c:383,402-404).  It only changes when a new element patches L[], so all threads (re)build the table and the
 			 * serial walker below just follows it. ---- */
 			const uint32_t blk = S.blk, first = S.p >= blk ? S.p - blk : 0;
+			/* backend.c:79-83 with factor2 == 0: candidate length k + 1 survives iff k == 1, or no element matches at p + k, or its length L obeys L * factor1 <= k + 1.
+			 * k <= 32, so only positions with L == 0 or L * factor1 <= 33 can let anything through: one bit per cached position (a ballot per 64), and a position looks at
+			 * the bits of ITS window from the top -- zero-heavy data (every L is 9 or more: no bit) is settled without a loop, text by its first candidate, where the
+			 * plain loop walked all m[p] <= 31 lengths upwards (config 5: 130 of 385 Mcycles of the parse) */
 			for (uint32_t i = first + tid; i < PB; i += X3_PARSE_THREADS) {
 				const uint32_t q = blk + i;
 				if (q >= n) break;
 				const uint32_t mp = sM[i];
 				uint32_t best = 0;
 				int vmax = -(1 << 20);
+				if (f2 == 0 && f1 > 0) {
+					best = mp ? 1u : 0u;
+					if (mp >= 2) {
+						const uint32_t wi = (i + 2) >> 5, sh = (i + 2) & 31;
+						const uint64_t two = (uint64_t)sSm[wi] | ((uint64_t)sSm[wi + 1] << 32);
+						uint32_t w = (uint32_t)(two >> sh) & (mp >= 33 ? 0xFFFFFFFFu : ((1u << (mp - 1)) - 1u)); /* bit t: k = t + 2 */
+						while (w) {
+							const uint32_t t = 31u - (uint32_t)x3_clz32(w), k = t + 2, Lk = sL[i + k];
+							if (Lk == 0 || (uint64_t)Lk * f1 <= (uint64_t)(k + 1)) { best = k; break; }
+							w ^= 1u << t;
+						}
+					}
+				} else
 				for (uint32_t k = 1; k <= mp; k++) {
 					const uint32_t Lk = sL[i + k];
 					bool ok = !(k >= 2 && f1 > 0 && Lk != 0 && (uint64_t)Lk * f1 > (uint64_t)(k + 1));
