@@ -427,10 +427,19 @@ def main():
             # K1 of this batch is the one HBM-bound hand-written kernel family of the path (scan3.hip: per-chunk radix sort + level tests, dense classes
             # refined by the same workgroup): algorithmic bytes = 80 per list element (8 keys out + 4 passes x 16 + 8 for the level-4 re-read), n + 3 elements per chunk
             k1_alg = 80 * (mtot + 3 * (len(moff) - 1))
-            line["many_chunks_batch"]["k1_roofline"] = {"bound": "hbm", "kernel": "x3_segscan_kernel (+ x3_segrefine_kernel / x3_walk_kernel: stage_ms.scan)", "algorithmic_bytes": k1_alg,
+            line["many_chunks_batch"]["k1_roofline"] = {"bound": "hbm", "kernel": "K1 stage = x3_segscan_kernel + x3_segrefine_kernel + x3_walk_kernel", "algorithmic_bytes": k1_alg,
+                                                        "divided_by": "stage_ms.scan (HIP events around the whole K1 stage on the library's stream)", "stage_ms": round(mst.ms_scan, 2),
                                                         "achieved": round(k1_alg / (mst.ms_scan * 1e-3) / 1e9, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                                                         "frac": round(k1_alg / (mst.ms_scan * 1e-3) / HBM_PEAK, 4),
-                                                        "note": "HIP events around the scan stage on the library's stream; PMC traffic of the kernel itself: hbm_traffic.by_family_GB"}
+                                                        "note": "x3_segscan_kernel alone (kernel trace, profiles/rNN_many_chunks_mix_kernel_stats.csv): frac_kernel below; its PMC traffic: hbm_traffic.by_family_GB"}
+            kpath = newest_profile("many_chunks_mix_kernel_stats.csv")
+            if kpath:  # the kernel's own average duration from the committed kernel trace of the same batch
+                import csv
+                for row in csv.DictReader(open(kpath)):
+                    if row.get("Name", "").startswith("x3_segscan_kernel"):
+                        kms = float(row["AverageNs"]) * 1e-6
+                        line["many_chunks_batch"]["k1_roofline"].update({"kernel_ms": round(kms, 3), "frac_kernel": round(k1_alg / (kms * 1e-3) / HBM_PEAK, 4),
+                                                                         "kernel_ms_source": f"profiles/{os.path.basename(kpath)}"})
             tdt, tlens, tst, _, d_tout, _ = chunk_batch(ctx, d_min[:q], q, mcb, prm, dev)  # the text half alone (round 1 measured tiled text)
             line["many_chunks_batch"]["text_only"] = {"total_bytes": q, "value": round(q / tdt / 1e6, 2), "unit": "MB/s", "ratio": round(q / float(tlens.sum()), 4)}
             # decoder (x3.c:285-353), one wavefront per stream: the whole fresh batch decoded back as ONE batch, streams and bytes resident in HBM
