@@ -277,6 +277,15 @@ def test_emulated_csb_count_kernel_body(emu_env, oracle):
     assert ctx.compress(data, _lib.make_params(**kw)) == oracle.compress(data, oracle_lib.params(**kw))
 
 
+def test_emulated_slices_arranged_by_the_per_stream_sort(emu_env, oracle):
+    """K3 in slices with the two arrangements of a slice made by x3_segsort_kernel (X3H_SLICE_SEGSORT=1: one workgroup per stream, any segment length) instead of the
+    LDS counting sort of small slices / the chip-wide sort of large ones"""
+    ctx = emu_env(X3H_SLICED_MIN="1024", X3H_SLICE_GAP="700", X3H_SLICE_ARRANGE="0", X3H_SLICE_SEGSORT="1")
+    data, kw = synth.english_like(5200, seed=8).tobytes(), dict(w_kib=2, t=6)
+    assert ctx.compress(data, _lib.make_params(**kw)) == oracle.compress(data, oracle_lib.params(**kw))
+    assert ctx.last_stats.pipelined == 2
+
+
 @pytest.mark.parametrize("sched", ["stage-after-stage", "sliced"])
 def test_emulated_sort_and_scan_kernels(emu_env, oracle, sched):
     """prims.hip's hand-written radix sort (histogram / scan / ranked scatter) and prefix scans themselves on the emulator (X3_EMU_PRIM_KERNELS=1; the other tests

@@ -66,7 +66,7 @@ ENVS = [dict(), dict(X3H_PIPE_MIN="1"), dict(X3H_PIPE_MIN="1", X3H_MODES="fixed"
         dict(X3H_SEG_MIN="1", X3H_SEG_LA_LDS="0"), dict(X3H_SEG_MIN="1", X3H_SEG_LA_LDS="0", X3H_SEG_SMALL_MAX="0"),
         # round 5: slices arranged by the per-stream sort (x3_segsort_kernel: what slices above 32 768 hits per stream take) instead of the LDS counting sort; every
         # environment runs the hand-written radix sort / chained scans of prims.hip (K1 of few streams, the generic coding stage) and K2's prefix-hash block fill
-        dict(X3H_SLICED_MIN="1", X3H_SLICE_GAP="64", X3H_SLICE_ARRANGE="0"), dict(X3H_SLICED_MIN="1", X3H_SLICE_GAP="300", X3H_SLICE_ARRANGE="0", X3H_SLICE_SUB="3"),
+        dict(X3H_SLICED_MIN="1", X3H_SLICE_GAP="64", X3H_SLICE_ARRANGE="0"), dict(X3H_SLICED_MIN="1", X3H_SLICE_GAP="300", X3H_SLICE_ARRANGE="0", X3H_SLICE_SEGSORT="1", X3H_SLICE_SUB="3"),
         dict(X3H_SLICED_MIN="1", X3H_SLICE_GAP="1000", X3H_SLICE_ARRANGE="0", X3H_SLICE_MARKS="0.004,0.02,0.05,0.10,0.17,0.26,0.36,0.47,0.59,0.72,0.86")]
 t0, cases = time.time(), 0
 while time.time() - t0 < budget:

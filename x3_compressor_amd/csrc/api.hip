@@ -60,9 +60,12 @@ struct x3h_ctx {
 	int sliced_max_streams = 192;                 /* X3H_SLICED_STREAMS: beyond, every CU has a stream of every stage anyway (stage after stage) */
 	/* X3H_SLICE_MARKS: small slices first (the coder starts after 2 % of the input), then each about 1.7 times the one before: the feature stages of a slice take
 	 * 0.35-0.6 of its coder time and the parse has to get there first, so the coder never runs dry -- and FEW slices: every slice is one coder launch for all
-	 * streams, which ends with its longest segment (eleven equal slices cost config 3, whose streams differ in symbols per byte, 19 % of coder time) */
-	double slice_marks[X3_MAX_CKPT] = { 0.02, 0.05, 0.11, 0.20, 0.35, 0.60 };
-	uint32_t slice_nmarks = 6;
+	 * streams, which ends with its longest segment (eleven equal slices cost config 3, whose streams differ in symbols per byte, 19 % of coder time).
+	 * Round 5: nine marks instead of six (0.02 .. 0.60) -- a smaller first slice (the coder starts after 1 %) and, above all, a smaller LAST one: behind the last coder
+	 * segment only its own bits remain to be written, and with a 40 % tail that was 10 ms of config 4's share (441.6 -> 419.3 ms; config 3 2 006 -> 1 957 ms;
+	 * profiles/r05_slice_marks.txt) */
+	double slice_marks[X3_MAX_CKPT] = { 0.01, 0.03, 0.07, 0.14, 0.25, 0.40, 0.58, 0.76, 0.90 };
+	uint32_t slice_nmarks = 9;
 	bool slice_marks_fixed = false;
 	X3SliceRun sr;
 	hipEvent_t ev_sf[X3S_MAX_SLICES + 2] = {}, ev_sb[X3S_MAX_SLICES + 2] = {}, ev_se[X3S_MAX_SLICES + 2] = {}, ev_sc[X3S_MAX_SLICES + 2] = {}, ev_sa[X3S_MAX_SLICES + 2] = {}, ev_s0 = nullptr;

@@ -992,7 +992,8 @@ int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_for
 		/* arrangement by (context1, time).  Small slices: one workgroup per stream, a counting sort on the stream-local key in LDS (x3_arrange_kernel, code3.hip: one
 		 * launch per 11 key bits; a slice's arrays are L2-resident, so its scattered stores cost nothing -- on whole streams they made this kernel lose against
 		 * the library sort).  Large slices: the chip-wide radix sort (a workgroup of four wavefronts per stream would be the bottleneck). */
-		bool arrange = nH / nc <= 32768, segsorted = false;
+		bool arrange = nH / nc <= 32768, segsorted = false, seg_big = false;
+		if (const char *e = getenv("X3H_SLICE_SEGSORT")) seg_big = e[0] == '1';
 		if (const char *e = getenv("X3H_SLICE_ARRANGE")) arrange = e[0] == '1';
 		uint32_t *d_aho = A[30], *d_akb = A[31]; /* (nc + 1 <= steps + 8 entries each) */
 		if ((uint64_t)nc + 1 > nS + 8) arrange = false;
@@ -1000,9 +1001,10 @@ int x3s_slice(X3SliceRun &R, hipStream_t st, hipStream_t side, hipEvent_t ev_for
 			const uint32_t nHs = (uint32_t)nH, ksh = dsh;
 			x3_foreach((size_t)nc + 1, st, X3_LAMBDA(size_t c) { d_aho[c] = c < nc ? d_sl[c].sh : nHs; d_akb[c] = (uint32_t)c << ksh; });
 			CHK(x3_arrange_run(st, nc, d_aho, d_akb, max_dict ? max_dict - 1 : 0, k1, nullptr, kA, vA, nullptr, A[28], A[29]));
-		} else if ((uint64_t)nc + 1 <= nS + 8) {
-			/* large slices: one workgroup per stream sorts its segment on the stream-local key in tiles of 4096 (x3_segsort_kernel, code3.hip) -- the chip-wide
-			 * library sort of rounds 1-4 is gone from this path (412 launches and 3.4 GB of HBM traffic per step of the dickens-sized stream) */
+		} else if (seg_big && (uint64_t)nc + 1 <= nS + 8) {
+			/* X3H_SLICE_SEGSORT=1 (tests / A-B): one workgroup per stream sorts its segment on the stream-local key in tiles of 4096 (x3_segsort_kernel, code3.hip).  Not the
+			 * default for large slices: a lone workgroup needs ~0.4 ms per 256 K hits and pass, and a slice of config 4's share is 2.9 M hits per stream -- the feature stages of a
+			 * slice (96 ms) then outlast the coder segment before it (profiles/r05_config4_timeline.txt); the chip-wide sort of prims.hip does all 16 streams in ~2 ms */
 			const uint32_t nHs = (uint32_t)nH, ksh = dsh;
 			x3_foreach((size_t)nc + 1, st, X3_LAMBDA(size_t c) { d_aho[c] = c < nc ? d_sl[c].sh : nHs; d_akb[c] = (uint32_t)c << ksh; });
 			CHK(x3_segsort_run(st, nc, d_aho, d_akb, max_dict ? max_dict - 1 : 0, k1, kA, vA, A[28], A[29], nullptr));
