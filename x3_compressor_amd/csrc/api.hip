@@ -77,6 +77,7 @@ struct x3h_ctx {
 	int slice_cumask = 1;
 	uint64_t slice_cumask_max_len = (uint64_t)2 << 20; /* X3H_SLICE_CUMASK_LEN: longest stream of the batch at most this long (long parses stay on the three plain streams: see sliced_setup) */
 	uint64_t slice_cumask_min_len = 0; /* X3H_SLICE_CUMASK_MIN: ... and at least this long (tuning) */
+	uint32_t slice_cumask_min_streams = 4; /* X3H_SLICE_CUMASK_STREAMS: batches of at least this many streams */
 	hipStream_t sm_feat = nullptr, sm_parse = nullptr, sm_coder = nullptr;
 	int sm_state = 0; /* 0: not tried, 1: ready, -1: not available on this device */
 	int slice_bstream = 0;                        /* X3H_SLICE_BSTREAM=1: stage B of a slice (mode chain, models, assembly) on the parse stream once the parse is done, beside stage A of the
@@ -177,6 +178,7 @@ extern "C" int x3h_ctx_create(x3h_ctx **out, int device)
 	{ const char *e = getenv("X3H_SLICE_CUMASK"); if (e && *e) c->slice_cumask = *e != '0'; }
 	{ const char *e = getenv("X3H_SLICE_CUMASK_LEN"); if (e && *e) c->slice_cumask_max_len = (uint64_t)atoll(e); }
 	{ const char *e = getenv("X3H_SLICE_CUMASK_MIN"); if (e && *e) c->slice_cumask_min_len = (uint64_t)atoll(e); }
+	{ const char *e = getenv("X3H_SLICE_CUMASK_STREAMS"); if (e && atoi(e) >= 1) c->slice_cumask_min_streams = (uint32_t)atoi(e); }
 	{ const char *e = getenv("X3H_SLICED_STREAMS"); if (e && *e) c->sliced_max_streams = atoi(e); }
 	{ const char *e = getenv("X3H_SLICE_MARKS");
 	  if (e && *e) {
@@ -560,7 +562,9 @@ static int run_sliced_body(x3h_ctx *c, X3ParseArgs &pa, const uint8_t *d_bytes, 
 	/* the three streams of the slices: features, parse (+ bit emission), coder -- plain ones, or the masked ones of the mid-size layout */
 	uint64_t longest_len = 0;
 	for (uint32_t i = 0; i < nc; i++) if (c->hchunks[i].len > longest_len) longest_len = c->hchunks[i].len;
-	const bool masked = c->slice_cumask && nc >= 4 && longest_len <= c->slice_cumask_max_len && longest_len >= c->slice_cumask_min_len && sliced_masked_setup(c);
+	/* (round 5: streams longer than X3H_SLICE_CUMASK_LEN take the masked layout too while the coder's 32 CUs hold at most two chains each -- config 4's share: feature stages 147 -> 55 ms
+	 * beside the coder, whose own lane shrinks 395 -> 383 ms, the call 427.8 -> 408.0 ms; config 3 1 957 -> 1 941 ms; profiles/r05_slice_marks.txt) */
+	const bool masked = c->slice_cumask && nc >= c->slice_cumask_min_streams && (longest_len <= c->slice_cumask_max_len || nc <= 64) && longest_len >= c->slice_cumask_min_len && sliced_masked_setup(c);
 	hipStream_t sF = masked ? c->sm_feat : c->stream, sP = masked ? c->sm_parse : c->s_parse, sC = masked ? c->sm_coder : c->s_coder;
 	/* how many slices: a slice costs a few hundred microseconds of launches and of latency-bound per-stream kernels whatever its size, so the longest stream is cut
 	 * about every 150 KB, into at most the full set of marks (small slices first: the coder starts early); X3H_SLICE_MARKS fixes the set */
