@@ -1228,12 +1228,20 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 	CHK(B.pp[0].reserve((size_t)nc * 16 + 64));
 	tokb = B.pp[0].as<uint32_t>();
 
+	/* new fragments: model_match_size (32 symbols) and model_chars (256 symbols) are adaptive order-0 models (x3.c:259-267); their inputs, one length symbol per
+	 * fragment and the fragments' bytes in order, are written by the per-stream token walk where that runs, else by an element-wise pass over the steps (below) */
+	const size_t nMS = nMSres + 4;
+	uint32_t *Q[16];
+	for (int i = 0; i < 16; i++) { CHK(B.ms[i].reserve(nMS * 4)); Q[i] = B.ms[i].as<uint32_t>(); }
+	uint32_t *lval = Q[0], *lsm = Q[1], *leq = Q[2], *bval = Q[3], *bsm = Q[4], *beq = Q[5];
+	bool frag_inputs_done = false;
 	if (nH > 0) {
 		if (streamk && dict_len) {
 			/* many streams: one workgroup per stream walks its tokens: running counts (stream-relative) + per-hit / per-touch records */
 			HIPCHK(hipMemsetAsync((void *)tokb, 0, (size_t)nc * 16, st));
 			CHK(x3_tokens_run(st, nc, d_chunks, d_parsed, tok_info, dict_len, (uint32_t *)tok_pos, (uint32_t *)tok_hb, (uint32_t *)tok_nb, (uint32_t *)tok_mb,
-			                  d_ho, d_eo, d_dof, h_tag, h_c1, h_pv, h_dk, h_step, e_tag, e_hit));
+			                  d_ho, d_eo, d_dof, h_tag, h_c1, h_pv, h_dk, h_step, e_tag, e_hit, d_bytes, d_mo, d_bo, lval, bval));
+			frag_inputs_done = true;
 		} else {
 			/* ---- F1: per step -> per hit / per event records ---- */
 			x3_foreach(nS, st, X3_LAMBDA(size_t gs) {
@@ -1552,11 +1560,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 
 	/* ---- new fragments: model_match_size (32 symbols) and model_chars (256 symbols) are adaptive order-0 models
 	 *      (x3.c:259-267): cum_freq = symbol + #{earlier smaller}, freq = 1 + #{earlier equal}, total = alphabet + index ---- */
-	const size_t nMS = nMSres + 4;
-	uint32_t *Q[16];
-	for (int i = 0; i < 16; i++) { CHK(B.ms[i].reserve(nMS * 4)); Q[i] = B.ms[i].as<uint32_t>(); }
-	uint32_t *lval = Q[0], *lsm = Q[1], *leq = Q[2], *bval = Q[3], *bsm = Q[4], *beq = Q[5];
-	x3_foreach(nS, st, X3_LAMBDA(size_t gs) {
+	if (!frag_inputs_done) x3_foreach(nS, st, X3_LAMBDA(size_t gs) {
 		const uint32_t c = find_chunk(d_so, nc, (uint32_t)gs);
 		const uint32_t k = (uint32_t)gs - d_so[c];
 		const uint64_t base = d_chunks[c].elem_off;

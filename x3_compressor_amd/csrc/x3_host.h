@@ -307,7 +307,8 @@ int x3_idxstat_run(hipStream_t st, uint32_t nc, uint64_t max_dict, const uint32_
                    const uint32_t *lhit, const uint32_t *h_dk, uint32_t *rfreq, uint32_t *rcum, uint32_t *itot);
 int x3_tokens_run(hipStream_t st, uint32_t nc, const X3Chunk *d_chunks, const X3ParseResult *d_parsed, const uint32_t *tok_info, const uint8_t *dict_len,
                   uint32_t *tok_pos, uint32_t *tok_hb, uint32_t *tok_nb, uint32_t *tok_mb, const uint32_t *d_ho, const uint32_t *d_eo, const uint32_t *d_dof,
-                  uint32_t *h_tag, uint32_t *h_c1, uint32_t *h_pv, uint32_t *h_dk, uint32_t *h_step, uint32_t *e_tag, uint32_t *e_hit);
+                  uint32_t *h_tag, uint32_t *h_c1, uint32_t *h_pv, uint32_t *h_dk, uint32_t *h_step, uint32_t *e_tag, uint32_t *e_hit,
+                  const uint8_t *d_bytes, const uint32_t *d_mo, const uint32_t *d_bo, uint32_t *lval, uint32_t *bval);
 /* stage seam for tests: x3_ac2_kernel on a caller-given symbol sequence (code2.hip) */
 int x3_coder_chain_run(X3Code2Bufs &B, hipStream_t st, const uint32_t *h_cum, const uint32_t *h_freq, const uint32_t *h_total, size_t n,
                        uint32_t *h_states, uint32_t *h_final_lo);
