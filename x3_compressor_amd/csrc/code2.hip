@@ -1311,7 +1311,7 @@ int x3_code_v2_run(X3Code2Bufs &B, hipStream_t st, int nchunks, const X3Chunk *h
 			uint4 *stat = B.stat.as<uint4>(), *stat0 = B.stat0.as<uint4>(); /* per hit {freq, total, cum, first}: context1 / context0.  Read in place by the mode kernel and the symbol
 			                                                                  * selection (no unpacking into six arrays: 60 bytes per hit less traffic) */
 			uint32_t npairs_total = 0;
-			/* by context1, time order inside: chip-wide stable radix sort (rocPRIM onesweep, 3.6 TB/s).  X3H_ARRANGE=1: one workgroup per stream, counting
+			/* by context1, time order inside: chip-wide stable radix sort (prims.hip; rounds 1-4: rocPRIM onesweep, 3.6 TB/s).  X3H_ARRANGE=1: one workgroup per stream, counting
 			 * sort on the stream-local key (x3_arrange_kernel, code3.hip) -- same order, measured SLOWER on the 1024-chunk batch (features 48 against
 			 * 40 ms: four wavefronts per stream walk their quarter as a chain of LDS round trips), so it stays an option, not the default */
 			bool seg_arrange = false;

@@ -1,7 +1,7 @@
 /*
  * x3_host.h -- host-side helpers shared by api.hip / code2.hip / prims.hip: growable device buffers, status macros,
  * an element-wise launcher (x3_foreach) and the three library primitives of the v2 coding stage
- * (stable radix sort of (key,value) pairs, exclusive sum scan, inclusive max scan -- rocPRIM on the GPU).
+ * (stable radix sort of (key,value) pairs, exclusive sum scan, inclusive max scan -- hand-written kernels, prims.hip).
  */
 #ifndef X3_HOST_H
 #define X3_HOST_H
