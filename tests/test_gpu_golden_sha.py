@@ -18,8 +18,10 @@ from x3_compressor_amd import _lib, synth
 pytestmark = pytest.mark.gpu
 MAN = json.load(open(os.path.join(golden_util.HERE, "manifest_sha.json")))
 PIECES = sorted(n for n in MAN if MAN[n]["generator"] == "piece")   # chunks of the batches bench.py times (round 5): tested in their batch, below
-MAXCHUNK = "big_english_maxchunk_w1_t4"   # ONE stream of X3H_MAX_CHUNK = 2^28 - 4096 bytes (round 5): its own test below (a decode of 2.2e8 steps would take minutes)
-CASES = sorted(n for n in MAN if not n.startswith("cli_") and n not in PIECES and n != MAXCHUNK)
+# ONE stream of X3H_MAX_CHUNK = 2^28 - 4096 bytes (round 5): text (1.2e8 parse steps) and Zipf bytes (nearly a step per byte: the event model's total reaches 2^28 -- hours of
+# reference time, in the manifest once tests/golden/make_golden_sha.py big_zipf_maxchunk has finished); their own test below (a decode of 1e8 steps would take minutes)
+MAXCHUNK = ("big_english_maxchunk_w1_t4", "big_zipf_maxchunk_w1_t4")
+CASES = sorted(n for n in MAN if not n.startswith("cli_") and n not in PIECES and n not in MAXCHUNK)
 LONG = [n for n in CASES if n.startswith(("big_", "cfg3_full_", "cfg5_full_"))]   # minutes to hours of reference time each
 PAST_2_24 = [n for n in LONG if MAN[n]["input_len"] >= (24 << 20)]   # 0.5-0.8 parse steps per byte: more than 2^24 steps (asserted below)
 
@@ -97,12 +99,13 @@ def test_long_streams_decode_back(inputs):
             assert b == d, n
 
 
-def test_longest_single_stream_equals_reference():
+@pytest.mark.parametrize("name", MAXCHUNK)
+def test_longest_single_stream_equals_reference(name):
     """the reference codes any input as ONE stream (x3.c:577-611); the library's longest stream is X3H_MAX_CHUNK = 2^28 - 4096 bytes (include/x3hip.h has the bound: every
     model total stays < 2^28, so a coder step is never a single value).  One stream of exactly that size -- 1.2e8 parse steps -- against the real reference's `x3 -z -w 1 -t 4`; one byte more is refused."""
-    if MAXCHUNK not in MAN:
-        pytest.skip("the reference stream of the longest single stream is not in the manifest yet (tests/golden/make_golden_sha.py big_english_maxchunk)")
-    e = MAN[MAXCHUNK]
+    if name not in MAN:
+        pytest.skip(f"the reference stream of {name} is not in the manifest yet (tests/golden/make_golden_sha.py {name}: hours of reference time)")
+    e = MAN[name]
     assert e["input_len"] == (1 << 28) - 4096
     data = golden_util.sha_input(e)
     with _lib.X3Context(0) as ctx:
