@@ -126,7 +126,7 @@ def test_emulated_decoder_random_streams(emu, oracle):
 def test_emulated_decoder_reaches_its_rare_paths(emu, oracle):
     """decode.hip counts, in emulator builds, how often its rare paths run (x3emu_dec_cover[]): a context0 block that moved reached through the item that still holds
     its old place (forwarding entry followed, the item patched -- also in the lanes when its list is the current context1), symbols and tags beyond entry 63 of a
-    list, blocks moving, ranks beyond 63.  Each input below is built for one of them; all of them must have run, and every round trip is exact."""
+    list, blocks moving, ranks in the second register of the recency list (64-127: this build keeps two, the product four) and behind the registers.  Each input below is built for one of them; all of them must have run, and every round trip is exact."""
     import ctypes as C
     cover = (C.c_uint * 8).in_dll(emu.lib, "x3emu_dec_cover")
     for i in range(8):
@@ -138,8 +138,9 @@ def test_emulated_decoder_reaches_its_rare_paths(emu, oracle):
     mixed = b"".join(bytes([int(a)]) * int(n) + words[int(w)] for a, n, w in zip(rng.integers(0, 3, 300), rng.integers(1, 9, 300), rng.integers(0, 20, 300)))
     for data, kw in ((vocab, dict(w_kib=8, t=1)), (zeros, dict(w_kib=1, t=2)), (mixed, dict(w_kib=2, t=2)), (synth.zipf_bytes(6000, offset=9).tobytes(), dict(w_kib=4, t=3))):
         assert emu.decompress(oracle.compress(data, oracle_lib.params(**kw)), len(data) + 5) == data
-    got = [int(cover[i]) for i in range(6)]
-    assert all(g > 0 for g in got), f"rare paths not reached: forward {got[0]}, far decode {got[1]}, far find {got[2]}, block moved {got[3]}, far rank {got[4]}, lane patch {got[5]}"
+    got = [int(cover[i]) for i in range(7)]
+    assert all(g > 0 for g in got), (f"rare paths not reached: forward {got[0]}, far decode {got[1]}, far find {got[2]}, block moved {got[3]}, rank behind the registers {got[4]}, "
+                                     f"lane patch {got[5]}, rank in a register behind the first {got[6]}")
 
 
 def test_emulated_device_resident_decode(emu, oracle):

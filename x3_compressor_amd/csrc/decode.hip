@@ -67,6 +67,13 @@ static inline uint32_t dec_shr1_fill(uint32_t v, uint32_t fill) { const int l = 
 
 /* Scalars of the chain that only its rare paths touch live in LDS (s_cold[]), not in registers: the step's state is ~100 scalars, and what the compiler
  * spills when they do not fit is not ours to choose (it took the token pointer).  Read with dec_cold(), written by lane 0. */
+/* The first 64 * X3_DEC_MTFR ranks of the recency list stay in registers (one register per 64 ranks).  Round 4 kept 64: on the 1 MB mr-like stream 52 % of the steps found
+ * their tag BEHIND rank 63 (31 % behind 127, 2.4 % behind 255; 256 KiB of text: 38 % / 1 % / 0), and each of those swept the list in LDS twice -- once for the rank, once to
+ * move everything in front of it down: 750 of the step's ~2 400 cycles (section clocks of a profile build, tools/dec_prof.py).  (The emulator build of the tests keeps two,
+ * so that its inputs still reach the sweeps.) */
+#ifndef X3_DEC_MTFR
+#define X3_DEC_MTFR 4
+#endif
 enum { DC_IN_LO, DC_IN_HI, DC_NWORDS, DC_LITPOS, DC_O00, DC_OFIRST, DC_E3, DC_E4, DC_COUNT, DC_MODELS = DC_COUNT + 2 * X3_WAVE /* behind the two stream blocks */ };
 #ifndef X3_EMU
 __device__ static __forceinline__ uint32_t dec_cold(const uint32_t *s_cold, int i) { return x3_uniform(s_cold[i]); }
@@ -281,11 +288,11 @@ __device__ static __forceinline__ void dec_mtf_to_front(T *mtf, uint32_t r, uint
 	if (lane == 0) mtf[0] = (T)tag;
 	x3_wave_order();
 }
-/* dict_get_index_by_tag (dict.c:174-183) from rank 64 on: rank of `tag`, X3D_NONE if it is not in the list */
+/* dict_get_index_by_tag (dict.c:174-183) from rank `from` on (behind the ranks held in registers): rank of `tag`, X3D_NONE if it is not in the list */
 template <typename T>
-__device__ static __forceinline__ uint32_t dec_mtf_rank_far(const T *mtf, uint32_t D, uint32_t tag, uint32_t lane)
+__device__ static __forceinline__ uint32_t dec_mtf_rank_far(const T *mtf, uint32_t D, uint32_t tag, uint32_t lane, uint32_t from = X3_WAVE)
 {
-	for (uint32_t base = X3_WAVE; base < D; base += X3_WAVE) {
+	for (uint32_t base = from; base < D; base += X3_WAVE) {
 		const uint32_t i = base + lane;
 		const uint64_t mask = x3_ballot(i < D && (uint32_t)mtf[i] == tag);
 		if (mask) return base + (uint32_t)x3_ctz64(mask);
@@ -425,7 +432,14 @@ __device__ static __forceinline__ uint32_t dec_loop(const DecT &T, DecS &S, uint
 	/* ranks [0, 64) of the recency list and of the index model stay in registers: recent elements are the usual ones, and then neither the rank
 	 * search nor the move-to-front nor the index model reads a table (lanes >= D: no tag / frequency 0) */
 	uint32_t m0, i0;
+	uint32_t mx[X3_DEC_MTFR > 1 ? X3_DEC_MTFR - 1 : 1]; /* ranks [64, 64 * X3_DEC_MTFR): X3D_NONE behind the last element */
 	if (LDS) { m0 = s_mtf[lane]; i0 = s_idx[lane]; } else { m0 = T.gmtf[lane]; i0 = T.gidx[lane]; }
+#define DEC_MTF_RELOAD                                                                                                              \
+	_Pragma("unroll") for (uint32_t k_ = 0; k_ + 1 < X3_DEC_MTFR; k_++) {                                                           \
+		const uint32_t j_ = (k_ + 1) * X3_WAVE + lane;                                                                              \
+		mx[k_] = j_ < D ? (LDS ? (uint32_t)s_mtf[j_ < NLDS ? j_ : 0] : T.gmtf[j_]) : X3D_NONE;                                       \
+	}
+	DEC_MTF_RELOAD
 	uint32_t code;
 	/* The blocks of the next step's contexts are requested (dec_request) as soon as their addresses are known -- before this step's interval update, rank search,
 	 * move-to-front and token -- and taken over (dec_take) after the NEXT event has been decoded. */
@@ -554,6 +568,7 @@ __device__ static __forceinline__ uint32_t dec_loop(const DecT &T, DecS &S, uint
 						if (LDS) { m0 = s_mtf[lane]; i0 = s_idx[lane]; } else { m0 = T.gmtf[lane]; i0 = T.gidx[lane]; }
 						dec_cold_set(s_cold, DC_LITPOS, litpos + len);
 						D++;
+						DEC_MTF_RELOAD
 					}
 					if (lane == 0) *tokp = newtag;
 					tokp++; tokleft--;
