@@ -207,7 +207,7 @@ extern "C" int x3h_ctx_set_batch_bytes(x3h_ctx *c, uint64_t input_bytes)
 	if (!c || input_bytes < ((uint64_t)1 << 20)) return X3H_E_ARG;
 	if (input_bytes > ((uint64_t)1 << 40)) input_bytes = (uint64_t)1 << 40; /* more than any GPU holds: "no sub-batches" */
 	c->batch_bytes = input_bytes;
-	/* the decoder cuts on output capacity, at ~200 B of workspace per byte (the context pool is sized for the worst case: 160 B); its rate is streams in flight x the per-stream rate.  An explicit
+	/* the decoder cuts on output capacity, at ~200 B of workspace per byte (the context pool is sized for the worst case: 192 B); its rate is streams in flight x the per-stream rate.  An explicit
 	 * X3H_DEC_BATCH_BYTES from the environment stays in force. */
 	if (!c->dec_batch_from_env) c->dec_batch_bytes = 2 * input_bytes;
 	return X3H_OK;
@@ -1136,7 +1136,8 @@ static int decompress_batch(x3h_ctx *c, const uint8_t *in, const uint64_t *in_of
 		if (dev && (in_offsets[i] & 3)) return X3H_E_ARG;
 		/* the context pool in 8-byte units, worst case per parse step: an item more in a context0 list (<= 5 units with the blocks it outgrew), a new pair (3),
 		 * an item more in a context1 list (<= 11); a new element costs 7.  Every block is read 64 entries at a time: two of those as slack. */
-		k.tag_off = toff; k.item_off = itoff; k.item_cap = 20 * cap + 512;
+		k.tag_off = toff; k.item_off = itoff; k.item_cap = 24 * cap + 512; /* (pool units of 8 bytes per step, worst case: an item appended to the context1 list, <= 8 with doubling and the blocks left behind, and a
+		                                  * new pair's context0 block of 1 + X3_DEC_CAP0 = 9 -- or an item appended to a context0 list, <= 5.2) */
 		k.ht_log2 = ceil_log2(2 * (cap + 1)); if (k.ht_log2 < 4) k.ht_log2 = 4; k.ht_off = hoff;
 		k.tok_off = koff; k.lit_off = loff; k._pad = 0;
 		ioff += align_up(ilen, 16) + 16; ooff += align_up(cap, 256) + 256;

@@ -74,6 +74,12 @@ static inline uint32_t dec_shr1_fill(uint32_t v, uint32_t fill) { const int l = 
 #ifndef X3_DEC_MTFR
 #define X3_DEC_MTFR 4
 #endif
+/* A context0 list (one per tag pair) starts with room for X3_DEC_CAP0 items (a power of two) and doubles from there.  Round 4 started at 2: 38 % of the steps append an
+ * item to their context0 list, the lists average 11 items, so a list moved at 2, 4 and 8 items -- 7-8 % of ALL steps copied a block through memory (load, wait, store,
+ * forwarding entry, patch of the item that names it) in the middle of the chain. */
+#ifndef X3_DEC_CAP0
+#define X3_DEC_CAP0 8u
+#endif
 enum { DC_IN_LO, DC_IN_HI, DC_NWORDS, DC_LITPOS, DC_O00, DC_OFIRST, DC_E3, DC_E4, DC_COUNT, DC_MODELS = DC_COUNT + 2 * X3_WAVE /* behind the two stream blocks */ };
 #ifndef X3_EMU
 __device__ static __forceinline__ uint32_t dec_cold(const uint32_t *s_cold, int i) { return x3_uniform(s_cold[i]); }
@@ -376,7 +382,7 @@ __device__ static __forceinline__ bool dec_touch(uint64_t *pool, uint32_t pool_c
 		} else if (lane == 0) { f += 1; blk_entry<STR>(pool, o, 0)[0] = f; blk_entry<STR>(pool, o, e)[0] += 1; }
 		return true;
 	}
-	if (X3_UNLIKELY(n >= 2 && (n & (n - 1)) == 0)) { /* full: twice the capacity somewhere else */
+	if (X3_UNLIKELY(n >= (STR == 1 ? X3_DEC_CAP0 : 2u) && (n & (n - 1)) == 0)) { /* full: twice the capacity somewhere else */
 		DEC_COVER(3)
 		const uint32_t top = STR == 2 ? (pool_top + 1) & ~1u : pool_top, units = STR * (1 + 2 * n);
 		if (X3_UNLIKELY((uint64_t)top + units + 2 * X3_WAVE > pool_cap)) return false;
@@ -629,11 +635,11 @@ __device__ static void x3_decode_body(const X3DecArgs &a)
 	dec_cold_set(s_cold, DC_LITPOS, 0);
 	s.ctx1tag = 0;
 	s.pc_wait = s.pc_flight = s.pc_chain = 0;
-	/* the pool starts with the context1 block of tag 0 (six units: header + two items) and the context0 block of pair number 0 (three units), both empty:
+	/* the pool starts with the context1 block of tag 0 (six units: header + two items) and the context0 block of pair number 0 (1 + X3_DEC_CAP0 units), both empty:
 	 * these are the contexts of the first step, before any element or pair exists */
 	s.o1 = 0; s.o0 = 6; s.ref0 = X3D_NONE;
 	dec_cold_set(s_cold, DC_OFIRST, 6); dec_cold_set(s_cold, DC_O00, X3D_NONE);
-	s.pool_top = 9;
+	s.pool_top = 6 + 1 + X3_DEC_CAP0;
 	if (lane == 0) { t.pool[0] = 0; t.pool[1] = 0; t.pool[6] = 0; }
 	for (uint32_t i = lane; i < X3_WAVE; i += X3_WAVE) { s_mtf[i] = 0xFFFFu; s_idx[i] = 0; }
 	if (lane == 0) s_c1[0] = 0;
