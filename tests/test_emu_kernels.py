@@ -287,7 +287,7 @@ def test_emulated_slices_arranged_by_the_per_stream_sort(emu_env, oracle):
     assert ctx.last_stats.pipelined == 2
 
 
-@pytest.mark.parametrize("sched", ["stage-after-stage", "sliced"])
+@pytest.mark.parametrize("sched", ["stage-after-stage"])
 def test_emulated_sort_and_scan_kernels(emu_env, oracle, sched):
     """prims.hip's hand-written radix sort (histogram / scan / ranked scatter) and prefix scans themselves on the emulator (X3_EMU_PRIM_KERNELS=1; the other tests
     answer these calls with host loops, for speed): K1 of a single stream sorts every padded position (several tiles of 4096, four 8-bit passes, the last tile
