@@ -841,7 +841,7 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 		                   prm.window_bytes, prm.max_match_count));
 	}
 	HIPCHK(hipEventRecord(c->ev[2], c->stream));
-	if (upto == STAGE_SCAN) { HIPCHK(hipStreamSynchronize(c->stream)); return X3H_OK; }
+	if (upto == STAGE_SCAN) { HIPCHK(hipStreamSynchronize(c->stream)); return x3p_check_error(c->stream); }
 
 	/* ---- K2 ---- */
 	/* pipelined schedule: a few long streams (the serial chains dominate); many short ones run stage after stage (the chip-wide passes dominate) */
@@ -937,6 +937,7 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 	if (!hest.empty() && !sliced) HIPCHK(hipMemcpyAsync(hest.data(), c->c2.est_out.p, hest.size() * 4, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 
+	const int scan_rc = x3p_check_error(c->stream); /* (a chained scan that gave up its wait: never seen, never to be returned as a result) */
 	int rc = X3H_OK;
 	for (int i = 0; i < nc; i++) {
 		const X3CodeResult &r = c->hcode[(size_t)i];
@@ -944,6 +945,7 @@ static int run_one(x3h_ctx *c, const x3h_params *prm_in, const RunIO &io, Stage 
 		else if (r.status != X3_ST_OK && rc == X3H_OK) rc = X3H_E_INTERNAL;
 		if (io.out_lens) io.out_lens[i] = r.out_len;
 	}
+	if (scan_rc != X3H_OK) rc = scan_rc;
 	if (rc == X3H_OK && !io.dst_dev) {
 		for (int i = 0; i < nc; i++) {
 			const X3Chunk &k = c->hchunks[(size_t)i];

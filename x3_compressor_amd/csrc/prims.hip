@@ -42,6 +42,14 @@ struct X3pScanArgs {
 	uint32_t ntiles, _pad;
 };
 
+/* set (and never cleared by a kernel) when a tile gave up waiting for a predecessor: the forward-progress argument above says this cannot happen, so if it ever does the
+ * call must fail loudly instead of returning a wrong prefix -- api.hip reads the word behind every call (x3p_check_error) */
+#ifndef X3_EMU
+__device__ uint32_t x3p_dev_error;
+#else
+uint32_t x3p_dev_error;
+#endif
+
 template <int MODE> __device__ static __forceinline__ uint32_t x3p_scan_load(const X3pScanArgs &a, size_t i)
 {
 	if (i >= a.n) return 0u;
@@ -128,7 +136,7 @@ template <int MODE> __device__ static void x3p_scan_body(const X3pScanArgs &a)
 #endif
 					if ((uint32_t)(w >> 32) == X3P_ST_EMPTY) w = x3p_status_load(a.status + mi);
 				}
-				if (x3_ballot((uint32_t)(w >> 32) == X3P_ST_EMPTY)) { if (lane == 0) atomicOr((uint32_t *)(a.status + a.ntiles) + 1, 1u); break; } /* gave up (never seen): results are wrong, nothing hangs */
+				if (x3_ballot((uint32_t)(w >> 32) == X3P_ST_EMPTY)) { if (lane == 0) { atomicOr((uint32_t *)(a.status + a.ntiles) + 1, 1u); atomicOr(&x3p_dev_error, 1u); } break; } /* gave up (never seen): results are wrong, nothing hangs */
 				const uint64_t known = x3_ballot((uint32_t)(w >> 32) == X3P_ST_INCL);
 				const uint32_t upto = known ? (uint32_t)x3_ctz64(known) : X3_WAVE - 1; /* lanes 0..upto contribute */
 				const uint32_t part = x3p_wave_incl<MODE>(lane <= upto ? (uint32_t)w : 0u);
@@ -348,4 +356,18 @@ int x3p_sort_pairs(DevBuf &tmp, const uint32_t *kin, uint32_t *kout, const uint3
 {
 	if (bits < 1) bits = 1;
 	return x3p_sort_pairs_bits(tmp, kin, kout, vin, vout, n, 0, bits > 32 ? 32 : bits, st);
+}
+
+/* X3H_OK, or X3H_E_INTERNAL if a scan tile of any call since the last check gave up its bounded wait (the word is cleared again).  Synchronises `st`. */
+int x3p_check_error(hipStream_t st)
+{
+	uint32_t e = 0;
+#ifndef X3_EMU
+	HIPCHK(hipMemcpyFromSymbolAsync(&e, HIP_SYMBOL(x3p_dev_error), 4, 0, hipMemcpyDeviceToHost, st));
+	HIPCHK(hipStreamSynchronize(st));
+	if (e) { const uint32_t z = 0; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(x3p_dev_error), &z, 4, 0, hipMemcpyHostToDevice)); }
+#else
+	(void)st; e = x3p_dev_error; x3p_dev_error = 0;
+#endif
+	return e ? X3H_E_INTERNAL : X3H_OK;
 }

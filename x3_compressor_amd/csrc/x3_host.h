@@ -74,6 +74,7 @@ int x3p_sort_pairs_bits(DevBuf &tmp, const uint32_t *kin, uint32_t *kout, const 
 /* out[i] = sum in[0..i) for i in [0,n]; `in` must have n+1 readable entries (in[n] is ignored), out n+1 writable */
 int x3p_excl_scan(DevBuf &tmp, const uint32_t *in, uint32_t *out, size_t n, hipStream_t st);
 int x3p_excl_scan_top_bit_w(DevBuf &tmp, const uint4 *rec, uint32_t *out, size_t n, hipStream_t st); /* out[i] = #{ j < i : rec[j].w >> 31 }, i <= n (rec[n] is read, not used) */
+int x3p_check_error(hipStream_t st); /* X3H_E_INTERNAL if a chained scan gave up its bounded wait since the last check (cannot happen; checked behind every call) */
 /* out[i] = max in[0..i] */
 int x3p_incl_max_scan(DevBuf &tmp, const uint32_t *in, uint32_t *out, size_t n, hipStream_t st);
 
