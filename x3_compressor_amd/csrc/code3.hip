@@ -417,7 +417,7 @@ struct X3TokArgs {
 	const X3ParseResult *parsed;
 	const uint32_t *tok_info;
 	const uint8_t *dict_len;
-	uint32_t *tok_pos, *tok_hb, *tok_nb, *tok_mb;        /* out per step (layout: chunk elem_off + step)              */
+	uint32_t *tok_pos, *tok_hb, *tok_nb, *tok_mb;        /* out per step (layout: chunk elem_off + step): tok_hb and tok_mb -- what the symbol assembly indexes with */
 	const uint32_t *ho, *eo, *dof;                       /* per chunk: first hit / first touch event / first tag      */
 	uint32_t *h_tag, *h_c1, *h_pv, *h_dk, *h_step;       /* out per hit                                               */
 	uint32_t *e_tag, *e_hit;                             /* out per touch event (hit or insertion)                    */
@@ -462,7 +462,7 @@ __device__ static void x3_tokens_body(const X3TokArgs &a)
 		uint32_t pinfo = x3_shfl_up_u32(info, 1);
 		if (in) {
 			if (lane == 0) pinfo = k == 0 ? X3_TOK_MISS : a.tok_info[base + k - 1];
-			a.tok_hb[base + k] = hb; a.tok_nb[base + k] = nb; a.tok_mb[base + k] = mbb; a.tok_pos[base + k] = pos;
+			a.tok_hb[base + k] = hb; a.tok_mb[base + k] = mbb; /* (the running element count and the position of a step stay in registers: nothing behind this walk reads them per step) */
 			if (hit) {
 				const uint32_t gh = ho + hb, ev = eo + hb + nb;
 				const bool pv = !(pinfo & X3_TOK_MISS);
