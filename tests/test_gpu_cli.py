@@ -125,6 +125,17 @@ def test_cli_says_when_it_writes_a_container_the_reference_cannot_read(tmp_path)
     small.write_bytes(b"abc" * 1000)
     r = run(["-z", str(small)])
     assert r.returncode == 0 and b"NOTE" not in r.stderr
+    # between the old limit (128 MiB) and the new one: ONE raw x3 stream, like the reference writes (x3.c:577-611), no container and no note
+    mid, midz, midb = tmp_path / "mid", tmp_path / "mid.x3", tmp_path / "midback"
+    nm = (200 << 20) + 3
+    with open(mid, "wb") as fh:
+        fh.truncate(nm)
+    r = run(["-z", "-w", "8", "-t", "16", str(mid)])
+    assert r.returncode == 0 and b"NOTE" not in r.stderr, r.stderr.decode()
+    assert midz.read_bytes()[:4] != b"X3C1" and os.path.getsize(midz) < 8192
+    r = run(["-d", str(midz), str(midb)])
+    assert r.returncode == 0, r.stderr.decode()
+    assert os.path.getsize(midb) == nm
 
 
 def test_cli_large_file_round_trip_pinned_to_reference(tmp_path):
